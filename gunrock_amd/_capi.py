@@ -1,0 +1,122 @@
+"""ctypes binding of include/grx.h (libgrx.so).
+
+The product path: if the HIP library is missing this module raises -- there is
+no CPU fallback anywhere in the package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgrx.so")
+
+GRX_SUCCESS = 0
+
+# operators::load_balance_t (include/gunrock/framework/operators/configs.hxx:52-60)
+thread_mapped, warp_mapped, block_mapped, bucketing, merge_path, merge_path_v2, work_stealing = range(7)
+# operators::filter_algorithm_t (configs.hxx:93-98)
+remove, predicated, compact, bypass = range(4)
+# operators::uniquify_algorithm_t
+unique, unique_copy = range(2)
+# operators::advance_direction_t
+forward, backward, optimized = range(3)
+
+FLAG_UNFUSED = 0x1
+FLAG_PROFILE = 0x2
+FLAG_SYNC_EACH_LEVEL = 0x4
+
+
+class grx_options_t(C.Structure):
+    _fields_ = [("advance_load_balance", C.c_int32),
+                ("filter_algorithm", C.c_int32),
+                ("enable_filter", C.c_int32),
+                ("enable_uniquify", C.c_int32),
+                ("uniquify_algorithm", C.c_int32),
+                ("best_effort_uniquify", C.c_int32),
+                ("uniquify_percent", C.c_float),
+                ("engine_flags", C.c_int32),
+                ("advance_direction", C.c_int32),
+                ("max_iterations", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
+
+
+class grx_run_stats_t(C.Structure):
+    _fields_ = [("edges_visited", C.c_int64),
+                ("vertices_visited", C.c_int64),
+                ("search_depth", C.c_int32),
+                ("n_levels_recorded", C.c_int32),
+                ("elapsed_ms", C.c_float),
+                ("reserved", C.c_float)]
+
+
+class grx_level_profile_t(C.Structure):
+    _fields_ = [("frontier_size", C.c_int64),
+                ("edges", C.c_int64),
+                ("advance_ms", C.c_float),
+                ("other_ms", C.c_float)]
+
+
+class GrxError(RuntimeError):
+    """Mirror of gunrock::error::exception_t (include/gunrock/error.hxx:20-45)."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "gunrock_amd: %s is missing. Build it with `python -m gunrock_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    P = C.POINTER
+    sig = {
+        "grx_options_default": (None, [P(grx_options_t)]),
+        "grx_last_error_string": (C.c_char_p, []),
+        "grx_version_string": (C.c_char_p, []),
+        "grx_context_create": (i32, [i32, vp, P(vp)]),
+        "grx_context_synchronize": (i32, [vp]),
+        "grx_context_destroy": (i32, [vp]),
+        "grx_context_stream": (vp, [vp]),
+        "grx_graph_create_csr": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, P(vp)]),
+        "grx_graph_destroy": (i32, [vp]),
+        "grx_graph_number_of_vertices": (i32, [vp]),
+        "grx_graph_number_of_edges": (i32, [vp]),
+        "grx_bfs": (i32, [vp, vp, i32, P(grx_options_t), vp, vp, P(f32)]),
+        "grx_sssp": (i32, [vp, vp, i32, P(grx_options_t), vp, vp, P(f32)]),
+        "grx_pr": (i32, [vp, vp, f32, f32, P(grx_options_t), vp, P(i32), P(f32)]),
+        "grx_get_run_stats": (i32, [vp, P(grx_run_stats_t)]),
+        "grx_get_level_profile": (i32, [vp, P(grx_level_profile_t), i32, P(i32)]),
+        "grx_host_csr_load_mtx": (i32, [C.c_char_p, P(vp)]),
+        "grx_host_csr_read_binary": (i32, [C.c_char_p, P(vp)]),
+        "grx_host_csr_write_binary": (i32, [vp, C.c_char_p]),
+        "grx_host_csr_from_coo": (i32, [i32, i32, i64, vp, vp, vp, P(vp)]),
+        "grx_host_csr_info": (i32, [vp, P(i32), P(i32), P(i32), P(i32), P(i32)]),
+        "grx_host_csr_row_offsets": (P(i32), [vp]),
+        "grx_host_csr_column_indices": (P(i32), [vp]),
+        "grx_host_csr_values": (P(f32), [vp]),
+        "grx_host_csr_destroy": (i32, [vp]),
+        "grx_host_csr_generate": (i32, [i32, i32, i64, f32, f32, f32, C.c_uint64, P(vp)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+DECLARED_SYMBOLS = None  # filled by tests from include/grx.h
+
+
+def check(status):
+    if status != GRX_SUCCESS:
+        msg = lib().grx_last_error_string()
+        raise GrxError(status, (msg or b"").decode() or ("grx error %d" % status))

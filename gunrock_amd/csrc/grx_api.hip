@@ -1,0 +1,228 @@
+// grx_api.hip -- context, graph view, scratch arena and statistics of the C ABI.
+#include "grx_engine.hpp"
+
+#include <mutex>
+
+namespace grx {
+
+static thread_local std::string g_error;
+
+void set_error(const std::string& msg) { g_error = msg; }
+grx_status_t fail(grx_status_t code, const std::string& msg) {
+  g_error = msg;
+  return code;
+}
+
+__global__ void fill_i32_kernel(int32_t* p, int32_t value, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // 16-byte stores on the aligned body
+  int64_t n4 = n / 4;
+  int4 v4 = make_int4(value, value, value, value);
+  int4* p4 = reinterpret_cast<int4*>(p);
+  for (int64_t j = i; j < n4; j += stride) p4[j] = v4;
+  for (int64_t j = n4 * 4 + i; j < n; j += stride) p[j] = value;
+}
+
+__global__ void fill_f32_kernel(float* p, float value, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t n4 = n / 4;
+  float4 v4 = make_float4(value, value, value, value);
+  float4* p4 = reinterpret_cast<float4*>(p);
+  for (int64_t j = i; j < n4; j += stride) p4[j] = v4;
+  for (int64_t j = n4 * 4 + i; j < n; j += stride) p[j] = value;
+}
+
+static int fill_grid(int64_t n) {
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  return (int)blocks;
+}
+
+hipError_t fill_i32(hipStream_t s, int32_t* p, int32_t value, int64_t n) {
+  if (n <= 0) return hipSuccess;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) != 0)  // caller buffer not 16-byte aligned
+    return hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p), value, (size_t)n, s);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(fill_grid(n)), dim3(256), 0, s, p, value, n);
+  return hipGetLastError();
+}
+
+hipError_t fill_f32(hipStream_t s, float* p, float value, int64_t n) {
+  if (n <= 0) return hipSuccess;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) {
+    int bits;
+    memcpy(&bits, &value, 4);
+    return hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p), bits, (size_t)n, s);
+  }
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(fill_grid(n)), dim3(256), 0, s, p, value, n);
+  return hipGetLastError();
+}
+
+grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
+  const size_t V = (size_t)g->V, E = (size_t)g->E;
+  const size_t grid = (size_t)advance_grid(ctx);
+  const size_t max_tiles = V / TILE + grid + 8;
+  const size_t max_chunks = E / CHUNK + max_tiles + 8;
+  for (int i = 0; i < 2; ++i) GRX_HIP(ctx->frontier[i].reserve(max_tiles * TILE * sizeof(int32_t)));
+  GRX_HIP(ctx->tile_chunks.reserve(max_tiles * sizeof(int32_t)));
+  GRX_HIP(ctx->tile_sums.reserve(max_tiles * sizeof(int32_t)));
+  GRX_HIP(ctx->chunk_prefix.reserve(max_tiles * sizeof(int32_t)));
+  GRX_HIP(ctx->chunk_tile.reserve(max_chunks * sizeof(int32_t)));
+  a->ro = g->ro;
+  a->ci = g->ci;
+  a->w = g->w;
+  a->V = g->V;
+  a->ctrl = ctx->d_ctrl;
+  a->mailbox = ctx->d_mailbox;
+  a->frontier[0] = ctx->frontier[0].as<int32_t>();
+  a->frontier[1] = ctx->frontier[1].as<int32_t>();
+  a->tile_chunks = ctx->tile_chunks.as<int32_t>();
+  a->tile_sums = ctx->tile_sums.as<int32_t>();
+  a->chunk_prefix = ctx->chunk_prefix.as<int32_t>();
+  a->chunk_tile = ctx->chunk_tile.as<int32_t>();
+  return GRX_SUCCESS;
+}
+
+}  // namespace grx
+
+using namespace grx;
+
+extern "C" {
+
+const char* grx_last_error_string(void) { return g_error.c_str(); }
+const char* grx_version_string(void) { return "grx 0.1 (gfx950)"; }
+
+void grx_options_default(grx_options_t* o) {
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->advance_load_balance = GRX_LB_BLOCK_MAPPED;
+  o->filter_algorithm = GRX_FILTER_PREDICATED;
+  o->enable_filter = 0;
+  o->enable_uniquify = 0;
+  o->uniquify_algorithm = GRX_UNIQUIFY_UNIQUE;
+  o->best_effort_uniquify = 1;
+  o->uniquify_percent = 100.0f;
+}
+
+grx_status_t grx_context_create(int32_t device, void* stream, grx_context_t* out) {
+  if (!out) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_context_create: null out");
+  int count = 0;
+  GRX_HIP(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count)
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_context_create: no such device");
+  GRX_HIP(hipSetDevice(device));
+  grx_context* c = new grx_context();
+  c->device = device;
+  if (stream) {
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+    c->own_stream = false;
+  } else {
+    GRX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  GRX_HIP(hipEventCreate(&c->ev_begin));
+  GRX_HIP(hipEventCreate(&c->ev_end));
+  hipDeviceProp_t prop;
+  GRX_HIP(hipGetDeviceProperties(&prop, device));
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_ctrl), sizeof(ctrl_t)));
+  GRX_HIP(hipMemset(c->d_ctrl, 0, sizeof(ctrl_t)));
+  GRX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ctrl), sizeof(ctrl_t), hipHostMallocDefault));
+  memset(c->h_ctrl, 0, sizeof(ctrl_t));
+  void* mb = nullptr;
+  GRX_HIP(hipHostMalloc(&mb, 64, hipHostMallocMapped));
+  memset(mb, 0, 64);
+  c->h_mailbox = reinterpret_cast<volatile int32_t*>(mb);
+  void* dmb = nullptr;
+  GRX_HIP(hipHostGetDevicePointer(&dmb, mb, 0));
+  c->d_mailbox = reinterpret_cast<int32_t*>(dmb);
+  *out = c;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_context_synchronize(grx_context_t ctx) {
+  if (!ctx) return fail(GRX_ERROR_INVALID_ARGUMENT, "null context");
+  GRX_HIP(hipStreamSynchronize(ctx->stream));
+  return GRX_SUCCESS;
+}
+
+void* grx_context_stream(grx_context_t ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+grx_status_t grx_context_destroy(grx_context_t ctx) {
+  if (!ctx) return GRX_SUCCESS;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& b : ctx->frontier) b.release();
+  ctx->tile_chunks.release();
+  ctx->tile_sums.release();
+  ctx->chunk_tile.release();
+  ctx->chunk_prefix.release();
+  for (auto& b : ctx->bitmap) b.release();
+  ctx->labels.release();
+  for (auto& b : ctx->fbuf) b.release();
+  ctx->misc.release();
+  if (ctx->d_ctrl) (void)hipFree(ctx->d_ctrl);
+  if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
+  if (ctx->h_mailbox) (void)hipHostFree((void*)ctx->h_mailbox);
+  if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+  if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_graph_create_csr(grx_context_t ctx, int32_t V, int32_t E, const int32_t* ro,
+                                  const int32_t* ci, const float* w, int32_t directed,
+                                  int32_t weighted, int32_t symmetric, grx_graph_t* out) {
+  if (!ctx || !out) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_graph_create_csr: null argument");
+  if (V < 0 || E < 0 || !ro || (E > 0 && !ci))
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_graph_create_csr: bad CSR arrays");
+  grx_graph* g = new grx_graph();
+  g->ctx = ctx;
+  g->V = V;
+  g->E = E;
+  g->ro = ro;
+  g->ci = ci;
+  g->w = w;
+  g->directed = directed;
+  g->weighted = weighted;
+  g->symmetric = symmetric;
+  *out = g;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_graph_destroy(grx_graph_t g) {
+  if (!g) return GRX_SUCCESS;
+  if (g->t_ro) (void)hipFree(g->t_ro);
+  if (g->t_ci) (void)hipFree(g->t_ci);
+  if (g->t_w) (void)hipFree(g->t_w);
+  delete g;
+  return GRX_SUCCESS;
+}
+
+int32_t grx_graph_number_of_vertices(grx_graph_t g) { return g ? g->V : 0; }
+int32_t grx_graph_number_of_edges(grx_graph_t g) { return g ? g->E : 0; }
+
+grx_status_t grx_get_run_stats(grx_context_t ctx, grx_run_stats_t* out) {
+  if (!ctx || !out) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_get_run_stats: null argument");
+  *out = ctx->stats;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_get_level_profile(grx_context_t ctx, grx_level_profile_t* out, int32_t capacity,
+                                   int32_t* n_levels) {
+  if (!ctx || !n_levels) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_get_level_profile: null argument");
+  const int32_t n = (int32_t)ctx->levels.size();
+  *n_levels = n;
+  for (int32_t i = 0; i < n && i < capacity && out; ++i) {
+    out[i].frontier_size = ctx->levels[i].frontier_size;
+    out[i].edges = ctx->levels[i].edges;
+    out[i].advance_ms = ctx->levels[i].advance_ms;
+    out[i].other_ms = ctx->levels[i].other_ms;
+  }
+  return GRX_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// grx_common.hpp -- host-side state shared by the C-ABI translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/grx.h"
+
+namespace grx {
+
+// ---- error plumbing --------------------------------------------------------
+void set_error(const std::string& msg);
+grx_status_t fail(grx_status_t code, const std::string& msg);
+
+#define GRX_HIP(expr)                                                              \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      return ::grx::fail(GRX_ERROR_HIP, std::string(hipGetErrorString(_e)) +       \
+                                            "\t: " #expr " (" __FILE__ ":" +       \
+                                            std::to_string(__LINE__) + ")");       \
+    }                                                                              \
+  } while (0)
+
+// ---- device scratch arena ----------------------------------------------------
+// One growable device allocation per purpose, kept across runs (the reference
+// re-allocates frontiers and a 1-element counter on every run / every advance:
+// framework/enactor.hxx:181-192, advance/block_mapped.hxx:244).
+struct dbuf {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  hipError_t reserve(size_t need) {
+    if (need <= bytes) return hipSuccess;
+    if (ptr) {
+      hipError_t e = hipFree(ptr);
+      if (e != hipSuccess) return e;
+      ptr = nullptr;
+      bytes = 0;
+    }
+    size_t want = need + need / 8 + 256;
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e != hipSuccess) return e;
+    bytes = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+  template <typename T>
+  T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+
+// Device-resident control block driving the level loop without host round
+// trips.  All kernels read their sizes from here; the host only polls `done`.
+struct ctrl_t {
+  int32_t level;          // enactor iteration
+  int32_t done;           // frontier empty / converged
+  int32_t n_tiles[2];     // frontier tiles (256 slots each) per parity buffer
+  int32_t n_items[2];     // valid frontier entries per parity buffer
+  int32_t total_chunks;   // advance work items of the current level
+  int32_t pad0;
+  int64_t edges_visited;
+  int64_t vertices_visited;
+  int32_t n_hub;          // spare counters for load-balance variants
+  int32_t spare[5];
+  // PageRank scalars
+  float pr_dsum;
+  float pr_err;
+  int32_t pr_iter;
+  int32_t pad1;
+};
+
+struct level_rec {
+  int64_t frontier_size;
+  int64_t edges;
+  float advance_ms;
+  float other_ms;
+};
+
+}  // namespace grx
+
+struct grx_context {
+  int32_t device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  int32_t num_cus = 256;
+
+  grx::ctrl_t* d_ctrl = nullptr;       // device control block
+  grx::ctrl_t* h_ctrl = nullptr;       // pinned host mirror (written by memcpy)
+  volatile int32_t* h_mailbox = nullptr;  // pinned, device-visible: [0]=done,[1]=level,[2]=n_items
+  int32_t* d_mailbox = nullptr;        // device pointer aliasing h_mailbox
+
+  // scratch
+  grx::dbuf frontier[2];   // vertex ids, tiled
+  grx::dbuf tile_chunks;   // per tile: number of advance chunks
+  grx::dbuf tile_sums;     // per tile: sum of degrees
+  grx::dbuf chunk_tile;    // per chunk: owning tile
+  grx::dbuf chunk_prefix;  // per tile: first chunk id
+  grx::dbuf bitmap[2];     // visited / scratch bitmaps
+  grx::dbuf labels;        // int32 per vertex (SSSP stamps etc.)
+  grx::dbuf fbuf[4];       // float per vertex (PR plast, iweights, x, ...)
+  grx::dbuf misc;          // reductions etc.
+
+  grx_run_stats_t stats{};
+  std::vector<grx::level_rec> levels;
+};
+
+struct grx_graph {
+  grx_context_t ctx = nullptr;
+  int32_t V = 0, E = 0;
+  const int32_t* ro = nullptr;
+  const int32_t* ci = nullptr;
+  const float* w = nullptr;  // may be null => 1.0
+  int32_t directed = 1, weighted = 1, symmetric = 0;
+  // lazily built transpose (CSC) for pull operators; owned
+  int32_t* t_ro = nullptr;
+  int32_t* t_ci = nullptr;
+  float* t_w = nullptr;
+  bool has_transpose = false;
+};
+
+struct grx_host_csr {
+  int32_t V = 0, cols = 0, E = 0;
+  int32_t directed = 1, weighted = 1, symmetric = 0;
+  std::vector<int32_t> ro, ci;
+  std::vector<float> w;
+};

@@ -1,0 +1,96 @@
+// grx_device.hpp -- wave64 device primitives for gfx950 (CDNA4).
+//
+// These replace what the reference takes from hipCUB / rocThrust on the hot
+// path (BlockScan in advance/block_mapped.hxx:89,123; transform_exclusive_scan
+// in advance/helpers.hxx:70; copy_if in filter/predicated.hxx:30).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace grx {
+namespace dev {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Number of set bits of `mask` strictly below this lane.
+__device__ __forceinline__ int mask_rank(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+__device__ __forceinline__ unsigned long long ballot(bool p) {
+  return __builtin_amdgcn_ballot_w64(p);
+}
+
+// Inclusive prefix sum across the 64 lanes of a wave.
+__device__ __forceinline__ int wave_inclusive_sum(int x) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    int y = __shfl_up(x, o, WAVE);
+    if (lane >= o) x += y;
+  }
+  return x;
+}
+
+__device__ __forceinline__ int wave_sum(int x) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
+  return x;
+}
+
+__device__ __forceinline__ float wave_sum_f(float x) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
+  return x;
+}
+
+__device__ __forceinline__ float wave_max_f(float x) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, WAVE));
+  return x;
+}
+
+// Exclusive prefix sum over a block of NT threads (NT multiple of 64, <= 1024).
+// `wave_tot` is LDS scratch of NT/64 + 1 ints.  Returns the exclusive prefix of
+// x; *total receives the block sum.  Contains two __syncthreads().
+template <int NT>
+__device__ __forceinline__ int block_exclusive_sum(int x, int* wave_tot, int* total) {
+  constexpr int NW = NT / WAVE;
+  const int lane = lane_id();
+  const int wid = threadIdx.x / WAVE;
+  int inc = wave_inclusive_sum(x);
+  if (lane == WAVE - 1) wave_tot[wid] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    int t = wave_tot[i];
+    if (i < wid) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - x;
+}
+
+// float min through integer atomics: exact for every non-NaN pair (the
+// reference uses a CAS loop, cuda/atomic_functions.hxx:34-44).  Returns the
+// previous value.
+__device__ __forceinline__ float atomic_min_f32(float* addr, float val) {
+  if (val >= 0.0f) {
+    int old = atomicMin(reinterpret_cast<int*>(addr), __float_as_int(val));
+    return __int_as_float(old);
+  } else {
+    unsigned old = atomicMax(reinterpret_cast<unsigned*>(addr), __float_as_uint(val));
+    return __uint_as_float(old);
+  }
+}
+
+}  // namespace dev
+}  // namespace grx

@@ -1,0 +1,44 @@
+// grx_engine.hpp -- host-side driver of the device-driven level loop
+// (the MI355X counterpart of enactor_t::enact(), framework/enactor.hxx:243-288).
+#pragma once
+
+#include "grx_frontier.hpp"
+
+namespace grx {
+
+// Fill kernels (problem_t::reset(): algorithms/bfs.hxx:59-69, sssp.hxx:63-80).
+__global__ void fill_i32_kernel(int32_t* p, int32_t value, int64_t n);
+__global__ void fill_f32_kernel(float* p, float value, int64_t n);
+
+hipError_t fill_i32(hipStream_t s, int32_t* p, int32_t value, int64_t n);
+hipError_t fill_f32(hipStream_t s, float* p, float value, int64_t n);
+
+// Size all pipeline scratch for graph g; fills `a`.
+grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a);
+
+// Launch configuration of the advance kernel (persistent workgroups).
+inline int advance_grid(grx_context_t ctx) { return ctx->num_cus * 8; }
+
+// Generic host loop: `launch_level(stream)` enqueues one level (plan + advance
+// [+ extra]); levels are enqueued in growing batches and the host only reads
+// the control block between batches.  Returns after `done`.
+template <class LaunchLevel, class AfterSync>
+grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel launch_level,
+                        AfterSync after_sync) {
+  const bool sync_each = (opt.engine_flags & (GRX_FLAG_SYNC_EACH_LEVEL | GRX_FLAG_PROFILE)) != 0;
+  int batch = sync_each ? 1 : 4;
+  int launched = 0;
+  const int max_levels = opt.max_iterations > 0 ? opt.max_iterations : 0x7fffffff;
+  for (;;) {
+    for (int i = 0; i < batch && launched < max_levels; ++i, ++launched) launch_level(ctx->stream, launched);
+    GRX_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost, ctx->stream));
+    GRX_HIP(hipStreamSynchronize(ctx->stream));
+    after_sync(*ctx->h_ctrl);
+    if (ctx->h_ctrl->done) break;
+    if (launched >= max_levels) break;
+    if (!sync_each && batch < 64) batch *= 2;
+  }
+  return GRX_SUCCESS;
+}
+
+}  // namespace grx

@@ -1,0 +1,243 @@
+// grx_frontier.hpp -- the device-driven frontier pipeline shared by BFS and SSSP.
+//
+// What it replaces in the reference (paths relative to /root/reference):
+//   framework/enactor.hxx:243-288            enact(): host while-loop, >= 2 blocking syncs/level
+//   operators/advance/helpers.hxx:41-111     per-level rocThrust scan + 4-byte D2H
+//   operators/advance/merge_path.hxx:112-362 merge-path advance (strided 11 atoms per thread)
+//   operators/filter/predicated.hxx:12-39    copy_if compaction (+ size readback)
+//
+// MI355X design
+//   * The frontier is a queue of TILEs (256 vertex slots, -1 = empty slot).  A
+//     tile carries its degree sum; a level's work is cut into CHUNKs of 2048
+//     edges ("atoms") that never straddle a tile, so a workgroup stages ONE tile
+//     (vertex ids, row starts, block-scanned degrees) in LDS and finds the owner
+//     of each atom by an 8-probe LDS binary search.  Lanes of a wave take
+//     CONSECUTIVE atoms, so column-index reads are coalesced inside a row.
+//   * plan_kernel (one workgroup) turns per-tile chunk counts into the
+//     chunk -> tile map of the level; it also detects the empty frontier.
+//   * advance_kernel runs the user policy per edge and compacts accepted
+//     neighbours on the fly: wave ballot + mbcnt rank inside the wave, an LDS
+//     counter per workgroup, and ONE global atomic per 256 emitted vertices
+//     (an output tile), whose degree sum is computed at emission time so the
+//     next level needs no separate scan over the frontier.
+//   * No kernel takes a level-dependent argument: sizes, parity and level come
+//     from a device control block, so the host enqueues levels blindly (or
+//     replays a hipGraph) and only looks at a `done` flag.
+#pragma once
+
+#include "grx_common.hpp"
+#include "grx_device.hpp"
+
+namespace grx {
+
+constexpr int TILE = 256;            // frontier slots per tile
+constexpr int ADV_BLOCK = 256;       // threads per advance workgroup
+constexpr int ADV_ITEMS = 8;         // atoms per thread per chunk
+constexpr int CHUNK = ADV_BLOCK * ADV_ITEMS;  // 2048 atoms
+constexpr int PLAN_BLOCK = 1024;
+
+struct pipe_args {
+  const int32_t* ro;
+  const int32_t* ci;
+  const float* w;
+  int32_t V;
+  ctrl_t* ctrl;
+  int32_t* mailbox;       // host-pinned, device-visible
+  int32_t* frontier[2];   // tiled queues by level parity
+  int32_t* tile_chunks;   // chunks per tile of the CURRENT input frontier
+  int32_t* tile_sums;     // degree sum per tile of the current input frontier
+  int32_t* chunk_prefix;  // first chunk id per tile
+  int32_t* chunk_tile;    // owning tile per chunk
+};
+
+// ---------------------------------------------------------------------------
+// plan: per-level bookkeeping + chunk map.  <<<1, 1024>>>
+// ---------------------------------------------------------------------------
+static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a) {
+  __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
+  __shared__ unsigned long long s_esum;
+  ctrl_t* c = a.ctrl;
+  const int tid = threadIdx.x;
+  const int done = c->done;
+  const int level = c->level + 1;
+  const int p = level & 1;
+  const int nt = c->n_tiles[p];
+  const int nitems = c->n_items[p];
+  if (tid == 0) s_esum = 0ull;
+  __syncthreads();
+  if (done) return;
+  if (nt == 0) {
+    if (tid == 0) {
+      c->done = 1;
+      c->level = level;  // == number of advance iterations executed
+      a.mailbox[1] = level;
+      a.mailbox[0] = 1;
+    }
+    return;
+  }
+  long long esum = 0;
+  int carry = 0;
+  for (int base = 0; base < nt; base += PLAN_BLOCK) {
+    const int i = base + tid;
+    int ch = 0;
+    if (i < nt) {
+      ch = a.tile_chunks[i];
+      esum += a.tile_sums[i];
+    }
+    int tot;
+    int ex = dev::block_exclusive_sum<PLAN_BLOCK>(ch, s_wave, &tot);
+    if (i < nt) {
+      const int pre = carry + ex;
+      a.chunk_prefix[i] = pre;
+      for (int j = 0; j < ch; ++j) a.chunk_tile[pre + j] = i;
+    }
+    carry += tot;
+  }
+  // 64-bit block reduction of the traversed-edge count
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
+  if (dev::lane_id() == 0) atomicAdd(&s_esum, (unsigned long long)esum);
+  __syncthreads();
+  if (tid == 0) {
+    c->level = level;
+    c->total_chunks = carry;
+    c->edges_visited += (long long)s_esum;
+    c->vertices_visited += nitems;
+    c->n_tiles[p ^ 1] = 0;
+    c->n_items[p ^ 1] = 0;
+    a.mailbox[1] = level;
+    a.mailbox[2] = nitems;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// advance + fused compaction.  Policy interface (all __device__):
+//   void begin(const ctrl_t*)                      once per workgroup
+//   src_state load_source(int v)                   per staged slot (e.g. dist[v])
+//   bool visit(int src, src_state, int nbr, int e) true => nbr joins the output
+// ---------------------------------------------------------------------------
+template <class Policy>
+__global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy pol) {
+  __shared__ int s_seg[TILE + 1];
+  __shared__ int s_start[TILE];
+  __shared__ int s_src[TILE];
+  __shared__ typename Policy::src_state s_state[TILE];
+  __shared__ int s_out[TILE + CHUNK];
+  __shared__ int s_wave[ADV_BLOCK / 64 + 1];
+  __shared__ int s_cnt;
+  __shared__ int s_tix;
+
+  ctrl_t* c = a.ctrl;
+  if (c->done) return;
+  const int tid = threadIdx.x;
+  const int lane = dev::lane_id();
+  const int wid = tid >> 6;
+  const int level = c->level;
+  const int p = level & 1;
+  const int total_chunks = c->total_chunks;
+  const int32_t* __restrict__ in = a.frontier[p];
+  int32_t* __restrict__ out = a.frontier[p ^ 1];
+  pol.begin(c);
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+
+  // Emit one output tile from s_out[lo, lo + n) (n <= TILE).
+  auto emit_tile = [&](int lo, int n) {
+    int x = -1, deg = 0;
+    if (tid < n) {
+      x = s_out[lo + tid];
+      deg = a.ro[x + 1] - a.ro[x];
+    }
+    int tsum = dev::wave_sum(deg);
+    if (lane == 0) s_wave[wid] = tsum;
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+#pragma unroll
+      for (int i = 0; i < ADV_BLOCK / 64; ++i) tot += s_wave[i];
+      // one device atomic per output tile: {n_items, n_tiles} packed in 64 bits
+      unsigned long long packed = ((unsigned long long)(unsigned)n << 32) | 1ull;
+      // n_tiles[q] and n_items[q] are not adjacent; use two atomics on distinct words
+      int tix = atomicAdd(&c->n_tiles[p ^ 1], 1);
+      atomicAdd(&c->n_items[p ^ 1], n);
+      (void)packed;
+      a.tile_sums[tix] = tot;
+      a.tile_chunks[tix] = (tot + CHUNK - 1) / CHUNK;
+      s_tix = tix;
+    }
+    __syncthreads();
+    out[(size_t)s_tix * TILE + tid] = x;
+  };
+
+  for (int chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+    const int t = a.chunk_tile[chunk];
+    const int lc = chunk - a.chunk_prefix[t];
+    // ---- stage the tile -------------------------------------------------
+    const int v = in[(size_t)t * TILE + tid];
+    int rs = 0, deg = 0;
+    typename Policy::src_state st{};
+    if (v >= 0) {
+      rs = a.ro[v];
+      deg = a.ro[v + 1] - rs;
+      st = pol.load_source(v);
+    }
+    int tot;
+    const int ex = dev::block_exclusive_sum<ADV_BLOCK>(deg, s_wave, &tot);
+    s_seg[tid] = ex;
+    s_start[tid] = rs;
+    s_src[tid] = v;
+    s_state[tid] = st;
+    if (tid == 0) s_seg[TILE] = tot;
+    __syncthreads();
+
+    // ---- atoms of this chunk ---------------------------------------------
+    const int a0 = lc * CHUNK;
+    const int a_end = min(tot, a0 + CHUNK);
+    int e_k[ADV_ITEMS], slot_k[ADV_ITEMS], n_k[ADV_ITEMS];
+#pragma unroll
+    for (int k = 0; k < ADV_ITEMS; ++k) {
+      const int atom = a0 + k * ADV_BLOCK + tid;
+      int lo = 0;
+      if (atom < a_end) {
+#pragma unroll
+        for (int step = TILE / 2; step >= 1; step >>= 1)
+          if (s_seg[lo + step] <= atom) lo += step;
+        e_k[k] = s_start[lo] + (atom - s_seg[lo]);
+      } else {
+        e_k[k] = -1;
+      }
+      slot_k[k] = lo;
+    }
+#pragma unroll
+    for (int k = 0; k < ADV_ITEMS; ++k) n_k[k] = (e_k[k] >= 0) ? a.ci[e_k[k]] : -1;
+    bool pre_k[ADV_ITEMS];
+#pragma unroll
+    for (int k = 0; k < ADV_ITEMS; ++k) pre_k[k] = (e_k[k] >= 0) && pol.precheck(n_k[k]);
+#pragma unroll
+    for (int k = 0; k < ADV_ITEMS; ++k) {
+      bool keep = false;
+      if (pre_k[k]) keep = pol.visit(s_src[slot_k[k]], s_state[slot_k[k]], n_k[k], e_k[k]);
+      const unsigned long long m = dev::ballot(keep);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_cnt, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (keep) s_out[base + dev::mask_rank(m)] = n_k[k];
+      }
+    }
+    __syncthreads();
+    // ---- flush full tiles --------------------------------------------------
+    int cnt = s_cnt;
+    while (cnt >= TILE) {
+      emit_tile(cnt - TILE, TILE);
+      cnt -= TILE;
+      __syncthreads();
+    }
+    if (tid == 0) s_cnt = cnt;
+    __syncthreads();
+  }
+  const int rem = s_cnt;
+  if (rem > 0) emit_tile(0, rem);
+}
+
+}  // namespace grx

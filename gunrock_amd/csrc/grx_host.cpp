@@ -1,0 +1,351 @@
+// grx_host.cpp -- host-side ingest: Matrix-Market / binary CSR readers, COO->CSR,
+// and the seeded synthetic stand-ins for the BASELINE.json graphs.
+//
+// Behaviour follows the reference loader so that EDGE ORDER is identical
+// (SURVEY.md Appendix B.1): include/gunrock/io/matrix_market.hxx:99-254 and
+// include/gunrock/formats/csr.hxx:81-228.  The parser itself is new: the file
+// is slurped once and tokenised in place instead of one fscanf per entry.
+#include "grx_common.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <numeric>
+#include <thread>
+
+using namespace grx;
+
+namespace {
+
+struct cursor {
+  const char* p;
+  const char* end;
+  void skip_ws() {
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n')) ++p;
+  }
+  bool eof() {
+    skip_ws();
+    return p >= end;
+  }
+  bool read_u64(uint64_t* out) {
+    skip_ws();
+    if (p >= end || *p < '0' || *p > '9') return false;
+    uint64_t v = 0;
+    while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (uint64_t)(*p++ - '0');
+    *out = v;
+    return true;
+  }
+  bool read_f64(double* out) {
+    skip_ws();
+    if (p >= end) return false;
+    char buf[64];
+    size_t n = 0;
+    while (p + n < end && n < 63 && !isspace((unsigned char)p[n])) ++n;
+    memcpy(buf, p, n);
+    buf[n] = 0;
+    char* stop = nullptr;
+    double v = strtod(buf, &stop);
+    if (stop == buf) return false;
+    p += (stop - buf);
+    *out = v;
+    return true;
+  }
+  std::string line() {
+    const char* s = p;
+    while (p < end && *p != '\n') ++p;
+    std::string r(s, p);
+    if (p < end) ++p;
+    return r;
+  }
+};
+
+std::string lowered(std::string s) {
+  for (auto& ch : s) ch = (char)tolower((unsigned char)ch);
+  return s;
+}
+
+// Stable bucket-by-row conversion: keeps duplicates, self loops and the COO
+// order inside each row (formats/csr.hxx:104-133 semantics).
+void coo_to_csr(int32_t rows, int64_t nnz, const int32_t* I, const int32_t* J, const float* X,
+                grx_host_csr* out) {
+  out->ro.assign((size_t)rows + 1, 0);
+  out->ci.resize((size_t)nnz);
+  out->w.resize((size_t)nnz);
+  std::vector<int32_t>& ro = out->ro;
+  for (int64_t k = 0; k < nnz; ++k) ++ro[(size_t)I[k] + 1];
+  for (int32_t r = 0; r < rows; ++r) ro[(size_t)r + 1] += ro[r];
+  std::vector<int32_t> fill(ro.begin(), ro.end() - 1);
+  for (int64_t k = 0; k < nnz; ++k) {
+    const int32_t pos = fill[I[k]]++;
+    out->ci[pos] = J[k];
+    out->w[pos] = X ? X[k] : 1.0f;
+  }
+  out->E = (int32_t)nnz;
+}
+
+inline uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+inline uint64_t rnd(uint64_t seed, uint64_t idx, uint64_t j) {
+  return mix64(mix64(seed ^ (idx * 0xD1342543DE82EF95ull)) + j * 0xA24BAED4963EE407ull);
+}
+
+template <class F>
+void parallel_for(int64_t n, F f) {
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (nt > 32) nt = 32;
+  if (n < (int64_t)1 << 16) nt = 1;
+  std::vector<std::thread> th;
+  const int64_t per = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const int64_t lo = (int64_t)t * per, hi = std::min<int64_t>(n, lo + per);
+    if (lo >= hi) break;
+    th.emplace_back([=] { f(lo, hi); });
+  }
+  for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+grx_status_t grx_host_csr_load_mtx(const char* filename, grx_host_csr_t* out) {
+  if (!filename || !out) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_host_csr_load_mtx: null argument");
+  std::ifstream in(filename, std::ios::binary | std::ios::ate);
+  if (!in) return fail(GRX_ERROR_IO, std::string("File could not be opened: ") + filename);
+  const std::streamsize sz = in.tellg();
+  in.seekg(0);
+  std::vector<char> buf((size_t)sz + 1);
+  if (sz > 0 && !in.read(buf.data(), sz)) return fail(GRX_ERROR_IO, "read failed");
+  buf[(size_t)sz] = 0;
+  cursor c{buf.data(), buf.data() + sz};
+
+  // banner
+  std::string banner = c.line();
+  char t0[64] = {0}, t1[64] = {0}, t2[64] = {0}, t3[64] = {0}, t4[64] = {0};
+  if (sscanf(banner.c_str(), "%63s %63s %63s %63s %63s", t0, t1, t2, t3, t4) != 5 ||
+      strncmp(t0, "%%MatrixMarket", 14) != 0 || lowered(t1) != "matrix")
+    return fail(GRX_ERROR_IO, "Could not process Matrix Market banner");
+  const std::string layout = lowered(t2), field = lowered(t3), symm = lowered(t4);
+  if (layout != "coordinate" && layout != "array")
+    return fail(GRX_ERROR_IO, "Could not process Matrix Market banner");
+  if (field != "real" && field != "integer" && field != "pattern" && field != "complex")
+    return fail(GRX_ERROR_IO, "Could not process Matrix Market banner");
+  if (symm != "general" && symm != "symmetric" && symm != "hermitian" && symm != "skew-symmetric")
+    return fail(GRX_ERROR_IO, "Could not process Matrix Market banner");
+  if (layout == "array") return fail(GRX_ERROR_IO, "File is not a sparse matrix");
+  if (field == "complex") return fail(GRX_ERROR_IO, "Unrecognized matrix market format type");
+  const bool pattern = field == "pattern";
+  const bool symmetric = symm == "symmetric";
+
+  // comments, then the size line
+  for (;;) {
+    if (c.p >= c.end) return fail(GRX_ERROR_IO, "Could not read file info (M, N, NNZ)");
+    if (*c.p == '%') { c.line(); continue; }
+    break;
+  }
+  uint64_t M = 0, N = 0, NZ = 0;
+  if (!c.read_u64(&M) || !c.read_u64(&N) || !c.read_u64(&NZ))
+    return fail(GRX_ERROR_IO, "Could not read file info (M, N, NNZ)");
+  if (M >= (uint64_t)INT32_MAX || N >= (uint64_t)INT32_MAX) return fail(GRX_ERROR_IO, "vertex_t overflow");
+  if (NZ >= (uint64_t)INT32_MAX) return fail(GRX_ERROR_IO, "edge_t overflow");
+
+  std::vector<int32_t> I, J;
+  std::vector<float> X;
+  const size_t reserve = (size_t)NZ * (symmetric ? 2 : 1);
+  I.reserve(reserve);
+  J.reserve(reserve);
+  X.reserve(reserve);
+  for (uint64_t k = 0; k < NZ; ++k) {
+    uint64_t r = 0, col = 0;
+    double val = 1.0;  // pattern entries carry weight 1.0
+    if (!c.read_u64(&r) || !c.read_u64(&col))
+      return fail(GRX_ERROR_IO, "Could not read edge from market file");
+    if (!pattern && !c.read_f64(&val))
+      return fail(GRX_ERROR_IO, "Could not read weighted edge from market file");
+    if (r == 0 || col == 0) return fail(GRX_ERROR_IO, "Market file is zero-indexed");
+    const int32_t i = (int32_t)r - 1, j = (int32_t)col - 1;
+    I.push_back(i); J.push_back(j); X.push_back((float)val);
+    if (symmetric && i != j) {  // mirrored entry sits right after its original
+      I.push_back(j); J.push_back(i); X.push_back((float)val);
+    }
+  }
+  if ((uint64_t)I.size() >= (uint64_t)INT32_MAX) return fail(GRX_ERROR_IO, "edge_t overflow");
+
+  grx_host_csr* h = new grx_host_csr();
+  h->V = (int32_t)M;
+  h->cols = (int32_t)N;
+  h->weighted = pattern ? 0 : 1;
+  h->symmetric = symmetric ? 1 : 0;
+  h->directed = symmetric ? 0 : 1;
+  coo_to_csr(h->V, (int64_t)I.size(), I.data(), J.data(), X.data(), h);
+  *out = h;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_host_csr_from_coo(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t* I,
+                                   const int32_t* J, const float* X, grx_host_csr_t* out) {
+  if (!out || n_rows < 0 || nnz < 0 || (nnz > 0 && (!I || !J)))
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_host_csr_from_coo: bad argument");
+  if (nnz >= (int64_t)INT32_MAX) return fail(GRX_ERROR_INVALID_ARGUMENT, "edge_t overflow");
+  for (int64_t k = 0; k < nnz; ++k)
+    if (I[k] < 0 || I[k] >= n_rows) return fail(GRX_ERROR_INVALID_ARGUMENT, "row index out of range");
+  grx_host_csr* h = new grx_host_csr();
+  h->V = n_rows;
+  h->cols = n_cols;
+  coo_to_csr(n_rows, nnz, I, J, X, h);
+  *out = h;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_host_csr_read_binary(const char* filename, grx_host_csr_t* out) {
+  if (!filename || !out) return fail(GRX_ERROR_INVALID_ARGUMENT, "null argument");
+  FILE* f = fopen(filename, "rb");
+  if (!f) return fail(GRX_ERROR_IO, std::string("File could not be opened: ") + filename);
+  int32_t hdr[3];
+  if (fread(hdr, sizeof(int32_t), 3, f) != 3 || hdr[0] < 0 || hdr[2] < 0) {
+    fclose(f);
+    return fail(GRX_ERROR_IO, "bad .csr header");
+  }
+  grx_host_csr* h = new grx_host_csr();
+  h->V = hdr[0]; h->cols = hdr[1]; h->E = hdr[2];
+  h->ro.resize((size_t)h->V + 1);
+  h->ci.resize((size_t)h->E);
+  h->w.resize((size_t)h->E);
+  bool ok = fread(h->ro.data(), sizeof(int32_t), h->ro.size(), f) == h->ro.size() &&
+            fread(h->ci.data(), sizeof(int32_t), h->ci.size(), f) == h->ci.size() &&
+            fread(h->w.data(), sizeof(float), h->w.size(), f) == h->w.size();
+  fclose(f);
+  if (!ok) { delete h; return fail(GRX_ERROR_IO, "truncated .csr file"); }
+  *out = h;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_host_csr_write_binary(grx_host_csr_t h, const char* filename) {
+  if (!h || !filename) return fail(GRX_ERROR_INVALID_ARGUMENT, "null argument");
+  FILE* f = fopen(filename, "wb");
+  if (!f) return fail(GRX_ERROR_IO, std::string("File could not be opened: ") + filename);
+  int32_t hdr[3] = {h->V, h->cols, h->E};
+  bool ok = fwrite(hdr, sizeof(int32_t), 3, f) == 3 &&
+            fwrite(h->ro.data(), sizeof(int32_t), h->ro.size(), f) == h->ro.size() &&
+            fwrite(h->ci.data(), sizeof(int32_t), h->ci.size(), f) == h->ci.size() &&
+            fwrite(h->w.data(), sizeof(float), h->w.size(), f) == h->w.size();
+  fclose(f);
+  return ok ? GRX_SUCCESS : fail(GRX_ERROR_IO, "short write");
+}
+
+grx_status_t grx_host_csr_info(grx_host_csr_t h, int32_t* V, int32_t* E, int32_t* directed,
+                               int32_t* weighted, int32_t* symmetric) {
+  if (!h) return fail(GRX_ERROR_INVALID_ARGUMENT, "null argument");
+  if (V) *V = h->V;
+  if (E) *E = h->E;
+  if (directed) *directed = h->directed;
+  if (weighted) *weighted = h->weighted;
+  if (symmetric) *symmetric = h->symmetric;
+  return GRX_SUCCESS;
+}
+const int32_t* grx_host_csr_row_offsets(grx_host_csr_t h) { return h ? h->ro.data() : nullptr; }
+const int32_t* grx_host_csr_column_indices(grx_host_csr_t h) { return h ? h->ci.data() : nullptr; }
+const float* grx_host_csr_values(grx_host_csr_t h) { return h ? h->w.data() : nullptr; }
+grx_status_t grx_host_csr_destroy(grx_host_csr_t h) {
+  delete h;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_host_csr_generate(int32_t kind, int32_t V, int64_t n_entries, float a, float b,
+                                   float c, uint64_t seed, grx_host_csr_t* out) {
+  if (!out || V <= 0) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_host_csr_generate: bad argument");
+  std::vector<int32_t> I, J;
+  std::vector<float> X;
+  grx_host_csr* h = new grx_host_csr();
+  h->V = V;
+  h->cols = V;
+
+  if (kind == 0 || kind == 1) {
+    if (n_entries < 0 || n_entries * (kind == 1 ? 2 : 1) >= (int64_t)INT32_MAX) {
+      delete h;
+      return fail(GRX_ERROR_INVALID_ARGUMENT, "edge_t overflow");
+    }
+    int scale = 0;
+    while (((int64_t)1 << scale) < (int64_t)V) ++scale;
+    const uint32_t ta = (uint32_t)std::lround(a * 65536.0);
+    const uint32_t tb = ta + (uint32_t)std::lround(b * 65536.0);
+    const uint32_t tc = tb + (uint32_t)std::lround(c * 65536.0);
+    // affine vertex relabelling so that hubs are not clustered at low ids
+    uint64_t mul = 0x9E3779B1ull % (uint64_t)V;
+    if (mul == 0) mul = 1;
+    while (std::gcd(mul, (uint64_t)V) != 1) ++mul;
+    const uint64_t add = mix64(seed) % (uint64_t)V;
+    std::vector<int32_t> U((size_t)n_entries), W((size_t)n_entries);
+    parallel_for(n_entries, [&](int64_t lo, int64_t hi) {
+      for (int64_t e = lo; e < hi; ++e) {
+        uint64_t u = 0, v = 0, word = 0;
+        for (int l = 0; l < scale; ++l) {
+          if ((l & 3) == 0) word = rnd(seed, (uint64_t)e, (uint64_t)(l >> 2));
+          const uint32_t r = (uint32_t)(word & 0xFFFF);
+          word >>= 16;
+          const uint32_t ub = r >= tb ? 1u : 0u;                      // quadrants c,d => row bit
+          const uint32_t vb = (r >= ta && r < tb) || r >= tc ? 1u : 0u;  // quadrants b,d => col bit
+          u = (u << 1) | ub;
+          v = (v << 1) | vb;
+        }
+        u %= (uint64_t)V;
+        v %= (uint64_t)V;
+        U[(size_t)e] = (int32_t)((u * mul + add) % (uint64_t)V);
+        W[(size_t)e] = (int32_t)((v * mul + add) % (uint64_t)V);
+      }
+    });
+    if (kind == 0) {
+      I.swap(U);
+      J.swap(W);
+      h->directed = 1; h->symmetric = 0; h->weighted = 0;
+    } else {
+      I.reserve((size_t)n_entries * 2);
+      J.reserve((size_t)n_entries * 2);
+      for (int64_t e = 0; e < n_entries; ++e) {
+        I.push_back(U[(size_t)e]); J.push_back(W[(size_t)e]);
+        if (U[(size_t)e] != W[(size_t)e]) { I.push_back(W[(size_t)e]); J.push_back(U[(size_t)e]); }
+      }
+      h->directed = 0; h->symmetric = 1; h->weighted = 0;
+    }
+  } else if (kind == 2) {
+    // road-like: side x side 4-neighbour lattice, each undirected edge kept with
+    // probability a; weights integer U{1..1000} when c > 0, else 1.0 (pattern)
+    int64_t side = (int64_t)std::floor(std::sqrt((double)V));
+    if (side * side != (int64_t)V) {
+      delete h;
+      return fail(GRX_ERROR_INVALID_ARGUMENT, "lattice generator needs a square vertex count");
+    }
+    const uint32_t keep = (uint32_t)std::lround(std::min(1.0f, std::max(0.0f, a)) * 65536.0);
+    const bool weighted = c > 0.0f;
+    for (int64_t id = 0; id < (int64_t)V; ++id) {
+      const int64_t x = id % side, y = id / side;
+      const uint64_t r = rnd(seed, (uint64_t)id, 0);
+      for (int dir = 0; dir < 2; ++dir) {
+        const bool has = dir == 0 ? (x + 1 < side) : (y + 1 < side);
+        if (!has) continue;
+        const uint32_t coin = (uint32_t)((r >> (16 * dir)) & 0xFFFF);
+        if (coin >= keep) continue;
+        const int64_t other = dir == 0 ? id + 1 : id + side;
+        const float wgt = weighted ? (float)(1 + (uint32_t)((r >> (32 + 10 * dir)) & 0x3FF) % 1000) : 1.0f;
+        I.push_back((int32_t)id); J.push_back((int32_t)other); X.push_back(wgt);
+        I.push_back((int32_t)other); J.push_back((int32_t)id); X.push_back(wgt);
+      }
+    }
+    h->directed = 0; h->symmetric = 1; h->weighted = weighted ? 1 : 0;
+  } else {
+    delete h;
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_host_csr_generate: unknown kind");
+  }
+  coo_to_csr(V, (int64_t)I.size(), I.data(), J.data(), X.empty() ? nullptr : X.data(), h);
+  *out = h;
+  return GRX_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+/*
+ * grx.h -- C ABI of the MI355X-native frontier engine (libgrx.so).
+ *
+ * This is the drop-in boundary for the hot path: every entry point below is
+ * what a foreign-function binding of the reference's BFS / SSSP / PageRank
+ * path would bind.  The reference (gunrock "essentials") has no C ABI of its
+ * own; its public surfaces are C++ templates, a CLI and a nanobind module that
+ * passes torch `data_ptr()` device pointers.  Each function cites the
+ * reference interface it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types;
+ *   - `d_` pointers are DEVICE memory owned by the caller (the reference's
+ *     result buffers are caller-allocated device memory too:
+ *     include/gunrock/algorithms/bfs.hxx:185-189);
+ *   - every call returns a grx_status_t; grx_last_error_string() gives the
+ *     message (the reference throws gunrock::error::exception_t,
+ *     include/gunrock/error.hxx:20-45);
+ *   - vertex_t = edge_t = int32, weight_t = float32, as every reference driver
+ *     and binding instantiates (examples/algorithms/bfs/bfs.cu:15-17,
+ *     python/src/gunrock/bindings.cu:49-51);
+ *   - elapsed times are milliseconds measured with two events on the
+ *     context's stream around the enact loop, reset excluded -- the
+ *     reference's timing scope (include/gunrock/framework/enactor.hxx:270-282).
+ */
+#ifndef GRX_H
+#define GRX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  GRX_SUCCESS = 0,
+  GRX_ERROR_INVALID_ARGUMENT = 1,
+  GRX_ERROR_HIP = 2,            /* a HIP runtime call failed */
+  GRX_ERROR_UNSUPPORTED = 3,    /* option combination not supported */
+  GRX_ERROR_IO = 4,             /* file could not be read / parsed */
+  GRX_ERROR_OUT_OF_MEMORY = 5,
+  GRX_ERROR_NOT_CONVERGED = 6
+} grx_status_t;
+
+/* operators::load_balance_t, include/gunrock/framework/operators/configs.hxx:52-60
+ * (same integer values; the Python module of the reference exposes the ints). */
+typedef enum {
+  GRX_LB_THREAD_MAPPED = 0,
+  GRX_LB_WARP_MAPPED = 1,   /* enum-only in the reference; real here (64-lane wave per vertex) */
+  GRX_LB_BLOCK_MAPPED = 2,  /* reference default */
+  GRX_LB_BUCKETING = 3,     /* stub in the reference; mapped to the degree-binned selector */
+  GRX_LB_MERGE_PATH = 4,
+  GRX_LB_MERGE_PATH_V2 = 5, /* NVIDIA-only in the reference; same kernel as MERGE_PATH here */
+  GRX_LB_WORK_STEALING = 6  /* enum-only in the reference; GRX_ERROR_UNSUPPORTED */
+} grx_load_balance_t;
+
+/* operators::filter_algorithm_t, configs.hxx:93-98 */
+typedef enum {
+  GRX_FILTER_REMOVE = 0,
+  GRX_FILTER_PREDICATED = 1,
+  GRX_FILTER_COMPACT = 2,   /* throws in the reference (filter/compact.hxx:21-24); real here */
+  GRX_FILTER_BYPASS = 3
+} grx_filter_algorithm_t;
+
+/* operators::uniquify_algorithm_t, configs.hxx:100-105 */
+typedef enum { GRX_UNIQUIFY_UNIQUE = 0, GRX_UNIQUIFY_UNIQUE_COPY = 1 } grx_uniquify_algorithm_t;
+
+/* operators::advance_direction_t, configs.hxx:78-82 */
+typedef enum { GRX_DIR_FORWARD = 0, GRX_DIR_BACKWARD = 1, GRX_DIR_OPTIMIZED = 2 } grx_direction_t;
+
+/* gunrock::options_t, include/gunrock/algorithms/algorithms.hxx:27-72 --
+ * the first seven fields mirror it field for field with the same defaults
+ * (grx_options_default).  The trailing fields are engine extensions; zero
+ * means "engine decides" so a zero-initialised tail keeps reference behaviour. */
+typedef struct grx_options {
+  int32_t advance_load_balance; /* grx_load_balance_t, default BLOCK_MAPPED */
+  int32_t filter_algorithm;     /* grx_filter_algorithm_t, default PREDICATED */
+  int32_t enable_filter;        /* default 0 */
+  int32_t enable_uniquify;      /* default 0 */
+  int32_t uniquify_algorithm;   /* default UNIQUE */
+  int32_t best_effort_uniquify; /* default 1 */
+  float uniquify_percent;       /* default 100 */
+  /* --- extensions --- */
+  int32_t engine_flags;         /* GRX_FLAG_* bitmask */
+  int32_t advance_direction;    /* grx_direction_t (ignored by the reference) */
+  int32_t max_iterations;       /* 0 = unbounded, as the reference */
+  int32_t reserved[5];
+} grx_options_t;
+
+/* engine_flags */
+#define GRX_FLAG_UNFUSED 0x1   /* run advance and filter as separate operators exactly as the
+                                  reference pipeline does (frontier with -1 holes between them) */
+#define GRX_FLAG_PROFILE 0x2   /* record per-iteration operator timings (adds events + syncs) */
+#define GRX_FLAG_SYNC_EACH_LEVEL 0x4 /* host reads the frontier size after every level */
+
+typedef struct grx_context* grx_context_t;
+typedef struct grx_graph* grx_graph_t;
+
+void grx_options_default(grx_options_t* options);
+
+const char* grx_last_error_string(void);
+const char* grx_version_string(void);
+
+/* gcuda::multi_context_t(device) / standard_context_t: device ordinal, one
+ * stream, an event pair (include/gunrock/cuda/context.hxx:54-216).  `stream`
+ * may be an existing hipStream_t (e.g. torch's current stream) or NULL to
+ * create a non-blocking one as the reference does (:84). */
+grx_status_t grx_context_create(int32_t device, void* stream, grx_context_t* out);
+grx_status_t grx_context_synchronize(grx_context_t ctx); /* context.hxx:124-128 */
+grx_status_t grx_context_destroy(grx_context_t ctx);
+void* grx_context_stream(grx_context_t ctx);
+
+/* graph::build<memory_space_t::device>(properties, csr),
+ * include/gunrock/graph/build.hxx:29-36 + graph/csr.hxx:218-226: a NON-OWNING
+ * view over the caller's device CSR arrays.  d_values may be NULL (treated as
+ * all 1.0, what the reference loader produces for pattern files,
+ * io/matrix_market.hxx:170-171). */
+grx_status_t grx_graph_create_csr(grx_context_t ctx,
+                                  int32_t n_vertices,
+                                  int32_t n_edges,
+                                  const int32_t* d_row_offsets,
+                                  const int32_t* d_column_indices,
+                                  const float* d_values,
+                                  int32_t directed,
+                                  int32_t weighted,
+                                  int32_t symmetric,
+                                  grx_graph_t* out);
+grx_status_t grx_graph_destroy(grx_graph_t graph);
+int32_t grx_graph_number_of_vertices(grx_graph_t graph); /* graph_t::get_number_of_vertices */
+int32_t grx_graph_number_of_edges(grx_graph_t graph);    /* graph_t::get_number_of_edges */
+
+/* float gunrock::bfs::run(G, param, result, context),
+ * include/gunrock/algorithms/bfs.hxx:162-182 (legacy overload :201-215).
+ * d_distances[V] int32: depth, INT32_MAX if unreached (bfs.hxx:65-66).
+ * d_predecessors may be NULL; like the reference it is accepted and never
+ * written (bfs.hxx:29). */
+grx_status_t grx_bfs(grx_context_t ctx,
+                     grx_graph_t graph,
+                     int32_t single_source,
+                     const grx_options_t* options, /* NULL = defaults */
+                     int32_t* d_distances,
+                     int32_t* d_predecessors,
+                     float* elapsed_ms);
+
+/* float gunrock::sssp::run(G, param, result, context),
+ * include/gunrock/algorithms/sssp.hxx:176-198.  d_distances[V] float32,
+ * FLT_MAX if unreached (sssp.hxx:72-73). */
+grx_status_t grx_sssp(grx_context_t ctx,
+                      grx_graph_t graph,
+                      int32_t single_source,
+                      const grx_options_t* options,
+                      float* d_distances,
+                      int32_t* d_predecessors,
+                      float* elapsed_ms);
+
+/* float gunrock::pr::run(G, param, result, context),
+ * include/gunrock/algorithms/pr.hxx:211-236.  d_p[V] float32 ranks.
+ * iterations (may be NULL) receives the number of loop() executions. */
+grx_status_t grx_pr(grx_context_t ctx,
+                    grx_graph_t graph,
+                    float alpha,
+                    float tol,
+                    const grx_options_t* options,
+                    float* d_p,
+                    int32_t* iterations,
+                    float* elapsed_ms);
+
+/* Run statistics of the last algorithm call on this context: what the
+ * reference's metrics build collects (include/gunrock/framework/benchmark.hxx:50-60,
+ * include/gunrock/util/performance.hxx:225-229 -- mteps = edges_visited /
+ * runtime_ms / 1000). */
+typedef struct grx_run_stats {
+  int64_t edges_visited;     /* sum over iterations of degrees of valid frontier vertices */
+  int64_t vertices_visited;  /* valid frontier vertices summed over iterations */
+  int32_t search_depth;      /* enactor iterations executed */
+  int32_t n_levels_recorded; /* entries valid in the per-level arrays (GRX_FLAG_PROFILE) */
+  float elapsed_ms;
+  float reserved;
+} grx_run_stats_t;
+grx_status_t grx_get_run_stats(grx_context_t ctx, grx_run_stats_t* out);
+
+/* Per-level profile of the last run with GRX_FLAG_PROFILE: up to `capacity`
+ * levels are copied; each entry is {frontier_size, edges, advance_ms, other_ms}. */
+typedef struct grx_level_profile {
+  int64_t frontier_size;
+  int64_t edges;
+  float advance_ms;
+  float other_ms;
+} grx_level_profile_t;
+grx_status_t grx_get_level_profile(grx_context_t ctx, grx_level_profile_t* out,
+                                   int32_t capacity, int32_t* n_levels);
+
+/* ---- host-side ingest (same semantics as the reference) ---- */
+
+/* io::matrix_market_t::load + format::csr_t::from_coo,
+ * include/gunrock/io/matrix_market.hxx:99-254, include/gunrock/formats/csr.hxx:81-140.
+ * Produces host CSR arrays owned by the returned handle. */
+typedef struct grx_host_csr* grx_host_csr_t;
+grx_status_t grx_host_csr_load_mtx(const char* filename, grx_host_csr_t* out);
+/* format::csr_t::read_binary / write_binary, formats/csr.hxx:142-228 */
+grx_status_t grx_host_csr_read_binary(const char* filename, grx_host_csr_t* out);
+grx_status_t grx_host_csr_write_binary(grx_host_csr_t csr, const char* filename);
+/* COO (host arrays, caller-owned) -> CSR with the reference's stable row
+ * bucket sort (formats/csr.hxx:81-140). */
+grx_status_t grx_host_csr_from_coo(int32_t n_rows, int32_t n_cols, int64_t nnz,
+                                   const int32_t* row_indices,
+                                   const int32_t* column_indices,
+                                   const float* values, /* NULL = 1.0 */
+                                   grx_host_csr_t* out);
+grx_status_t grx_host_csr_info(grx_host_csr_t csr, int32_t* n_vertices, int32_t* n_edges,
+                               int32_t* directed, int32_t* weighted, int32_t* symmetric);
+const int32_t* grx_host_csr_row_offsets(grx_host_csr_t csr);
+const int32_t* grx_host_csr_column_indices(grx_host_csr_t csr);
+const float* grx_host_csr_values(grx_host_csr_t csr);
+grx_status_t grx_host_csr_destroy(grx_host_csr_t csr);
+
+/* Seeded synthetic stand-ins for the BASELINE.json graphs;
+ * counter-based generator, identical output for identical arguments on any
+ * machine.  kind: 0 = R-MAT(a,b,c) directed pattern, 1 = R-MAT symmetric
+ * pattern (Kronecker-style, entries doubled as the loader does), 2 = road-like
+ * lattice symmetric (p_keep = a; weighted with integer weights 1..1000 if
+ * c > 0, else unit weights). */
+grx_status_t grx_host_csr_generate(int32_t kind, int32_t n_vertices, int64_t n_entries,
+                                   float a, float b, float c, uint64_t seed,
+                                   grx_host_csr_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRX_H */

@@ -1,0 +1,164 @@
+// ref_shim.cpp -- thin extern "C" shim over the REFERENCE's own code, compiled
+// from the sources where they lie under /root/reference (see oracle/Makefile).
+//
+// TEST INFRASTRUCTURE ONLY.  Output goes to oracle/_ref/ (git-ignored).  No
+// reference source is copied into this repository: this file only #includes
+// the reference headers at build time and forwards plain arrays to them.
+//
+//   libgunrock_ref_cpu.so : the reference's CPU oracle
+//       examples/algorithms/bfs/bfs_cpu.hxx, examples/algorithms/sssp/sssp_cpu.hxx
+//       + its Matrix-Market loader and COO->CSR conversion
+//       include/gunrock/io/matrix_market.hxx, include/gunrock/formats/csr.hxx
+//   libgunrock_ref_gpu.so : additionally the reference's hipified GPU path
+//       include/gunrock/algorithms/{bfs,sssp,pr}.hxx  (same-hardware baseline)
+#include <gunrock/algorithms/algorithms.hxx>
+#ifdef REF_GPU
+#include <gunrock/algorithms/bfs.hxx>
+#include <gunrock/algorithms/sssp.hxx>
+#include <gunrock/algorithms/pr.hxx>
+#endif
+
+#include "bfs/bfs_cpu.hxx"
+#include "sssp/sssp_cpu.hxx"
+
+#include <cstring>
+#include <cstdlib>
+
+using namespace gunrock;
+using namespace memory;
+
+using vertex_t = int;
+using edge_t = int;
+using weight_t = float;
+using hcsr_t = format::csr_t<memory_space_t::host, vertex_t, edge_t, weight_t>;
+
+static hcsr_t make_host_csr(int V, int E, const int* ro, const int* ci, const float* w) {
+  hcsr_t csr(V, V, E);
+  csr.row_offsets.resize(V + 1);
+  csr.column_indices.resize(E);
+  csr.nonzero_values.resize(E);
+  for (int i = 0; i <= V; ++i) csr.row_offsets[i] = ro[i];
+  for (int i = 0; i < E; ++i) csr.column_indices[i] = ci[i];
+  for (int i = 0; i < E; ++i) csr.nonzero_values[i] = w ? w[i] : 1.0f;
+  return csr;
+}
+
+extern "C" {
+
+float ref_bfs_cpu(int V, int E, const int* ro, const int* ci, int src, int* dist) {
+  hcsr_t csr = make_host_csr(V, E, ro, ci, nullptr);
+  vertex_t s = src;
+  return bfs_cpu::run<hcsr_t, vertex_t, edge_t>(csr, s, dist, (vertex_t*)nullptr);
+}
+
+float ref_sssp_cpu(int V, int E, const int* ro, const int* ci, const float* w, int src, float* dist) {
+  hcsr_t csr = make_host_csr(V, E, ro, ci, w);
+  vertex_t s = src;
+  return sssp_cpu::run<hcsr_t, vertex_t, edge_t, weight_t>(csr, s, dist, (vertex_t*)nullptr);
+}
+
+// Loads with the reference's own loader + from_coo; arrays are malloc'ed, the
+// caller frees them with ref_free.  props = {directed, weighted, symmetric}.
+int ref_load_mtx(const char* path, int* V, int* E, int** ro, int** ci, float** w, int* props) {
+  io::matrix_market_t<vertex_t, edge_t, weight_t> mm;
+  auto [properties, coo] = mm.load(path);
+  hcsr_t csr;
+  csr.from_coo(coo);
+  *V = csr.number_of_rows;
+  *E = csr.number_of_nonzeros;
+  *ro = (int*)malloc(sizeof(int) * (size_t)(*V + 1));
+  *ci = (int*)malloc(sizeof(int) * (size_t)(*E > 0 ? *E : 1));
+  *w = (float*)malloc(sizeof(float) * (size_t)(*E > 0 ? *E : 1));
+  for (int i = 0; i <= *V; ++i) (*ro)[i] = csr.row_offsets[i];
+  for (int i = 0; i < *E; ++i) { (*ci)[i] = csr.column_indices[i]; (*w)[i] = csr.nonzero_values[i]; }
+  props[0] = properties.directed; props[1] = properties.weighted; props[2] = properties.symmetric;
+  return 0;
+}
+
+void ref_free(void* p) { free(p); }
+
+#ifdef REF_GPU
+using dcsr_t = format::csr_t<memory_space_t::device, vertex_t, edge_t, weight_t>;
+
+struct ref_graph {
+  dcsr_t csr;
+  graph::graph_properties_t props;
+};
+
+void* ref_gpu_graph_create(int V, int E, const int* ro, const int* ci, const float* w) {
+  auto* g = new ref_graph();
+  hcsr_t h = make_host_csr(V, E, ro, ci, w);
+  g->csr = dcsr_t(h);
+  return g;
+}
+void ref_gpu_graph_destroy(void* g) { delete (ref_graph*)g; }
+
+static options_t mk_options(int lb, int enable_filter, int filter_alg) {
+  options_t o;
+  o.advance_load_balance = (operators::load_balance_t)lb;
+  o.enable_filter = enable_filter != 0;
+  o.filter_algorithm = (operators::filter_algorithm_t)filter_alg;
+  return o;
+}
+
+// Returns enact() milliseconds, negative on exception.
+float ref_gpu_bfs(void* gh, int src, int lb, int enable_filter, int filter_alg, int* h_dist) {
+  try {
+    auto* g = (ref_graph*)gh;
+    auto G = graph::build<memory_space_t::device>(g->props, g->csr);
+    auto ctx = std::make_shared<gcuda::multi_context_t>(0);
+    int V = G.get_number_of_vertices();
+    thrust::device_vector<vertex_t> d(V), p(V);
+    bfs::param_t<vertex_t> param(src, mk_options(lb, enable_filter, filter_alg));
+    bfs::result_t<vertex_t> result(d.data().get(), p.data().get());
+    float ms = bfs::run(G, param, result, ctx);
+    ctx->get_context(0)->synchronize();
+    thrust::copy(d.begin(), d.end(), h_dist);
+    return ms;
+  } catch (std::exception& e) {
+    fprintf(stderr, "ref_gpu_bfs: %s\n", e.what());
+    return -1.0f;
+  }
+}
+
+float ref_gpu_sssp(void* gh, int src, int lb, float* h_dist) {
+  try {
+    auto* g = (ref_graph*)gh;
+    auto G = graph::build<memory_space_t::device>(g->props, g->csr);
+    auto ctx = std::make_shared<gcuda::multi_context_t>(0);
+    int V = G.get_number_of_vertices();
+    thrust::device_vector<weight_t> d(V);
+    thrust::device_vector<vertex_t> p(V);
+    sssp::param_t<vertex_t> param(src, mk_options(lb, 0, 1));
+    sssp::result_t<vertex_t, weight_t> result(d.data().get(), p.data().get(), V);
+    float ms = sssp::run(G, param, result, ctx);
+    ctx->get_context(0)->synchronize();
+    thrust::copy(d.begin(), d.end(), h_dist);
+    return ms;
+  } catch (std::exception& e) {
+    fprintf(stderr, "ref_gpu_sssp: %s\n", e.what());
+    return -1.0f;
+  }
+}
+
+float ref_gpu_pr(void* gh, float alpha, float tol, float* h_p) {
+  try {
+    auto* g = (ref_graph*)gh;
+    auto G = graph::build<memory_space_t::device>(g->props, g->csr);
+    auto ctx = std::make_shared<gcuda::multi_context_t>(0);
+    int V = G.get_number_of_vertices();
+    thrust::device_vector<weight_t> p(V);
+    pr::param_t<weight_t> param(alpha, tol);
+    pr::result_t<weight_t> result(p.data().get());
+    float ms = pr::run(G, param, result, ctx);
+    ctx->get_context(0)->synchronize();
+    thrust::copy(p.begin(), p.end(), h_p);
+    return ms;
+  } catch (std::exception& e) {
+    fprintf(stderr, "ref_gpu_pr: %s\n", e.what());
+    return -1.0f;
+  }
+}
+#endif
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+"""ctypes loader for the test-only CPU oracle (oracle/liboracle.so) and, when it
+has been built, the reference's own code (oracle/_ref/*.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+class _Coo(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("nnz", C.c_int32),
+                ("row_indices", C.POINTER(C.c_int32)),
+                ("column_indices", C.POINTER(C.c_int32)),
+                ("nonzero_values", C.POINTER(C.c_float)),
+                ("directed", C.c_int32), ("weighted", C.c_int32),
+                ("symmetric", C.c_int32)]
+
+
+class _Csr(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("nnz", C.c_int32),
+                ("row_offsets", C.POINTER(C.c_int32)),
+                ("column_indices", C.POINTER(C.c_int32)),
+                ("nonzero_values", C.POINTER(C.c_float))]
+
+
+def build_oracle():
+    if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
+            os.path.join(ORACLE_DIR, "oracle.c")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        L = C.CDLL(_LIB)
+        L.orc_mtx_load.argtypes = [C.c_char_p, C.POINTER(_Coo)]
+        L.orc_mtx_load.restype = C.c_int
+        L.orc_csr_from_coo.argtypes = [C.POINTER(_Coo), C.POINTER(_Csr)]
+        L.orc_csr_from_coo.restype = C.c_int
+        L.orc_coo_free.argtypes = [C.POINTER(_Coo)]
+        L.orc_csr_free.argtypes = [C.POINTER(_Csr)]
+        L.orc_bfs.argtypes = [C.c_int32, i32p, i32p, C.c_int32, i32p]
+        L.orc_bfs.restype = C.c_double
+        L.orc_bfs_queue.argtypes = [C.c_int32, i32p, i32p, C.c_int32, i32p,
+                                    C.POINTER(C.c_int64)]
+        L.orc_bfs_queue.restype = C.c_double
+        L.orc_sssp.argtypes = [C.c_int32, i32p, i32p, f32p, C.c_int32, f32p]
+        L.orc_sssp.restype = C.c_double
+        L.orc_pr_f32.argtypes = [C.c_int32, i32p, i32p, f32p, C.c_float,
+                                 C.c_float, C.c_int, f32p, C.POINTER(C.c_double)]
+        L.orc_pr_f32.restype = C.c_int
+        L.orc_pr_f64.argtypes = [C.c_int32, i32p, i32p, f32p, C.c_double,
+                                 C.c_double, C.c_int, C.c_int, f64p,
+                                 C.POINTER(C.c_double)]
+        L.orc_pr_f64.restype = C.c_int
+        L.orc_check_bfs.argtypes = [C.c_int32, i32p, i32p, C.c_int32, i32p]
+        L.orc_check_bfs.restype = C.c_int64
+        L.orc_check_sssp.argtypes = [C.c_int32, i32p, i32p, f32p, C.c_int32, f32p]
+        L.orc_check_sssp.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+class Csr:
+    """Host CSR as numpy arrays (int32 offsets/indices, float32 values)."""
+
+    def __init__(self, row_offsets, column_indices, values, props=None):
+        self.row_offsets = np.ascontiguousarray(row_offsets, dtype=np.int32)
+        self.column_indices = np.ascontiguousarray(column_indices, dtype=np.int32)
+        self.values = np.ascontiguousarray(values, dtype=np.float32)
+        self.n_vertices = len(self.row_offsets) - 1
+        self.n_edges = len(self.column_indices)
+        self.props = props or {"directed": 1, "weighted": 1, "symmetric": 0}
+
+
+def load_mtx(path):
+    """(.mtx) -> Csr via the oracle's restated loader + from_coo."""
+    L = lib()
+    coo = _Coo()
+    rc = L.orc_mtx_load(path.encode(), C.byref(coo))
+    if rc != 0:
+        raise RuntimeError("orc_mtx_load failed with code %d for %s" % (rc, path))
+    csr = _Csr()
+    rc = L.orc_csr_from_coo(C.byref(coo), C.byref(csr))
+    if rc != 0:
+        raise RuntimeError("orc_csr_from_coo failed: %d" % rc)
+    V, E = csr.rows, csr.nnz
+    ro = np.ctypeslib.as_array(csr.row_offsets, shape=(V + 1,)).copy()
+    ci = (np.ctypeslib.as_array(csr.column_indices, shape=(max(E, 1),))[:E]).copy()
+    w = (np.ctypeslib.as_array(csr.nonzero_values, shape=(max(E, 1),))[:E]).copy()
+    props = {"directed": coo.directed, "weighted": coo.weighted,
+             "symmetric": coo.symmetric}
+    L.orc_csr_free(C.byref(csr))
+    L.orc_coo_free(C.byref(coo))
+    return Csr(ro, ci, w, props)
+
+
+def bfs(g, src):
+    d = np.empty(g.n_vertices, dtype=np.int32)
+    ms = lib().orc_bfs(g.n_vertices, g.row_offsets, g.column_indices, int(src), d)
+    return d, ms
+
+
+def bfs_queue(g, src):
+    d = np.empty(g.n_vertices, dtype=np.int32)
+    ev = C.c_int64(0)
+    ms = lib().orc_bfs_queue(g.n_vertices, g.row_offsets, g.column_indices,
+                             int(src), d, C.byref(ev))
+    return d, ms, ev.value
+
+
+def sssp(g, src):
+    d = np.empty(g.n_vertices, dtype=np.float32)
+    ms = lib().orc_sssp(g.n_vertices, g.row_offsets, g.column_indices, g.values,
+                        int(src), d)
+    return d, ms
+
+
+def pr_f32(g, alpha=0.85, tol=1e-6, max_iterations=0):
+    p = np.empty(g.n_vertices, dtype=np.float32)
+    ms = C.c_double(0)
+    it = lib().orc_pr_f32(g.n_vertices, g.row_offsets, g.column_indices, g.values,
+                          alpha, tol, max_iterations, p, C.byref(ms))
+    return p, it, ms.value
+
+
+def pr_f64(g, alpha=0.85, tol=1e-6, max_iterations=0, force_iterations=0):
+    p = np.empty(g.n_vertices, dtype=np.float64)
+    ms = C.c_double(0)
+    it = lib().orc_pr_f64(g.n_vertices, g.row_offsets, g.column_indices, g.values,
+                          alpha, tol, max_iterations, force_iterations, p,
+                          C.byref(ms))
+    return p, it, ms.value
+
+
+def check_bfs(g, src, dist):
+    return lib().orc_check_bfs(g.n_vertices, g.row_offsets, g.column_indices,
+                               int(src), np.ascontiguousarray(dist, dtype=np.int32))
+
+
+def check_sssp(g, src, dist):
+    return lib().orc_check_sssp(g.n_vertices, g.row_offsets, g.column_indices,
+                                g.values, int(src),
+                                np.ascontiguousarray(dist, dtype=np.float32))
+
+
+# --------------------------------------------------------------------------
+# The reference's own code (oracle/_ref), when built.
+# --------------------------------------------------------------------------
+_REF_CPU = os.path.join(ORACLE_DIR, "_ref", "libgunrock_ref_cpu.so")
+_REF_GPU = os.path.join(ORACLE_DIR, "_ref", "libgunrock_ref_gpu.so")
+_ref_cpu = None
+_ref_gpu = None
+
+
+def have_ref_cpu():
+    return os.path.exists(_REF_CPU)
+
+
+def have_ref_gpu():
+    return os.path.exists(_REF_GPU)
+
+
+def _bind_cpu(L):
+    L.ref_bfs_cpu.argtypes = [C.c_int, C.c_int, i32p, i32p, C.c_int, i32p]
+    L.ref_bfs_cpu.restype = C.c_float
+    L.ref_sssp_cpu.argtypes = [C.c_int, C.c_int, i32p, i32p, f32p, C.c_int, f32p]
+    L.ref_sssp_cpu.restype = C.c_float
+    L.ref_load_mtx.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                               C.POINTER(C.POINTER(C.c_int)),
+                               C.POINTER(C.POINTER(C.c_int)),
+                               C.POINTER(C.POINTER(C.c_float)),
+                               C.POINTER(C.c_int)]
+    L.ref_load_mtx.restype = C.c_int
+    L.ref_free.argtypes = [C.c_void_p]
+
+
+def ref_cpu():
+    global _ref_cpu
+    if _ref_cpu is None:
+        L = C.CDLL(_REF_CPU)
+        _bind_cpu(L)
+        _ref_cpu = L
+    return _ref_cpu
+
+
+def ref_gpu():
+    global _ref_gpu
+    if _ref_gpu is None:
+        L = C.CDLL(_REF_GPU)
+        _bind_cpu(L)
+        L.ref_gpu_graph_create.argtypes = [C.c_int, C.c_int, i32p, i32p, f32p]
+        L.ref_gpu_graph_create.restype = C.c_void_p
+        L.ref_gpu_graph_destroy.argtypes = [C.c_void_p]
+        L.ref_gpu_bfs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, i32p]
+        L.ref_gpu_bfs.restype = C.c_float
+        L.ref_gpu_sssp.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p]
+        L.ref_gpu_sssp.restype = C.c_float
+        L.ref_gpu_pr.argtypes = [C.c_void_p, C.c_float, C.c_float, f32p]
+        L.ref_gpu_pr.restype = C.c_float
+        _ref_gpu = L
+    return _ref_gpu
+
+
+def ref_bfs_cpu(g, src):
+    d = np.empty(g.n_vertices, dtype=np.int32)
+    ms = ref_cpu().ref_bfs_cpu(g.n_vertices, g.n_edges, g.row_offsets,
+                               g.column_indices, int(src), d)
+    return d, ms
+
+
+def ref_sssp_cpu(g, src):
+    d = np.empty(g.n_vertices, dtype=np.float32)
+    ms = ref_cpu().ref_sssp_cpu(g.n_vertices, g.n_edges, g.row_offsets,
+                                g.column_indices, g.values, int(src), d)
+    return d, ms
+
+
+def ref_load_mtx(path):
+    L = ref_cpu()
+    V, E = C.c_int(0), C.c_int(0)
+    ro = C.POINTER(C.c_int)()
+    ci = C.POINTER(C.c_int)()
+    w = C.POINTER(C.c_float)()
+    props = (C.c_int * 3)()
+    L.ref_load_mtx(path.encode(), C.byref(V), C.byref(E), C.byref(ro), C.byref(ci),
+                   C.byref(w), props)
+    v, e = V.value, E.value
+    a = np.ctypeslib.as_array(ro, shape=(v + 1,)).astype(np.int32).copy()
+    b = np.ctypeslib.as_array(ci, shape=(max(e, 1),))[:e].astype(np.int32).copy()
+    c = np.ctypeslib.as_array(w, shape=(max(e, 1),))[:e].astype(np.float32).copy()
+    for ptr in (ro, ci, w):
+        L.ref_free(C.cast(ptr, C.c_void_p))
+    return Csr(a, b, c, {"directed": props[0], "weighted": props[1],
+                         "symmetric": props[2]})

@@ -1,0 +1,132 @@
+"""BFS parity on the GPU, through the C ABI (gunrock_amd -> libgrx.so):
+bit-exact depths against the oracle and the reference-produced goldens."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+INF = np.iinfo(np.int32).max
+
+
+def run_bfs(gr, ctx, ro, ci, src, options=None, w=None):
+    import torch
+    csr = gr.csr_t.from_arrays(ro, ci, w)
+    G = gr.build_graph(gr.graph_properties_t(directed=True, weighted=False, symmetric=False), csr, ctx)
+    dist = torch.full((G.get_number_of_vertices(),), -7, dtype=torch.int32, device="cuda:0")
+    pred = torch.empty_like(dist)
+    ms = gr.bfs(G, src, dist, pred, ctx, options)
+    assert ms >= 0
+    return dist.cpu().numpy(), gr.run_stats(ctx)
+
+
+def all_options(gr):
+    yield None
+    for lb in (gr.thread_mapped, gr.warp_mapped, gr.block_mapped, gr.merge_path, gr.merge_path_v2, gr.bucketing):
+        yield gr.options_t(advance_load_balance=lb)
+    yield gr.options_t(advance_load_balance=gr.merge_path, enable_filter=True, filter_algorithm=gr.compact)
+    yield gr.options_t(engine_flags=gr.FLAG_SYNC_EACH_LEVEL)
+    yield gr.options_t(engine_flags=gr.FLAG_PROFILE)
+
+
+def test_chesapeake_golden(gr, gpu_ctx, golden):
+    props, coo = gr.matrix_market_t().load(os.path.join(GOLDEN, "chesapeake.mtx"))
+    csr = gr.csr_t().from_coo(coo)
+    for opt in all_options(gr):
+        for s in (0, 5, 38):
+            d, st = run_bfs(gr, gpu_ctx, csr.row_offsets, csr.column_indices, s, opt)
+            assert np.array_equal(d, golden["chesapeake_bfs_%d" % s])
+            assert st["search_depth"] == d.max() + 1
+
+
+def test_synthetic_goldens(gr, gpu_ctx, golden):
+    for opt in all_options(gr):
+        d, st = run_bfs(gr, gpu_ctx, golden["rmat_ro"], golden["rmat_ci"], int(golden["rmat_src"][0]), opt)
+        assert np.array_equal(d, golden["rmat_bfs"])
+        d, _ = run_bfs(gr, gpu_ctx, golden["road_ro"], golden["road_ci"], int(golden["road_src"][0]), opt)
+        assert np.array_equal(d, golden["road_bfs"])
+
+
+def test_edges_visited_matches_definition(gr, gpu_ctx, golden):
+    # edges_visited = sum of out-degrees of reached vertices (benchmark.hxx LOG_EDGE_VISITED semantics)
+    g = O.Csr(golden["rmat_ro"], golden["rmat_ci"], np.ones(len(golden["rmat_ci"]), np.float32))
+    src = int(golden["rmat_src"][0])
+    d, st = run_bfs(gr, gpu_ctx, g.row_offsets, g.column_indices, src)
+    _, _, ev = O.bfs_queue(g, src)
+    assert st["edges_visited"] == ev
+    assert st["vertices_visited"] == int((d != INF).sum())
+
+
+def test_edge_cases(gr, gpu_ctx):
+    # single vertex, no edges
+    d, st = run_bfs(gr, gpu_ctx, [0, 0], [], 0)
+    assert d.tolist() == [0]
+    # isolated source in a bigger graph; self loops and duplicate edges
+    ro = np.array([0, 0, 3, 5, 5, 6], dtype=np.int32)
+    ci = np.array([1, 2, 2, 3, 3, 1], dtype=np.int32)
+    g = O.Csr(ro, ci, np.ones(6, np.float32))
+    for s in range(5):
+        d, _ = run_bfs(gr, gpu_ctx, ro, ci, s)
+        assert np.array_equal(d, O.bfs(g, s)[0])
+    # source out of range -> error, like an exception in the reference
+    with pytest.raises(gr.GrxError):
+        run_bfs(gr, gpu_ctx, ro, ci, 5)
+    with pytest.raises(gr.GrxError):
+        run_bfs(gr, gpu_ctx, ro, ci, 0, gr.options_t(advance_load_balance=gr.work_stealing))
+
+
+def test_star_and_chain(gr, gpu_ctx):
+    # one hub with 100k leaves (many chunks from one tile), leaves link back
+    n = 100_001
+    ro = np.concatenate([[0, n - 1], n - 1 + np.arange(1, n)]).astype(np.int32)
+    ci = np.concatenate([np.arange(1, n), np.zeros(n - 1)]).astype(np.int32)
+    g = O.Csr(ro, ci, np.ones(len(ci), np.float32))
+    for s in (0, 77):
+        d, _ = run_bfs(gr, gpu_ctx, ro, ci, s)
+        assert np.array_equal(d, O.bfs_queue(g, s)[0])
+    # long chain: 3000 levels of frontier size 1
+    n = 3000
+    ro = np.minimum(np.arange(n + 1), n - 1).astype(np.int32)
+    ci = np.arange(1, n).astype(np.int32)
+    d, st = run_bfs(gr, gpu_ctx, ro, ci, 0)
+    assert np.array_equal(d, np.arange(n))
+    assert st["search_depth"] == n
+
+
+def test_random_graphs_vs_oracle(gr, gpu_ctx):
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        V = int(rng.integers(300, 20000))
+        E = int(rng.integers(V, 12 * V))
+        _, c = gr.generate("rmat", V, E, seed=100 + trial)
+        g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+        for src in (int(np.argmax(np.diff(g.row_offsets))), int(rng.integers(0, V))):
+            d, _ = run_bfs(gr, gpu_ctx, g.row_offsets, g.column_indices, src)
+            assert np.array_equal(d, O.bfs(g, src)[0])
+
+
+def test_medium_rmat_and_repeatability(gr, gpu_ctx):
+    _, c = gr.generate("rmat", 1 << 18, 4_000_000, seed=42)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    src = int(np.argmax(np.diff(g.row_offsets)))
+    want, _, ev = O.bfs_queue(g, src)
+    for opt in all_options(gr):
+        d, st = run_bfs(gr, gpu_ctx, g.row_offsets, g.column_indices, src, opt)
+        assert np.array_equal(d, want)
+        assert st["edges_visited"] == ev
+
+
+def test_full_size_livejournal_standin_properties(gr, gpu_ctx):
+    """BASELINE.json configs[1] size (4,847,571 V / 68,993,773 E): the oracle's
+    exact fixed-point characterisation (orc_check_bfs) instead of a second CPU run."""
+    _, c = gr.generate("rmat", 4_847_571, 68_993_773, seed=42)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    src = int(np.argmax(np.diff(g.row_offsets)))
+    d, st = run_bfs(gr, gpu_ctx, g.row_offsets, g.column_indices, src)
+    assert O.check_bfs(g, src, d) == 0
+    reached = d != INF
+    assert st["vertices_visited"] == int(reached.sum())
+    assert st["edges_visited"] == int(np.diff(g.row_offsets)[reached].sum())

@@ -1,0 +1,124 @@
+"""The oracle (oracle/oracle.c) pinned against the reference's own outputs:
+golden vectors produced by the reference's loader and CPU oracle
+(tests/golden/make_golden.py) and the SURVEY 8c chesapeake vector."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import GOLDEN
+
+CHESAPEAKE_SRC0 = [0, 2, 2, 2, 2, 2, 1, 1, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 2, 2, 2,
+                   2, 2, 2, 2, 2, 2, 2, 1, 1, 2, 1, 2, 1]
+
+
+def test_loader_chesapeake(golden):
+    g = O.load_mtx(os.path.join(GOLDEN, "chesapeake.mtx"))
+    assert (g.n_vertices, g.n_edges) == (39, 340)
+    assert np.array_equal(g.row_offsets, golden["chesapeake_ro"])
+    assert np.array_equal(g.column_indices, golden["chesapeake_ci"])
+    assert np.array_equal(g.values, golden["chesapeake_w"])
+    assert [g.props["directed"], g.props["weighted"], g.props["symmetric"]] == list(golden["chesapeake_props"])
+
+
+def test_bfs_chesapeake_golden_vector(golden):
+    g = O.load_mtx(os.path.join(GOLDEN, "chesapeake.mtx"))
+    d, _ = O.bfs(g, 0)
+    assert d.tolist() == CHESAPEAKE_SRC0
+    for s in (0, 5, 38):
+        assert np.array_equal(O.bfs(g, s)[0], golden["chesapeake_bfs_%d" % s])
+        assert np.array_equal(O.sssp(g, s)[0], golden["chesapeake_sssp_%d" % s])
+        assert np.array_equal(O.bfs_queue(g, s)[0], golden["chesapeake_bfs_%d" % s])
+
+
+def test_loader_edge_cases(golden):
+    t = O.load_mtx(os.path.join(GOLDEN, "tiny_real_general.mtx"))
+    assert np.array_equal(t.row_offsets, golden["tiny_ro"])
+    assert np.array_equal(t.column_indices, golden["tiny_ci"])
+    assert np.array_equal(t.values, golden["tiny_w"])
+    assert np.array_equal(O.sssp(t, 0)[0], golden["tiny_sssp_0"])
+    assert np.array_equal(O.bfs(t, 0)[0], golden["tiny_bfs_0"])
+    s = O.load_mtx(os.path.join(GOLDEN, "tiny_int_symmetric.mtx"))
+    assert np.array_equal(s.row_offsets, golden["tsym_ro"])
+    assert np.array_equal(s.column_indices, golden["tsym_ci"])
+    assert np.array_equal(s.values, golden["tsym_w"])
+    assert [s.props["directed"], s.props["weighted"], s.props["symmetric"]] == list(golden["tsym_props"])
+    assert np.array_equal(O.sssp(s, 0)[0], golden["tsym_sssp_0"])
+
+
+def test_loader_errors(tmp_path):
+    p = tmp_path / "bad.mtx"
+    p.write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    with pytest.raises(RuntimeError):
+        O.load_mtx(str(p))
+    p.write_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n0 1 1.0\n")
+    with pytest.raises(RuntimeError):
+        O.load_mtx(str(p))
+    with pytest.raises(RuntimeError):
+        O.load_mtx(str(tmp_path / "missing.mtx"))
+
+
+def test_synthetic_goldens(golden):
+    g = O.Csr(golden["rmat_ro"], golden["rmat_ci"], np.ones(len(golden["rmat_ci"]), np.float32))
+    src = int(golden["rmat_src"][0])
+    d, _ = O.bfs(g, src)
+    assert np.array_equal(d, golden["rmat_bfs"])
+    assert O.check_bfs(g, src, d) == 0
+    r = O.Csr(golden["road_ro"], golden["road_ci"], golden["road_w"])
+    rs = int(golden["road_src"][0])
+    s, _ = O.sssp(r, rs)
+    assert np.array_equal(s, golden["road_sssp"])
+    assert (s < 1e30).sum() > r.n_vertices // 2
+    assert np.array_equal(O.bfs(r, rs)[0], golden["road_bfs"])
+    assert O.check_sssp(r, rs, s) == 0
+
+
+def test_checkers_detect_corruption(golden):
+    g = O.Csr(golden["rmat_ro"], golden["rmat_ci"], np.ones(len(golden["rmat_ci"]), np.float32))
+    src = int(golden["rmat_src"][0])
+    d = golden["rmat_bfs"].copy()
+    reached = np.flatnonzero((d != np.iinfo(np.int32).max) & (d > 0))
+    d[reached[3]] += 1
+    assert O.check_bfs(g, src, d) > 0
+    r = O.Csr(golden["road_ro"], golden["road_ci"], golden["road_w"])
+    s = golden["road_sssp"].copy()
+    k = int(np.flatnonzero((s > 0) & (s < 1e30))[5])
+    s[k] = np.float32(s[k] + 1)
+    assert O.check_sssp(r, int(golden["road_src"][0]), s) > 0
+
+
+@pytest.mark.skipif(not O.have_ref_cpu(), reason="oracle/_ref not built (no /root/reference here)")
+def test_oracle_equals_reference_cpu_on_random_graphs():
+    rng = np.random.default_rng(3)
+    for trial in range(5):
+        V = int(rng.integers(50, 400))
+        E = int(rng.integers(V, 6 * V))
+        I = rng.integers(0, V, E).astype(np.int32)
+        J = rng.integers(0, V, E).astype(np.int32)
+        W = rng.integers(1, 50, E).astype(np.float32) / np.float32(4)
+        order = np.argsort(I, kind="stable")
+        ro = np.zeros(V + 1, np.int32)
+        np.add.at(ro, I + 1, 1)
+        ro = np.cumsum(ro).astype(np.int32)
+        g = O.Csr(ro, J[order], W[order])
+        src = int(rng.integers(0, V))
+        assert np.array_equal(O.bfs(g, src)[0], O.ref_bfs_cpu(g, src)[0])
+        assert np.array_equal(O.sssp(g, src)[0], O.ref_sssp_cpu(g, src)[0])
+
+
+def test_pr_restatement_selfconsistent(golden):
+    """PR parity is unpinned by the reference (no PR oracle / test exists there);
+    the fp32 restatement must agree with its own float64 evaluation."""
+    g = O.load_mtx(os.path.join(GOLDEN, "chesapeake.mtx"))
+    p32, it32, _ = O.pr_f32(g)
+    p64, it64, _ = O.pr_f64(g)
+    assert it32 == it64
+    assert abs(p32.sum() - 1.0) < 1e-5
+    assert np.abs(p32 - p64).max() < 1e-6
+    # dangling vertices: directed graph with sinks keeps total mass 1
+    r = O.Csr(golden["rmat_ro"], golden["rmat_ci"], np.ones(len(golden["rmat_ci"]), np.float32))
+    q32, itq, _ = O.pr_f32(r)
+    q64, _, _ = O.pr_f64(r, force_iterations=itq)
+    assert abs(q32.sum() - 1.0) < 1e-4
+    assert np.abs(q32 - q64).max() < 1e-6
