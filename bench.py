@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""bench.py -- MTEPS of the BFS hot path on the BASELINE.json configs[1] workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload lj|kron|road|small]
+
+A "step" is one full pass of the hot path: problem reset + the enact loop
+(frontier seed -> convergence) of one BFS from the fixed source over the graph
+already resident in HBM.  value = traversed edges of all ranks / wall time of K
+steps (barrier + synchronize on both sides, max over ranks), in MTEPS
+(= edges_visited / (elapsed_ms * 1000), include/gunrock/util/performance.hxx:225-229
+of the reference).
+
+Extra objects on the JSON line:
+  roofline      advance kernel: algorithmic bytes (12*|F| + 12*m_F per
+                launch, summed over the launches of one BFS) / HIP-event time of
+                those launches on the engine's stream, against 8 TB/s HBM.
+  cpu_baseline  the oracle (port of the reference's priority-queue CPU path)
+                timed on this box's host, rank 0, N=1 only, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: soc-LiveJournal1 stand-in (SURVEY.md 8d C2')
+    "lj": dict(kind="rmat", V=4_847_571, entries=68_993_773, a=0.57, b=0.19, c=0.19,
+               name="BFS soc-LiveJournal1 stand-in: R-MAT(0.57,0.19,0.19,0.05) 4,847,571 V / 68,993,773 E, "
+                    "src = max out-degree vertex"),
+    "kron": dict(kind="rmat_sym", V=1 << 21, entries=91_042_010, a=0.57, b=0.19, c=0.19,
+                 name="BFS kron_g500-logn21 stand-in"),
+    "road": dict(kind="road", V=4894 * 4894, entries=0, a=0.602, b=0.0, c=0.0,
+                 name="BFS road_usa stand-in: 4894x4894 lattice p=0.602"),
+    "small": dict(kind="rmat", V=1 << 18, entries=4_000_000, a=0.57, b=0.19, c=0.19,
+                  name="BFS R-MAT 262,144 V / 4,000,000 E (smoke size)"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="lj", choices=sorted(WORKLOADS))
+    ap.add_argument("--lb", default="merge_path")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import gunrock_amd as gr
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
+
+    wl = WORKLOADS[args.workload]
+    t0 = time.time()
+    props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], wl["c"], seed=42)
+    deg = np.diff(csr.row_offsets)
+    # sources: rank r runs BFS from the r-th highest out-degree vertex (rank 0 =
+    # the config's source); ranks share no data => no collective on the data path
+    order = np.argsort(-deg, kind="stable")
+    src = int(order[rank])
+    ctx = gr.multi_context_t(local_rank)
+    G = gr.build_graph(props, csr, ctx, device=dev)
+    V, E = G.get_number_of_vertices(), G.get_number_of_edges()
+    dist_t = torch.empty(V, dtype=torch.int32, device=dev)
+    t_setup = time.time() - t0
+
+    lb = getattr(gr, args.lb)
+    opts = gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact)
+
+    def barrier():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        gr.bfs(G, src, dist_t, None, ctx, opts)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        gr.bfs(G, src, dist_t, None, ctx, opts)
+    barrier()
+    elapsed = time.perf_counter() - t1
+    st = gr.run_stats(ctx)
+    edges_rank = st["edges_visited"]
+    enact_ms = st["elapsed_ms"]
+
+    if dist_on:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        ee = torch.tensor([edges_rank], dtype=torch.int64, device=dev)
+        dist.all_reduce(ee, op=dist.ReduceOp.SUM)
+        edges_total = int(ee.item())
+    else:
+        edges_total = edges_rank
+    ms_per_step = elapsed * 1e3 / args.steps
+    mteps = edges_total / (ms_per_step * 1e3)
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (advance), HIP events on the engine stream
+        popts = gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact,
+                             engine_flags=gr.FLAG_PROFILE)
+        best = None
+        for _ in range(3):
+            gr.bfs(G, src, dist_t, None, ctx, popts)
+            prof = gr.level_profile(ctx)
+            adv_ms = sum(l["advance_ms"] for l in prof)
+            if best is None or adv_ms < best[0]:
+                best = (adv_ms, prof)
+        adv_ms, prof = best
+        alg_bytes = sum(12 * l["frontier_size"] + 12 * l["edges"] for l in prof)
+        n_launch = max(1, len(prof))
+        achieved = alg_bytes / (adv_ms * 1e-3) / 1e9 if adv_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": "advance_kernel<bfs_policy>", "launches_per_step": n_launch,
+                    "alg_bytes_per_step": int(alg_bytes), "kernel_ms_per_step": round(adv_ms, 4),
+                    "avg_launch_us": round(adv_ms * 1e3 / n_launch, 2),
+                    "levels": [[l["frontier_size"], l["edges"], round(l["advance_ms"], 4), round(l["other_ms"], 4)]
+                               for l in prof]}
+        # ---- CPU baseline: the oracle (port of the reference's PQ CPU path), bounded sample
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
+            t_cpu, runs, ev_cpu, budget = 0.0, 0, 0, 12.0
+            while t_cpu < budget * 1e3 and runs < 64:
+                d_cpu, ms = O.bfs(g, src)
+                t_cpu += ms
+                runs += 1
+                ev_cpu += edges_rank
+            ok = bool(np.array_equal(d_cpu, dist_t.cpu().numpy()))
+            cpu = {"value": round(ev_cpu / (t_cpu * 1e3), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+                   "sample": "%d full BFS runs of the same workload/source with oracle/oracle.c orc_bfs "
+                             "(priority-queue search of examples/algorithms/bfs/bfs_cpu.hxx), %.1f s"
+                             % (runs, t_cpu / 1e3),
+                   "matches_gpu": ok}
+        out = {"metric": "MTEPS (million traversed edges/sec) BFS", "value": round(mteps, 1), "unit": "MTEPS",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+               "config": {"workload": wl["name"], "n_vertices": V, "n_edges": E, "source": src,
+                          "advance_load_balance": args.lb, "filter": "compact (fused into advance)",
+                          "parallelism": "1 graph replica per GPU, independent sources" if world > 1 else "single GPU",
+                          "edges_visited_per_step": edges_rank, "search_depth": st["search_depth"],
+                          "enact_ms_last": round(enact_ms, 4), "setup_s": round(t_setup, 1)},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
