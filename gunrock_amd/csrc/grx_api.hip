@@ -198,6 +198,9 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->t_ro) (void)hipFree(g->t_ro);
   if (g->t_ci) (void)hipFree(g->t_ci);
   if (g->t_w) (void)hipFree(g->t_w);
+  if (g->pr_blocks) (void)hipFree(g->pr_blocks);
+  if (g->pr_piece) (void)hipFree(g->pr_piece);
+  if (g->pr_long) (void)hipFree(g->pr_long);
   delete g;
   return GRX_SUCCESS;
 }

@@ -23,7 +23,7 @@ struct bfs_policy {
 
   __device__ __forceinline__ void begin(const ctrl_t* c) { next_depth = c->level + 1; }
   __device__ __forceinline__ src_state load_source(int) const { return 0; }
-  __device__ __forceinline__ bool precheck(int n) const {
+  __device__ __forceinline__ bool precheck(src_state, int n, int) const {
     return (visited[n >> 5] & (1u << (n & 31))) == 0u;
   }
   __device__ __forceinline__ bool visit(int, src_state, int n, int) const {

@@ -125,6 +125,12 @@ struct grx_graph {
   int32_t* t_ci = nullptr;
   float* t_w = nullptr;
   bool has_transpose = false;
+  std::vector<int32_t> h_t_ro;  // host copy of the transpose offsets (for static partitions)
+  // static PageRank pull partition (built once per graph)
+  void* pr_blocks = nullptr;    // int4 {row0, nrows, e0, e1}; nrows == 0 => piece of a long row
+  int32_t* pr_piece = nullptr;  // piece id per block (-1 for ordinary blocks)
+  int32_t* pr_long = nullptr;   // int {row, first_piece, n_pieces} per long row
+  int32_t n_pr_blocks = 0, n_pr_pieces = 0, n_pr_long = 0;
 };
 
 struct grx_host_csr {

@@ -16,6 +16,9 @@ hipError_t fill_f32(hipStream_t s, float* p, float value, int64_t n);
 // Size all pipeline scratch for graph g; fills `a`.
 grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a);
 
+// Build (once) and cache the transpose of g in the graph handle.
+grx_status_t graph_build_transpose(grx_context_t ctx, grx_graph_t g);
+
 // Launch configuration of the advance kernel (persistent workgroups).
 inline int advance_grid(grx_context_t ctx) { return ctx->num_cus * 8; }
 

@@ -112,9 +112,10 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a) {
 
 // ---------------------------------------------------------------------------
 // advance + fused compaction.  Policy interface (all __device__):
-//   void begin(const ctrl_t*)                      once per workgroup
-//   src_state load_source(int v)                   per staged slot (e.g. dist[v])
-//   bool visit(int src, src_state, int nbr, int e) true => nbr joins the output
+//   void begin(const ctrl_t*)                         once per workgroup
+//   src_state load_source(int v)                      per staged slot (e.g. dist[v])
+//   bool precheck(src_state, int nbr, int e)          cheap, read-only filter
+//   bool visit(int src, src_state, int nbr, int e)    true => nbr joins the output
 // ---------------------------------------------------------------------------
 template <class Policy>
 __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy pol) {
@@ -212,7 +213,8 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
     for (int k = 0; k < ADV_ITEMS; ++k) n_k[k] = (e_k[k] >= 0) ? a.ci[e_k[k]] : -1;
     bool pre_k[ADV_ITEMS];
 #pragma unroll
-    for (int k = 0; k < ADV_ITEMS; ++k) pre_k[k] = (e_k[k] >= 0) && pol.precheck(n_k[k]);
+    for (int k = 0; k < ADV_ITEMS; ++k)
+      pre_k[k] = (e_k[k] >= 0) && pol.precheck(s_state[slot_k[k]], n_k[k], e_k[k]);
 #pragma unroll
     for (int k = 0; k < ADV_ITEMS; ++k) {
       bool keep = false;

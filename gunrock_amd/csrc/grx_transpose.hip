@@ -1,0 +1,73 @@
+// grx_transpose.hip -- one-time device build of the transpose (CSC) of a CSR
+// graph: the layout behind the pull operators (PageRank pull, bottom-up BFS).
+// The reference has CSC as a separate user-built view (include/gunrock/graph/csc.hxx,
+// formats/csc.hxx) and its advance ignores `direction` (operators/configs.hxx:78-82);
+// here the engine derives it lazily and caches it in the graph handle.
+//
+// Column order: positions inside a column are claimed with an atomic cursor, so
+// the order of a column's entries is not reproducible run to run (fp32 sums over
+// in-edges may differ in the last ulp, as the reference's atomicAdd order does).
+#include "grx_engine.hpp"
+#include "grx_scan.hpp"
+
+namespace grx {
+
+__global__ void tr_count_kernel(const int32_t* __restrict__ ci, int64_t E, int32_t* cnt) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride)
+    atomicAdd(&cnt[ci[e]], 1);
+}
+
+// One wave per CSR row chunk: rows are walked in order by a grid-stride loop
+// over rows; each lane takes edges of the row.  Position inside the column is
+// claimed with an atomic cursor, so a per-column sort follows.
+__global__ void tr_fill_kernel(const int32_t* __restrict__ ro, const int32_t* __restrict__ ci,
+                               const float* __restrict__ w, int32_t V, int32_t* cursor,
+                               int32_t* t_ci, float* t_w) {
+  const int lane = dev::lane_id();
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t v = wave; v < V; v += nwaves) {
+    const int b = ro[v], e = ro[v + 1];
+    for (int k = b + lane; k < e; k += 64) {
+      const int dst = ci[k];
+      const int pos = atomicAdd(&cursor[dst], 1);
+      t_ci[pos] = (int32_t)v;
+      if (t_w) t_w[pos] = w ? w[k] : 1.0f;
+    }
+  }
+}
+
+}  // namespace grx
+
+using namespace grx;
+
+grx_status_t grx::graph_build_transpose(grx_context_t ctx, grx_graph_t g) {
+  if (g->has_transpose) return GRX_SUCCESS;
+  const int32_t V = g->V;
+  const int64_t E = g->E;
+  hipStream_t s = ctx->stream;
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->t_ro), ((size_t)V + 2) * sizeof(int32_t)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->t_ci), (size_t)(E > 0 ? E : 1) * sizeof(int32_t)));
+  const bool weighted = g->w != nullptr;
+  if (weighted) GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->t_w), (size_t)(E > 0 ? E : 1) * sizeof(float)));
+  int32_t *cnt = nullptr, *bs = nullptr;
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&cnt), ((size_t)V + 2) * sizeof(int32_t)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&bs), ((size_t)scan_num_blocks(V + 1) + 2) * sizeof(int32_t)));
+  GRX_HIP(hipMemsetAsync(cnt, 0, ((size_t)V + 2) * sizeof(int32_t), s));
+  if (E > 0) hipLaunchKernelGGL(tr_count_kernel, dim3(2048), dim3(256), 0, s, g->ci, E, cnt);
+  exclusive_scan_i32(s, cnt, (int64_t)V, g->t_ro, bs);
+  GRX_HIP(hipMemcpyAsync(cnt, g->t_ro, ((size_t)V + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  if (E > 0)
+    hipLaunchKernelGGL(tr_fill_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, g->w, V, cnt, g->t_ci,
+                       g->t_w);
+  GRX_HIP(hipStreamSynchronize(s));
+  std::vector<int32_t> h_ro((size_t)V + 1);
+  GRX_HIP(hipMemcpy(h_ro.data(), g->t_ro, ((size_t)V + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  (void)hipFree(cnt);
+  (void)hipFree(bs);
+  GRX_HIP(hipGetLastError());
+  g->h_t_ro.swap(h_ro);
+  g->has_transpose = true;
+  return GRX_SUCCESS;
+}

@@ -1,0 +1,100 @@
+"""SSSP parity on the GPU through the C ABI: distances bit-exact (fp32 ==)
+against the oracle / reference CPU Dijkstra -- the reference's own --validate
+convention (exact != on floats, util/compare.hxx:21)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+FMAX = np.finfo(np.float32).max
+
+
+def run_sssp(gr, ctx, ro, ci, w, src, options=None, weighted=True):
+    import torch
+    csr = gr.csr_t.from_arrays(ro, ci, w)
+    G = gr.build_graph(gr.graph_properties_t(directed=True, weighted=weighted, symmetric=False), csr, ctx)
+    dist = torch.full((G.get_number_of_vertices(),), -1.0, dtype=torch.float32, device="cuda:0")
+    pred = torch.empty(G.get_number_of_vertices(), dtype=torch.int32, device="cuda:0")
+    gr.sssp(G, src, dist, pred, ctx, options)
+    return dist.cpu().numpy(), gr.run_stats(ctx)
+
+
+def test_goldens(gr, gpu_ctx, golden):
+    for s in (0, 5, 38):
+        d, _ = run_sssp(gr, gpu_ctx, golden["chesapeake_ro"], golden["chesapeake_ci"], golden["chesapeake_w"], s)
+        assert np.array_equal(d, golden["chesapeake_sssp_%d" % s])
+    d, _ = run_sssp(gr, gpu_ctx, golden["tiny_ro"], golden["tiny_ci"], golden["tiny_w"], 0)
+    assert np.array_equal(d, golden["tiny_sssp_0"])
+    assert d[3] == FMAX  # unreached stays FLT_MAX, not inf (sssp.hxx:72-73)
+    d, _ = run_sssp(gr, gpu_ctx, golden["tsym_ro"], golden["tsym_ci"], golden["tsym_w"], 0)
+    assert np.array_equal(d, golden["tsym_sssp_0"])
+    d, _ = run_sssp(gr, gpu_ctx, golden["road_ro"], golden["road_ci"], golden["road_w"], int(golden["road_src"][0]))
+    assert np.array_equal(d, golden["road_sssp"])
+
+
+def test_pattern_graph_equals_bfs_depths(gr, gpu_ctx, golden):
+    # pattern => unit weights => SSSP == BFS depths as floats; values=None path
+    ro, ci = golden["rmat_ro"], golden["rmat_ci"]
+    src = int(golden["rmat_src"][0])
+    import torch
+    csr = gr.csr_t.from_arrays(ro, ci)
+    G = gr.graph_t(gr.graph_properties_t(True, False, False),
+                   (csr.to_device()[0], csr.to_device()[1], None), gpu_ctx)
+    dist = torch.empty(len(ro) - 1, dtype=torch.float32, device="cuda:0")
+    gr.sssp(G, src, dist, None, gpu_ctx)
+    want = golden["rmat_bfs"].astype(np.float64)
+    want[golden["rmat_bfs"] == np.iinfo(np.int32).max] = FMAX
+    assert np.array_equal(dist.cpu().numpy(), want.astype(np.float32))
+
+
+def test_random_weighted_graphs_vs_oracle(gr, gpu_ctx):
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        V = int(rng.integers(200, 30000))
+        E = int(rng.integers(V, 10 * V))
+        _, c = gr.generate("rmat", V, E, seed=500 + trial)
+        # non-trivial fp32 weights (not exactly representable sums)
+        w = (rng.random(E, dtype=np.float32) * np.float32(9.7) + np.float32(0.01)).astype(np.float32)
+        g = O.Csr(c.row_offsets, c.column_indices, w)
+        for src in (int(np.argmax(np.diff(g.row_offsets))), int(rng.integers(0, V))):
+            for opt in (None, gr.options_t(advance_load_balance=gr.merge_path),
+                        gr.options_t(advance_load_balance=gr.warp_mapped, enable_uniquify=True)):
+                d, _ = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, w, src, opt)
+                assert np.array_equal(d, O.sssp(g, src)[0])
+
+
+def test_zero_weights_self_loops_duplicates(gr, gpu_ctx):
+    ro = np.array([0, 3, 5, 6, 6, 8], dtype=np.int32)
+    ci = np.array([1, 1, 0, 2, 4, 0, 4, 3], dtype=np.int32)
+    w = np.array([2.0, 0.5, 1.0, 0.0, 3.0, 1.0, 0.0, 0.25], dtype=np.float32)
+    g = O.Csr(ro, ci, w)
+    for s in range(5):
+        d, _ = run_sssp(gr, gpu_ctx, ro, ci, w, s)
+        assert np.array_equal(d, O.sssp(g, s)[0])
+
+
+def test_medium_weighted_rmat(gr, gpu_ctx):
+    _, c = gr.generate("rmat", 1 << 18, 3_000_000, seed=9)
+    rng = np.random.default_rng(1)
+    w = rng.integers(1, 1001, c.number_of_nonzeros).astype(np.float32)
+    g = O.Csr(c.row_offsets, c.column_indices, w)
+    src = int(np.argmax(np.diff(g.row_offsets)))
+    d, st = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, w, src)
+    assert np.array_equal(d, O.sssp(g, src)[0])
+    assert O.check_sssp(g, src, d) == 0
+
+
+def test_full_size_road_standin_properties(gr, gpu_ctx):
+    """BASELINE.json configs[2] size: 4894x4894 lattice (23,951,236 V, ~57.7 M E),
+    weighted variant U{1..1000}; exact fixed-point characterisation by the oracle."""
+    _, c = gr.generate("road", 4894 * 4894, a=0.602, c=1.0, seed=42)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    assert 55_000_000 < g.n_edges < 60_000_000
+    src = (4894 // 2) * 4894 + 4894 // 2
+    d, st = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src)
+    assert (d < FMAX).sum() > g.n_vertices // 2
+    assert O.check_sssp(g, src, d) == 0
