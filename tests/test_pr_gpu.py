@@ -4,8 +4,12 @@ The reference pins nothing for PR (no CPU oracle, no test); its own GPU result
 depends on atomicAdd order.  Tolerances (north_star + SURVEY 8c): against the
 float64 evaluation of the same recurrence run for the SAME number of
 iterations, |delta| <= 1e-6 absolute and <= 1e-4 relative; the iteration count
-must equal the fp32 restatement's (+-1 only where the convergence test is
-within rounding of the threshold)."""
+must equal the float64 recurrence's (+-1 where the convergence test sits within
+rounding of the threshold).  The sequential fp32 restatement is NOT the yardstick
+for the count on hub-heavy graphs: summing 1e5 tiny terms into one fp32
+accumulator leaves ~1e-5 absolute noise at hubs, above tol=1e-6, so it (like the
+reference's atomicAdd order) needs 16 iterations where float64 needs 9 on the
+kron stand-in; the pull kernel's blocked sums track float64."""
 import os
 
 import numpy as np
@@ -31,8 +35,8 @@ def run_pr(gr, ctx, g, alpha=0.85, tol=1e-6, weighted=True, max_iterations=0):
 
 
 def check(g, p, it, alpha=0.85, tol=1e-6):
-    p32, it32, _ = O.pr_f32(g, alpha, tol)
-    assert abs(it - it32) <= 1, (it, it32)
+    _, it64, _ = O.pr_f64(g, alpha, tol)
+    assert abs(it - it64) <= 1, (it, it64)
     p64, _, _ = O.pr_f64(g, alpha, tol, force_iterations=it)
     diff = np.abs(p.astype(np.float64) - p64)
     assert diff.max() <= ABS_TOL, diff.max()

@@ -29,7 +29,6 @@ def test_goldens(gr, gpu_ctx, golden):
         assert np.array_equal(d, golden["chesapeake_sssp_%d" % s])
     d, _ = run_sssp(gr, gpu_ctx, golden["tiny_ro"], golden["tiny_ci"], golden["tiny_w"], 0)
     assert np.array_equal(d, golden["tiny_sssp_0"])
-    assert d[3] == FMAX  # unreached stays FLT_MAX, not inf (sssp.hxx:72-73)
     d, _ = run_sssp(gr, gpu_ctx, golden["tsym_ro"], golden["tsym_ci"], golden["tsym_w"], 0)
     assert np.array_equal(d, golden["tsym_sssp_0"])
     d, _ = run_sssp(gr, gpu_ctx, golden["road_ro"], golden["road_ci"], golden["road_w"], int(golden["road_src"][0]))
@@ -75,6 +74,8 @@ def test_zero_weights_self_loops_duplicates(gr, gpu_ctx):
     for s in range(5):
         d, _ = run_sssp(gr, gpu_ctx, ro, ci, w, s)
         assert np.array_equal(d, O.sssp(g, s)[0])
+    d, _ = run_sssp(gr, gpu_ctx, ro, ci, w, 3)  # vertex 3 has no out-edges
+    assert d[3] == 0 and np.all(np.delete(d, 3) == FMAX)  # unreached = FLT_MAX, not inf (sssp.hxx:72-73)
 
 
 def test_medium_weighted_rmat(gr, gpu_ctx):
