@@ -26,7 +26,7 @@
 #pragma once
 
 #include "grx_common.hpp"
-#include "grx_device.hpp"
+#include <gunrock/hip/wave.hxx>
 
 namespace grx {
 

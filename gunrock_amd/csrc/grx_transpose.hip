@@ -8,7 +8,7 @@
 // the order of a column's entries is not reproducible run to run (fp32 sums over
 // in-edges may differ in the last ulp, as the reference's atomicAdd order does).
 #include "grx_engine.hpp"
-#include "grx_scan.hpp"
+#include <gunrock/hip/scan.hxx>
 
 namespace grx {
 

@@ -1,0 +1,118 @@
+// advance.hxx -- the advance operator: visit the out-edges of every element of
+// the input frontier, call `op(src, nbr, edge, weight)` and emit `nbr` (or the
+// invalid sentinel -1) into the output frontier.
+// API parity: include/gunrock/framework/operators/advance/advance.hxx:94-275
+// (reference): execute<lb, direction, input_type, output_type>(G, op, in*, out*,
+// segments, context); the enactor overload execute<...>(G, E, op, context,
+// swap_buffers = true); execute_runtime(G, E, op, lb, context, swap_buffers).
+// Same error behaviour: unsupported load balancing throws
+// error::exception_t("Load balance type not supported."), multi-context throws
+// "`context.size() != 1` not supported".
+// What differs: warp_mapped is real, bucketing and merge_path_v2 map onto
+// merge_path, graph-as-input uses the row offsets as the scan (no scan launch),
+// and no kernel is followed by a host synchronise.
+#pragma once
+
+#include <gunrock/cuda/context.hxx>
+#include <gunrock/error.hxx>
+#include <gunrock/framework/benchmark.hxx>
+#include <gunrock/framework/operators/advance/block_mapped.hxx>
+#include <gunrock/framework/operators/advance/helpers.hxx>
+#include <gunrock/framework/operators/advance/merge_path.hxx>
+#include <gunrock/framework/operators/advance/thread_mapped.hxx>
+#include <gunrock/framework/operators/advance/warp_mapped.hxx>
+#include <gunrock/framework/operators/configs.hxx>
+
+namespace gunrock {
+namespace operators {
+namespace advance {
+
+template <load_balance_t lb = load_balance_t::merge_path,
+          advance_direction_t direction = advance_direction_t::forward,
+          advance_io_type_t input_type = advance_io_type_t::vertices,
+          advance_io_type_t output_type = advance_io_type_t::vertices, typename graph_t, typename operator_t,
+          typename frontier_t, typename work_tiles_t>
+void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, work_tiles_t& segments,
+             gcuda::multi_context_t& context) {
+  using type_t = typename frontier_t::type_t;
+  using edge_t = typename graph_t::edge_type;
+  error::throw_if_exception(context.size() != 1, "`context.size() != 1` not supported");
+  static_assert(input_type != advance_io_type_t::edges && input_type != advance_io_type_t::none,
+                "advance input must be `vertices` or `graph`");
+  static_assert(lb != load_balance_t::work_stealing, "Load balance type not supported.");
+  auto& ctx = *context.get_context(0);
+
+  constexpr bool whole_graph = input_type == advance_io_type_t::graph;
+  const type_t* in = whole_graph ? nullptr : input->data();
+  const std::size_t n = whole_graph ? (std::size_t)G.get_number_of_vertices() : input->get_number_of_elements();
+
+  std::size_t total;
+  const edge_t* seg;
+  if constexpr (whole_graph) {
+    total = (std::size_t)G.get_number_of_edges();  // the CSR offsets ARE the scan
+    seg = G.get_row_offsets();
+  } else {
+    total = compute_output_offsets(G, input, segments, ctx, false);
+    seg = memory::raw_pointer_cast(segments.data());
+  }
+  benchmark::LOG_EDGES_HOST(total);
+  benchmark::LOG_VERTICES_HOST(n);
+
+  type_t* out = nullptr;
+  if constexpr (output_type != advance_io_type_t::none) {
+    if (output->get_capacity() < total) output->reserve(total);
+    output->set_number_of_elements(total);
+    out = output->data();
+  }
+  if (total == 0) return;
+
+  if constexpr (lb == load_balance_t::thread_mapped)
+    thread_mapped::launch<output_type>(G, op, in, n, out, seg, ctx);
+  else if constexpr (lb == load_balance_t::warp_mapped)
+    warp_mapped::launch<output_type>(G, op, in, n, out, seg, ctx);
+  else if constexpr (lb == load_balance_t::block_mapped)
+    block_mapped::launch<output_type>(G, op, in, n, out, seg, ctx);
+  else
+    merge_path::launch<output_type>(G, op, in, n, out, seg, total, ctx);
+}
+
+template <load_balance_t lb = load_balance_t::merge_path,
+          advance_direction_t direction = advance_direction_t::forward,
+          advance_io_type_t input_type = advance_io_type_t::vertices,
+          advance_io_type_t output_type = advance_io_type_t::vertices, typename graph_t, typename enactor_type,
+          typename operator_type>
+void execute(graph_t& G, enactor_type* E, operator_type op, gcuda::multi_context_t& context,
+             bool swap_buffers = true) {
+  execute<lb, direction, input_type, output_type>(G, op, E->get_input_frontier(), E->get_output_frontier(),
+                                                  E->scanned_work_domain, context);
+  if (swap_buffers && output_type != advance_io_type_t::none) E->swap_frontier_buffers();
+}
+
+template <typename graph_t, typename enactor_type, typename operator_type>
+void execute_runtime(graph_t& G, enactor_type* E, operator_type op, load_balance_t lb,
+                     gcuda::multi_context_t& context, bool swap_buffers = true) {
+  constexpr auto fwd = advance_direction_t::forward;
+  constexpr auto vtx = advance_io_type_t::vertices;
+  switch (lb) {
+    case load_balance_t::thread_mapped:
+      execute<load_balance_t::thread_mapped, fwd, vtx, vtx>(G, E, op, context, swap_buffers);
+      break;
+    case load_balance_t::warp_mapped:
+      execute<load_balance_t::warp_mapped, fwd, vtx, vtx>(G, E, op, context, swap_buffers);
+      break;
+    case load_balance_t::block_mapped:
+      execute<load_balance_t::block_mapped, fwd, vtx, vtx>(G, E, op, context, swap_buffers);
+      break;
+    case load_balance_t::bucketing:
+    case load_balance_t::merge_path:
+    case load_balance_t::merge_path_v2:
+      execute<load_balance_t::merge_path, fwd, vtx, vtx>(G, E, op, context, swap_buffers);
+      break;
+    default:
+      error::throw_if_exception(hipErrorUnknown, "Load balance type not supported.");
+  }
+}
+
+}  // namespace advance
+}  // namespace operators
+}  // namespace gunrock

@@ -1,0 +1,119 @@
+// helpers.hxx -- output sizing and the shared LDS expansion of advance.
+// API parity: include/gunrock/framework/operators/advance/helpers.hxx:41-161
+// (reference): compute_output_offsets (exclusive scan of the degrees of the
+// input frontier into `segments[0..n]`, invalid slots count 0) and
+// compute_output_length.  The reference runs rocThrust transform_exclusive_scan
+// and copies the total back through a 1-element host_vector; here the degree
+// transform is fused into our own three-launch scan and the total comes back
+// through the context's pinned mailbox (one stream sync per advance).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <gunrock/cuda/context.hxx>
+#include <gunrock/framework/operators/configs.hxx>
+#include <gunrock/hip/scan.hxx>
+#include <gunrock/hip/wave.hxx>
+#include <gunrock/memory.hxx>
+#include <gunrock/util/type_limits.hxx>
+
+namespace gunrock {
+namespace operators {
+namespace advance {
+namespace detail {
+
+constexpr int BLOCK = 256;                // threads per workgroup == slots per window
+constexpr int ATOMS_PER_BLOCK = 2048;     // merge-path: edges per workgroup
+
+template <typename graph_t, typename type_t, typename edge_t>
+__global__ void degrees_kernel(graph_t G, const type_t* input, std::size_t n, edge_t* degrees) {
+  for (std::size_t i = (std::size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (std::size_t)gridDim.x * blockDim.x) {
+    const type_t v = input ? input[i] : (type_t)i;
+    degrees[i] = gunrock::util::limits::is_valid(v) ? G.get_number_of_neighbors(v) : 0;
+  }
+}
+
+// Expand the edges ("atoms") [atom_lo, atom_hi) of a staged window of up to
+// BLOCK input slots.  s_seg[0..nslots] is the window-relative exclusive degree
+// scan, s_start the first edge id of each slot, s_src the slot's vertex.  Lanes
+// take consecutive atoms, so column-index / weight reads are coalesced inside a
+// row.  `out` points at the output position of window atom 0 (may be null).
+template <advance_io_type_t output_type, typename graph_t, typename operator_t, typename type_t>
+__device__ __forceinline__ void expand_window(const graph_t& G, operator_t& op, const int* s_seg,
+                                              const int* s_start, const type_t* s_src, int nslots,
+                                              int atom_lo, int atom_hi, type_t* out) {
+  using vertex_t = typename graph_t::vertex_type;
+  using edge_t = typename graph_t::edge_type;
+  using weight_t = typename graph_t::weight_type;
+  for (int atom = atom_lo + (int)threadIdx.x; atom < atom_hi; atom += BLOCK) {
+    int lo = 0;
+#pragma unroll
+    for (int step = BLOCK / 2; step >= 1; step >>= 1)
+      if (lo + step < nslots && s_seg[lo + step] <= atom) lo += step;
+    const edge_t e = (edge_t)(s_start[lo] + (atom - s_seg[lo]));
+    const vertex_t src = (vertex_t)s_src[lo];
+    const vertex_t nbr = G.get_destination_vertex(e);
+    const weight_t w = G.get_edge_weight(e);
+    const bool keep = op(src, nbr, e, w);
+    if constexpr (output_type != advance_io_type_t::none) {
+      const type_t emitted = (output_type == advance_io_type_t::edges) ? (type_t)e : (type_t)nbr;
+      out[atom] = keep ? emitted : gunrock::numeric_limits<type_t>::invalid();
+    }
+  }
+}
+
+}  // namespace detail
+
+// segments[0..n] = exclusive scan of the input frontier's degrees; returns the
+// total (host value).  input == nullptr means "every vertex of the graph".
+template <typename graph_t, typename type_t, typename work_tiles_t>
+std::size_t compute_output_offsets(graph_t& G, const type_t* input, std::size_t n, work_tiles_t& segments,
+                                   gcuda::standard_context_t& context) {
+  using edge_t = typename graph_t::edge_type;
+  static_assert(sizeof(edge_t) == 4, "offsets are 32-bit in this engine");
+  if (segments.size() < n + 1) segments.resize(n + 1);
+  edge_t* seg = memory::raw_pointer_cast(segments.data());
+  if (n == 0) return 0;
+  hipStream_t s = context.stream();
+  int32_t* block_sums = context.scratch<int32_t>(0, (std::size_t)grx::scan_num_blocks((int64_t)n) + 2);
+  std::size_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL((detail::degrees_kernel<graph_t, type_t, edge_t>), dim3((unsigned)g), dim3(256), 0, s, G, input,
+                     n, seg);
+  grx::exclusive_scan_i32(s, reinterpret_cast<const int32_t*>(seg), (int64_t)n, reinterpret_cast<int32_t*>(seg),
+                          block_sums);
+  return (std::size_t)context.read_back(reinterpret_cast<const int*>(seg + n))[0];
+}
+
+template <typename graph_t, typename frontier_t, typename work_tiles_t>
+std::size_t compute_output_offsets(graph_t& G, frontier_t* input, work_tiles_t& segments,
+                                   gcuda::standard_context_t& context, bool graph_as_frontier = false) {
+  using type_t = typename frontier_t::type_t;
+  if (graph_as_frontier)
+    return compute_output_offsets<graph_t, type_t>(G, (const type_t*)nullptr,
+                                                   (std::size_t)G.get_number_of_vertices(), segments, context);
+  return compute_output_offsets<graph_t, type_t>(G, input->data(), input->get_number_of_elements(), segments,
+                                                 context);
+}
+
+template <typename graph_t, typename frontier_t>
+std::size_t compute_output_length(graph_t& G, frontier_t* input, gcuda::standard_context_t& context,
+                                  bool graph_as_frontier = false) {
+  using edge_t = typename graph_t::edge_type;
+  if (graph_as_frontier) return (std::size_t)G.get_number_of_edges();
+  const std::size_t n = input->get_number_of_elements();
+  edge_t* tmp = context.scratch<edge_t>(1, n + 2);
+  struct view_t {
+    edge_t* p;
+    std::size_t n;
+    std::size_t size() const { return n; }
+    void resize(std::size_t) {}
+    edge_t* data() { return p; }
+  } v{tmp, n + 2};
+  return compute_output_offsets(G, input, v, context, false);
+}
+
+}  // namespace advance
+}  // namespace operators
+}  // namespace gunrock

@@ -1,0 +1,53 @@
+// warp_mapped.hxx -- one 64-lane wavefront per input vertex; lanes stride the
+// neighbour list, so column-index / weight reads of a row are fully coalesced.
+// The reference only declares the enum (operators/configs.hxx:54) and throws
+// "Load balance type not supported." (advance/advance.hxx:272-274); this is the
+// real thing.  Best for medium-to-high uniform degrees.
+#pragma once
+
+#include <gunrock/framework/operators/advance/helpers.hxx>
+
+namespace gunrock {
+namespace operators {
+namespace advance {
+namespace warp_mapped {
+
+template <advance_io_type_t output_type, typename graph_t, typename operator_t, typename type_t, typename edge_t>
+__global__ __launch_bounds__(256) void kernel(graph_t G, operator_t op, const type_t* input, std::size_t n,
+                                              type_t* output, const edge_t* segments) {
+  using vertex_t = typename graph_t::vertex_type;
+  const int lane = grx::dev::lane_id();
+  const std::size_t waves = ((std::size_t)gridDim.x * blockDim.x) >> 6;
+  for (std::size_t i = ((std::size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += waves) {
+    const type_t v = input ? input[i] : (type_t)i;
+    if (!gunrock::util::limits::is_valid(v)) continue;
+    const edge_t first = G.get_starting_edge((vertex_t)v);
+    const edge_t deg = G.get_number_of_neighbors((vertex_t)v);
+    const edge_t base = segments[i];
+    for (edge_t k = lane; k < deg; k += 64) {
+      const edge_t e = first + k;
+      const vertex_t nbr = G.get_destination_vertex(e);
+      const bool keep = op((vertex_t)v, nbr, e, G.get_edge_weight(e));
+      if constexpr (output_type != advance_io_type_t::none) {
+        const type_t emitted = (output_type == advance_io_type_t::edges) ? (type_t)e : (type_t)nbr;
+        output[base + k] = keep ? emitted : gunrock::numeric_limits<type_t>::invalid();
+      }
+    }
+  }
+}
+
+template <advance_io_type_t output_type, typename graph_t, typename operator_t, typename type_t, typename edge_t>
+void launch(graph_t& G, operator_t op, const type_t* input, std::size_t n, type_t* output, const edge_t* segments,
+            gcuda::standard_context_t& context) {
+  if (n == 0) return;
+  std::size_t blocks = (n + 3) / 4;  // 4 waves per workgroup
+  const std::size_t cap = (std::size_t)context.props().multiProcessorCount * 16;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL((kernel<output_type, graph_t, operator_t, type_t, edge_t>), dim3((unsigned)blocks), dim3(256), 0,
+                     context.stream(), G, op, input, n, output, segments);
+}
+
+}  // namespace warp_mapped
+}  // namespace advance
+}  // namespace operators
+}  // namespace gunrock

@@ -1,10 +1,10 @@
-// grx_scan.hpp -- device-wide exclusive prefix sum (int32) in three launches.
+// scan.hxx -- device-wide exclusive prefix sum (int32) in three launches.
 // Used off the per-level hot path (transpose build, generic operators'
 // output sizing); replaces thrust::transform_exclusive_scan
 // (include/gunrock/framework/operators/advance/helpers.hxx:70-79).
 #pragma once
 
-#include "grx_device.hpp"
+#include <gunrock/hip/wave.hxx>
 
 namespace grx {
 

@@ -1,4 +1,4 @@
-// grx_device.hpp -- wave64 device primitives for gfx950 (CDNA4).
+// wave.hxx -- wave64 device primitives for gfx950 (CDNA4).
 //
 // These replace what the reference takes from hipCUB / rocThrust on the hot
 // path (BlockScan in advance/block_mapped.hxx:89,123; transform_exclusive_scan
