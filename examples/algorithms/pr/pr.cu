@@ -1,6 +1,6 @@
 // pr.cu -- `pr --market graph.mtx [-n runs]`
 // CLI parity: examples/algorithms/pr/pr.cu (reference): alpha = 0.85, tol = 1e-6
-// hard-coded (pr.cu:46-47), prints "GPU p[:40] = " and "GPU Elapsed Time : ".
+// hard-coded (pr.cu:46-47), prints "GPU rank[:40] = " and "GPU Elapsed Time : ".
 #include <gunrock/algorithms/pr.hxx>
 #include <gunrock/framework/benchmark.hxx>
 #include <gunrock/util/performance.hxx>
@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
     util::stats::export_performance_stats(metrics, n_edges, n_vertices, run_times, "pr", arguments.filename, "market",
                                           arguments.json_dir, arguments.json_file, no_sources, tags, argc, argv);
   }
-  print::head(p, 40, "GPU p");
+  print::head(p, 40, "GPU rank");
   std::cout << "GPU Elapsed Time : " << run_times.back() << " (ms)" << std::endl;
   std::cout << "Iterations : " << iterations << std::endl;
   return 0;

@@ -74,8 +74,8 @@ def test_readme_commands_on_chesapeake(binaries):
     # reference README.md:97-111: bfs --market chesapeake.mtx --src 0 ; tuned: merge_path + compact filter
     r = run([os.path.join(BIN, "bfs"), "--market", CHES, "--src", "0", "--validate"])
     assert "Source : 0" in r.stdout
-    assert "GPU distances[:40] = " + CHES_HEAD in r.stdout.replace(" \n", "\n")
-    assert "CPU Distances[:40] = " + CHES_HEAD in r.stdout.replace(" \n", "\n")
+    assert "GPU distances[:39] = " + CHES_HEAD in r.stdout.replace(" \n", "\n")
+    assert "CPU Distances[:39] = " + CHES_HEAD in r.stdout.replace(" \n", "\n")
     assert re.search(r"GPU Elapsed Time : [0-9.e+-]+ \(ms\)", r.stdout)
     assert "Number of errors : 0" in r.stdout
     r = run([os.path.join(BIN, "bfs"), "-m", CHES, "-s", "0", "--advance_load_balance", "merge_path",
@@ -84,7 +84,7 @@ def test_readme_commands_on_chesapeake(binaries):
     r = run([os.path.join(BIN, "sssp"), "--market=" + CHES, "--src=5", "--validate"])
     assert "Number of errors : 0" in r.stdout
     r = run([os.path.join(BIN, "pr"), "--market", CHES, "-n", "2"])
-    assert "GPU p[:40] = " in r.stdout and "GPU Elapsed Time" in r.stdout
+    assert "GPU rank[:39] = " in r.stdout and "GPU Elapsed Time" in r.stdout
 
 
 @pytest.mark.gpu
@@ -118,7 +118,7 @@ def test_every_operator_combination_validates(binaries, gr, tmp_path):
     assert r.returncode != 0
     # PR: engine (pull) vs generic (push on the operators) agree
     def ranks(out):
-        line = [l for l in out.splitlines() if l.startswith("GPU p[:40]")][0]
+        line = [l for l in out.splitlines() if l.startswith("GPU rank[:")][0]
         return np.array(line.split("=")[1].split(), dtype=np.float64)
     a = ranks(run([os.path.join(BIN, "pr"), "--market", weighted]).stdout)
     b = ranks(run([os.path.join(BIN, "pr_generic"), "--market", weighted]).stdout)
@@ -156,7 +156,7 @@ def test_reference_sources_run_on_our_framework(gr, tmp_path):
              "--advance_load_balance", "merge_path", "--enable_filter", "--filter_algorithm", "compact"])
     assert "Number of errors : 0" in r.stdout  # throws upstream (filter/compact.hxx:21-24); works here
     def ranks(out):
-        line = [l for l in out.splitlines() if l.startswith("GPU p[:40]")][0]
+        line = [l for l in out.splitlines() if l.startswith("GPU rank[:")][0]
         return np.array(line.split("=")[1].split(), dtype=np.float64)
     a = ranks(run([os.path.join(DROPIN, "refalg_pr"), "--market", CHES]).stdout)
     b = ranks(run([os.path.join(BIN, "pr"), "--market", CHES]).stdout)
