@@ -382,7 +382,7 @@ def run_stats(context):
     s = grx_run_stats_t()
     _capi.check(_capi.lib().grx_get_run_stats(context._h, C.byref(s)))
     return {"edges_visited": s.edges_visited, "vertices_visited": s.vertices_visited,
-            "search_depth": s.search_depth, "elapsed_ms": s.elapsed_ms}
+            "search_depth": s.search_depth, "elapsed_ms": s.elapsed_ms, "aux": s.reserved}
 
 
 def level_profile(context, capacity=65536):

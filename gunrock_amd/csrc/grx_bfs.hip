@@ -15,18 +15,29 @@
 
 namespace grx {
 
-struct bfs_policy {
+// VARIANT 0: bitmap claim (default).  Tuning variants kept for A/B runs
+// (engine_flags bits 8..): 1 = atomicMin on the label array like upstream,
+// 2 = bitmap with an agent-scope (L1-bypassing) pre-check, 3 = variant 0 that
+// also counts attempted atomics into ctrl->spare[0].
+template <int VARIANT>
+struct bfs_policy_t {
   using src_state = int;
   int32_t* dist;
   unsigned* visited;
   int next_depth;
+  ctrl_t* ctrl;
 
-  __device__ __forceinline__ void begin(const ctrl_t* c) { next_depth = c->level + 1; }
+  __device__ __forceinline__ void begin(ctrl_t* c) { next_depth = c->level + 1; ctrl = c; }
   __device__ __forceinline__ src_state load_source(int) const { return 0; }
   __device__ __forceinline__ bool precheck(src_state, int n, int) const {
+    if constexpr (VARIANT == 1) return dist[n] > next_depth;
+    if constexpr (VARIANT == 2)
+      return (__hip_atomic_load(&visited[n >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << (n & 31))) == 0u;
     return (visited[n >> 5] & (1u << (n & 31))) == 0u;
   }
   __device__ __forceinline__ bool visit(int, src_state, int n, int) const {
+    if constexpr (VARIANT == 1) return next_depth < atomicMin(&dist[n], next_depth);
+    if constexpr (VARIANT == 3) atomicAdd(&ctrl->spare[0], 1);
     const unsigned bit = 1u << (n & 31);
     const unsigned old = atomicOr(&visited[n >> 5], bit);
     if (old & bit) return false;
@@ -34,6 +45,7 @@ struct bfs_policy {
     return true;
   }
 };
+using bfs_policy = bfs_policy_t<0>;
 
 __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, int src) {
   const int tid = threadIdx.x;
@@ -53,6 +65,7 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
     c->total_chunks = 0;
     c->edges_visited = 0;
     c->vertices_visited = 0;
+    c->spare[0] = 0;
     dist[src] = 0;
     visited[src >> 5] = 1u << (src & 31);
     a.mailbox[0] = 0;
@@ -92,7 +105,8 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   GRX_HIP(hipEventRecord(ctx->ev_begin, s));
   hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, visited, src);
 
-  bfs_policy pol{d_dist, visited, 0};
+  bfs_policy pol{d_dist, visited, 0, nullptr};
+  const int variant = (opt.engine_flags >> 8) & 3;
   const int grid = advance_grid(ctx);
   const bool profile = (opt.engine_flags & GRX_FLAG_PROFILE) != 0;
   ctx->levels.clear();
@@ -105,7 +119,15 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (profile) (void)hipEventRecord(pe[0], stream);
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a);
     if (profile) (void)hipEventRecord(pe[1], stream);
-    hipLaunchKernelGGL((advance_kernel<bfs_policy>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
+    switch (variant) {
+      case 1: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<1>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
+                                 bfs_policy_t<1>{d_dist, visited, 0, nullptr}); break;
+      case 2: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<2>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
+                                 bfs_policy_t<2>{d_dist, visited, 0, nullptr}); break;
+      case 3: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<3>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
+                                 bfs_policy_t<3>{d_dist, visited, 0, nullptr}); break;
+      default: hipLaunchKernelGGL((advance_kernel<bfs_policy>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
+    }
     if (profile) {
       (void)hipEventRecord(pe[2], stream);
       (void)hipEventSynchronize(pe[2]);
@@ -144,6 +166,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   ctx->stats.search_depth = ctx->h_ctrl->level;
   ctx->stats.elapsed_ms = ms;
   ctx->stats.n_levels_recorded = (int32_t)ctx->levels.size();
+  ctx->stats.reserved = (float)ctx->h_ctrl->spare[0];  // tuning variant 3: attempted atomics
   if (elapsed_ms) *elapsed_ms = ms;
   return GRX_SUCCESS;
 }

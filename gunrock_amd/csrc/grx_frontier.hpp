@@ -112,7 +112,7 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a) {
 
 // ---------------------------------------------------------------------------
 // advance + fused compaction.  Policy interface (all __device__):
-//   void begin(const ctrl_t*)                         once per workgroup
+//   void begin(ctrl_t*)                               once per workgroup
 //   src_state load_source(int v)                      per staged slot (e.g. dist[v])
 //   bool precheck(src_state, int nbr, int e)          cheap, read-only filter
 //   bool visit(int src, src_state, int nbr, int e)    true => nbr joins the output

@@ -25,7 +25,7 @@ struct sssp_policy {
   const float* w;
   int level;
 
-  __device__ __forceinline__ void begin(const ctrl_t* c) { level = c->level; }
+  __device__ __forceinline__ void begin(ctrl_t* c) { level = c->level; }
   __device__ __forceinline__ src_state load_source(int v) const { return dist[v]; }
   __device__ __forceinline__ float edge_weight(int e) const { return w ? w[e] : 1.0f; }
   __device__ __forceinline__ bool precheck(src_state d_src, int n, int e) const {

@@ -1,0 +1,44 @@
+"""Tiny workload driver for profiling: run one algorithm a few times on a bench workload.
+    python tools/run_algo.py bfs|sssp|pr lj|kron|road|small [runs] [engine_flags] [lb]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gunrock_amd as gr  # noqa: E402
+from bench import WORKLOADS  # noqa: E402
+
+algo = sys.argv[1]
+wl = WORKLOADS[sys.argv[2]]
+runs = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+lb = getattr(gr, sys.argv[5]) if len(sys.argv) > 5 else gr.merge_path
+props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], wl["c"], seed=42)
+if algo == "sssp" and not props.weighted:
+    rng = np.random.default_rng(1)
+    csr.nonzero_values = rng.integers(1, 1001, csr.number_of_nonzeros).astype(np.float32)
+    csr._device = None
+src = int(np.argmax(np.diff(csr.row_offsets)))
+if sys.argv[2] == "road":
+    src = (4894 // 2) * 4894 + 4894 // 2
+ctx = gr.multi_context_t(0)
+G = gr.build_graph(props, csr, ctx)
+V = G.get_number_of_vertices()
+o = gr.options_t(advance_load_balance=lb, engine_flags=flags)
+times = []
+for _ in range(runs):
+    if algo == "bfs":
+        d = torch.empty(V, dtype=torch.int32, device="cuda")
+        times.append(gr.bfs(G, src, d, None, ctx, o))
+    elif algo == "sssp":
+        d = torch.empty(V, dtype=torch.float32, device="cuda")
+        times.append(gr.sssp(G, src, d, None, ctx, o))
+    else:
+        p = torch.empty(V, dtype=torch.float32, device="cuda")
+        res = gr.pr_result_t(p)
+        times.append(gr.pr_run(G, gr.pr_param_t(0.85, 1e-6, o), res, ctx))
+st = gr.run_stats(ctx)
+print("algo", algo, "ms", [round(t, 3) for t in times], "stats", st,
+      "mteps", round(st["edges_visited"] / (min(times) * 1e3), 1))
