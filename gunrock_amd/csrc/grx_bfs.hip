@@ -4,21 +4,34 @@
 //   reset   :59-69   distances = INT_MAX, distances[source] = 0
 //   advance :105-128 old = atomicMin(&dist[nbr], iteration + 1); keep if improved
 //   filter  :130-146 drop the invalid (-1) slots
-// Result parity: depths are bit-identical (first discovery level is unique).
-// MI355X implementation: the claim is an atomicOr on a visited BITMAP
-// (V/8 bytes, L2-resident) instead of an atomicMin on the 4V-byte label array;
-// exactly one thread wins a vertex, writes its depth with a plain store and
-// emits it -- so advance and filter are one kernel and no -1 ever reaches HBM.
+// Result parity: depths are bit-identical (the first-discovery level is unique).
+//
+// MI355X implementation
+//  * top-down levels: advance_kernel<bfs_policy> -- stale pre-check on the label,
+//    then the reference's atomicMin claim; exactly one thread wins a vertex and
+//    emits it, so advance and filter are one kernel and no -1 reaches HBM.
+//  * bottom-up levels (advance_direction = optimized; the reference declares the
+//    enum, operators/configs.hxx:78-82, and ignores it): every unvisited vertex
+//    scans its IN-edges until it finds a parent in the frontier bitmap.  A wave
+//    owns 64 consecutive vertices, so bitmap words are assembled with a ballot and
+//    written with plain stores -- no atomics at all; the frontier bitmap is
+//    read-only during the level and stays L2 resident.  The switch follows Beamer's
+//    heuristic (frontier edges vs unexplored edges / alpha; frontier size vs V / beta)
+//    and is taken ON THE DEVICE by bfs_decide_kernel, so the host still enqueues
+//    levels blindly.
 #include "grx_engine.hpp"
 
 #include <climits>
 
 namespace grx {
 
-// VARIANT 0: bitmap claim (default).  Tuning variants kept for A/B runs
-// (engine_flags bits 8..): 1 = atomicMin on the label array like upstream,
-// 2 = bitmap with an agent-scope (L1-bypassing) pre-check, 3 = variant 0 that
-// also counts attempted atomics into ctrl->spare[0].
+constexpr int DO_ALPHA = 14;
+constexpr int DO_BETA = 24;
+
+// VARIANT 0: the reference's claim, atomicMin on the label array with a stale
+// pre-check (fastest measured).  Tuning variants for A/B runs (engine_flags bits
+// 8-9): 1 = claim on a visited bitmap (atomicOr), 2 = same with an agent-scope
+// pre-check, 3 = variant 1 counting attempted atomics in ctrl->spare[0].
 template <int VARIANT>
 struct bfs_policy_t {
   using src_state = int;
@@ -30,13 +43,13 @@ struct bfs_policy_t {
   __device__ __forceinline__ void begin(ctrl_t* c) { next_depth = c->level + 1; ctrl = c; }
   __device__ __forceinline__ src_state load_source(int) const { return 0; }
   __device__ __forceinline__ bool precheck(src_state, int n, int) const {
-    if constexpr (VARIANT == 1) return dist[n] > next_depth;
+    if constexpr (VARIANT == 0) return dist[n] > next_depth;
     if constexpr (VARIANT == 2)
       return (__hip_atomic_load(&visited[n >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << (n & 31))) == 0u;
     return (visited[n >> 5] & (1u << (n & 31))) == 0u;
   }
   __device__ __forceinline__ bool visit(int, src_state, int n, int) const {
-    if constexpr (VARIANT == 1) return next_depth < atomicMin(&dist[n], next_depth);
+    if constexpr (VARIANT == 0) return next_depth < atomicMin(&dist[n], next_depth);
     if constexpr (VARIANT == 3) atomicAdd(&ctrl->spare[0], 1);
     const unsigned bit = 1u << (n & 31);
     const unsigned old = atomicOr(&visited[n >> 5], bit);
@@ -46,6 +59,17 @@ struct bfs_policy_t {
   }
 };
 using bfs_policy = bfs_policy_t<0>;
+
+struct dobfs_args {
+  const int32_t* t_ro;   // in-edges (transpose; the CSR itself for symmetric graphs)
+  const int32_t* t_ci;
+  int32_t* dist;
+  unsigned* visited;     // bitmap, maintained only while running bottom-up
+  unsigned* fbits[2];    // frontier bitmaps by level parity
+  int32_t n_words;       // 32-bit words per bitmap (even)
+  int32_t n_edges;
+  int32_t enabled;       // direction optimisation on
+};
 
 __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, int src) {
   const int tid = threadIdx.x;
@@ -66,11 +90,216 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
     c->edges_visited = 0;
     c->vertices_visited = 0;
     c->spare[0] = 0;
+    c->mode = 0;
+    c->frontier_bitmap = 0;
+    c->convert = 0;
+    c->bu_count[0] = c->bu_count[1] = 0;
+    c->bu_edges[0] = c->bu_edges[1] = 0;
+    c->q_edges[0] = deg;
+    c->q_edges[1] = 0;
     dist[src] = 0;
-    visited[src >> 5] = 1u << (src & 31);
+    if (visited) visited[src >> 5] = 1u << (src & 31);
     a.mailbox[0] = 0;
     a.mailbox[1] = 0;
     a.mailbox[2] = 0;
+  }
+}
+
+// Level bookkeeping + direction choice.  <<<1, 64>>>
+__global__ void bfs_decide_kernel(pipe_args a, dobfs_args d) {
+  if (threadIdx.x != 0) return;
+  ctrl_t* c = a.ctrl;
+  if (c->done) return;
+  const int level = c->level + 1;
+  const int p = level & 1;
+  const int is_bitmap = c->frontier_bitmap;
+  const long long n_f = is_bitmap ? c->bu_count[p] : c->n_items[p];
+  const long long m_f = is_bitmap ? c->bu_edges[p] : c->q_edges[p];
+  if (n_f == 0) {
+    c->done = 1;
+    c->level = level;
+    a.mailbox[1] = level;
+    a.mailbox[0] = 1;
+    return;
+  }
+  int mode = c->mode;
+  if (d.enabled) {
+    const long long m_u = (long long)d.n_edges - c->edges_visited;  // edges of still-unexpanded vertices
+    if (mode == 0) {
+      if (m_f > m_u / DO_ALPHA && n_f > 256) mode = 1;
+    } else {
+      if (n_f < (long long)a.V / DO_BETA) mode = 0;
+    }
+  }
+  c->convert = (mode == 0 && is_bitmap) ? 1 : ((mode == 1 && !is_bitmap) ? 2 : 0);
+  c->mode = mode;
+  c->level = level;
+  c->edges_visited += m_f;
+  c->vertices_visited += n_f;
+  c->n_tiles[p ^ 1] = 0;
+  c->n_items[p ^ 1] = 0;
+  c->q_edges[p ^ 1] = 0;
+  c->bu_count[p ^ 1] = 0;
+  c->bu_edges[p ^ 1] = 0;
+  if (c->convert == 1) {  // the queue of this level is rebuilt from the bitmap
+    c->n_tiles[p] = 0;
+    c->n_items[p] = 0;
+    c->q_edges[p] = 0;
+  }
+  c->frontier_bitmap = mode;  // format of the frontier this level PRODUCES
+  a.mailbox[1] = level;
+  a.mailbox[2] = (int)n_f;
+}
+
+// Frontier format change at a direction switch.
+//   convert == 2 (top-down -> bottom-up): rebuild BOTH bitmaps from the labels with
+//     coalesced reads: visited = (dist != INF), frontier = (dist == level).
+//   convert == 1 (bottom-up -> top-down): expand the frontier bitmap into tiles.
+__global__ __launch_bounds__(ADV_BLOCK) void bfs_convert_kernel(pipe_args a, dobfs_args d) {
+  __shared__ int s_out[TILE + ADV_BLOCK * 32];
+  __shared__ int s_wave[ADV_BLOCK / 64 + 1];
+  __shared__ int s_tix;
+  __shared__ int s_cnt;
+  ctrl_t* c = a.ctrl;
+  if (c->done) return;
+  const int convert = c->convert;
+  if (convert == 0) return;
+  const int level = c->level;
+  const int p = level & 1;
+  const int tid = threadIdx.x;
+  const int lane = dev::lane_id();
+  if (convert == 2) {
+    unsigned* fin = d.fbits[p];
+    const int n_chunks = d.n_words / 2;
+    const int wave = (blockIdx.x * ADV_BLOCK + tid) >> 6;
+    const int n_waves = (gridDim.x * ADV_BLOCK) >> 6;
+    for (int ch = wave; ch < n_chunks; ch += n_waves) {
+      const int v = ch * 64 + lane;
+      const int dv = v < a.V ? d.dist[v] : INT_MAX;
+      const unsigned long long vis = dev::ballot(dv != INT_MAX);
+      const unsigned long long fr = dev::ballot(dv == level);
+      if (lane == 0) {
+        d.visited[2 * ch] = (unsigned)vis;
+        d.visited[2 * ch + 1] = (unsigned)(vis >> 32);
+        fin[2 * ch] = (unsigned)fr;
+        fin[2 * ch + 1] = (unsigned)(fr >> 32);
+      }
+    }
+    return;
+  }
+  // convert == 1: each thread takes one bitmap word per round
+  const unsigned* fin = d.fbits[p];
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  for (int base = blockIdx.x * ADV_BLOCK; base < d.n_words; base += gridDim.x * ADV_BLOCK) {
+    const int w = base + tid;
+    unsigned bits = w < d.n_words ? fin[w] : 0u;
+    int cnt = __popc(bits);
+    int tot;
+    int at = s_cnt + dev::block_exclusive_sum<ADV_BLOCK>(cnt, s_wave, &tot);
+    while (bits) {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      s_out[at++] = w * 32 + b;
+    }
+    __syncthreads();
+    int have = s_cnt + tot;
+    __syncthreads();
+    while (have >= TILE) {
+      emit_tile(a, c, p, s_out, have - TILE, TILE, s_wave, &s_tix);
+      have -= TILE;
+      __syncthreads();
+    }
+    if (tid == 0) s_cnt = have;
+    __syncthreads();
+  }
+  const int rem = s_cnt;
+  if (rem > 0) emit_tile(a, c, p, s_out, 0, rem, s_wave, &s_tix);
+}
+
+// Bottom-up level.  One wave per 64 consecutive vertices.
+__global__ __launch_bounds__(ADV_BLOCK) void bfs_bottomup_kernel(pipe_args a, dobfs_args d) {
+  __shared__ int s_cnt[ADV_BLOCK / 64];
+  __shared__ long long s_deg[ADV_BLOCK / 64];
+  ctrl_t* c = a.ctrl;
+  if (c->done || c->mode != 1) return;
+  const int level = c->level;
+  const int p = level & 1;
+  const unsigned* __restrict__ fin = d.fbits[p];
+  unsigned* fout = d.fbits[p ^ 1];
+  const int lane = dev::lane_id();
+  const int wid = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * ADV_BLOCK + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * ADV_BLOCK) >> 6;
+  const int n_chunks = d.n_words / 2;
+  int my_cnt = 0;
+  long long my_deg = 0;
+  constexpr int SERIAL = 8;
+  for (int ch = wave; ch < n_chunks; ch += n_waves) {
+    const unsigned long long vis =
+        (unsigned long long)d.visited[2 * ch] | ((unsigned long long)d.visited[2 * ch + 1] << 32);
+    const int v = ch * 64 + lane;
+    const bool open = v < a.V && !((vis >> lane) & 1ull);
+    if (dev::ballot(open) == 0ull) {
+      if (lane == 0) { fout[2 * ch] = 0u; fout[2 * ch + 1] = 0u; }
+      continue;
+    }
+    int b = 0, e = 0;
+    if (open) { b = d.t_ro[v]; e = d.t_ro[v + 1]; }
+    bool found = false;
+    // phase A: a few serial probes per lane (most vertices find a parent at once)
+    const int stop = min(e, b + SERIAL);
+    for (int k = b; k < stop; ++k) {
+      const int u = d.t_ci[k];
+      if (fin[u >> 5] & (1u << (u & 31))) { found = true; break; }
+    }
+    // phase B: long in-lists are scanned by the whole wave, 64 edges per step
+    unsigned long long pend = dev::ballot(open && !found && e > b + SERIAL);
+    while (pend) {
+      const int src_lane = __builtin_ctzll(pend);
+      pend &= pend - 1;
+      const int bb = __shfl(b, src_lane, 64) + SERIAL, ee = __shfl(e, src_lane, 64);
+      bool hit = false;
+      for (int k = bb; k < ee; k += 64) {
+        const int kk = k + lane;
+        bool h = false;
+        if (kk < ee) {
+          const int u = d.t_ci[kk];
+          h = (fin[u >> 5] & (1u << (u & 31))) != 0u;
+        }
+        if (dev::ballot(h)) { hit = true; break; }
+      }
+      if (lane == src_lane) found = hit;
+    }
+    const unsigned long long nw = dev::ballot(found);
+    if (lane == 0) {
+      fout[2 * ch] = (unsigned)nw;
+      fout[2 * ch + 1] = (unsigned)(nw >> 32);
+      const unsigned long long nv = vis | nw;
+      d.visited[2 * ch] = (unsigned)nv;
+      d.visited[2 * ch + 1] = (unsigned)(nv >> 32);
+    }
+    if (found) {
+      d.dist[v] = level + 1;
+      my_cnt += 1;
+      my_deg += a.ro[v + 1] - a.ro[v];
+    }
+  }
+  // per-workgroup totals -> two atomics per workgroup
+  my_cnt = dev::wave_sum(my_cnt);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) my_deg += __shfl_xor(my_deg, o, 64);
+  if (lane == 0) { s_cnt[wid] = my_cnt; s_deg[wid] = my_deg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tc = 0;
+    long long td = 0;
+#pragma unroll
+    for (int i = 0; i < ADV_BLOCK / 64; ++i) { tc += s_cnt[i]; td += s_deg[i]; }
+    if (tc) {
+      atomicAdd(&c->bu_count[p ^ 1], tc);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&c->bu_edges[p ^ 1]), (unsigned long long)td);
+    }
   }
 }
 
@@ -93,20 +322,45 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   pipe_args a;
   grx_status_t st = pipeline_prepare(ctx, g, &a);
   if (st != GRX_SUCCESS) return st;
-  const size_t bm_words = ((size_t)g->V + 31) / 32;
-  GRX_HIP(ctx->bitmap[0].reserve(bm_words * sizeof(unsigned)));
-  unsigned* visited = ctx->bitmap[0].as<unsigned>();
+  const int variant = (opt.engine_flags >> 8) & 3;
+  const bool dopt = opt.advance_direction == GRX_DIR_OPTIMIZED && variant == 0;
+  const size_t bm_words = 2 * (((size_t)g->V + 63) / 64);
   hipStream_t s = ctx->stream;
+
+  dobfs_args d{};
+  d.dist = d_dist;
+  d.n_words = (int32_t)bm_words;
+  d.n_edges = g->E;
+  d.enabled = dopt ? 1 : 0;
+  unsigned* visited = nullptr;
+  if (dopt) {
+    // in-edges: the CSR itself when the graph is symmetric, else the cached transpose
+    if (g->symmetric) {
+      d.t_ro = g->ro;
+      d.t_ci = g->ci;
+    } else {
+      st = graph_build_transpose(ctx, g);
+      if (st != GRX_SUCCESS) return st;
+      d.t_ro = g->t_ro;
+      d.t_ci = g->t_ci;
+    }
+    GRX_HIP(ctx->bitmap[0].reserve(bm_words * sizeof(unsigned)));
+    GRX_HIP(ctx->bitmap[1].reserve(2 * bm_words * sizeof(unsigned)));
+    d.visited = ctx->bitmap[0].as<unsigned>();
+    d.fbits[0] = ctx->bitmap[1].as<unsigned>();
+    d.fbits[1] = d.fbits[0] + bm_words;
+  } else if (variant != 0) {
+    GRX_HIP(ctx->bitmap[0].reserve(bm_words * sizeof(unsigned)));
+    visited = ctx->bitmap[0].as<unsigned>();
+  }
 
   // problem.reset() -- outside the timed region, as in the reference
   GRX_HIP(fill_i32(s, d_dist, INT_MAX, g->V));
-  GRX_HIP(hipMemsetAsync(visited, 0, bm_words * sizeof(unsigned), s));
+  if (visited) GRX_HIP(hipMemsetAsync(visited, 0, bm_words * sizeof(unsigned), s));
 
   GRX_HIP(hipEventRecord(ctx->ev_begin, s));
   hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, visited, src);
 
-  bfs_policy pol{d_dist, visited, 0, nullptr};
-  const int variant = (opt.engine_flags >> 8) & 3;
   const int grid = advance_grid(ctx);
   const bool profile = (opt.engine_flags & GRX_FLAG_PROFILE) != 0;
   ctx->levels.clear();
@@ -115,9 +369,16 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
 
   hipError_t launch_err = hipSuccess;
   int64_t prof_v = 0, prof_e = 0;
+  int launches = 0;
   st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
     if (profile) (void)hipEventRecord(pe[0], stream);
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a);
+    if (dopt) {
+      hipLaunchKernelGGL(bfs_decide_kernel, dim3(1), dim3(64), 0, stream, a, d);
+      hipLaunchKernelGGL(bfs_convert_kernel, dim3(grid / 2), dim3(ADV_BLOCK), 0, stream, a, d);
+      hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 1);
+    } else {
+      hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
+    }
     if (profile) (void)hipEventRecord(pe[1], stream);
     switch (variant) {
       case 1: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<1>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
@@ -126,8 +387,11 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
                                  bfs_policy_t<2>{d_dist, visited, 0, nullptr}); break;
       case 3: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<3>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
                                  bfs_policy_t<3>{d_dist, visited, 0, nullptr}); break;
-      default: hipLaunchKernelGGL((advance_kernel<bfs_policy>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
+      default: hipLaunchKernelGGL((advance_kernel<bfs_policy>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
+                                  bfs_policy{d_dist, nullptr, 0, nullptr});
     }
+    if (dopt) hipLaunchKernelGGL(bfs_bottomup_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d);
+    ++launches;
     if (profile) {
       (void)hipEventRecord(pe[2], stream);
       (void)hipEventSynchronize(pe[2]);
@@ -146,6 +410,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       level_rec& r = ctx->levels.back();
       r.frontier_size = h.vertices_visited - prof_v;
       r.edges = h.edges_visited - prof_e;
+      if (h.mode == 1) r.frontier_size = -r.frontier_size;  // negative marks a bottom-up level
       prof_v = h.vertices_visited;
       prof_e = h.edges_visited;
     } else if (profile && h.done && !ctx->levels.empty()) {
@@ -166,7 +431,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   ctx->stats.search_depth = ctx->h_ctrl->level;
   ctx->stats.elapsed_ms = ms;
   ctx->stats.n_levels_recorded = (int32_t)ctx->levels.size();
-  ctx->stats.reserved = (float)ctx->h_ctrl->spare[0];  // tuning variant 3: attempted atomics
+  ctx->stats.reserved = variant == 3 ? (float)ctx->h_ctrl->spare[0] : (float)launches;
   if (elapsed_ms) *elapsed_ms = ms;
   return GRX_SUCCESS;
 }

@@ -75,6 +75,14 @@ struct ctrl_t {
   float pr_err;
   int32_t pr_iter;
   int32_t pad1;
+  // direction-optimising BFS
+  int32_t mode;             // direction of the CURRENT level: 0 top-down (queue), 1 bottom-up (bitmap)
+  int32_t frontier_bitmap;  // 1 if the frontier entering the next decide step is a bitmap
+  int32_t convert;          // this level: 0 none, 1 bitmap -> queue, 2 labels -> bitmaps
+  int32_t bu_count[2];      // vertices discovered by a bottom-up level, by output parity
+  int32_t pad2;
+  int64_t bu_edges[2];      // their out-degree sum
+  int64_t q_edges[2];       // out-degree sum of the queue frontier, accumulated at tile emission
 };
 
 struct level_rec {

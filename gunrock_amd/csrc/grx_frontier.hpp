@@ -53,20 +53,25 @@ struct pipe_args {
 // ---------------------------------------------------------------------------
 // plan: per-level bookkeeping + chunk map.  <<<1, 1024>>>
 // ---------------------------------------------------------------------------
-static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a) {
+// external_control != 0: level bookkeeping, termination and counters are done by
+// another kernel (direction-optimising BFS); this one only builds the chunk map of
+// a top-down level and leaves when the level runs bottom-up.
+static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, int external_control) {
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
   __shared__ unsigned long long s_esum;
   ctrl_t* c = a.ctrl;
   const int tid = threadIdx.x;
   const int done = c->done;
-  const int level = c->level + 1;
+  const int level = external_control ? c->level : c->level + 1;
   const int p = level & 1;
   const int nt = c->n_tiles[p];
   const int nitems = c->n_items[p];
+  const int mode = c->mode;
   if (tid == 0) s_esum = 0ull;
   __syncthreads();
   if (done) return;
-  if (nt == 0) {
+  if (external_control && mode != 0) return;
+  if (!external_control && nt == 0) {
     if (tid == 0) {
       c->done = 1;
       c->level = level;  // == number of advance iterations executed
@@ -99,15 +104,49 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a) {
   if (dev::lane_id() == 0) atomicAdd(&s_esum, (unsigned long long)esum);
   __syncthreads();
   if (tid == 0) {
-    c->level = level;
     c->total_chunks = carry;
-    c->edges_visited += (long long)s_esum;
-    c->vertices_visited += nitems;
-    c->n_tiles[p ^ 1] = 0;
-    c->n_items[p ^ 1] = 0;
-    a.mailbox[1] = level;
-    a.mailbox[2] = nitems;
+    if (!external_control) {
+      c->level = level;
+      c->edges_visited += (long long)s_esum;
+      c->vertices_visited += nitems;
+      c->n_tiles[p ^ 1] = 0;
+      c->n_items[p ^ 1] = 0;
+      c->q_edges[p ^ 1] = 0;
+      a.mailbox[1] = level;
+      a.mailbox[2] = nitems;
+    }
   }
+}
+
+// Emit n (<= TILE) vertices s_out[lo .. lo+n) as one tile of the frontier with
+// parity q: degree sum computed here, ONE tile-index atomic per 256 vertices.
+// Block-wide call (contains __syncthreads); s_wave/s_tix are LDS scratch.
+__device__ __forceinline__ void emit_tile(const pipe_args& a, ctrl_t* c, int q, const int* s_out, int lo, int n,
+                                          int* s_wave, int* s_tix) {
+  const int tid = threadIdx.x;
+  const int lane = dev::lane_id();
+  const int wid = tid >> 6;
+  int x = -1, deg = 0;
+  if (tid < n) {
+    x = s_out[lo + tid];
+    deg = a.ro[x + 1] - a.ro[x];
+  }
+  const int tsum = dev::wave_sum(deg);
+  if (lane == 0) s_wave[wid] = tsum;
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+#pragma unroll
+    for (int i = 0; i < ADV_BLOCK / 64; ++i) tot += s_wave[i];
+    const int tix = atomicAdd(&c->n_tiles[q], 1);
+    atomicAdd(&c->n_items[q], n);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&c->q_edges[q]), (unsigned long long)tot);
+    a.tile_sums[tix] = tot;
+    a.tile_chunks[tix] = (tot + CHUNK - 1) / CHUNK;
+    *s_tix = tix;
+  }
+  __syncthreads();
+  a.frontier[q][(size_t)(*s_tix) * TILE + tid] = x;
 }
 
 // ---------------------------------------------------------------------------
@@ -136,39 +175,11 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
   const int level = c->level;
   const int p = level & 1;
   const int total_chunks = c->total_chunks;
+  if (c->mode != 0) return;  // this level runs bottom-up
   const int32_t* __restrict__ in = a.frontier[p];
-  int32_t* __restrict__ out = a.frontier[p ^ 1];
   pol.begin(c);
   if (tid == 0) s_cnt = 0;
   __syncthreads();
-
-  // Emit one output tile from s_out[lo, lo + n) (n <= TILE).
-  auto emit_tile = [&](int lo, int n) {
-    int x = -1, deg = 0;
-    if (tid < n) {
-      x = s_out[lo + tid];
-      deg = a.ro[x + 1] - a.ro[x];
-    }
-    int tsum = dev::wave_sum(deg);
-    if (lane == 0) s_wave[wid] = tsum;
-    __syncthreads();
-    if (tid == 0) {
-      int tot = 0;
-#pragma unroll
-      for (int i = 0; i < ADV_BLOCK / 64; ++i) tot += s_wave[i];
-      // one device atomic per output tile: {n_items, n_tiles} packed in 64 bits
-      unsigned long long packed = ((unsigned long long)(unsigned)n << 32) | 1ull;
-      // n_tiles[q] and n_items[q] are not adjacent; use two atomics on distinct words
-      int tix = atomicAdd(&c->n_tiles[p ^ 1], 1);
-      atomicAdd(&c->n_items[p ^ 1], n);
-      (void)packed;
-      a.tile_sums[tix] = tot;
-      a.tile_chunks[tix] = (tot + CHUNK - 1) / CHUNK;
-      s_tix = tix;
-    }
-    __syncthreads();
-    out[(size_t)s_tix * TILE + tid] = x;
-  };
 
   for (int chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
     const int t = a.chunk_tile[chunk];
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
     // ---- flush full tiles --------------------------------------------------
     int cnt = s_cnt;
     while (cnt >= TILE) {
-      emit_tile(cnt - TILE, TILE);
+      emit_tile(a, c, p ^ 1, s_out, cnt - TILE, TILE, s_wave, &s_tix);
       cnt -= TILE;
       __syncthreads();
     }
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
     __syncthreads();
   }
   const int rem = s_cnt;
-  if (rem > 0) emit_tile(0, rem);
+  if (rem > 0) emit_tile(a, c, p ^ 1, s_out, 0, rem, s_wave, &s_tix);
 }
 
 }  // namespace grx

@@ -58,6 +58,9 @@ __global__ void sssp_init_kernel(pipe_args a, float* dist, int src) {
     c->total_chunks = 0;
     c->edges_visited = 0;
     c->vertices_visited = 0;
+    c->mode = 0;
+    c->q_edges[0] = 0;
+    c->q_edges[1] = 0;
     dist[src] = 0.0f;
     a.mailbox[0] = 0;
   }
@@ -98,7 +101,7 @@ extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
   ctx->levels.clear();
   hipError_t launch_err = hipSuccess;
   st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
     hipLaunchKernelGGL((advance_kernel<sssp_policy>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) launch_err = e;

@@ -29,6 +29,9 @@ def all_options(gr):
         yield gr.options_t(advance_load_balance=lb)
     yield gr.options_t(advance_load_balance=gr.merge_path, enable_filter=True, filter_algorithm=gr.compact)
     yield gr.options_t(engine_flags=gr.FLAG_SYNC_EACH_LEVEL)
+    yield gr.options_t(advance_direction=gr.optimized)  # direction-optimising (bottom-up fat levels)
+    yield gr.options_t(advance_direction=gr.optimized, engine_flags=gr.FLAG_PROFILE)
+    yield gr.options_t(engine_flags=1 << 8)  # tuning variant: bitmap claim
     yield gr.options_t(engine_flags=gr.FLAG_PROFILE)
 
 
@@ -108,6 +111,29 @@ def test_random_graphs_vs_oracle(gr, gpu_ctx):
             assert np.array_equal(d, O.bfs(g, src)[0])
 
 
+def test_direction_optimizing_switches_and_matches(gr, gpu_ctx):
+    """Symmetric (in-edges = CSR) and directed (engine builds the transpose) graphs;
+    the fat levels must actually run bottom-up and depths / counters must not change."""
+    import torch
+    for kind, V, E in (("rmat_sym", 1 << 17, 1_500_000), ("rmat", 1 << 17, 3_000_000)):
+        props, c = gr.generate(kind, V, E, seed=77)
+        g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+        src = int(np.argmax(np.diff(g.row_offsets)))
+        want, _, ev = O.bfs_queue(g, src)
+        G = gr.build_graph(props, c, gpu_ctx)
+        dist = torch.empty(V, dtype=torch.int32, device="cuda:0")
+        gr.bfs(G, src, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.optimized, engine_flags=gr.FLAG_PROFILE))
+        st = gr.run_stats(gpu_ctx)
+        prof = gr.level_profile(gpu_ctx)
+        assert np.array_equal(dist.cpu().numpy(), want)
+        assert st["edges_visited"] == ev and st["vertices_visited"] == int((want != INF).sum())
+        assert any(l["frontier_size"] < 0 for l in prof), "no level ran bottom-up"
+        assert prof[0]["frontier_size"] == 1  # the first level is always top-down
+        for s2 in (0, 17, V - 1):  # low-degree / isolated sources: may never switch
+            gr.bfs(G, s2, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.optimized))
+            assert np.array_equal(dist.cpu().numpy(), O.bfs_queue(g, s2)[0])
+
+
 def test_medium_rmat_and_repeatability(gr, gpu_ctx):
     _, c = gr.generate("rmat", 1 << 18, 4_000_000, seed=42)
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
@@ -125,8 +151,9 @@ def test_full_size_livejournal_standin_properties(gr, gpu_ctx):
     _, c = gr.generate("rmat", 4_847_571, 68_993_773, seed=42)
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
     src = int(np.argmax(np.diff(g.row_offsets)))
-    d, st = run_bfs(gr, gpu_ctx, g.row_offsets, g.column_indices, src)
-    assert O.check_bfs(g, src, d) == 0
-    reached = d != INF
-    assert st["vertices_visited"] == int(reached.sum())
-    assert st["edges_visited"] == int(np.diff(g.row_offsets)[reached].sum())
+    for opt in (None, gr.options_t(advance_direction=gr.optimized)):
+        d, st = run_bfs(gr, gpu_ctx, g.row_offsets, g.column_indices, src, opt)
+        assert O.check_bfs(g, src, d) == 0
+        reached = d != INF
+        assert st["vertices_visited"] == int(reached.sum())
+        assert st["edges_visited"] == int(np.diff(g.row_offsets)[reached].sum())
