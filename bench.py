@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--workload", default="lj", choices=sorted(WORKLOADS))
     ap.add_argument("--lb", default="merge_path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--topdown-only", action="store_true",
+                    help="advance_direction=forward: every level runs the top-down advance kernel")
     args = ap.parse_args()
 
     import torch
@@ -83,7 +85,9 @@ def main():
     t_setup = time.time() - t0
 
     lb = getattr(gr, args.lb)
-    opts = gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact)
+    direction = gr.forward if args.topdown_only else gr.optimized
+    opts = gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact,
+                        advance_direction=direction)
 
     def barrier():
         if dist_on:
@@ -117,27 +121,56 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel (advance), HIP events on the engine stream
-        popts = gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact,
-                             engine_flags=gr.FLAG_PROFILE)
-        best = None
-        for _ in range(3):
-            gr.bfs(G, src, dist_t, None, ctx, popts)
-            prof = gr.level_profile(ctx)
-            adv_ms = sum(l["advance_ms"] for l in prof)
-            if best is None or adv_ms < best[0]:
-                best = (adv_ms, prof)
-        adv_ms, prof = best
-        alg_bytes = sum(12 * l["frontier_size"] + 12 * l["edges"] for l in prof)
-        n_launch = max(1, len(prof))
-        achieved = alg_bytes / (adv_ms * 1e-3) / 1e9 if adv_ms > 0 else 0.0
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "kernel": "advance_kernel<bfs_policy>", "launches_per_step": n_launch,
-                    "alg_bytes_per_step": int(alg_bytes), "kernel_ms_per_step": round(adv_ms, 4),
-                    "avg_launch_us": round(adv_ms * 1e3 / n_launch, 2),
-                    "levels": [[l["frontier_size"], l["edges"], round(l["advance_ms"], 4), round(l["other_ms"], 4)]
-                               for l in prof]}
+        # ---- rooflines, HIP events on the engine stream (GRX_FLAG_PROFILE records per-level
+        # kernel times with events on ctx's stream and syncs after every level)
+        def profile(direction_):
+            popts = gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact,
+                                 advance_direction=direction_, engine_flags=gr.FLAG_PROFILE)
+            best_ = None
+            for _ in range(3):
+                gr.bfs(G, src, dist_t, None, ctx, popts)
+                prof_ = gr.level_profile(ctx)
+                t_ = sum(l["advance_ms"] for l in prof_)
+                if best_ is None or t_ < best_[0]:
+                    best_ = (t_, prof_)
+            return best_[1]
+
+        def roof(levels, bytes_of, kernel):
+            ms = sum(l["advance_ms"] for l in levels)
+            byt = sum(bytes_of(l) for l in levels)
+            ach = byt / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+                    "launches_per_step": len(levels), "alg_bytes_per_step": int(byt),
+                    "kernel_ms_per_step": round(ms, 4),
+                    "avg_launch_us": round(ms * 1e3 / max(1, len(levels)), 2)}
+
+        # top-down advance kernel: BASELINE.md / SURVEY 8d, 12 B per frontier slot + 12 B per edge
+        td_bytes = lambda l: 12 * l["frontier_size"] + 12 * l["edges"]
+        # bottom-up kernel: bytes it must touch -- visited r/w + next-frontier bitmap (3 * V/8),
+        # two in-offsets per open vertex (8), column index + frontier-bitmap word per probed
+        # in-edge (8), label + two out-offsets per discovered vertex (12)
+        bu_bytes = lambda l, nxt: 3 * (V // 8) + 8 * l["bu_open"] + 8 * l["bu_probes"] + 12 * nxt
+        prof_td = profile(gr.forward)
+        roofline_td = roof(prof_td, td_bytes, "advance_kernel<bfs_policy> (top-down only run)")
+        roofline_td["levels"] = [[l["frontier_size"], l["edges"], round(l["advance_ms"], 4), round(l["other_ms"], 4)]
+                                 for l in prof_td]
+        if args.topdown_only:
+            roofline, roofline_other = roofline_td, None
+        else:
+            prof_do = profile(gr.optimized)
+            sizes = [l["frontier_size"] for l in prof_do] + [0]
+            bu = [dict(l, nxt=sizes[i + 1]) for i, l in enumerate(prof_do) if l["bottom_up"]]
+            td = [l for l in prof_do if not l["bottom_up"]]
+            t_bu = sum(l["advance_ms"] for l in bu)
+            t_td = sum(l["advance_ms"] for l in td)
+            r_bu = roof(bu, lambda l: bu_bytes(l, l["nxt"]), "bfs_bottomup_kernel")
+            r_bu["levels"] = [[l["frontier_size"], l["edges"], l["bu_open"], l["bu_probes"], round(l["advance_ms"], 4),
+                               round(l["other_ms"], 4)] for l in bu]
+            r_bu["share_of_step_kernel_time"] = round(t_bu / max(t_bu + t_td, 1e-9), 3)
+            roofline, roofline_other = (r_bu, roofline_td) if t_bu >= t_td or not td else (roofline_td, r_bu)
+            roofline["all_levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
+                                       round(l["other_ms"], 4)] for l in prof_do]
         # ---- CPU baseline: the oracle (port of the reference's PQ CPU path), bounded sample
         cpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -162,10 +195,12 @@ def main():
                "vs_baseline": None, "dtype": "int32", "data": "synthetic",
                "config": {"workload": wl["name"], "n_vertices": V, "n_edges": E, "source": src,
                           "advance_load_balance": args.lb, "filter": "compact (fused into advance)",
+                          "advance_direction": "forward" if args.topdown_only else "optimized",
+                          "kernel_launch_groups_per_step": int(st["aux"]),
                           "parallelism": "1 graph replica per GPU, independent sources" if world > 1 else "single GPU",
                           "edges_visited_per_step": edges_rank, "search_depth": st["search_depth"],
                           "enact_ms_last": round(enact_ms, 4), "setup_s": round(t_setup, 1)},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "roofline_topdown_advance": roofline_other, "cpu_baseline": cpu}
         print(json.dumps(out))
     if dist_on:
         dist.barrier()

@@ -390,7 +390,8 @@ def level_profile(context, capacity=65536):
     n = C.c_int32(0)
     _capi.check(_capi.lib().grx_get_level_profile(context._h, arr, capacity, C.byref(n)))
     return [{"frontier_size": arr[i].frontier_size, "edges": arr[i].edges,
-             "advance_ms": arr[i].advance_ms, "other_ms": arr[i].other_ms}
+             "advance_ms": arr[i].advance_ms, "other_ms": arr[i].other_ms,
+             "bottom_up": arr[i].bottom_up, "bu_open": arr[i].bu_open, "bu_probes": arr[i].bu_probes}
             for i in range(min(n.value, capacity))]
 
 

@@ -52,7 +52,11 @@ class grx_level_profile_t(C.Structure):
     _fields_ = [("frontier_size", C.c_int64),
                 ("edges", C.c_int64),
                 ("advance_ms", C.c_float),
-                ("other_ms", C.c_float)]
+                ("other_ms", C.c_float),
+                ("bottom_up", C.c_int32),
+                ("reserved", C.c_int32),
+                ("bu_open", C.c_int64),
+                ("bu_probes", C.c_int64)]
 
 
 class GrxError(RuntimeError):

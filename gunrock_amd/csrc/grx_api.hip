@@ -63,11 +63,12 @@ hipError_t fill_f32(hipStream_t s, float* p, float value, int64_t n) {
 grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   const size_t V = (size_t)g->V, E = (size_t)g->E;
   const size_t grid = (size_t)advance_grid(ctx);
-  const size_t max_tiles = V / TILE + grid + 8;
+  const size_t max_tiles = V / TILE + grid * (TILE_RESERVE + 1) + 8;
   const size_t max_chunks = E / CHUNK + max_tiles + 8;
   for (int i = 0; i < 2; ++i) GRX_HIP(ctx->frontier[i].reserve(max_tiles * TILE * sizeof(int32_t)));
   GRX_HIP(ctx->tile_chunks.reserve(max_tiles * sizeof(int32_t)));
   GRX_HIP(ctx->tile_sums.reserve(max_tiles * sizeof(int32_t)));
+  GRX_HIP(ctx->tile_count.reserve(max_tiles * sizeof(int32_t)));
   GRX_HIP(ctx->chunk_prefix.reserve(max_tiles * sizeof(int32_t)));
   GRX_HIP(ctx->chunk_tile.reserve(max_chunks * sizeof(int32_t)));
   a->ro = g->ro;
@@ -80,6 +81,7 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   a->frontier[1] = ctx->frontier[1].as<int32_t>();
   a->tile_chunks = ctx->tile_chunks.as<int32_t>();
   a->tile_sums = ctx->tile_sums.as<int32_t>();
+  a->tile_count = ctx->tile_count.as<int32_t>();
   a->chunk_prefix = ctx->chunk_prefix.as<int32_t>();
   a->chunk_tile = ctx->chunk_tile.as<int32_t>();
   return GRX_SUCCESS;
@@ -157,6 +159,8 @@ grx_status_t grx_context_destroy(grx_context_t ctx) {
   for (auto& b : ctx->frontier) b.release();
   ctx->tile_chunks.release();
   ctx->tile_sums.release();
+  ctx->tile_count.release();
+  ctx->bu_part.release();
   ctx->chunk_tile.release();
   ctx->chunk_prefix.release();
   for (auto& b : ctx->bitmap) b.release();
@@ -224,6 +228,10 @@ grx_status_t grx_get_level_profile(grx_context_t ctx, grx_level_profile_t* out, 
     out[i].edges = ctx->levels[i].edges;
     out[i].advance_ms = ctx->levels[i].advance_ms;
     out[i].other_ms = ctx->levels[i].other_ms;
+    out[i].bottom_up = ctx->levels[i].bottom_up;
+    out[i].reserved = 0;
+    out[i].bu_open = ctx->levels[i].bu_open;
+    out[i].bu_probes = ctx->levels[i].bu_probes;
   }
   return GRX_SUCCESS;
 }

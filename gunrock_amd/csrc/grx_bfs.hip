@@ -69,6 +69,8 @@ struct dobfs_args {
   int32_t n_words;       // 32-bit words per bitmap (even)
   int32_t n_edges;
   int32_t enabled;       // direction optimisation on
+  long long* bu_part;    // per workgroup {found, out-degree sum, open, probes} of the last bottom-up launch
+  int32_t bu_grid;       // workgroups of the bottom-up launch
 };
 
 __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, int src) {
@@ -80,6 +82,7 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
     const int deg = a.ro[src + 1] - a.ro[src];
     a.tile_sums[0] = deg;
     a.tile_chunks[0] = (deg + CHUNK - 1) / CHUNK;
+    a.tile_count[0] = 1;
     c->level = -1;
     c->done = 0;
     c->n_tiles[0] = 1;
@@ -93,10 +96,10 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
     c->mode = 0;
     c->frontier_bitmap = 0;
     c->convert = 0;
-    c->bu_count[0] = c->bu_count[1] = 0;
-    c->bu_edges[0] = c->bu_edges[1] = 0;
     c->q_edges[0] = deg;
     c->q_edges[1] = 0;
+    c->bu_open = 0;
+    c->bu_probes = 0;
     dist[src] = 0;
     if (visited) visited[src >> 5] = 1u << (src & 31);
     a.mailbox[0] = 0;
@@ -105,16 +108,53 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
   }
 }
 
-// Level bookkeeping + direction choice.  <<<1, 64>>>
-__global__ void bfs_decide_kernel(pipe_args a, dobfs_args d) {
-  if (threadIdx.x != 0) return;
+// Level bookkeeping + direction choice.  <<<1, 1024>>>
+// The size of the frontier entering this level is reduced here from per-tile
+// (queue) or per-workgroup (bitmap) partials, so producers need no counter atomics.
+__global__ __launch_bounds__(PLAN_BLOCK) void bfs_decide_kernel(pipe_args a, dobfs_args d) {
+  __shared__ unsigned long long s_n, s_m, s_open, s_probe;
   ctrl_t* c = a.ctrl;
-  if (c->done) return;
+  const int tid = threadIdx.x;
+  const int done = c->done;
   const int level = c->level + 1;
   const int p = level & 1;
   const int is_bitmap = c->frontier_bitmap;
-  const long long n_f = is_bitmap ? c->bu_count[p] : c->n_items[p];
-  const long long m_f = is_bitmap ? c->bu_edges[p] : c->q_edges[p];
+  const int nt = c->n_tiles[p];
+  if (tid == 0) { s_n = 0; s_m = 0; s_open = 0; s_probe = 0; }
+  __syncthreads();
+  if (done) return;
+  long long n = 0, m = 0, op = 0, pr = 0;
+  if (is_bitmap) {
+    for (int i = tid; i < d.bu_grid; i += PLAN_BLOCK) {
+      n += d.bu_part[4 * i];
+      m += d.bu_part[4 * i + 1];
+      op += d.bu_part[4 * i + 2];
+      pr += d.bu_part[4 * i + 3];
+    }
+  } else {
+    for (int i = tid; i < nt; i += PLAN_BLOCK) {
+      n += a.tile_count[i];
+      m += a.tile_sums[i];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    n += __shfl_xor(n, o, 64);
+    m += __shfl_xor(m, o, 64);
+    op += __shfl_xor(op, o, 64);
+    pr += __shfl_xor(pr, o, 64);
+  }
+  if (dev::lane_id() == 0) {
+    atomicAdd(&s_n, (unsigned long long)n);
+    atomicAdd(&s_m, (unsigned long long)m);
+    atomicAdd(&s_open, (unsigned long long)op);
+    atomicAdd(&s_probe, (unsigned long long)pr);
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  const long long n_f = (long long)s_n, m_f = (long long)s_m;
+  c->bu_open += (long long)s_open;
+  c->bu_probes += (long long)s_probe;
   if (n_f == 0) {
     c->done = 1;
     c->level = level;
@@ -136,17 +176,11 @@ __global__ void bfs_decide_kernel(pipe_args a, dobfs_args d) {
   c->level = level;
   c->edges_visited += m_f;
   c->vertices_visited += n_f;
+  c->n_items[p] = (int)n_f;
+  c->q_edges[p] = m_f;
   c->n_tiles[p ^ 1] = 0;
-  c->n_items[p ^ 1] = 0;
-  c->q_edges[p ^ 1] = 0;
-  c->bu_count[p ^ 1] = 0;
-  c->bu_edges[p ^ 1] = 0;
-  if (c->convert == 1) {  // the queue of this level is rebuilt from the bitmap
-    c->n_tiles[p] = 0;
-    c->n_items[p] = 0;
-    c->q_edges[p] = 0;
-  }
-  c->frontier_bitmap = mode;  // format of the frontier this level PRODUCES
+  if (c->convert == 1) c->n_tiles[p] = 0;  // the queue of this level is rebuilt from the bitmap
+  c->frontier_bitmap = mode;               // format of the frontier this level PRODUCES
   a.mailbox[1] = level;
   a.mailbox[2] = (int)n_f;
 }
@@ -158,7 +192,7 @@ __global__ void bfs_decide_kernel(pipe_args a, dobfs_args d) {
 __global__ __launch_bounds__(ADV_BLOCK) void bfs_convert_kernel(pipe_args a, dobfs_args d) {
   __shared__ int s_out[TILE + ADV_BLOCK * 32];
   __shared__ int s_wave[ADV_BLOCK / 64 + 1];
-  __shared__ int s_tix;
+  __shared__ int s_res[3];
   __shared__ int s_cnt;
   ctrl_t* c = a.ctrl;
   if (c->done) return;
@@ -176,7 +210,9 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_convert_kernel(pipe_args a, dob
     for (int ch = wave; ch < n_chunks; ch += n_waves) {
       const int v = ch * 64 + lane;
       const int dv = v < a.V ? d.dist[v] : INT_MAX;
-      const unsigned long long vis = dev::ballot(dv != INT_MAX);
+      // a vertex without in-edges can never be discovered bottom-up: close it
+      const bool no_in = v < a.V ? (d.t_ro[v + 1] == d.t_ro[v]) : true;
+      const unsigned long long vis = dev::ballot(dv != INT_MAX || no_in);
       const unsigned long long fr = dev::ballot(dv == level);
       if (lane == 0) {
         d.visited[2 * ch] = (unsigned)vis;
@@ -189,7 +225,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_convert_kernel(pipe_args a, dob
   }
   // convert == 1: each thread takes one bitmap word per round
   const unsigned* fin = d.fbits[p];
-  if (tid == 0) s_cnt = 0;
+  if (tid == 0) { s_cnt = 0; s_res[0] = 0; s_res[1] = 0; }
   __syncthreads();
   for (int base = blockIdx.x * ADV_BLOCK; base < d.n_words; base += gridDim.x * ADV_BLOCK) {
     const int w = base + tid;
@@ -206,7 +242,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_convert_kernel(pipe_args a, dob
     int have = s_cnt + tot;
     __syncthreads();
     while (have >= TILE) {
-      emit_tile(a, c, p, s_out, have - TILE, TILE, s_wave, &s_tix);
+      emit_tile(a, c, p, s_out, have - TILE, TILE, s_wave, s_res);
       have -= TILE;
       __syncthreads();
     }
@@ -214,13 +250,20 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_convert_kernel(pipe_args a, dob
     __syncthreads();
   }
   const int rem = s_cnt;
-  if (rem > 0) emit_tile(a, c, p, s_out, 0, rem, s_wave, &s_tix);
+  if (rem > 0) emit_tile(a, c, p, s_out, 0, rem, s_wave, s_res);
+  __syncthreads();
+  release_tiles(a, s_res);
 }
 
-// Bottom-up level.  One wave per 64 consecutive vertices.
+// Bottom-up level.  A wave owns 64 consecutive vertices (one "chunk") and works on
+// BATCH chunks at a time so that the dependent load chain (visited word -> in-offsets
+// -> in-neighbour -> frontier word) of several chunks is in flight together.
+// `visited` already counts vertices without in-edges as closed (bfs_convert_kernel).
 __global__ __launch_bounds__(ADV_BLOCK) void bfs_bottomup_kernel(pipe_args a, dobfs_args d) {
   __shared__ int s_cnt[ADV_BLOCK / 64];
   __shared__ long long s_deg[ADV_BLOCK / 64];
+  __shared__ int s_open[ADV_BLOCK / 64];
+  __shared__ long long s_probe[ADV_BLOCK / 64];
   ctrl_t* c = a.ctrl;
   if (c->done || c->mode != 1) return;
   const int level = c->level;
@@ -232,74 +275,126 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_bottomup_kernel(pipe_args a, do
   const int wave = (blockIdx.x * ADV_BLOCK + threadIdx.x) >> 6;
   const int n_waves = (gridDim.x * ADV_BLOCK) >> 6;
   const int n_chunks = d.n_words / 2;
+  const bool same_csr = d.t_ro == a.ro;  // symmetric graph: out-degree == in-degree
   int my_cnt = 0;
   long long my_deg = 0;
+  long long my_probes = 0;  // in-edges actually read (roofline accounting)
+  int my_open = 0;
   constexpr int SERIAL = 8;
-  for (int ch = wave; ch < n_chunks; ch += n_waves) {
-    const unsigned long long vis =
-        (unsigned long long)d.visited[2 * ch] | ((unsigned long long)d.visited[2 * ch + 1] << 32);
-    const int v = ch * 64 + lane;
-    const bool open = v < a.V && !((vis >> lane) & 1ull);
-    if (dev::ballot(open) == 0ull) {
-      if (lane == 0) { fout[2 * ch] = 0u; fout[2 * ch + 1] = 0u; }
-      continue;
+  constexpr int BATCH = 4;
+  for (int ch0 = wave * BATCH; ch0 < n_chunks; ch0 += n_waves * BATCH) {
+    unsigned long long vis[BATCH];
+    int b[BATCH], e[BATCH], odeg[BATCH];
+    bool open[BATCH], found[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int ch = ch0 + j;
+      vis[j] = ~0ull;
+      if (ch < n_chunks)
+        vis[j] = (unsigned long long)d.visited[2 * ch] | ((unsigned long long)d.visited[2 * ch + 1] << 32);
     }
-    int b = 0, e = 0;
-    if (open) { b = d.t_ro[v]; e = d.t_ro[v + 1]; }
-    bool found = false;
-    // phase A: a few serial probes per lane (most vertices find a parent at once)
-    const int stop = min(e, b + SERIAL);
-    for (int k = b; k < stop; ++k) {
-      const int u = d.t_ci[k];
-      if (fin[u >> 5] & (1u << (u & 31))) { found = true; break; }
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int v = (ch0 + j) * 64 + lane;
+      open[j] = v < a.V && !((vis[j] >> lane) & 1ull);
+      found[j] = false;
+      b[j] = e[j] = odeg[j] = 0;
+      if (open[j]) {
+        b[j] = d.t_ro[v];
+        e[j] = d.t_ro[v + 1];
+        ++my_open;
+      }
+    }
+    if (!same_csr) {
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int v = (ch0 + j) * 64 + lane;
+        if (open[j]) odeg[j] = a.ro[v + 1] - a.ro[v];
+      }
+    }
+    // phase A: up to SERIAL probes per lane, the BATCH chunks advance in lock step
+    for (int r = 0; r < SERIAL; ++r) {
+      int u[BATCH];
+      bool act[BATCH];
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        act[j] = open[j] && !found[j] && b[j] + r < e[j];
+        u[j] = act[j] ? d.t_ci[b[j] + r] : 0;
+        any |= act[j];
+      }
+      if (dev::ballot(any) == 0ull) break;
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        if (act[j]) {
+          ++my_probes;
+          if (fin[u[j] >> 5] & (1u << (u[j] & 31))) found[j] = true;
+        }
+      }
     }
     // phase B: long in-lists are scanned by the whole wave, 64 edges per step
-    unsigned long long pend = dev::ballot(open && !found && e > b + SERIAL);
-    while (pend) {
-      const int src_lane = __builtin_ctzll(pend);
-      pend &= pend - 1;
-      const int bb = __shfl(b, src_lane, 64) + SERIAL, ee = __shfl(e, src_lane, 64);
-      bool hit = false;
-      for (int k = bb; k < ee; k += 64) {
-        const int kk = k + lane;
-        bool h = false;
-        if (kk < ee) {
-          const int u = d.t_ci[kk];
-          h = (fin[u >> 5] & (1u << (u & 31))) != 0u;
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      unsigned long long pend = dev::ballot(open[j] && !found[j] && e[j] > b[j] + SERIAL);
+      while (pend) {
+        const int src_lane = __builtin_ctzll(pend);
+        pend &= pend - 1;
+        const int bb = __shfl(b[j], src_lane, 64) + SERIAL, ee = __shfl(e[j], src_lane, 64);
+        bool hit = false;
+        for (int k = bb; k < ee; k += 64) {
+          const int kk = k + lane;
+          bool h = false;
+          if (kk < ee) {
+            const int u = d.t_ci[kk];
+            ++my_probes;
+            h = (fin[u >> 5] & (1u << (u & 31))) != 0u;
+          }
+          if (dev::ballot(h)) { hit = true; break; }
         }
-        if (dev::ballot(h)) { hit = true; break; }
+        if (lane == src_lane) found[j] = hit;
       }
-      if (lane == src_lane) found = hit;
     }
-    const unsigned long long nw = dev::ballot(found);
-    if (lane == 0) {
-      fout[2 * ch] = (unsigned)nw;
-      fout[2 * ch + 1] = (unsigned)(nw >> 32);
-      const unsigned long long nv = vis | nw;
-      d.visited[2 * ch] = (unsigned)nv;
-      d.visited[2 * ch + 1] = (unsigned)(nv >> 32);
-    }
-    if (found) {
-      d.dist[v] = level + 1;
-      my_cnt += 1;
-      my_deg += a.ro[v + 1] - a.ro[v];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int ch = ch0 + j;
+      if (ch >= n_chunks) continue;
+      const unsigned long long nw = dev::ballot(found[j]);
+      if (lane == 0) {
+        fout[2 * ch] = (unsigned)nw;
+        fout[2 * ch + 1] = (unsigned)(nw >> 32);
+        if (nw) {
+          const unsigned long long nv = vis[j] | nw;
+          d.visited[2 * ch] = (unsigned)nv;
+          d.visited[2 * ch + 1] = (unsigned)(nv >> 32);
+        }
+      }
+      if (found[j]) {
+        d.dist[ch * 64 + lane] = level + 1;
+        my_cnt += 1;
+        my_deg += same_csr ? (e[j] - b[j]) : odeg[j];
+      }
     }
   }
-  // per-workgroup totals -> two atomics per workgroup
+  // per-workgroup totals -> a handful of atomics per workgroup
   my_cnt = dev::wave_sum(my_cnt);
+  my_open = dev::wave_sum(my_open);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) my_deg += __shfl_xor(my_deg, o, 64);
-  if (lane == 0) { s_cnt[wid] = my_cnt; s_deg[wid] = my_deg; }
+  for (int o = 32; o > 0; o >>= 1) {
+    my_deg += __shfl_xor(my_deg, o, 64);
+    my_probes += __shfl_xor(my_probes, o, 64);
+  }
+  if (lane == 0) { s_cnt[wid] = my_cnt; s_deg[wid] = my_deg; s_open[wid] = my_open; s_probe[wid] = my_probes; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int tc = 0;
-    long long td = 0;
+    int tc = 0, to = 0;
+    long long td = 0, tp = 0;
 #pragma unroll
-    for (int i = 0; i < ADV_BLOCK / 64; ++i) { tc += s_cnt[i]; td += s_deg[i]; }
-    if (tc) {
-      atomicAdd(&c->bu_count[p ^ 1], tc);
-      atomicAdd(reinterpret_cast<unsigned long long*>(&c->bu_edges[p ^ 1]), (unsigned long long)td);
-    }
+    for (int i = 0; i < ADV_BLOCK / 64; ++i) { tc += s_cnt[i]; td += s_deg[i]; to += s_open[i]; tp += s_probe[i]; }
+    // plain stores; bfs_decide_kernel of the next level reduces them
+    d.bu_part[4 * blockIdx.x] = tc;
+    d.bu_part[4 * blockIdx.x + 1] = td;
+    d.bu_part[4 * blockIdx.x + 2] = to;
+    d.bu_part[4 * blockIdx.x + 3] = tp;
   }
 }
 
@@ -349,6 +444,9 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     d.visited = ctx->bitmap[0].as<unsigned>();
     d.fbits[0] = ctx->bitmap[1].as<unsigned>();
     d.fbits[1] = d.fbits[0] + bm_words;
+    d.bu_grid = advance_grid(ctx);
+    GRX_HIP(ctx->bu_part.reserve((size_t)d.bu_grid * 4 * sizeof(long long)));
+    d.bu_part = ctx->bu_part.as<long long>();
   } else if (variant != 0) {
     GRX_HIP(ctx->bitmap[0].reserve(bm_words * sizeof(unsigned)));
     visited = ctx->bitmap[0].as<unsigned>();
@@ -368,13 +466,13 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   if (profile) for (auto& e : pe) GRX_HIP(hipEventCreate(&e));
 
   hipError_t launch_err = hipSuccess;
-  int64_t prof_v = 0, prof_e = 0;
+  int64_t prof_v = 0, prof_e = 0, prof_open = 0, prof_probe = 0;
   int launches = 0;
   st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
     if (profile) (void)hipEventRecord(pe[0], stream);
     if (dopt) {
-      hipLaunchKernelGGL(bfs_decide_kernel, dim3(1), dim3(64), 0, stream, a, d);
-      hipLaunchKernelGGL(bfs_convert_kernel, dim3(grid / 2), dim3(ADV_BLOCK), 0, stream, a, d);
+      hipLaunchKernelGGL(bfs_decide_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d);
+      hipLaunchKernelGGL(bfs_convert_kernel, dim3(grid / 4), dim3(ADV_BLOCK), 0, stream, a, d);
       hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 1);
     } else {
       hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
@@ -406,17 +504,27 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) launch_err = e;
   }, [&](const ctrl_t& h) {
-    if (profile && !ctx->levels.empty() && !h.done) {
-      level_rec& r = ctx->levels.back();
-      r.frontier_size = h.vertices_visited - prof_v;
-      r.edges = h.edges_visited - prof_e;
-      if (h.mode == 1) r.frontier_size = -r.frontier_size;  // negative marks a bottom-up level
-      prof_v = h.vertices_visited;
-      prof_e = h.edges_visited;
-    } else if (profile && h.done && !ctx->levels.empty()) {
-      ctx->levels.pop_back();  // the level that only detected the empty frontier
+    if (!profile || ctx->levels.empty()) return;
+    // bottom-up open/probe counters are reduced by the NEXT level's decide kernel:
+    // the delta seen now belongs to the previous level's record
+    if (ctx->levels.size() >= 2) {
+      level_rec& prev = ctx->levels[ctx->levels.size() - 2];
+      prev.bu_open = h.bu_open - prof_open;
+      prev.bu_probes = h.bu_probes - prof_probe;
     }
-  });
+    prof_open = h.bu_open;
+    prof_probe = h.bu_probes;
+    if (h.done) {
+      ctx->levels.pop_back();  // the level that only detected the empty frontier
+      return;
+    }
+    level_rec& r = ctx->levels.back();
+    r.frontier_size = h.vertices_visited - prof_v;
+    r.edges = h.edges_visited - prof_e;
+    r.bottom_up = h.mode;
+    prof_v = h.vertices_visited;
+    prof_e = h.edges_visited;
+  }, /*first_batch=*/(g->V > 0 && (long long)g->E >= 8ll * g->V) ? 8 : 4);
   if (st != GRX_SUCCESS) return st;
   if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));
 

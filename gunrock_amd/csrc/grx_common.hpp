@@ -79,10 +79,10 @@ struct ctrl_t {
   int32_t mode;             // direction of the CURRENT level: 0 top-down (queue), 1 bottom-up (bitmap)
   int32_t frontier_bitmap;  // 1 if the frontier entering the next decide step is a bitmap
   int32_t convert;          // this level: 0 none, 1 bitmap -> queue, 2 labels -> bitmaps
-  int32_t bu_count[2];      // vertices discovered by a bottom-up level, by output parity
-  int32_t pad2;
-  int64_t bu_edges[2];      // their out-degree sum
-  int64_t q_edges[2];       // out-degree sum of the queue frontier, accumulated at tile emission
+  int32_t pad2[3];
+  int64_t q_edges[2];       // out-degree sum of the frontier entering the level (set by plan/decide)
+  int64_t bu_open;          // bottom-up accounting: unvisited vertices examined (cumulative)
+  int64_t bu_probes;        // bottom-up accounting: in-edges read (cumulative)
 };
 
 struct level_rec {
@@ -90,6 +90,9 @@ struct level_rec {
   int64_t edges;
   float advance_ms;
   float other_ms;
+  int32_t bottom_up = 0;
+  int64_t bu_open = 0;
+  int64_t bu_probes = 0;
 };
 
 }  // namespace grx
@@ -110,6 +113,8 @@ struct grx_context {
   grx::dbuf frontier[2];   // vertex ids, tiled
   grx::dbuf tile_chunks;   // per tile: number of advance chunks
   grx::dbuf tile_sums;     // per tile: sum of degrees
+  grx::dbuf tile_count;    // per tile: valid vertices
+  grx::dbuf bu_part;       // per workgroup partial counters of the bottom-up kernel
   grx::dbuf chunk_tile;    // per chunk: owning tile
   grx::dbuf chunk_prefix;  // per tile: first chunk id
   grx::dbuf bitmap[2];     // visited / scratch bitmaps

@@ -27,9 +27,9 @@ inline int advance_grid(grx_context_t ctx) { return ctx->num_cus * 8; }
 // the control block between batches.  Returns after `done`.
 template <class LaunchLevel, class AfterSync>
 grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel launch_level,
-                        AfterSync after_sync) {
+                        AfterSync after_sync, int first_batch = 4) {
   const bool sync_each = (opt.engine_flags & (GRX_FLAG_SYNC_EACH_LEVEL | GRX_FLAG_PROFILE)) != 0;
-  int batch = sync_each ? 1 : 4;
+  int batch = sync_each ? 1 : first_batch;
   int launched = 0;
   const int max_levels = opt.max_iterations > 0 ? opt.max_iterations : 0x7fffffff;
   for (;;) {

@@ -35,6 +35,7 @@ constexpr int ADV_BLOCK = 256;       // threads per advance workgroup
 constexpr int ADV_ITEMS = 8;         // atoms per thread per chunk
 constexpr int CHUNK = ADV_BLOCK * ADV_ITEMS;  // 2048 atoms
 constexpr int PLAN_BLOCK = 1024;
+constexpr int TILE_RESERVE = 4;      // tile indices a workgroup reserves per global atomic
 
 struct pipe_args {
   const int32_t* ro;
@@ -46,6 +47,7 @@ struct pipe_args {
   int32_t* frontier[2];   // tiled queues by level parity
   int32_t* tile_chunks;   // chunks per tile of the CURRENT input frontier
   int32_t* tile_sums;     // degree sum per tile of the current input frontier
+  int32_t* tile_count;    // valid vertices per tile
   int32_t* chunk_prefix;  // first chunk id per tile
   int32_t* chunk_tile;    // owning tile per chunk
 };
@@ -65,7 +67,6 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, in
   const int level = external_control ? c->level : c->level + 1;
   const int p = level & 1;
   const int nt = c->n_tiles[p];
-  const int nitems = c->n_items[p];
   const int mode = c->mode;
   if (tid == 0) s_esum = 0ull;
   __syncthreads();
@@ -87,7 +88,8 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, in
     int ch = 0;
     if (i < nt) {
       ch = a.tile_chunks[i];
-      esum += a.tile_sums[i];
+      // {edges, vertices} packed: vertices in the top 24 bits of a 64-bit sum
+      esum += (long long)a.tile_sums[i] + ((long long)a.tile_count[i] << 40);
     }
     int tot;
     int ex = dev::block_exclusive_sum<PLAN_BLOCK>(ch, s_wave, &tot);
@@ -106,12 +108,14 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, in
   if (tid == 0) {
     c->total_chunks = carry;
     if (!external_control) {
+      const long long edges = (long long)(s_esum & ((1ull << 40) - 1));
+      const int nitems = (int)(s_esum >> 40);
       c->level = level;
-      c->edges_visited += (long long)s_esum;
+      c->edges_visited += edges;
       c->vertices_visited += nitems;
+      c->n_items[p] = nitems;
+      c->q_edges[p] = edges;
       c->n_tiles[p ^ 1] = 0;
-      c->n_items[p ^ 1] = 0;
-      c->q_edges[p ^ 1] = 0;
       a.mailbox[1] = level;
       a.mailbox[2] = nitems;
     }
@@ -119,10 +123,16 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, in
 }
 
 // Emit n (<= TILE) vertices s_out[lo .. lo+n) as one tile of the frontier with
-// parity q: degree sum computed here, ONE tile-index atomic per 256 vertices.
-// Block-wide call (contains __syncthreads); s_wave/s_tix are LDS scratch.
+// parity q; its degree sum is computed here so the next level needs no scan over
+// the frontier.  Tile indices are RESERVED TILE_RESERVE at a time: one global
+// atomic per 4 x 256 emitted vertices (all workgroups hit the same counter word,
+// and a single word sustains only ~90 atomics/us on this part).  Per-tile
+// vertex counts and degree sums are summed by the next plan/decide kernel
+// instead of being accumulated with more atomics.
+// Block-wide call (contains __syncthreads); s_wave / s_res are LDS scratch,
+// s_res = {next reserved tile, end of reservation, tile of this emit}.
 __device__ __forceinline__ void emit_tile(const pipe_args& a, ctrl_t* c, int q, const int* s_out, int lo, int n,
-                                          int* s_wave, int* s_tix) {
+                                          int* s_wave, int* s_res) {
   const int tid = threadIdx.x;
   const int lane = dev::lane_id();
   const int wid = tid >> 6;
@@ -138,15 +148,28 @@ __device__ __forceinline__ void emit_tile(const pipe_args& a, ctrl_t* c, int q, 
     int tot = 0;
 #pragma unroll
     for (int i = 0; i < ADV_BLOCK / 64; ++i) tot += s_wave[i];
-    const int tix = atomicAdd(&c->n_tiles[q], 1);
-    atomicAdd(&c->n_items[q], n);
-    atomicAdd(reinterpret_cast<unsigned long long*>(&c->q_edges[q]), (unsigned long long)tot);
+    if (s_res[0] == s_res[1]) {
+      s_res[0] = atomicAdd(&c->n_tiles[q], TILE_RESERVE);
+      s_res[1] = s_res[0] + TILE_RESERVE;
+    }
+    const int tix = s_res[0]++;
     a.tile_sums[tix] = tot;
     a.tile_chunks[tix] = (tot + CHUNK - 1) / CHUNK;
-    *s_tix = tix;
+    a.tile_count[tix] = n;
+    s_res[2] = tix;
   }
   __syncthreads();
-  a.frontier[q][(size_t)(*s_tix) * TILE + tid] = x;
+  a.frontier[q][(size_t)s_res[2] * TILE + tid] = x;
+}
+
+// Reserved but unused tile indices become empty tiles (never staged: 0 chunks).
+__device__ __forceinline__ void release_tiles(const pipe_args& a, const int* s_res) {
+  const int t = s_res[0] + (int)threadIdx.x;
+  if (t < s_res[1]) {
+    a.tile_sums[t] = 0;
+    a.tile_chunks[t] = 0;
+    a.tile_count[t] = 0;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -165,7 +188,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
   __shared__ int s_out[TILE + CHUNK];
   __shared__ int s_wave[ADV_BLOCK / 64 + 1];
   __shared__ int s_cnt;
-  __shared__ int s_tix;
+  __shared__ int s_res[3];
 
   ctrl_t* c = a.ctrl;
   if (c->done) return;
@@ -178,7 +201,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
   if (c->mode != 0) return;  // this level runs bottom-up
   const int32_t* __restrict__ in = a.frontier[p];
   pol.begin(c);
-  if (tid == 0) s_cnt = 0;
+  if (tid == 0) { s_cnt = 0; s_res[0] = 0; s_res[1] = 0; }
   __syncthreads();
 
   for (int chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
@@ -242,7 +265,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
     // ---- flush full tiles --------------------------------------------------
     int cnt = s_cnt;
     while (cnt >= TILE) {
-      emit_tile(a, c, p ^ 1, s_out, cnt - TILE, TILE, s_wave, &s_tix);
+      emit_tile(a, c, p ^ 1, s_out, cnt - TILE, TILE, s_wave, s_res);
       cnt -= TILE;
       __syncthreads();
     }
@@ -250,7 +273,9 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
     __syncthreads();
   }
   const int rem = s_cnt;
-  if (rem > 0) emit_tile(a, c, p ^ 1, s_out, 0, rem, s_wave, &s_tix);
+  if (rem > 0) emit_tile(a, c, p ^ 1, s_out, 0, rem, s_wave, s_res);
+  __syncthreads();
+  release_tiles(a, s_res);
 }
 
 }  // namespace grx

@@ -49,6 +49,7 @@ __global__ void sssp_init_kernel(pipe_args a, float* dist, int src) {
     const int deg = a.ro[src + 1] - a.ro[src];
     a.tile_sums[0] = deg;
     a.tile_chunks[0] = (deg + CHUNK - 1) / CHUNK;
+    a.tile_count[0] = 1;
     c->level = -1;
     c->done = 0;
     c->n_tiles[0] = 1;

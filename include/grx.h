@@ -180,12 +180,16 @@ typedef struct grx_run_stats {
 grx_status_t grx_get_run_stats(grx_context_t ctx, grx_run_stats_t* out);
 
 /* Per-level profile of the last run with GRX_FLAG_PROFILE: up to `capacity`
- * levels are copied; each entry is {frontier_size, edges, advance_ms, other_ms}. */
+ * levels are copied; fields below. */
 typedef struct grx_level_profile {
-  int64_t frontier_size;
-  int64_t edges;
-  float advance_ms;
-  float other_ms;
+  int64_t frontier_size;  /* valid vertices of the input frontier */
+  int64_t edges;          /* their out-degree sum (the level's traversed edges) */
+  float advance_ms;       /* advance (top-down) or bottom-up kernel time */
+  float other_ms;         /* planning / direction / conversion kernels */
+  int32_t bottom_up;      /* 1 if the level ran bottom-up (direction-optimising BFS) */
+  int32_t reserved;
+  int64_t bu_open;        /* bottom-up: unvisited vertices examined */
+  int64_t bu_probes;      /* bottom-up: in-edges read */
 } grx_level_profile_t;
 grx_status_t grx_get_level_profile(grx_context_t ctx, grx_level_profile_t* out,
                                    int32_t capacity, int32_t* n_levels);

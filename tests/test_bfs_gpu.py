@@ -127,7 +127,8 @@ def test_direction_optimizing_switches_and_matches(gr, gpu_ctx):
         prof = gr.level_profile(gpu_ctx)
         assert np.array_equal(dist.cpu().numpy(), want)
         assert st["edges_visited"] == ev and st["vertices_visited"] == int((want != INF).sum())
-        assert any(l["frontier_size"] < 0 for l in prof), "no level ran bottom-up"
+        assert any(l["bottom_up"] for l in prof), "no level ran bottom-up"
+        assert all(l["bu_probes"] > 0 and l["bu_open"] > 0 for l in prof if l["bottom_up"])
         assert prof[0]["frontier_size"] == 1  # the first level is always top-down
         for s2 in (0, 17, V - 1):  # low-degree / isolated sources: may never switch
             gr.bfs(G, s2, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.optimized))
