@@ -258,9 +258,27 @@ grx_status_t grx_host_csr_destroy(grx_host_csr_t h) {
   return GRX_SUCCESS;
 }
 
+static grx_status_t generate_impl(int32_t kind, int32_t V, int64_t n_entries, float a, float b, float c,
+                                  uint64_t seed, int32_t row_lo, int32_t row_hi, grx_host_csr_t* out);
+
 grx_status_t grx_host_csr_generate(int32_t kind, int32_t V, int64_t n_entries, float a, float b,
                                    float c, uint64_t seed, grx_host_csr_t* out) {
+  return generate_impl(kind, V, n_entries, a, b, c, seed, 0, V, out);
+}
+
+grx_status_t grx_host_csr_generate_rows(int32_t kind, int32_t V, int64_t n_entries, float a, float b, float c,
+                                        uint64_t seed, int32_t row_lo, int32_t row_hi, grx_host_csr_t* out) {
+  if (kind != 0 && kind != 1) return fail(GRX_ERROR_INVALID_ARGUMENT, "row slices: R-MAT kinds only");
+  if (row_lo < 0 || row_hi > V || row_lo > row_hi) return fail(GRX_ERROR_INVALID_ARGUMENT, "bad row range");
+  return generate_impl(kind, V, n_entries, a, b, c, seed, row_lo, row_hi, out);
+}
+
+}  // extern "C"
+
+static grx_status_t generate_impl(int32_t kind, int32_t V, int64_t n_entries, float a, float b, float c,
+                                  uint64_t seed, int32_t row_lo, int32_t row_hi, grx_host_csr_t* out) {
   if (!out || V <= 0) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_host_csr_generate: bad argument");
+  const bool sliced = !(row_lo == 0 && row_hi == V);
   std::vector<int32_t> I, J;
   std::vector<float> X;
   grx_host_csr* h = new grx_host_csr();
@@ -301,16 +319,25 @@ grx_status_t grx_host_csr_generate(int32_t kind, int32_t V, int64_t n_entries, f
         W[(size_t)e] = (int32_t)((v * mul + add) % (uint64_t)V);
       }
     });
+    auto owned = [&](int32_t r) { return r >= row_lo && r < row_hi; };
     if (kind == 0) {
-      I.swap(U);
-      J.swap(W);
+      if (!sliced) {
+        I.swap(U);
+        J.swap(W);
+      } else {
+        for (int64_t e = 0; e < n_entries; ++e)
+          if (owned(U[(size_t)e])) { I.push_back(U[(size_t)e]); J.push_back(W[(size_t)e]); }
+      }
       h->directed = 1; h->symmetric = 0; h->weighted = 0;
     } else {
-      I.reserve((size_t)n_entries * 2);
-      J.reserve((size_t)n_entries * 2);
+      if (!sliced) {
+        I.reserve((size_t)n_entries * 2);
+        J.reserve((size_t)n_entries * 2);
+      }
       for (int64_t e = 0; e < n_entries; ++e) {
-        I.push_back(U[(size_t)e]); J.push_back(W[(size_t)e]);
-        if (U[(size_t)e] != W[(size_t)e]) { I.push_back(W[(size_t)e]); J.push_back(U[(size_t)e]); }
+        const int32_t u = U[(size_t)e], w = W[(size_t)e];
+        if (owned(u)) { I.push_back(u); J.push_back(w); }
+        if (u != w && owned(w)) { I.push_back(w); J.push_back(u); }
       }
       h->directed = 0; h->symmetric = 1; h->weighted = 0;
     }
@@ -347,5 +374,3 @@ grx_status_t grx_host_csr_generate(int32_t kind, int32_t V, int64_t n_entries, f
   *out = h;
   return GRX_SUCCESS;
 }
-
-}  // extern "C"

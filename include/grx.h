@@ -194,6 +194,27 @@ typedef struct grx_level_profile {
 grx_status_t grx_get_level_profile(grx_context_t ctx, grx_level_profile_t* out,
                                    int32_t capacity, int32_t* n_levels);
 
+/* ---- multi-GPU: level-stepping interface of the BFS enactor ------------------------
+ * The reference has no multi-GPU execution (every operator throws when
+ * context.size() != 1: framework/operators/advance/advance.hxx:129-132).  One process
+ * per GPU drives these calls and exchanges the buckets with RCCL (torch.distributed
+ * all_to_all); see gunrock_amd/distributed.py and DESIGN.md section 6.
+ * Rank r owns vertices [bounds[r], bounds[r+1]); `graph` holds the CSR rows of the
+ * owned vertices with GLOBAL column ids (n_vertices = global V, other rows empty).
+ * d_send: device int32[V]; the bucket for owner j starts at d_send + bounds[j].
+ * d_distances: device int32[V]; authoritative on the owned range after the run. */
+grx_status_t grx_bfs_dist_begin(grx_context_t ctx, grx_graph_t graph, int32_t source_if_owned /* -1 if not */,
+                                const int32_t* bounds /* host, n_ranks + 1 */, int32_t n_ranks, int32_t my_rank,
+                                int32_t* d_send, int32_t* d_distances);
+/* expand the owned frontier by one level, then bin non-owned winners by owner;
+ * d_counts: device int64[n_ranks] bucket sizes.  Asynchronous on the context stream. */
+grx_status_t grx_bfs_dist_advance(grx_context_t ctx, long long* d_counts);
+/* claim n received candidates (global ids owned by this rank); winners join the next frontier */
+grx_status_t grx_bfs_dist_apply(grx_context_t ctx, const int32_t* d_recv, long long n);
+/* size of the next frontier (owned vertices, their out-edges); synchronises the stream */
+grx_status_t grx_bfs_dist_frontier(grx_context_t ctx, long long* n_vertices, long long* n_edges);
+grx_status_t grx_bfs_dist_end(grx_context_t ctx, grx_run_stats_t* stats);
+
 /* ---- host-side ingest (same semantics as the reference) ---- */
 
 /* io::matrix_market_t::load + format::csr_t::from_coo,
@@ -227,6 +248,12 @@ grx_status_t grx_host_csr_destroy(grx_host_csr_t csr);
 grx_status_t grx_host_csr_generate(int32_t kind, int32_t n_vertices, int64_t n_entries,
                                    float a, float b, float c, uint64_t seed,
                                    grx_host_csr_t* out);
+/* Same generator, keeping only the rows [row_lo, row_hi) (the slice a rank owns);
+ * the result still has n_vertices rows (the others empty) and global column ids.
+ * kinds 0 and 1 only. */
+grx_status_t grx_host_csr_generate_rows(int32_t kind, int32_t n_vertices, int64_t n_entries,
+                                        float a, float b, float c, uint64_t seed,
+                                        int32_t row_lo, int32_t row_hi, grx_host_csr_t* out);
 
 #ifdef __cplusplus
 }
