@@ -65,19 +65,89 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # GRX_BENCH_BACKEND=gloo lets the N > 1 path be exercised with several ranks sharing
+        # one GPU (tests); the driver's multi-GPU runs use nccl (= RCCL), one rank per GPU
+        backend = os.environ.get("GRX_BENCH_BACKEND", "nccl")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
 
     wl = WORKLOADS[args.workload]
     t0 = time.time()
+    if dist_on:
+        # ---- N > 1: ONE graph, N times the single-GPU size (weak scaling), vertex-range
+        # partitioned; per level an RCCL all-to-all of the non-owned discoveries
+        # (gunrock_amd/distributed.py).  At N = 8 this is BASELINE.json configs[4] scale
+        # (soc-twitter-2010: 21 M V / 530 M E) -- here 38.8 M V / 552 M E.
+        from gunrock_amd import distributed as D
+        if wl["kind"] not in ("rmat", "rmat_sym"):
+            raise SystemExit("multi-GPU bench supports the R-MAT workloads")
+        V = wl["V"] * world
+        entries = wl["entries"] * world
+        bounds = D.vertex_bounds(V, world)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        props, mine = gr.generate_rows(wl["kind"], V, entries, lo, hi, wl["a"], wl["b"], wl["c"], seed=42)
+        deg = np.diff(mine.row_offsets)
+        cdev = dev if dist.get_backend() == "nccl" else "cpu"
+        best = torch.tensor([int(deg.max())], dtype=torch.int64, device=cdev)
+        dist.all_reduce(best, op=dist.ReduceOp.MAX)
+        cand = int(np.argmax(deg)) if int(deg.max()) == int(best.item()) else V
+        srct = torch.tensor([cand], dtype=torch.int64, device=cdev)
+        dist.all_reduce(srct, op=dist.ReduceOp.MIN)
+        src = int(srct.item())
+        eng = D.GrxEngine(props, mine, bounds, rank, dev)
+        E = int(mine.number_of_nonzeros)
+        dist_t = torch.empty(V, dtype=torch.int32, device=dev)
+        recv = torch.empty(max(hi - lo, 1) * max(world - 1, 1), dtype=torch.int32, device=dev)
+        t_setup = time.time() - t0
+
+        def barrier():
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            st = D.bfs(eng, dist, src, dist_t, bounds, rank, recv)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            st = D.bfs(eng, dist, src, dist_t, bounds, rank, recv)
+        barrier()
+        elapsed = time.perf_counter() - t1
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        ee = torch.tensor([st["edges_visited"], E], dtype=torch.int64, device=cdev)
+        dist.all_reduce(ee, op=dist.ReduceOp.SUM)
+        edges_total, e_total = int(ee[0].item()), int(ee[1].item())
+        ms_per_step = elapsed * 1e3 / args.steps
+        mteps = edges_total / (ms_per_step * 1e3)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "MTEPS (million traversed edges/sec) BFS", "value": round(mteps, 1), "unit": "MTEPS",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+                "data": "synthetic",
+                "config": {"workload": "BFS R-MAT(0.57,0.19,0.19,0.05), %d x the single-GPU size: %d V / %d E, "
+                                       "src = max out-degree vertex" % (world, V, e_total),
+                           "n_vertices": V, "n_edges": e_total, "source": src,
+                           "parallelism": "vertex-range partition over %d GPUs, RCCL all-to-all frontier exchange "
+                                          "per level, all-reduce termination" % world,
+                           "advance_direction": "forward (top-down on every rank)",
+                           "edges_visited_per_step": edges_total, "search_depth": st["search_depth"],
+                           "setup_s": round(t_setup, 1)},
+                "roofline": None, "cpu_baseline": None}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
     props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], wl["c"], seed=42)
     deg = np.diff(csr.row_offsets)
-    # sources: rank r runs BFS from the r-th highest out-degree vertex (rank 0 =
-    # the config's source); ranks share no data => no collective on the data path
-    order = np.argsort(-deg, kind="stable")
-    src = int(order[rank])
+    src = int(np.argmax(deg))
     ctx = gr.multi_context_t(local_rank)
     G = gr.build_graph(props, csr, ctx, device=dev)
     V, E = G.get_number_of_vertices(), G.get_number_of_edges()
@@ -90,8 +160,6 @@ def main():
                         advance_direction=direction)
 
     def barrier():
-        if dist_on:
-            dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()
 
@@ -106,16 +174,7 @@ def main():
     st = gr.run_stats(ctx)
     edges_rank = st["edges_visited"]
     enact_ms = st["elapsed_ms"]
-
-    if dist_on:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        ee = torch.tensor([edges_rank], dtype=torch.int64, device=dev)
-        dist.all_reduce(ee, op=dist.ReduceOp.SUM)
-        edges_total = int(ee.item())
-    else:
-        edges_total = edges_rank
+    edges_total = edges_rank
     ms_per_step = elapsed * 1e3 / args.steps
     mteps = edges_total / (ms_per_step * 1e3)
 
@@ -197,7 +256,7 @@ def main():
                           "advance_load_balance": args.lb, "filter": "compact (fused into advance)",
                           "advance_direction": "forward" if args.topdown_only else "optimized",
                           "kernel_launch_groups_per_step": int(st["aux"]),
-                          "parallelism": "1 graph replica per GPU, independent sources" if world > 1 else "single GPU",
+                          "parallelism": "single GPU",
                           "edges_visited_per_step": edges_rank, "search_depth": st["search_depth"],
                           "enact_ms_last": round(enact_ms, 4), "setup_s": round(t_setup, 1)},
                "roofline": roofline, "roofline_topdown_advance": roofline_other, "cpu_baseline": cpu}

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void dist_collect_kernel(pipe_args a, di
   if (tid < DIST_MAX_RANKS) s_hist[tid] = 0;
   __syncthreads();
   for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+    if (a.tile_count[t] == 0) continue;  // reserved-but-unused tile: its slots are stale
     const int v = out[(size_t)t * TILE + tid];
     if (v >= 0 && (v < lo || v >= hi)) atomicAdd(&s_hist[owner_of(d, v)], 1);
   }
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void dist_collect_kernel(pipe_args a, di
   }
   __syncthreads();
   for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+    if (a.tile_count[t] == 0) continue;
     if (tid == 0) s_removed = 0;
     __syncthreads();
     const size_t slot = (size_t)t * TILE + tid;

@@ -100,7 +100,7 @@ void parallel_for(int64_t n, F f) {
   unsigned nt = std::thread::hardware_concurrency();
   if (nt == 0) nt = 1;
   if (nt > 32) nt = 32;
-  if (n < (int64_t)1 << 16) nt = 1;
+  if (n < 64) nt = 1;
   std::vector<std::thread> th;
   const int64_t per = (n + nt - 1) / nt;
   for (unsigned t = 0; t < nt; ++t) {
@@ -300,47 +300,67 @@ static grx_status_t generate_impl(int32_t kind, int32_t V, int64_t n_entries, fl
     if (mul == 0) mul = 1;
     while (std::gcd(mul, (uint64_t)V) != 1) ++mul;
     const uint64_t add = mix64(seed) % (uint64_t)V;
-    std::vector<int32_t> U((size_t)n_entries), W((size_t)n_entries);
-    parallel_for(n_entries, [&](int64_t lo, int64_t hi) {
-      for (int64_t e = lo; e < hi; ++e) {
-        uint64_t u = 0, v = 0, word = 0;
-        for (int l = 0; l < scale; ++l) {
-          if ((l & 3) == 0) word = rnd(seed, (uint64_t)e, (uint64_t)(l >> 2));
-          const uint32_t r = (uint32_t)(word & 0xFFFF);
-          word >>= 16;
-          const uint32_t ub = r >= tb ? 1u : 0u;                      // quadrants c,d => row bit
-          const uint32_t vb = (r >= ta && r < tb) || r >= tc ? 1u : 0u;  // quadrants b,d => col bit
-          u = (u << 1) | ub;
-          v = (v << 1) | vb;
-        }
-        u %= (uint64_t)V;
-        v %= (uint64_t)V;
-        U[(size_t)e] = (int32_t)((u * mul + add) % (uint64_t)V);
-        W[(size_t)e] = (int32_t)((v * mul + add) % (uint64_t)V);
+    auto endpoints = [&](int64_t e, int32_t* pu, int32_t* pw) {
+      uint64_t u = 0, v = 0, word = 0;
+      for (int l = 0; l < scale; ++l) {
+        if ((l & 3) == 0) word = rnd(seed, (uint64_t)e, (uint64_t)(l >> 2));
+        const uint32_t r = (uint32_t)(word & 0xFFFF);
+        word >>= 16;
+        const uint32_t ub = r >= tb ? 1u : 0u;                         // quadrants c,d => row bit
+        const uint32_t vb = (r >= ta && r < tb) || r >= tc ? 1u : 0u;  // quadrants b,d => col bit
+        u = (u << 1) | ub;
+        v = (v << 1) | vb;
       }
-    });
+      u %= (uint64_t)V;
+      v %= (uint64_t)V;
+      *pu = (int32_t)((u * mul + add) % (uint64_t)V);
+      *pw = (int32_t)((v * mul + add) % (uint64_t)V);
+    };
     auto owned = [&](int32_t r) { return r >= row_lo && r < row_hi; };
-    if (kind == 0) {
-      if (!sliced) {
+    if (!sliced) {
+      std::vector<int32_t> U((size_t)n_entries), W((size_t)n_entries);
+      parallel_for(n_entries, [&](int64_t lo, int64_t hi) {
+        for (int64_t e = lo; e < hi; ++e) endpoints(e, &U[(size_t)e], &W[(size_t)e]);
+      });
+      if (kind == 0) {
         I.swap(U);
         J.swap(W);
       } else {
-        for (int64_t e = 0; e < n_entries; ++e)
-          if (owned(U[(size_t)e])) { I.push_back(U[(size_t)e]); J.push_back(W[(size_t)e]); }
-      }
-      h->directed = 1; h->symmetric = 0; h->weighted = 0;
-    } else {
-      if (!sliced) {
         I.reserve((size_t)n_entries * 2);
         J.reserve((size_t)n_entries * 2);
+        for (int64_t e = 0; e < n_entries; ++e) {
+          I.push_back(U[(size_t)e]); J.push_back(W[(size_t)e]);
+          if (U[(size_t)e] != W[(size_t)e]) { I.push_back(W[(size_t)e]); J.push_back(U[(size_t)e]); }
+        }
       }
-      for (int64_t e = 0; e < n_entries; ++e) {
-        const int32_t u = U[(size_t)e], w = W[(size_t)e];
-        if (owned(u)) { I.push_back(u); J.push_back(w); }
-        if (u != w && owned(w)) { I.push_back(w); J.push_back(u); }
+    } else {
+      // a rank's slice: generate every entry, keep the owned rows, never hold the
+      // whole edge list (fixed number of chunks, concatenated in entry order)
+      const int n_parts = 64;
+      std::vector<std::vector<int32_t>> PI(n_parts), PJ(n_parts);
+      const int64_t per = (n_entries + n_parts - 1) / n_parts;
+      parallel_for(n_parts, [&](int64_t plo, int64_t phi) {
+        for (int64_t pi = plo; pi < phi; ++pi) {
+          const int64_t lo = pi * per, hi = std::min<int64_t>(n_entries, lo + per);
+          for (int64_t e = lo; e < hi; ++e) {
+            int32_t u, w;
+            endpoints(e, &u, &w);
+            if (owned(u)) { PI[pi].push_back(u); PJ[pi].push_back(w); }
+            if (kind == 1 && u != w && owned(w)) { PI[pi].push_back(w); PJ[pi].push_back(u); }
+          }
+        }
+      });
+      size_t tot = 0;
+      for (auto& x : PI) tot += x.size();
+      I.reserve(tot);
+      J.reserve(tot);
+      for (int pi = 0; pi < n_parts; ++pi) {
+        I.insert(I.end(), PI[pi].begin(), PI[pi].end());
+        J.insert(J.end(), PJ[pi].begin(), PJ[pi].end());
       }
-      h->directed = 0; h->symmetric = 1; h->weighted = 0;
     }
+    if (kind == 0) { h->directed = 1; h->symmetric = 0; h->weighted = 0; }
+    else { h->directed = 0; h->symmetric = 1; h->weighted = 0; }
   } else if (kind == 2) {
     // road-like: side x side 4-neighbour lattice, each undirected edge kept with
     // probability a; weights integer U{1..1000} when c > 0, else 1.0 (pattern)

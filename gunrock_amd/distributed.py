@@ -45,18 +45,27 @@ def edge_balanced_bounds(row_offsets, n_ranks):
 
 
 class GrxEngine:
-    """Device side: the level-stepping C ABI (grx_bfs_dist_*)."""
+    """Device side: the level-stepping C ABI (grx_bfs_dist_*).
 
-    def __init__(self, graph, context, bounds, rank, device):
+    The engine context is created ON a torch stream, and every torch operation of the
+    exchange runs on that same stream, so kernels, bucket reads and collectives are
+    stream-ordered without extra synchronisation."""
+
+    def __init__(self, properties, csr_rows, bounds, rank, device):
         import torch
+        from . import build_graph, multi_context_t
         self.torch = torch
-        self.g, self.ctx, self.rank = graph, context, rank
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.ctx = multi_context_t(self.device.index or 0, stream=self.stream)
+        with torch.cuda.stream(self.stream):
+            self.g = build_graph(properties, csr_rows, self.ctx, device=device)
+        self.rank = rank
         self.bounds = np.ascontiguousarray(bounds, dtype=np.int32)
         self.P = len(self.bounds) - 1
-        V = graph.get_number_of_vertices()
+        V = self.g.get_number_of_vertices()
         self.send = torch.empty(max(V, 1), dtype=torch.int32, device=device)
         self.counts = torch.zeros(self.P, dtype=torch.int64, device=device)
-        self.device = device
 
     def begin(self, source, dist):
         lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
@@ -143,19 +152,24 @@ def bfs(engine, dist, source, distances, bounds, rank, recv=None):
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     if recv is None:
         recv = torch.empty(max(hi - lo, 1) * max(P - 1, 1), dtype=torch.int32, device=distances.device)
-    engine.begin(source, distances)
-    levels = 0
-    while True:
-        send, counts = engine.advance()
-        n_recv = _exchange(dist, engine, send, counts, bounds, rank, P, recv) if P > 1 else 0
-        engine.apply(recv, n_recv)
-        nv, _ = engine.frontier()
-        total = torch.tensor([nv], dtype=torch.int64, device=distances.device if dist.get_backend() == "nccl" else "cpu")
-        if P > 1:
-            dist.all_reduce(total)
-        levels += 1
-        if int(total.item()) == 0:
-            break
-    stats = engine.end()
+    import contextlib
+    on_stream = torch.cuda.stream(engine.stream) if getattr(engine, "stream", None) is not None \
+        else contextlib.nullcontext()
+    with on_stream:
+        engine.begin(source, distances)
+        levels = 0
+        while True:
+            send, counts = engine.advance()
+            n_recv = _exchange(dist, engine, send, counts, bounds, rank, P, recv) if P > 1 else 0
+            engine.apply(recv, n_recv)
+            nv, _ = engine.frontier()
+            total = torch.tensor([nv], dtype=torch.int64,
+                                 device=distances.device if dist.get_backend() == "nccl" else "cpu")
+            if P > 1:
+                dist.all_reduce(total)
+            levels += 1
+            if int(total.item()) == 0:
+                break
+        stats = engine.end()
     stats["search_depth"] = levels
     return stats

@@ -103,9 +103,7 @@ def _worker(rank, world, port, use_gpu, out_dir):
         _, mine = gr.generate_rows(kind, V, E, lo, hi, seed=seed)
         src = int(np.argmax(np.diff(full.row_offsets)))
         if use_gpu:
-            ctx = gr.multi_context_t(0)
-            G = gr.build_graph(props, mine, ctx)
-            eng = D.GrxEngine(G, ctx, bounds, rank, "cuda:0")
+            eng = D.GrxEngine(props, mine, bounds, rank, "cuda:0")
             d = torch.empty(V, dtype=torch.int32, device="cuda:0")
         else:
             eng = FakeEngine(mine.row_offsets, mine.column_indices, bounds, rank)
@@ -178,12 +176,29 @@ def test_single_rank_dist_path_equals_plain_bfs(gr, gpu_ctx):
             return "none"
     V, E = 1 << 16, 1 << 20
     props, c = gr.generate("rmat", V, E, seed=2)
-    G = gr.build_graph(props, c, gpu_ctx)
     bounds = D.vertex_bounds(V, 1)
-    eng = D.GrxEngine(G, gpu_ctx, bounds, 0, "cuda:0")
+    eng = D.GrxEngine(props, c, bounds, 0, "cuda:0")
     d = torch.empty(V, dtype=torch.int32, device="cuda:0")
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
     src = int(np.argmax(np.diff(g.row_offsets)))
     st = D.bfs(eng, NoDist, src, d, bounds, 0)
     want, _, ev = O.bfs_queue(g, src)
     assert np.array_equal(d.cpu().numpy(), want) and st["edges_visited"] == ev
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path(tmp_path):
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run), except
+    that both ranks share cuda:0 and gloo carries the exchange."""
+    import json
+    import subprocess
+    env = dict(os.environ, GRX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "small"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["n_vertices"] == 2 * (1 << 18)
