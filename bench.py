@@ -194,6 +194,14 @@ def main():
                     best_ = (t_, prof_)
             return best_[1]
 
+        # HBM traffic of the same kernels from the committed rocprofv3 PMC passes of this round
+        # (FETCH_SIZE / WRITE_SIZE, separate --pmc runs; tools/profile.sh, profiles/r1_bench_pmc.json)
+        pmc = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_pmc.json")))
+        except Exception:
+            pass
+
         def roof(levels, bytes_of, kernel):
             ms = sum(l["advance_ms"] for l in levels)
             byt = sum(bytes_of(l) for l in levels)
@@ -212,6 +220,11 @@ def main():
         bu_bytes = lambda l, nxt: 3 * (V // 8) + 8 * l["bu_open"] + 8 * l["bu_probes"] + 12 * nxt
         prof_td = profile(gr.forward)
         roofline_td = roof(prof_td, td_bytes, "advance_kernel<bfs_policy> (top-down only run)")
+        if pmc and args.workload == "lj":
+            k = pmc["advance_kernel"]
+            roofline_td["traffic"] = int((k["fetch_bytes_per_topdown_bfs_approx"] + k["write_bytes_per_topdown_bfs_approx"])
+                                         / max(1, len(prof_td)))
+            roofline_td["traffic_source"] = "profiles/r1_bench_pmc.json (FETCH_SIZE+WRITE_SIZE per launch, this workload)"
         roofline_td["levels"] = [[l["frontier_size"], l["edges"], round(l["advance_ms"], 4), round(l["other_ms"], 4)]
                                  for l in prof_td]
         if args.topdown_only:
@@ -227,6 +240,10 @@ def main():
             r_bu["levels"] = [[l["frontier_size"], l["edges"], l["bu_open"], l["bu_probes"], round(l["advance_ms"], 4),
                                round(l["other_ms"], 4)] for l in bu]
             r_bu["share_of_step_kernel_time"] = round(t_bu / max(t_bu + t_td, 1e-9), 3)
+            if pmc and args.workload == "lj" and bu:
+                k = pmc["bfs_bottomup_kernel"]
+                r_bu["traffic"] = int((k["fetch_bytes_per_bfs"] + k["write_bytes_per_bfs"]) / len(bu))
+                r_bu["traffic_source"] = "profiles/r1_bench_pmc.json (FETCH_SIZE+WRITE_SIZE per launch, this workload)"
             roofline, roofline_other = (r_bu, roofline_td) if t_bu >= t_td or not td else (roofline_td, r_bu)
             roofline["all_levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
                                        round(l["other_ms"], 4)] for l in prof_do]
