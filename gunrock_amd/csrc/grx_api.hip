@@ -161,6 +161,7 @@ grx_status_t grx_context_destroy(grx_context_t ctx) {
   ctx->tile_sums.release();
   ctx->tile_count.release();
   ctx->bu_part.release();
+  for (auto& b : ctx->far) b.release();
   ctx->chunk_tile.release();
   ctx->chunk_prefix.release();
   for (auto& b : ctx->bitmap) b.release();

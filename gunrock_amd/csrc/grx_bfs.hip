@@ -418,7 +418,9 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   grx_status_t st = pipeline_prepare(ctx, g, &a);
   if (st != GRX_SUCCESS) return st;
   const int variant = (opt.engine_flags >> 8) & 3;
-  const bool dopt = opt.advance_direction == GRX_DIR_OPTIMIZED && variant == 0;
+  // bottom-up pays off on low-diameter graphs; with fewer than 4 edges per vertex the
+  // frontier never gets heavy enough to switch and the extra per-level kernels only cost
+  const bool dopt = opt.advance_direction == GRX_DIR_OPTIMIZED && variant == 0 && (long long)g->E >= 4ll * g->V;
   const size_t bm_words = 2 * (((size_t)g->V + 63) / 64);
   hipStream_t s = ctx->stream;
 
@@ -444,7 +446,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     d.visited = ctx->bitmap[0].as<unsigned>();
     d.fbits[0] = ctx->bitmap[1].as<unsigned>();
     d.fbits[1] = d.fbits[0] + bm_words;
-    d.bu_grid = advance_grid(ctx);
+    d.bu_grid = advance_grid_for(ctx, g);
     GRX_HIP(ctx->bu_part.reserve((size_t)d.bu_grid * 4 * sizeof(long long)));
     d.bu_part = ctx->bu_part.as<long long>();
   } else if (variant != 0) {
@@ -459,7 +461,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   GRX_HIP(hipEventRecord(ctx->ev_begin, s));
   hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, visited, src);
 
-  const int grid = advance_grid(ctx);
+  const int grid = advance_grid_for(ctx, g);
   const bool profile = (opt.engine_flags & GRX_FLAG_PROFILE) != 0;
   ctx->levels.clear();
   hipEvent_t pe[3] = {nullptr, nullptr, nullptr};

@@ -81,6 +81,15 @@ struct ctrl_t {
   int32_t convert;          // this level: 0 none, 1 bitmap -> queue, 2 labels -> bitmaps
   int32_t pad2[3];
   int64_t q_edges[2];       // out-degree sum of the frontier entering the level (set by plan/decide)
+  // near-far (delta-stepping) SSSP
+  float nf_lo, nf_hi;       // current bucket [lo, hi)
+  float nf_delta;
+  uint32_t nf_min_far;      // min tentative distance in the far pile (ordered bits)
+  int32_t nf_far_n[2];      // entries in the far piles
+  int32_t nf_sel;           // far pile receiving appends
+  int32_t nf_split;         // this iteration moves bucket [lo, hi) from far[sel ^ 1] to the frontier
+  int32_t nf_overflow;      // far pile capacity exceeded (host reruns label-correcting)
+  int32_t nf_phases;
   int64_t bu_open;          // bottom-up accounting: unvisited vertices examined (cumulative)
   int64_t bu_probes;        // bottom-up accounting: in-edges read (cumulative)
 };
@@ -115,6 +124,7 @@ struct grx_context {
   grx::dbuf tile_sums;     // per tile: sum of degrees
   grx::dbuf tile_count;    // per tile: valid vertices
   grx::dbuf bu_part;       // per workgroup partial counters of the bottom-up kernel
+  grx::dbuf far[2];        // near-far SSSP: far piles
   grx::dbuf chunk_tile;    // per chunk: owning tile
   grx::dbuf chunk_prefix;  // per tile: first chunk id
   grx::dbuf bitmap[2];     // visited / scratch bitmaps
@@ -138,6 +148,7 @@ struct grx_graph {
   int32_t* t_ci = nullptr;
   float* t_w = nullptr;
   bool has_transpose = false;
+  double weight_sum = -1.0;  // sum of edge weights (lazy; near-far SSSP bucket width)
   std::vector<int32_t> h_t_ro;  // host copy of the transpose offsets (for static partitions)
   // static PageRank pull partition (built once per graph)
   void* pr_blocks = nullptr;    // int4 {row0, nrows, e0, e1}; nrows == 0 => piece of a long row

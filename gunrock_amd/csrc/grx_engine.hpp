@@ -19,8 +19,16 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a);
 // Build (once) and cache the transpose of g in the graph handle.
 grx_status_t graph_build_transpose(grx_context_t ctx, grx_graph_t g);
 
-// Launch configuration of the advance kernel (persistent workgroups).
+// Launch configuration of the advance kernel (persistent workgroups striding over chunks).
+// Upper bound used for sizing scratch:
 inline int advance_grid(grx_context_t ctx) { return ctx->num_cus * 8; }
+// Low-degree (road-like) graphs have thousands of tiny levels: a level is a handful of
+// chunks, and dispatching 2048 idle workgroups per launch would dominate.  One workgroup
+// per CU is plenty there; scale-free graphs get the full 8 per CU.
+inline int advance_grid_for(grx_context_t ctx, grx_graph_t g) {
+  const bool road_like = g->V > 0 && (long long)g->E < 4ll * g->V;
+  return road_like ? ctx->num_cus : ctx->num_cus * 8;
+}
 
 // Generic host loop: `launch_level(stream)` enqueues one level (plan + advance
 // [+ extra]); levels are enqueued in growing batches and the host only reads

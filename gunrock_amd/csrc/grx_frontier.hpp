@@ -25,6 +25,8 @@
 //     replays a hipGraph) and only looks at a `done` flag.
 #pragma once
 
+#include <type_traits>
+
 #include "grx_common.hpp"
 #include <gunrock/hip/wave.hxx>
 
@@ -71,7 +73,7 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, in
   if (tid == 0) s_esum = 0ull;
   __syncthreads();
   if (done) return;
-  if (external_control && mode != 0) return;
+  if (external_control == 1 && mode != 0) return;
   if (!external_control && nt == 0) {
     if (tid == 0) {
       c->done = 1;
@@ -107,17 +109,19 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, in
   __syncthreads();
   if (tid == 0) {
     c->total_chunks = carry;
-    if (!external_control) {
+    if (external_control != 1) {
       const long long edges = (long long)(s_esum & ((1ull << 40) - 1));
       const int nitems = (int)(s_esum >> 40);
-      c->level = level;
       c->edges_visited += edges;
       c->vertices_visited += nitems;
       c->n_items[p] = nitems;
       c->q_edges[p] = edges;
-      c->n_tiles[p ^ 1] = 0;
-      a.mailbox[1] = level;
-      a.mailbox[2] = nitems;
+      if (!external_control) {
+        c->level = level;
+        c->n_tiles[p ^ 1] = 0;
+        a.mailbox[1] = level;
+        a.mailbox[2] = nitems;
+      }
     }
   }
 }
@@ -177,10 +181,22 @@ __device__ __forceinline__ void release_tiles(const pipe_args& a, const int* s_r
 //   void begin(ctrl_t*)                               once per workgroup
 //   src_state load_source(int v)                      per staged slot (e.g. dist[v])
 //   bool precheck(src_state, int nbr, int e)          cheap, read-only filter
-//   bool visit(int src, src_state, int nbr, int e)    true => nbr joins the output
+//   int  visit(int src, src_state, int nbr, int e)    1/true => nbr joins the output,
+//                                                     2 => nbr goes to the policy's SIDE pile
+//                                                     (policies with `has_side`), 0 => dropped
+//   side pile (has_side): side_reserve(ctrl, n) -> base index or -1, side_store(i, v)
 // ---------------------------------------------------------------------------
+template <class Policy, class = void>
+struct policy_has_side : std::false_type {};
+template <class Policy>
+struct policy_has_side<Policy, std::void_t<decltype(Policy::has_side)>> : std::bool_constant<Policy::has_side> {};
+
 template <class Policy>
 __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy pol) {
+  constexpr bool SIDE = policy_has_side<Policy>::value;
+  __shared__ int s_side[SIDE ? (CHUNK + ADV_BLOCK) : 1];
+  __shared__ int s_side_cnt;
+  __shared__ int s_side_base;
   __shared__ int s_seg[TILE + 1];
   __shared__ int s_start[TILE];
   __shared__ int s_src[TILE];
@@ -194,14 +210,13 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
   if (c->done) return;
   const int tid = threadIdx.x;
   const int lane = dev::lane_id();
-  const int wid = tid >> 6;
   const int level = c->level;
   const int p = level & 1;
   const int total_chunks = c->total_chunks;
   if (c->mode != 0) return;  // this level runs bottom-up
   const int32_t* __restrict__ in = a.frontier[p];
   pol.begin(c);
-  if (tid == 0) { s_cnt = 0; s_res[0] = 0; s_res[1] = 0; }
+  if (tid == 0) { s_cnt = 0; s_res[0] = 0; s_res[1] = 0; s_side_cnt = 0; }
   __syncthreads();
 
   for (int chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
@@ -251,8 +266,9 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
       pre_k[k] = (e_k[k] >= 0) && pol.precheck(s_state[slot_k[k]], n_k[k], e_k[k]);
 #pragma unroll
     for (int k = 0; k < ADV_ITEMS; ++k) {
-      bool keep = false;
-      if (pre_k[k]) keep = pol.visit(s_src[slot_k[k]], s_state[slot_k[k]], n_k[k], e_k[k]);
+      int code = 0;
+      if (pre_k[k]) code = (int)pol.visit(s_src[slot_k[k]], s_state[slot_k[k]], n_k[k], e_k[k]);
+      const bool keep = code == 1;
       const unsigned long long m = dev::ballot(keep);
       if (m) {
         int base = 0;
@@ -260,8 +276,32 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
         base = __shfl(base, 0, 64);
         if (keep) s_out[base + dev::mask_rank(m)] = n_k[k];
       }
+      if constexpr (SIDE) {
+        const bool aside = code == 2;
+        const unsigned long long ms = dev::ballot(aside);
+        if (ms) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&s_side_cnt, __popcll(ms));
+          base = __shfl(base, 0, 64);
+          if (aside) s_side[base + dev::mask_rank(ms)] = n_k[k];
+        }
+      }
     }
     __syncthreads();
+    if constexpr (SIDE) {
+      // flush the side pile when it could overflow on the next chunk
+      const int sc = s_side_cnt;
+      if (sc >= ADV_BLOCK) {
+        if (tid == 0) s_side_base = pol.side_reserve(c, sc);
+        __syncthreads();
+        const int sb = s_side_base;
+        if (sb >= 0)
+          for (int i = tid; i < sc; i += ADV_BLOCK) pol.side_store(sb + i, s_side[i]);
+        __syncthreads();
+        if (tid == 0) s_side_cnt = 0;
+        __syncthreads();
+      }
+    }
     // ---- flush full tiles --------------------------------------------------
     int cnt = s_cnt;
     while (cnt >= TILE) {
@@ -276,6 +316,16 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
   if (rem > 0) emit_tile(a, c, p ^ 1, s_out, 0, rem, s_wave, s_res);
   __syncthreads();
   release_tiles(a, s_res);
+  if constexpr (SIDE) {
+    const int sc = s_side_cnt;
+    if (sc > 0) {
+      if (tid == 0) s_side_base = pol.side_reserve(c, sc);
+      __syncthreads();
+      const int sb = s_side_base;
+      if (sb >= 0)
+        for (int i = tid; i < sc; i += ADV_BLOCK) pol.side_store(sb + i, s_side[i]);
+    }
+  }
 }
 
 }  // namespace grx

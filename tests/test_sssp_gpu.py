@@ -61,7 +61,9 @@ def test_random_weighted_graphs_vs_oracle(gr, gpu_ctx):
         g = O.Csr(c.row_offsets, c.column_indices, w)
         for src in (int(np.argmax(np.diff(g.row_offsets))), int(rng.integers(0, V))):
             for opt in (None, gr.options_t(advance_load_balance=gr.merge_path),
-                        gr.options_t(advance_load_balance=gr.warp_mapped, enable_uniquify=True)):
+                        gr.options_t(advance_load_balance=gr.warp_mapped, enable_uniquify=True),
+                        gr.options_t(engine_flags=0x10),   # 0x10: plain label-correcting schedule
+                        gr.options_t(engine_flags=0x20)):  # 0x20: near-far even on dense graphs
                 d, _ = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, w, src, opt)
                 assert np.array_equal(d, O.sssp(g, src)[0])
 
@@ -76,6 +78,33 @@ def test_zero_weights_self_loops_duplicates(gr, gpu_ctx):
         assert np.array_equal(d, O.sssp(g, s)[0])
     d, _ = run_sssp(gr, gpu_ctx, ro, ci, w, 3)  # vertex 3 has no out-edges
     assert d[3] == 0 and np.all(np.delete(d, 3) == FMAX)  # unreached = FLT_MAX, not inf (sssp.hxx:72-73)
+
+
+def test_near_far_schedule_equals_plain_and_does_less_work(gr, gpu_ctx):
+    """Delta-stepping (near-far) and plain label-correcting must give the same bits; on a
+    weighted lattice the near-far schedule must relax far fewer edges."""
+    _, c = gr.generate("road", 300 * 300, a=0.75, c=1.0, seed=3)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    src = 150 * 300 + 150
+    want = O.sssp(g, src)[0]
+    d_nf, st_nf = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src)
+    d_pl, st_pl = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src, gr.options_t(engine_flags=0x10))
+    assert np.array_equal(d_nf, want) and np.array_equal(d_pl, want)
+    assert st_nf["aux"] > 1  # several buckets were opened
+    assert st_nf["edges_visited"] < st_pl["edges_visited"] / 3
+    # heavy-tailed weights: most buckets empty -> the bucket jump must skip them
+    w = c.nonzero_values.copy()
+    rng = np.random.default_rng(0)
+    w[rng.random(len(w)) < 0.01] = 1.0e6
+    g2 = O.Csr(c.row_offsets, c.column_indices, w)
+    d2, _ = run_sssp(gr, gpu_ctx, g2.row_offsets, g2.column_indices, w, src)
+    assert np.array_equal(d2, O.sssp(g2, src)[0])
+    # tiny fractional weights next to huge ones (fp guard of the bucket bound)
+    w3 = (rng.random(len(w), dtype=np.float32) * np.float32(1e-3) + np.float32(1e-6)).astype(np.float32)
+    w3[rng.random(len(w)) < 0.02] = np.float32(3.0e7)
+    g3 = O.Csr(c.row_offsets, c.column_indices, w3)
+    d3, _ = run_sssp(gr, gpu_ctx, g3.row_offsets, g3.column_indices, w3, src)
+    assert np.array_equal(d3, O.sssp(g3, src)[0])
 
 
 def test_medium_weighted_rmat(gr, gpu_ctx):
