@@ -191,39 +191,47 @@ struct policy_has_side : std::false_type {};
 template <class Policy>
 struct policy_has_side<Policy, std::void_t<decltype(Policy::has_side)>> : std::bool_constant<Policy::has_side> {};
 
+// LDS of one advance workgroup.
 template <class Policy>
-__global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy pol) {
-  constexpr bool SIDE = policy_has_side<Policy>::value;
-  __shared__ int s_side[SIDE ? (CHUNK + ADV_BLOCK) : 1];
-  __shared__ int s_side_cnt;
-  __shared__ int s_side_base;
-  __shared__ int s_seg[TILE + 1];
-  __shared__ int s_start[TILE];
-  __shared__ int s_src[TILE];
-  __shared__ typename Policy::src_state s_state[TILE];
-  __shared__ int s_out[TILE + CHUNK];
-  __shared__ int s_wave[ADV_BLOCK / 64 + 1];
-  __shared__ int s_cnt;
-  __shared__ int s_res[3];
+struct advance_smem {
+  static constexpr bool SIDE = policy_has_side<Policy>::value;
+  int side[SIDE ? (CHUNK + ADV_BLOCK) : 1];
+  int side_cnt;
+  int side_base;
+  int seg[TILE + 1];
+  int start[TILE];
+  int src[TILE];
+  typename Policy::src_state state[TILE];
+  int out[TILE + CHUNK];
+  int wave[ADV_BLOCK / 64 + 1];
+  int cnt;
+  int res[3];
+};
 
-  ctrl_t* c = a.ctrl;
-  if (c->done) return;
+// The work of one advance workgroup on one level: chunks chunk_first, chunk_first +
+// chunk_stride, ... of the frontier with parity p; winners are emitted as tiles of parity
+// p ^ 1.  FRESH: re-read the frontier slots past the CU's L1 (for callers whose slots were
+// written by the same workgroup earlier in the same launch).
+template <class Policy, bool FRESH>
+__device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Policy& pol, advance_smem<Policy>& sm,
+                                              int p, int chunk_first, int chunk_stride, int total_chunks,
+                                              const int* chunk_tile, const int* chunk_prefix) {
+  constexpr bool SIDE = policy_has_side<Policy>::value;
   const int tid = threadIdx.x;
   const int lane = dev::lane_id();
-  const int level = c->level;
-  const int p = level & 1;
-  const int total_chunks = c->total_chunks;
-  if (c->mode != 0) return;  // this level runs bottom-up
-  const int32_t* __restrict__ in = a.frontier[p];
-  pol.begin(c);
-  if (tid == 0) { s_cnt = 0; s_res[0] = 0; s_res[1] = 0; s_side_cnt = 0; }
+  const int32_t* in = a.frontier[p];
+  if (tid == 0) { sm.cnt = 0; sm.res[0] = 0; sm.res[1] = 0; sm.side_cnt = 0; }
   __syncthreads();
 
-  for (int chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
-    const int t = a.chunk_tile[chunk];
-    const int lc = chunk - a.chunk_prefix[t];
+  for (int chunk = chunk_first; chunk < total_chunks; chunk += chunk_stride) {
+    const int t = chunk_tile[chunk];
+    const int lc = chunk - chunk_prefix[t];
     // ---- stage the tile -------------------------------------------------
-    const int v = in[(size_t)t * TILE + tid];
+    int v;
+    if constexpr (FRESH)
+      v = __hip_atomic_load(&in[(size_t)t * TILE + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      v = in[(size_t)t * TILE + tid];
     int rs = 0, deg = 0;
     typename Policy::src_state st{};
     if (v >= 0) {
@@ -232,12 +240,12 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
       st = pol.load_source(v);
     }
     int tot;
-    const int ex = dev::block_exclusive_sum<ADV_BLOCK>(deg, s_wave, &tot);
-    s_seg[tid] = ex;
-    s_start[tid] = rs;
-    s_src[tid] = v;
-    s_state[tid] = st;
-    if (tid == 0) s_seg[TILE] = tot;
+    const int ex = dev::block_exclusive_sum<ADV_BLOCK>(deg, sm.wave, &tot);
+    sm.seg[tid] = ex;
+    sm.start[tid] = rs;
+    sm.src[tid] = v;
+    sm.state[tid] = st;
+    if (tid == 0) sm.seg[TILE] = tot;
     __syncthreads();
 
     // ---- atoms of this chunk ---------------------------------------------
@@ -251,8 +259,8 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
       if (atom < a_end) {
 #pragma unroll
         for (int step = TILE / 2; step >= 1; step >>= 1)
-          if (s_seg[lo + step] <= atom) lo += step;
-        e_k[k] = s_start[lo] + (atom - s_seg[lo]);
+          if (sm.seg[lo + step] <= atom) lo += step;
+        e_k[k] = sm.start[lo] + (atom - sm.seg[lo]);
       } else {
         e_k[k] = -1;
       }
@@ -263,69 +271,82 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
     bool pre_k[ADV_ITEMS];
 #pragma unroll
     for (int k = 0; k < ADV_ITEMS; ++k)
-      pre_k[k] = (e_k[k] >= 0) && pol.precheck(s_state[slot_k[k]], n_k[k], e_k[k]);
+      pre_k[k] = (e_k[k] >= 0) && pol.precheck(sm.state[slot_k[k]], n_k[k], e_k[k]);
 #pragma unroll
     for (int k = 0; k < ADV_ITEMS; ++k) {
       int code = 0;
-      if (pre_k[k]) code = (int)pol.visit(s_src[slot_k[k]], s_state[slot_k[k]], n_k[k], e_k[k]);
+      if (pre_k[k]) code = (int)pol.visit(sm.src[slot_k[k]], sm.state[slot_k[k]], n_k[k], e_k[k]);
       const bool keep = code == 1;
       const unsigned long long m = dev::ballot(keep);
       if (m) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(&s_cnt, __popcll(m));
+        if (lane == 0) base = atomicAdd(&sm.cnt, __popcll(m));
         base = __shfl(base, 0, 64);
-        if (keep) s_out[base + dev::mask_rank(m)] = n_k[k];
+        if (keep) sm.out[base + dev::mask_rank(m)] = n_k[k];
       }
       if constexpr (SIDE) {
         const bool aside = code == 2;
         const unsigned long long ms = dev::ballot(aside);
         if (ms) {
           int base = 0;
-          if (lane == 0) base = atomicAdd(&s_side_cnt, __popcll(ms));
+          if (lane == 0) base = atomicAdd(&sm.side_cnt, __popcll(ms));
           base = __shfl(base, 0, 64);
-          if (aside) s_side[base + dev::mask_rank(ms)] = n_k[k];
+          if (aside) sm.side[base + dev::mask_rank(ms)] = n_k[k];
         }
       }
     }
     __syncthreads();
     if constexpr (SIDE) {
       // flush the side pile when it could overflow on the next chunk
-      const int sc = s_side_cnt;
+      const int sc = sm.side_cnt;
       if (sc >= ADV_BLOCK) {
-        if (tid == 0) s_side_base = pol.side_reserve(c, sc);
+        if (tid == 0) sm.side_base = pol.side_reserve(c, sc);
         __syncthreads();
-        const int sb = s_side_base;
+        const int sb = sm.side_base;
         if (sb >= 0)
-          for (int i = tid; i < sc; i += ADV_BLOCK) pol.side_store(sb + i, s_side[i]);
+          for (int i = tid; i < sc; i += ADV_BLOCK) pol.side_store(sb + i, sm.side[i]);
         __syncthreads();
-        if (tid == 0) s_side_cnt = 0;
+        if (tid == 0) sm.side_cnt = 0;
         __syncthreads();
       }
     }
     // ---- flush full tiles --------------------------------------------------
-    int cnt = s_cnt;
+    int cnt = sm.cnt;
     while (cnt >= TILE) {
-      emit_tile(a, c, p ^ 1, s_out, cnt - TILE, TILE, s_wave, s_res);
+      emit_tile(a, c, p ^ 1, sm.out, cnt - TILE, TILE, sm.wave, sm.res);
       cnt -= TILE;
       __syncthreads();
     }
-    if (tid == 0) s_cnt = cnt;
+    if (tid == 0) sm.cnt = cnt;
     __syncthreads();
   }
-  const int rem = s_cnt;
-  if (rem > 0) emit_tile(a, c, p ^ 1, s_out, 0, rem, s_wave, s_res);
+  const int rem = sm.cnt;
+  if (rem > 0) emit_tile(a, c, p ^ 1, sm.out, 0, rem, sm.wave, sm.res);
   __syncthreads();
-  release_tiles(a, s_res);
+  release_tiles(a, sm.res);
   if constexpr (SIDE) {
-    const int sc = s_side_cnt;
+    const int sc = sm.side_cnt;
     if (sc > 0) {
-      if (tid == 0) s_side_base = pol.side_reserve(c, sc);
+      if (tid == 0) sm.side_base = pol.side_reserve(c, sc);
       __syncthreads();
-      const int sb = s_side_base;
+      const int sb = sm.side_base;
       if (sb >= 0)
-        for (int i = tid; i < sc; i += ADV_BLOCK) pol.side_store(sb + i, s_side[i]);
+        for (int i = tid; i < sc; i += ADV_BLOCK) pol.side_store(sb + i, sm.side[i]);
     }
   }
+  __syncthreads();
+}
+
+template <class Policy>
+__global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy pol) {
+  __shared__ advance_smem<Policy> sm;
+  ctrl_t* c = a.ctrl;
+  if (c->done) return;
+  if (c->mode != 0) return;  // this level runs bottom-up
+  const int p = c->level & 1;
+  pol.begin(c);
+  advance_block<Policy, false>(a, c, pol, sm, p, blockIdx.x, gridDim.x, c->total_chunks, a.chunk_tile,
+                               a.chunk_prefix);
 }
 
 }  // namespace grx

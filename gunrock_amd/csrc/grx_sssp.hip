@@ -38,7 +38,11 @@ struct sssp_policy {
   int level;
 
   __device__ __forceinline__ void begin(ctrl_t* c) { level = c->level; }
-  __device__ __forceinline__ src_state load_source(int v) const { return dist[v]; }
+  // past the CU's L1: the label may have been lowered by an atomic (performed at L2) of
+  // this very launch (multi-level kernel), and relaxing from a stale label would lose it
+  __device__ __forceinline__ src_state load_source(int v) const {
+    return __hip_atomic_load(&dist[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __device__ __forceinline__ float edge_weight(int e) const { return w ? w[e] : 1.0f; }
   __device__ __forceinline__ bool precheck(src_state d_src, int n, int e) const {
     // dist[] only decreases, so a possibly stale read can only be too large:
