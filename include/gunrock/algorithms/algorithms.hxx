@@ -20,6 +20,9 @@ struct options_t {
   /// engine extension: 0 = fused engine when available; bit 0 = run the generic
   /// operator pipeline (advance -> filter -> uniquify as separate launches).
   int engine_flags = 0;
+  /// engine extension: the reference declares advance_direction_t (operators/configs.hxx:78-82)
+  /// but never reads it; `optimized` = direction-optimising BFS (bottom-up fat levels).
+  operators::advance_direction_t advance_direction = operators::advance_direction_t::forward;
 
   options_t() = default;
   options_t(operators::load_balance_t _advance_load_balance,

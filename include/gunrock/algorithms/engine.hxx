@@ -76,6 +76,8 @@ inline grx_options_t to_c(const options_like_t& o) {
   c.uniquify_algorithm = (int32_t)o.uniquify_algorithm;
   c.best_effort_uniquify = o.best_effort_uniquify;
   c.uniquify_percent = o.uniquify_percent;
+  c.advance_direction = (int32_t)o.advance_direction;
+  c.engine_flags = (o.engine_flags & ~1);  // bit 0 selects the generic path on the C++ side
   return c;
 }
 

@@ -75,6 +75,7 @@ struct parameters_t {
   bool best_effort_uniquify = true;
   float uniquify_percent = 100.0f;
   int engine_flags = 0;  // --generic_operators sets bit 0
+  operators::advance_direction_t advance_direction = operators::advance_direction_t::forward;
 
   parameters_t(int argc, char** argv, std::string algorithm) {
     struct spec_t { bool takes_value; std::string help; };
@@ -94,6 +95,7 @@ struct parameters_t {
         {"best_effort_uniquify", {false, "Best-effort uniquification (skip sorting)"}},
         {"uniquify_percent", {true, "Percentage of elements to uniquify (0-100)"}},
         {"generic_operators", {false, "Run the generic operator pipeline instead of the fused engine"}},
+        {"advance_direction", {true, "Advance direction (forward, optimized = direction-optimising BFS)"}},
         {"num_runs", {true, "Number of runs"}}};
     std::map<char, std::string> shorts = {{'m', "market"}, {'d', "json_dir"}, {'f', "json_file"},
                                           {'t', "tag"},    {'n', "num_runs"}};
@@ -175,6 +177,13 @@ struct parameters_t {
     if (seen.count("best_effort_uniquify")) best_effort_uniquify = true;
     if (seen.count("uniquify_percent")) uniquify_percent = std::stof(seen["uniquify_percent"]);
     if (seen.count("generic_operators")) engine_flags |= 1;
+    if (seen.count("advance_direction")) {
+      std::string d = seen["advance_direction"];
+      std::transform(d.begin(), d.end(), d.begin(), ::tolower);
+      advance_direction = d == "optimized" ? operators::advance_direction_t::optimized
+                          : d == "backward" ? operators::advance_direction_t::backward
+                                            : operators::advance_direction_t::forward;
+    }
   }
 
   gunrock::options_t get_options() const {
@@ -187,6 +196,7 @@ struct parameters_t {
     o.best_effort_uniquify = best_effort_uniquify;
     o.uniquify_percent = uniquify_percent;
     o.engine_flags = engine_flags;
+    o.advance_direction = advance_direction;
     return o;
   }
 };

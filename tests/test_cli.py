@@ -100,6 +100,9 @@ def test_every_operator_combination_validates(binaries, gr, tmp_path):
     lbs = ["thread_mapped", "warp_mapped", "block_mapped", "merge_path", "merge_path_v2", "bucketing"]
     filters = [[], ["--enable_filter"], ["--enable_filter", "--filter_algorithm", "compact"],
                ["--enable_filter", "--filter_algorithm", "remove"], ["--enable_filter", "--filter_algorithm", "bypass"]]
+    r = run([os.path.join(BIN, "bfs"), "--market", unweighted, "--src", src, "--validate",
+             "--advance_direction", "optimized"])
+    assert "Number of errors : 0" in r.stdout
     for exe, extra in (("bfs", []), ("bfs", ["--generic_operators"]), ("bfs_generic", [])):
         for lb in lbs:
             for flt in filters:
