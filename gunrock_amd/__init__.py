@@ -189,8 +189,10 @@ class multi_context_t:
         self._h = C.c_void_p()
         self.device_id = int(device_id)
         sp = None
+        self._stream_handle = None
         if stream is not None:
-            sp = C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
+            self._stream_handle = int(getattr(stream, "cuda_stream", stream))
+            sp = C.c_void_p(self._stream_handle)
         _capi.check(L.grx_context_create(self.device_id, sp, C.byref(self._h)))
 
     def synchronize(self):
@@ -303,6 +305,22 @@ def build_graph(properties, csr, context=None, device="cuda:0"):
     return graph_t(properties, csr.to_device(device), ctx)
 
 
+def _order_after_producer(ctx, *tensors):
+    """The engine works on ITS context's stream (non-blocking, like the reference's
+    standard_context_t).  Work queued on torch's current stream that produces the
+    tensors handed in (e.g. `torch.full` just before the call) must be finished first;
+    when the context was created on that very stream nothing needs to be done."""
+    for t in tensors:
+        dev = getattr(t, "device", None)
+        if dev is None or getattr(dev, "type", "") != "cuda":
+            continue
+        import torch
+        cur = torch.cuda.current_stream(dev)
+        if getattr(ctx, "_stream_handle", None) != cur.cuda_stream:
+            cur.synchronize()
+        return
+
+
 def _ptr(t, dtype_name):
     if t is None:
         return None
@@ -321,6 +339,7 @@ def bfs(graph, single_source, distances, predecessors=None, context=None, option
     ctx = context or graph._ctx
     ms = C.c_float(0)
     o = (options or options_t())._c()
+    _order_after_producer(ctx, distances, predecessors)
     _capi.check(_capi.lib().grx_bfs(ctx._h, graph._h, int(single_source), C.byref(o),
                                     _ptr(distances, "int32"), _ptr(predecessors, "int32"),
                                     C.byref(ms)))
@@ -332,6 +351,7 @@ def sssp(graph, single_source, distances, predecessors=None, context=None, optio
     ctx = context or graph._ctx
     ms = C.c_float(0)
     o = (options or options_t())._c()
+    _order_after_producer(ctx, distances, predecessors)
     _capi.check(_capi.lib().grx_sssp(ctx._h, graph._h, int(single_source), C.byref(o),
                                      _ptr(distances, "float32"), _ptr(predecessors, "int32"),
                                      C.byref(ms)))
@@ -371,6 +391,7 @@ def pr_run(graph, param, result, context=None):
     ms = C.c_float(0)
     it = C.c_int32(0)
     o = param.options._c()
+    _order_after_producer(ctx, result.p)
     _capi.check(_capi.lib().grx_pr(ctx._h, graph._h, float(param.alpha), float(param.tol),
                                    C.byref(o), _ptr(result.p, "float32"), C.byref(it),
                                    C.byref(ms)))

@@ -140,10 +140,10 @@ def test_medium_rmat_and_repeatability(gr, gpu_ctx):
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
     src = int(np.argmax(np.diff(g.row_offsets)))
     want, _, ev = O.bfs_queue(g, src)
-    for opt in all_options(gr):
+    for i, opt in enumerate(all_options(gr)):
         d, st = run_bfs(gr, gpu_ctx, g.row_offsets, g.column_indices, src, opt)
-        assert np.array_equal(d, want)
-        assert st["edges_visited"] == ev
+        assert np.array_equal(d, want), i
+        assert st["edges_visited"] == ev, (i, st, ev)
 
 
 def test_full_size_livejournal_standin_properties(gr, gpu_ctx):
