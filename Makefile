@@ -12,7 +12,10 @@ lib:
 bin/%: examples/algorithms/%/*.cu $(HDRS) | lib
 	@mkdir -p bin
 	$(HIPCC) $(FLAGS) $< -o $@ $(LINK)
-header_only: bin/bfs_generic bin/sssp_generic bin/pr_generic
+bin/test_operators: tests/cpp/test_operators.cu $(HDRS)
+	@mkdir -p bin
+	$(HIPCC) $(FLAGS) -DGUNROCK_HEADER_ONLY $< -o $@
+header_only: bin/bfs_generic bin/sssp_generic bin/pr_generic bin/test_operators
 bin/%_generic: examples/algorithms/%/*.cu $(HDRS)
 	@mkdir -p bin
 	$(HIPCC) $(FLAGS) -DGUNROCK_HEADER_ONLY $< -o $@

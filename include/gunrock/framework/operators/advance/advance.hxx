@@ -8,8 +8,8 @@
 // Same error behaviour: unsupported load balancing throws
 // error::exception_t("Load balance type not supported."), multi-context throws
 // "`context.size() != 1` not supported".
-// What differs: warp_mapped is real, bucketing and merge_path_v2 map onto
-// merge_path, graph-as-input uses the row offsets as the scan (no scan launch),
+// What differs: warp_mapped is real, bucketing picks the kernel per frontier from a degree
+// histogram (bucketing.hxx), merge_path_v2 maps onto merge_path, graph-as-input uses the row offsets as the scan (no scan launch),
 // and no kernel is followed by a host synchronise.
 #pragma once
 
@@ -17,6 +17,7 @@
 #include <gunrock/error.hxx>
 #include <gunrock/framework/benchmark.hxx>
 #include <gunrock/framework/operators/advance/block_mapped.hxx>
+#include <gunrock/framework/operators/advance/bucketing.hxx>
 #include <gunrock/framework/operators/advance/helpers.hxx>
 #include <gunrock/framework/operators/advance/merge_path.hxx>
 #include <gunrock/framework/operators/advance/thread_mapped.hxx>
@@ -72,7 +73,15 @@ void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, w
     warp_mapped::launch<output_type>(G, op, in, n, out, seg, ctx);
   else if constexpr (lb == load_balance_t::block_mapped)
     block_mapped::launch<output_type>(G, op, in, n, out, seg, ctx);
-  else
+  else if constexpr (lb == load_balance_t::bucketing) {
+    // chosen per frontier from its degree histogram
+    switch (bucketing::select(seg, n, total, ctx)) {
+      case load_balance_t::thread_mapped: thread_mapped::launch<output_type>(G, op, in, n, out, seg, ctx); break;
+      case load_balance_t::warp_mapped: warp_mapped::launch<output_type>(G, op, in, n, out, seg, ctx); break;
+      case load_balance_t::block_mapped: block_mapped::launch<output_type>(G, op, in, n, out, seg, ctx); break;
+      default: merge_path::launch<output_type>(G, op, in, n, out, seg, total, ctx);
+    }
+  } else
     merge_path::launch<output_type>(G, op, in, n, out, seg, total, ctx);
 }
 
@@ -104,6 +113,8 @@ void execute_runtime(graph_t& G, enactor_type* E, operator_type op, load_balance
       execute<load_balance_t::block_mapped, fwd, vtx, vtx>(G, E, op, context, swap_buffers);
       break;
     case load_balance_t::bucketing:
+      execute<load_balance_t::bucketing, fwd, vtx, vtx>(G, E, op, context, swap_buffers);
+      break;
     case load_balance_t::merge_path:
     case load_balance_t::merge_path_v2:
       execute<load_balance_t::merge_path, fwd, vtx, vtx>(G, E, op, context, swap_buffers);

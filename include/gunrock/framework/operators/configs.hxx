@@ -10,7 +10,7 @@ enum load_balance_t {
   thread_mapped,  // one input vertex per thread
   warp_mapped,    // one 64-lane wave per input vertex (enum-only in the reference)
   block_mapped,   // 256 input vertices per workgroup, edges shared through LDS
-  bucketing,      // degree-binned: thread / wave / workgroup by vertex degree
+  bucketing,      // kernel chosen per frontier from its log2 degree histogram
   merge_path,     // equal number of edges per workgroup
   merge_path_v2,  // same kernel as merge_path here
   work_stealing   // not supported

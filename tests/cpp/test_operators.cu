@@ -1,0 +1,264 @@
+// Operator-level parity checks against the reference SEMANTICS (not its code):
+//   advance: neighbour k of input slot i lands at output[segments[i] + k], rejected -> -1
+//            (thread_mapped.hxx:68-80, merge_path.hxx:218-279 of the reference), invalid
+//            input slots are skipped, every load balance gives the same frontier;
+//   filter : predicated/remove are STABLE compactions, compact keeps the same multiset,
+//            bypass keeps positions and writes -1, `op` is never called on -1;
+//   uniquify, parallel_for, frontier_t host API, bucketing's kernel choice.
+// Prints "CHECK <name> ok|FAILED" lines and exits non-zero on any failure.
+#include <gunrock/algorithms/algorithms.hxx>
+
+#include <algorithm>
+#include <numeric>
+#include <random>
+
+using namespace gunrock;
+using vertex_t = int;
+using edge_t = int;
+using weight_t = float;
+using csr_t = format::csr_t<memory_space_t::device, vertex_t, edge_t, weight_t>;
+
+static int failures = 0;
+static void check(const char* name, bool ok) {
+  printf("CHECK %s %s\n", name, ok ? "ok" : "FAILED");
+  if (!ok) ++failures;
+}
+
+struct even_neighbors_t {  // keep neighbours with even id, count calls per source
+  int* calls;
+  __host__ __device__ bool operator()(vertex_t const& s, vertex_t const& n, edge_t const&, weight_t const&) const {
+    math::atomic::add(calls + s, 1);
+    return (n & 1) == 0;
+  }
+};
+struct less_than_t {
+  vertex_t bound;
+  int* seen_invalid;
+  __host__ __device__ bool operator()(vertex_t const& v) const {
+    if (v < 0) math::atomic::add(seen_invalid, 1);
+    return v < bound;
+  }
+};
+struct mark_t {
+  int* out;
+  __host__ __device__ void operator()(vertex_t const& v) const { out[v] = v * 3; }
+};
+
+// Operators are asynchronous on the context's (non-blocking) stream -- unlike upstream,
+// which synchronises after every operator (thread_mapped.hxx:94) -- so host reads of a
+// frontier in the middle of a loop must synchronise the context first.
+static std::shared_ptr<gcuda::multi_context_t> g_context;
+template <typename E>
+static std::vector<vertex_t> download(E& f) {
+  if (g_context) g_context->get_context(0)->synchronize();
+  std::vector<vertex_t> h(f.get_number_of_elements());
+  if (!h.empty()) hipMemcpy(h.data(), f.data(), h.size() * sizeof(vertex_t), hipMemcpyDeviceToHost);
+  return h;
+}
+
+struct dummy_problem_t : gunrock::problem_t<decltype(graph::build<memory_space_t::device>(
+                             std::declval<graph::graph_properties_t>(), std::declval<csr_t&>()))> {
+  using graph_type = decltype(graph::build<memory_space_t::device>(std::declval<graph::graph_properties_t>(),
+                                                                  std::declval<csr_t&>()));
+  dummy_problem_t(graph_type& G, std::shared_ptr<gcuda::multi_context_t> c) : gunrock::problem_t<graph_type>(G, c) {}
+  void init() override {}
+  void reset() override {}
+};
+struct dummy_enactor_t : gunrock::enactor_t<dummy_problem_t> {
+  using gunrock::enactor_t<dummy_problem_t>::enactor_t;
+  void loop(gcuda::multi_context_t&) override {}
+};
+
+int main() {
+  // ---- a skewed random graph: one hub, many small rows, some empty rows -------------
+  const int V = 3000;
+  std::mt19937 rng(7);
+  std::vector<std::vector<int>> adj(V);
+  for (int v = 0; v < V; ++v) {
+    int deg = (v == 5) ? 9000 : (v % 7 == 0 ? 0 : (int)(rng() % 12));
+    for (int k = 0; k < deg; ++k) adj[v].push_back((int)(rng() % V));
+  }
+  format::coo_t<memory_space_t::host, vertex_t, edge_t, weight_t> coo(V, V, 0);
+  std::vector<int> I, J;
+  for (int v = 0; v < V; ++v)
+    for (int n : adj[v]) { I.push_back(v); J.push_back(n); }
+  coo = format::coo_t<memory_space_t::host, vertex_t, edge_t, weight_t>(V, V, (edge_t)I.size());
+  for (size_t k = 0; k < I.size(); ++k) { coo.row_indices[k] = I[k]; coo.column_indices[k] = J[k]; coo.nonzero_values[k] = 1.0f; }
+  csr_t csr;
+  csr.from_coo(coo);
+  graph::graph_properties_t props;
+  props.directed = true;
+  auto G = graph::build<memory_space_t::device>(props, csr);
+  auto context = std::make_shared<gcuda::multi_context_t>(0);
+  g_context = context;
+  dummy_problem_t problem(G, context);
+  dummy_enactor_t E(&problem, context);
+
+  // ---- frontier host API ---------------------------------------------------------
+  {
+    frontier::frontier_t<vertex_t, edge_t> f;
+    check("frontier.empty", f.is_empty() && f.get_number_of_elements() == 0);
+    f.push_back(4); f.push_back(9);
+    f.resize(5);  // new slots are invalid (-1)
+    auto h = download(f);
+    check("frontier.push_back+resize", h == std::vector<int>({4, 9, -1, -1, -1}));
+    f.sequence(10, 6);
+    check("frontier.sequence", download(f) == std::vector<int>({10, 11, 12, 13, 14, 15}));
+    f.fill(2);
+    check("frontier.fill", download(f) == std::vector<int>(6, 2));
+    f.set_number_of_elements(3);
+    check("frontier.set_number_of_elements", f.get_number_of_elements() == 3 && !f.is_empty());
+    frontier::frontier_t<vertex_t, edge_t> g2 = f;  // copies share storage
+    check("frontier.copy_shares_storage", g2.data() == f.data());
+  }
+
+  // ---- advance: same output for every load balance, reference slot semantics -----
+  std::vector<int> input = {5, 17, -1, 21, 0, 5, 2999, 8};  // hub twice, an invalid slot, an empty row (0, 21)
+  std::vector<int> expect;
+  std::vector<int> expect_calls(V, 0);
+  for (int v : input) {
+    if (v < 0) continue;
+    for (int n : adj[v]) { expect.push_back((n & 1) == 0 ? n : -1); expect_calls[v]++; }
+  }
+  thrust::device_vector<int> calls(V);
+  auto run_advance = [&](operators::load_balance_t lb, const char* name) {
+    thrust::fill(calls.begin(), calls.end(), 0);
+    auto* in = E.get_input_frontier();
+    in->set_number_of_elements(0);
+    for (int v : input) in->push_back(v);
+    operators::advance::execute_runtime(G, &E, even_neighbors_t{calls.data().get()}, lb, *context);
+    auto out = download(*E.get_input_frontier());  // buffers were swapped (download synchronises)
+    thrust::host_vector<int> hc = calls;
+    bool ok = out == expect;
+    for (int v = 0; v < V && ok; ++v) ok = hc[v] == expect_calls[v];
+    check(name, ok);
+  };
+  run_advance(operators::load_balance_t::thread_mapped, "advance.thread_mapped");
+  run_advance(operators::load_balance_t::warp_mapped, "advance.warp_mapped");
+  run_advance(operators::load_balance_t::block_mapped, "advance.block_mapped");
+  run_advance(operators::load_balance_t::merge_path, "advance.merge_path");
+  run_advance(operators::load_balance_t::merge_path_v2, "advance.merge_path_v2");
+  run_advance(operators::load_balance_t::bucketing, "advance.bucketing");
+  {
+    bool threw = false;
+    try {
+      operators::advance::execute_runtime(G, &E, even_neighbors_t{calls.data().get()},
+                                          operators::load_balance_t::work_stealing, *context);
+    } catch (error::exception_t& e) {
+      threw = std::string(e.what()).find("Load balance type not supported.") != std::string::npos;
+    }
+    check("advance.work_stealing_throws", threw);
+  }
+  // whole graph as input, no output: op called exactly once per edge
+  {
+    thrust::fill(calls.begin(), calls.end(), 0);
+    operators::advance::execute<operators::load_balance_t::merge_path, operators::advance_direction_t::forward,
+                                operators::advance_io_type_t::graph, operators::advance_io_type_t::none>(
+        G, &E, even_neighbors_t{calls.data().get()}, *context);
+    context->get_context(0)->synchronize();
+    thrust::host_vector<int> hc = calls;
+    bool ok = true;
+    for (int v = 0; v < V; ++v) ok = ok && hc[v] == (int)adj[v].size();
+    check("advance.graph_input_no_output", ok);
+  }
+  // bucketing's choice follows the frontier's degree histogram
+  {
+    using operators::advance::bucketing::select;
+    auto& ctx = *context->get_context(0);
+    thrust::device_vector<int> seg;
+    auto choice = [&](std::vector<int> degs) {
+      std::vector<int> s(degs.size() + 1, 0);
+      for (size_t i = 0; i < degs.size(); ++i) s[i + 1] = s[i] + degs[i];
+      seg = s;
+      return select(seg.data().get(), degs.size(), (size_t)s.back(), ctx);
+    };
+    check("bucketing.low_degree->thread_mapped", choice(std::vector<int>(5000, 3)) == operators::load_balance_t::thread_mapped);
+    check("bucketing.uniform_high->warp_mapped", choice(std::vector<int>(500, 200)) == operators::load_balance_t::warp_mapped);
+    std::vector<int> skew(4000, 4); skew[7] = 50000;
+    check("bucketing.hub->merge_path", choice(skew) == operators::load_balance_t::merge_path);
+    std::vector<int> mid(2000, 20); mid[3] = 300;
+    check("bucketing.moderate->block_mapped", choice(mid) == operators::load_balance_t::block_mapped);
+  }
+
+  // ---- filter ---------------------------------------------------------------------
+  std::vector<int> fin(20000);
+  for (auto& x : fin) x = (rng() % 5 == 0) ? -1 : (int)(rng() % 1000);
+  std::vector<int> stable;
+  for (int x : fin) if (x >= 0 && x < 400) stable.push_back(x);
+  thrust::device_vector<int> invalid_seen(1);
+  auto run_filter = [&](operators::filter_algorithm_t alg) {
+    invalid_seen[0] = 0;
+    auto* in = E.get_input_frontier();
+    in->resize(fin.size());
+    hipMemcpy(in->data(), fin.data(), fin.size() * sizeof(int), hipMemcpyHostToDevice);
+    operators::filter::execute_runtime(G, &E, less_than_t{400, invalid_seen.data().get()}, alg, *context);
+    return download(*E.get_input_frontier());
+  };
+  check("filter.predicated_stable", run_filter(operators::filter_algorithm_t::predicated) == stable && invalid_seen[0] == 0);
+  check("filter.remove_stable", run_filter(operators::filter_algorithm_t::remove) == stable);
+  {
+    auto got = run_filter(operators::filter_algorithm_t::compact);
+    auto a = got, b = stable;
+    std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+    check("filter.compact_same_multiset", a == b && invalid_seen[0] == 0);
+  }
+  {
+    auto got = run_filter(operators::filter_algorithm_t::bypass);
+    bool ok = got.size() == fin.size();
+    for (size_t i = 0; i < fin.size() && ok; ++i) ok = got[i] == ((fin[i] >= 0 && fin[i] < 400) ? fin[i] : -1);
+    check("filter.bypass_keeps_positions", ok && invalid_seen[0] == 0);
+  }
+  // ---- uniquify -------------------------------------------------------------------
+  {
+    auto* in = E.get_input_frontier();
+    in->resize(fin.size());
+    hipMemcpy(in->data(), fin.data(), fin.size() * sizeof(int), hipMemcpyHostToDevice);
+    operators::uniquify::execute<operators::uniquify_algorithm_t::unique>(&E, *context, false, 100);
+    auto got = download(*E.get_input_frontier());
+    std::vector<int> want;
+    for (int x : fin) if (x >= 0) want.push_back(x);
+    std::sort(want.begin(), want.end());
+    want.erase(std::unique(want.begin(), want.end()), want.end());
+    check("uniquify.full", got == want);
+    in = E.get_input_frontier();
+    std::vector<int> runs = {3, 3, 3, 7, -1, 7, 7, 2, 2, 3};
+    in->resize(runs.size());
+    hipMemcpy(in->data(), runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice);
+    operators::uniquify::execute<operators::uniquify_algorithm_t::unique>(&E, *context, true, 100);
+    check("uniquify.best_effort_adjacent_runs", download(*E.get_input_frontier()) == std::vector<int>({3, 7, 7, 2, 3}));
+  }
+  // ---- parallel_for ---------------------------------------------------------------
+  {
+    thrust::device_vector<int> marks(V, -5);
+    operators::parallel_for::execute<operators::parallel_for_each_t::vertex>(G, mark_t{marks.data().get()}, *context);
+    context->get_context(0)->synchronize();
+    thrust::host_vector<int> h = marks;
+    bool ok = true;
+    for (int v = 0; v < V; ++v) ok = ok && h[v] == 3 * v;
+    check("parallel_for.vertex", ok);
+    thrust::fill(marks.begin(), marks.end(), -5);
+    frontier::frontier_t<vertex_t, edge_t> f;
+    f.push_back(4); f.push_back(-1); f.push_back(10);
+    operators::parallel_for::execute<operators::parallel_for_each_t::element>(f, mark_t{marks.data().get()}, *context);
+    context->get_context(0)->synchronize();
+    h = marks;
+    check("parallel_for.element_skips_invalid", h[4] == 12 && h[10] == 30 && h[0] == -5);
+  }
+  // ---- graph view accessors (graph/csr.hxx of the reference) -------------------------
+  {
+    thrust::host_vector<int> ro = csr.row_offsets;
+    auto Gh_csr = format::csr_t<memory_space_t::host, vertex_t, edge_t, weight_t>(csr);
+    auto Gh = graph::build<memory_space_t::host>(props, Gh_csr);
+    bool ok = Gh.get_number_of_vertices() == V && Gh.get_number_of_edges() == (int)I.size();
+    for (int v : {0, 5, 6, 2999}) {
+      ok = ok && Gh.get_number_of_neighbors(v) == (int)adj[v].size() && Gh.get_starting_edge(v) == ro[v];
+      if (!adj[v].empty()) {
+        ok = ok && Gh.get_destination_vertex(ro[v]) == adj[v][0];
+        ok = ok && Gh.get_source_vertex(ro[v]) == v && Gh.get_source_vertex(ro[v + 1] - 1) == v;
+      }
+    }
+    check("graph.accessors", ok && Gh.is_directed());
+  }
+  printf(failures ? "FAILED %d checks\n" : "ALL CHECKS PASSED\n", failures);
+  return failures ? 1 : 0;
+}

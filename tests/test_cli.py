@@ -129,6 +129,15 @@ def test_every_operator_combination_validates(binaries, gr, tmp_path):
 
 
 @pytest.mark.gpu
+def test_operator_level_semantics(binaries):
+    """tests/cpp/test_operators.cu: frontier API, advance slot semantics for every load
+    balance, filter stability, uniquify, parallel_for, bucketing's histogram choice."""
+    r = run([os.path.join(BIN, "test_operators")], check=False)
+    assert "ALL CHECKS PASSED" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("CHECK ") >= 25
+
+
+@pytest.mark.gpu
 def test_export_metrics_json(binaries, tmp_path):
     import json
     run([os.path.join(BIN, "bfs"), "--market", CHES, "--src", "0,5", "--export_metrics", "--json_dir", str(tmp_path),
