@@ -41,6 +41,7 @@ struct bfs_policy_t {
   ctrl_t* ctrl;
 
   __device__ __forceinline__ void begin(ctrl_t* c) { next_depth = c->level + 1; ctrl = c; }
+  __device__ __forceinline__ void set_level(int level) { next_depth = level + 1; }
   __device__ __forceinline__ src_state load_source(int) const { return 0; }
   __device__ __forceinline__ bool precheck(src_state, int n, int) const {
     if constexpr (VARIANT == 0) return dist[n] > next_depth;
@@ -472,6 +473,9 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   int launches = 0;
   st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
     if (profile) (void)hipEventRecord(pe[0], stream);
+    if (variant == 0 && !profile)  // tiny levels (the tail of a scale-free BFS, most of a road BFS) in one launch
+      hipLaunchKernelGGL((tiny_levels_kernel<bfs_policy>), dim3(1), dim3(TINY_THREADS), 0, stream, a,
+                         bfs_policy{d_dist, nullptr, 0, nullptr}, dopt ? 1 : 0, (long long)g->E);
     if (dopt) {
       hipLaunchKernelGGL(bfs_decide_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d);
       hipLaunchKernelGGL(bfs_convert_kernel, dim3(grid / 4), dim3(ADV_BLOCK), 0, stream, a, d);

@@ -149,6 +149,7 @@ struct grx_graph {
   float* t_w = nullptr;
   bool has_transpose = false;
   double weight_sum = -1.0;  // sum of edge weights (lazy; near-far SSSP bucket width)
+  bool uniform_weights = false;
   std::vector<int32_t> h_t_ro;  // host copy of the transpose offsets (for static partitions)
   // static PageRank pull partition (built once per graph)
   void* pr_blocks = nullptr;    // int4 {row0, nrows, e0, e1}; nrows == 0 => piece of a long row

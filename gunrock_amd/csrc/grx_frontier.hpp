@@ -349,4 +349,133 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
                                a.chunk_prefix);
 }
 
+// ---------------------------------------------------------------------------
+// Many TINY levels in one launch.  A single 1024-thread workgroup keeps the frontier in
+// LDS (<= TINY_CAP vertices, <= TINY_CAP out-edges per level) and plays plan + advance
+// itself, so a level costs three dependent global round trips (row offsets -> column
+// index -> claim) instead of a group of kernel launches (13.7 us per level measured).
+// High-diameter graphs (road networks: thousands of levels of a few hundred vertices)
+// live here; on scale-free graphs it absorbs the last few levels.  It starts from the
+// tiled queue the regular kernels left, and when a level is too big (or could switch
+// direction) it spills the frontier back as tiles and leaves the control block exactly
+// as plan_kernel / bfs_decide_kernel expect it.  <<<1, 1024>>>
+// ---------------------------------------------------------------------------
+constexpr int TINY_CAP = 4096;
+constexpr int TINY_THREADS = 1024;
+
+template <class Policy>
+__global__ __launch_bounds__(TINY_THREADS) void tiny_levels_kernel(pipe_args a, Policy pol, int do_enabled,
+                                                                   long long n_edges_total) {
+  __shared__ int s_buf[2][TINY_CAP];
+  __shared__ int s_seg[TINY_CAP + 1];
+  __shared__ int s_start[TINY_CAP];
+  __shared__ typename Policy::src_state s_state[TINY_CAP];
+  __shared__ int s_wave[TINY_THREADS / 64 + 1];
+  __shared__ int s_n;
+  ctrl_t* c = a.ctrl;
+  const int tid = threadIdx.x;
+  if (c->done) return;
+  if (c->frontier_bitmap) return;  // direction-optimising BFS: the frontier is a bitmap right now
+  int level = c->level + 1;        // next level to run
+  {
+    const int p = level & 1;
+    const int nt = c->n_tiles[p];
+    if (nt * TILE > TINY_CAP) return;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int32_t* in = a.frontier[p];
+    for (int slot = tid; slot < nt * TILE; slot += TINY_THREADS) {
+      if (a.tile_count[slot / TILE] == 0) continue;  // reserved-but-unused tile: stale slots
+      const int v = in[slot];
+      if (v >= 0) s_buf[0][atomicAdd(&s_n, 1)] = v;
+    }
+    __syncthreads();
+  }
+  int n = s_n;
+  int sel = 0;
+  long long edges_done = 0, vertices_done = 0;
+  const long long edges_before = c->edges_visited;
+  constexpr int PER = TINY_CAP / TINY_THREADS;  // frontier slots per thread in the degree scan
+  for (;;) {
+    const int* cur = s_buf[sel];
+    int* nxt = s_buf[sel ^ 1];
+    if (n == 0) {
+      if (tid == 0) {
+        c->done = 1;
+        c->level = level;
+        c->edges_visited = edges_before + edges_done;
+        c->vertices_visited += vertices_done;
+        a.mailbox[1] = level;
+        a.mailbox[0] = 1;
+      }
+      return;
+    }
+    // ---- degrees + exclusive scan (each thread owns PER consecutive slots) ----------
+    int deg[PER], local = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid * PER + k;
+      deg[k] = 0;
+      if (i < n) {
+        const int v = cur[i];
+        const int rs = a.ro[v];
+        deg[k] = a.ro[v + 1] - rs;
+        s_start[i] = rs;
+        s_state[i] = pol.load_source(v);
+      }
+      local += deg[k];
+    }
+    int m;
+    int ex = dev::block_exclusive_sum<TINY_THREADS>(local, s_wave, &m);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid * PER + k;
+      if (i < n) s_seg[i] = ex;
+      ex += deg[k];
+    }
+    if (tid == 0) { s_seg[n] = m; s_n = 0; }
+    __syncthreads();
+    const bool heavy = do_enabled && (long long)m > (n_edges_total - edges_before - edges_done) / 14 && n > 256;
+    if (m > TINY_CAP || heavy) {
+      // ---- too big for LDS (or the direction might switch): hand the frontier back as tiles
+      const int p = level & 1;
+      const int tiles = (n + TILE - 1) / TILE;
+      for (int slot = tid; slot < tiles * TILE; slot += TINY_THREADS) a.frontier[p][slot] = slot < n ? cur[slot] : -1;
+      if (tid < tiles) {
+        const int lo = tid * TILE, hi = min(n, lo + TILE);
+        const int sum = s_seg[hi] - s_seg[lo];
+        a.tile_sums[tid] = sum;
+        a.tile_chunks[tid] = (sum + CHUNK - 1) / CHUNK;
+        a.tile_count[tid] = hi - lo;
+      }
+      if (tid == 0) {
+        c->n_tiles[p] = tiles;
+        c->level = level - 1;
+        c->edges_visited = edges_before + edges_done;
+        c->vertices_visited += vertices_done;
+      }
+      return;
+    }
+    // ---- the level itself -----------------------------------------------------------
+    pol.set_level(level);
+    for (int atom = tid; atom < m; atom += TINY_THREADS) {
+      int lo = 0;
+#pragma unroll
+      for (int step = TINY_CAP / 2; step >= 1; step >>= 1)
+        if (lo + step < n && s_seg[lo + step] <= atom) lo += step;
+      const int e = s_start[lo] + (atom - s_seg[lo]);
+      const int nb = a.ci[e];
+      const auto st = s_state[lo];
+      if (pol.precheck(st, nb, e) && (int)pol.visit(cur[lo], st, nb, e) == 1) nxt[atomicAdd(&s_n, 1)] = nb;
+    }
+    edges_done += m;
+    vertices_done += n;
+    __syncthreads();
+    n = s_n;
+    sel ^= 1;
+    ++level;
+    __syncthreads();
+  }
+}
+
 }  // namespace grx

@@ -38,6 +38,7 @@ struct sssp_policy {
   int level;
 
   __device__ __forceinline__ void begin(ctrl_t* c) { level = c->level; }
+  __device__ __forceinline__ void set_level(int l) { level = l; }
   // past the CU's L1: the label may have been lowered by an atomic (performed at L2) of
   // this very launch (multi-level kernel), and relaxing from a stale label would lose it
   __device__ __forceinline__ src_state load_source(int v) const {
@@ -298,13 +299,28 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_split_kernel(pipe_args a, sssp
   if (lane == 0 && kept_min != 0x7f7fffffu) atomicMin(&c->nf_min_far, kept_min);
 }
 
-__global__ void weight_sum_kernel(const float* w, int64_t n, double* out) {
+// out[0] = sum of weights; bits[0] / bits[1] = min / max weight as ordered uints (w >= 0)
+__global__ void weight_sum_kernel(const float* w, int64_t n, double* out, unsigned* bits) {
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    acc += (double)w[i];
+  unsigned lo = 0xffffffffu, hi = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = w[i];
+    acc += (double)x;
+    const unsigned u = x >= 0.0f ? __float_as_uint(x) : 0u;
+    lo = min(lo, u);
+    hi = max(hi, u);
+  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (dev::lane_id() == 0) atomicAdd(out, acc);
+  for (int o = 32; o > 0; o >>= 1) {
+    acc += __shfl_xor(acc, o, 64);
+    lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
+    hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64));
+  }
+  if (dev::lane_id() == 0) {
+    atomicAdd(out, acc);
+    atomicMin(&bits[0], lo);
+    atomicMax(&bits[1], hi);
+  }
 }
 
 }  // namespace grx
@@ -353,6 +369,8 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
   } else {
     sssp_policy pol{d_dist, stamp, g->w, 0};
     st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
+      hipLaunchKernelGGL((tiny_levels_kernel<sssp_policy>), dim3(1), dim3(TINY_THREADS), 0, stream, a, pol, 0,
+                         (long long)g->E);
       hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
       hipLaunchKernelGGL((advance_kernel<sssp_policy>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
       hipError_t e = hipGetLastError();
@@ -397,13 +415,21 @@ extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (g->weight_sum < 0.0) {
       GRX_HIP(ctx->misc.reserve(64));
       double* d_sum = reinterpret_cast<double*>(ctx->misc.as<unsigned char>());
-      GRX_HIP(hipMemsetAsync(d_sum, 0, sizeof(double), ctx->stream));
-      hipLaunchKernelGGL(weight_sum_kernel, dim3(1024), dim3(256), 0, ctx->stream, g->w, (int64_t)g->E, d_sum);
-      double h = 0.0;
-      GRX_HIP(hipMemcpyAsync(&h, d_sum, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      unsigned* d_bits = reinterpret_cast<unsigned*>(d_sum + 1);
+      const unsigned init[4] = {0u, 0u, 0xffffffffu, 0u};  // sum = 0.0, min, max
+      GRX_HIP(hipMemcpyAsync(d_sum, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(weight_sum_kernel, dim3(1024), dim3(256), 0, ctx->stream, g->w, (int64_t)g->E, d_sum, d_bits);
+      unsigned char h[16];
+      GRX_HIP(hipMemcpyAsync(h, d_sum, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
       GRX_HIP(hipStreamSynchronize(ctx->stream));
-      g->weight_sum = h;
+      memcpy(&g->weight_sum, h, sizeof(double));
+      unsigned lohi[2];
+      memcpy(lohi, h + 8, sizeof(lohi));
+      g->uniform_weights = lohi[0] == lohi[1];
     }
+    // all weights equal (e.g. a pattern .mtx loaded with 1.0 everywhere): the search is
+    // level-synchronous already, nothing is ever re-relaxed
+    if (g->uniform_weights) near_far = false;
     const double mean_w = g->weight_sum / (double)g->E;
     const double mean_deg = std::max(1.0, (double)g->E / (double)std::max(1, g->V));
     const double dlt = 32.0 * mean_w / mean_deg;
