@@ -141,10 +141,25 @@ __global__ __launch_bounds__(PR_BLOCK) void pr_pull_kernel(pr_args a, int iter) 
     const int4 d = a.blocks[b];  // {row0, nrows, e0, e1}
     const int n = d.w - d.z;
     if (d.y > 0) {
-      for (int i = tid; i < n; i += PR_BLOCK) {
-        const int e = d.z + i;
-        const float xv = a.x[a.t_ci[e]];
-        s_prod[i] = a.t_w ? xv * a.t_w[e] : xv;
+      // all index loads first, then all gathers: PR_NNZ / PR_BLOCK independent chains in
+      // flight per thread.  The index / weight streams are read once per iteration and are
+      // loaded non-temporally so that they do not push x[] (the gathered vector) out of L2.
+      constexpr int PER = PR_NNZ / PR_BLOCK;
+      int src[PER];
+      float wv[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * PR_BLOCK;
+        src[k] = i < n ? __builtin_nontemporal_load(&a.t_ci[d.z + i]) : -1;
+        wv[k] = (a.t_w && i < n) ? __builtin_nontemporal_load(&a.t_w[d.z + i]) : 1.0f;
+      }
+      float xv[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) xv[k] = src[k] >= 0 ? a.x[src[k]] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * PR_BLOCK;
+        if (i < n) s_prod[i] = a.t_w ? xv[k] * wv[k] : xv[k];
       }
       __syncthreads();
       for (int r = tid; r < d.y; r += PR_BLOCK) {
@@ -159,11 +174,20 @@ __global__ __launch_bounds__(PR_BLOCK) void pr_pull_kernel(pr_args a, int iter) 
       __syncthreads();
     } else {
       // piece of a long row: fixed-shape tree => reproducible partial
+      constexpr int PER = PR_NNZ / PR_BLOCK;
+      int src[PER];
+      float wv[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * PR_BLOCK;
+        src[k] = i < n ? __builtin_nontemporal_load(&a.t_ci[d.z + i]) : -1;
+        wv[k] = (a.t_w && i < n) ? __builtin_nontemporal_load(&a.t_w[d.z + i]) : 1.0f;
+      }
       float acc = 0.0f;
-      for (int i = tid; i < n; i += PR_BLOCK) {
-        const int e = d.z + i;
-        const float xv = a.x[a.t_ci[e]];
-        acc += a.t_w ? xv * a.t_w[e] : xv;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {  // fixed order => reproducible partial
+        const float xv = src[k] >= 0 ? a.x[src[k]] : 0.0f;
+        acc += a.t_w ? xv * wv[k] : xv;
       }
       acc = dev::wave_sum_f(acc);
       if (dev::lane_id() == 0) s_w[tid >> 6] = acc;
