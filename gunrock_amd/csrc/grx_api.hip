@@ -206,6 +206,12 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->pr_blocks) (void)hipFree(g->pr_blocks);
   if (g->pr_piece) (void)hipFree(g->pr_piece);
   if (g->pr_long) (void)hipFree(g->pr_long);
+  if (g->xb_ro) (void)hipFree(g->xb_ro);
+  if (g->xb_ci) (void)hipFree(g->xb_ci);
+  if (g->xb_w) (void)hipFree(g->xb_w);
+  if (g->xb_blocks) (void)hipFree(g->xb_blocks);
+  if (g->xb_piece) (void)hipFree(g->xb_piece);
+  if (g->xb_long) (void)hipFree(g->xb_long);
   delete g;
   return GRX_SUCCESS;
 }

@@ -156,6 +156,17 @@ struct grx_graph {
   int32_t* pr_piece = nullptr;  // piece id per block (-1 for ordinary blocks)
   int32_t* pr_long = nullptr;   // int {row, first_piece, n_pieces} per long row
   int32_t n_pr_blocks = 0, n_pr_pieces = 0, n_pr_long = 0;
+  // XCD-blocked pull layout (dense graphs): in-edges bucketed by SOURCE block so that the
+  // slice of x[] a workgroup gathers from fits its XCD's L2
+  int32_t* xb_ro = nullptr;     // NB * (V + 1) + 1 offsets, block-major
+  int32_t* xb_ci = nullptr;
+  float* xb_w = nullptr;
+  void* xb_blocks = nullptr;    // int4 row blocks, the NB lists concatenated
+  int32_t* xb_piece = nullptr;
+  int32_t* xb_long = nullptr;   // {block-major row index, first piece, n pieces}
+  int32_t xb_begin[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t n_xb_pieces = 0, n_xb_long = 0;
+  bool has_xb = false;
 };
 
 struct grx_host_csr {

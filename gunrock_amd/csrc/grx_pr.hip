@@ -14,6 +14,7 @@
 // The problem is bandwidth bound (~0.17 flop/byte); MFMA has nothing to offer
 // at one multiply-add per 12 gathered bytes and is deliberately not used.
 #include "grx_engine.hpp"
+#include <gunrock/hip/scan.hxx>
 
 #include <algorithm>
 
@@ -44,7 +45,19 @@ struct pr_args {
   float alpha, tol;
   unsigned* err_bits;    // [2] max |p - plast| as ordered uint, by iteration parity
   float* base;           // scalar (1 - alpha + dsum) / V
+  // XCD-blocked variant
+  const int32_t* xb_ro;
+  const int32_t* xb_ci;
+  const float* xb_w;
+  const int4* xb_blocks;
+  const int32_t* xb_piece;
+  const int32_t* xb_long;
+  int32_t xb_begin[9];
+  int32_t n_xb_long;
+  float* partial_y;      // NB * V partial sums, block-major
 };
+
+constexpr int XB = 8;  // source blocks == XCDs
 
 // iweights (pr.hxx:78-88): wave per 64 rows; long rows summed cooperatively.
 __global__ void pr_iweights_kernel(pr_args a) {
@@ -218,6 +231,128 @@ __global__ void pr_long_kernel(pr_args a, int iter) {
   if (err > 0.0f) atomicMax(&a.err_bits[iter & 1], __float_as_uint(err));
 }
 
+// ---- XCD-blocked pull -------------------------------------------------------------
+// The 8 XCDs of an MI355X have private 4 MB L2s; workgroup b is dispatched to XCD b % 8
+// (observed placement; used for speed only).  In-edges are bucketed by SOURCE block s
+// (V/8 consecutive vertices), and workgroups with b % 8 == s process bucket s only, so the
+// slice of x[] they gather from (V/8 floats: 1 MB for 2 M vertices) stays resident in
+// THEIR L2 instead of 8 MB of x[] thrashing through every L2.  Each (s, row) gets a partial
+// sum; pr_combine_kernel adds the 8 partials of a row in fixed order.
+__global__ __launch_bounds__(PR_BLOCK) void pr_pull_xcd_kernel(pr_args a) {
+  __shared__ float s_prod[PR_NNZ];
+  __shared__ float s_w[PR_BLOCK / 64];
+  if (a.ctrl->done) return;
+  const int tid = threadIdx.x;
+  const int s = blockIdx.x % XB;
+  const int lane_b = blockIdx.x / XB, stride_b = gridDim.x / XB;
+  const int32_t* ro = a.xb_ro + (size_t)s * ((size_t)a.V + 1);
+  float* y = a.partial_y + (size_t)s * (size_t)a.V;
+  constexpr int PER = PR_NNZ / PR_BLOCK;
+  for (int b = a.xb_begin[s] + lane_b; b < a.xb_begin[s + 1]; b += stride_b) {
+    const int4 d = a.xb_blocks[b];  // {row0, nrows, e0, e1}; nrows == 0 => piece of a long row
+    const int n = d.w - d.z;
+    int src[PER];
+    float wv[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * PR_BLOCK;
+      src[k] = i < n ? __builtin_nontemporal_load(&a.xb_ci[d.z + i]) : -1;
+      wv[k] = (a.xb_w && i < n) ? __builtin_nontemporal_load(&a.xb_w[d.z + i]) : 1.0f;
+    }
+    if (d.y > 0) {
+      float xv[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) xv[k] = src[k] >= 0 ? a.x[src[k]] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * PR_BLOCK;
+        if (i < n) s_prod[i] = a.xb_w ? xv[k] * wv[k] : xv[k];
+      }
+      __syncthreads();
+      for (int r = tid; r < d.y; r += PR_BLOCK) {
+        const int row = d.x + r;
+        const int lo = ro[row] - d.z, hi = ro[row + 1] - d.z;
+        float acc = 0.0f;
+        for (int i = lo; i < hi; ++i) acc += s_prod[i];
+        y[row] = acc;
+      }
+      __syncthreads();
+    } else {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const float xv = src[k] >= 0 ? a.x[src[k]] : 0.0f;
+        acc += a.xb_w ? xv * wv[k] : xv;
+      }
+      acc = dev::wave_sum_f(acc);
+      if (dev::lane_id() == 0) s_w[tid >> 6] = acc;
+      __syncthreads();
+      if (tid == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < PR_BLOCK / 64; ++i) t += s_w[i];
+        a.piece_sum[a.xb_piece[b]] = t;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void pr_long_xcd_kernel(pr_args a) {
+  if (a.ctrl->done) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_xb_long) return;
+  const int idx = a.xb_long[3 * i], first = a.xb_long[3 * i + 1], np = a.xb_long[3 * i + 2];
+  float acc = 0.0f;
+  for (int k = 0; k < np; ++k) acc += a.piece_sum[first + k];
+  a.partial_y[idx] = acc;  // idx = s * V + row
+}
+
+__global__ __launch_bounds__(256) void pr_combine_kernel(pr_args a, int iter) {
+  if (a.ctrl->done) return;
+  const float base = *a.base;
+  float err = 0.0f;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < a.V; v += (int64_t)gridDim.x * 256) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int s = 0; s < XB; ++s) acc += a.partial_y[(size_t)s * (size_t)a.V + v];
+    const float np = base + acc;
+    err = fmaxf(err, fabsf(np - a.p[v]));
+    a.p[v] = np;
+  }
+  err = dev::wave_max_f(err);
+  if (dev::lane_id() == 0 && err > 0.0f) atomicMax(&a.err_bits[iter & 1], __float_as_uint(err));
+}
+
+// bucket in-edges by (source block, destination): counts, then fill with cursors
+__global__ void xb_count_kernel(const int32_t* __restrict__ ro, const int32_t* __restrict__ ci, int32_t V,
+                                int32_t per_block, int32_t* cnt) {
+  const int lane = dev::lane_id();
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t u = wave; u < V; u += nwaves) {
+    const int s = (int)(u / per_block);
+    const int b = ro[u], e = ro[u + 1];
+    for (int k = b + lane; k < e; k += 64) atomicAdd(&cnt[(size_t)s * ((size_t)V + 1) + ci[k]], 1);
+  }
+}
+__global__ void xb_fill_kernel(const int32_t* __restrict__ ro, const int32_t* __restrict__ ci,
+                               const float* __restrict__ w, int32_t V, int32_t per_block, int32_t* cursor,
+                               int32_t* out_ci, float* out_w) {
+  const int lane = dev::lane_id();
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t u = wave; u < V; u += nwaves) {
+    const int s = (int)(u / per_block);
+    const int b = ro[u], e = ro[u + 1];
+    for (int k = b + lane; k < e; k += 64) {
+      const int pos = atomicAdd(&cursor[(size_t)s * ((size_t)V + 1) + ci[k]], 1);
+      out_ci[pos] = (int32_t)u;
+      if (out_w) out_w[pos] = w[k];
+    }
+  }
+}
+
 __global__ void pr_init_kernel(pr_args a) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     ctrl_t* c = a.ctrl;
@@ -282,6 +417,79 @@ static grx_status_t build_pr_partition(grx_graph_t g) {
   return GRX_SUCCESS;
 }
 
+static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
+  if (g->has_xb) return GRX_SUCCESS;
+  const int32_t V = g->V;
+  const int64_t E = g->E;
+  const size_t n_off = (size_t)XB * ((size_t)V + 1);
+  const int32_t per_block = (V + XB - 1) / XB;
+  hipStream_t s = ctx->stream;
+  int32_t *cnt = nullptr, *bs = nullptr;
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ro), (n_off + 2) * sizeof(int32_t)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ci), (size_t)E * sizeof(int32_t)));
+  if (g->w) GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_w), (size_t)E * sizeof(float)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&cnt), (n_off + 2) * sizeof(int32_t)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&bs), ((size_t)scan_num_blocks((int64_t)n_off) + 2) * sizeof(int32_t)));
+  GRX_HIP(hipMemsetAsync(cnt, 0, (n_off + 2) * sizeof(int32_t), s));
+  hipLaunchKernelGGL(xb_count_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, V, per_block, cnt);
+  exclusive_scan_i32(s, cnt, (int64_t)n_off, g->xb_ro, bs);
+  GRX_HIP(hipMemcpyAsync(cnt, g->xb_ro, n_off * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(xb_fill_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, g->w, V, per_block, cnt, g->xb_ci,
+                     g->xb_w);
+  std::vector<int32_t> off(n_off + 1);
+  GRX_HIP(hipMemcpyAsync(off.data(), g->xb_ro, (n_off + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  GRX_HIP(hipStreamSynchronize(s));
+  (void)hipFree(cnt);
+  (void)hipFree(bs);
+  // static partition, one list per source block (same packing rule as the plain layout)
+  std::vector<int4> blocks;
+  std::vector<int32_t> piece, longrows;
+  int32_t n_pieces = 0;
+  for (int sb = 0; sb < XB; ++sb) {
+    g->xb_begin[sb] = (int32_t)blocks.size();
+    const int32_t* ro = off.data() + (size_t)sb * ((size_t)V + 1);
+    int32_t row0 = 0;
+    auto flush = [&](int32_t row_end) {
+      if (row_end > row0) {
+        blocks.push_back(make_int4(row0, row_end - row0, ro[row0], ro[row_end]));
+        piece.push_back(-1);
+      }
+      row0 = row_end;
+    };
+    for (int32_t v = 0; v < V; ++v) {
+      const int32_t deg = ro[v + 1] - ro[v];
+      if (deg > PR_LONG) {
+        flush(v);
+        longrows.push_back((int32_t)((size_t)sb * (size_t)V + (size_t)v));
+        longrows.push_back(n_pieces);
+        int32_t np = 0;
+        for (int32_t e = ro[v]; e < ro[v + 1]; e += PR_NNZ) {
+          blocks.push_back(make_int4(v, 0, e, std::min(ro[v + 1], e + PR_NNZ)));
+          piece.push_back(n_pieces++);
+          ++np;
+        }
+        longrows.push_back(np);
+        row0 = v + 1;
+        continue;
+      }
+      if (ro[v + 1] - ro[row0] > PR_NNZ || v - row0 >= PR_MAXROWS) flush(v);
+    }
+    flush(V);
+  }
+  g->xb_begin[XB] = (int32_t)blocks.size();
+  g->n_xb_pieces = n_pieces;
+  g->n_xb_long = (int32_t)(longrows.size() / 3);
+  GRX_HIP(hipMalloc(&g->xb_blocks, std::max<size_t>(1, blocks.size()) * sizeof(int4)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_piece), std::max<size_t>(1, piece.size()) * sizeof(int32_t)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_long), std::max<size_t>(1, longrows.size()) * sizeof(int32_t)));
+  GRX_HIP(hipMemcpy(g->xb_blocks, blocks.data(), blocks.size() * sizeof(int4), hipMemcpyHostToDevice));
+  GRX_HIP(hipMemcpy(g->xb_piece, piece.data(), piece.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!longrows.empty())
+    GRX_HIP(hipMemcpy(g->xb_long, longrows.data(), longrows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  g->has_xb = true;
+  return GRX_SUCCESS;
+}
+
 }  // namespace grx
 
 using namespace grx;
@@ -298,17 +506,31 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
 
   // one-time per graph: transpose + static partition (graph preparation, like
   // the CSR build it is outside the timed enact region)
-  grx_status_t st = graph_build_transpose(ctx, g);
-  if (st != GRX_SUCCESS) return st;
-  st = build_pr_partition(g);
-  if (st != GRX_SUCCESS) return st;
+  // Layout: dense graphs whose gathered vector exceeds one XCD's L2 use the XCD-blocked
+  // buckets (8 partial sums per row are cheap next to E gathers); sparse graphs (the 8 V
+  // row visits would rival E) and small ones keep the plain transpose.
+  // engine_flags: 0x40 = never, 0x80 = always (tests / A-B runs)
+  const bool xcd_blocked = (opt.engine_flags & 0x80) != 0 ||
+                           ((long long)g->E >= 16ll * g->V && (size_t)g->V * sizeof(float) > ((size_t)3 << 20) &&
+                            !(opt.engine_flags & 0x40));
+  grx_status_t st;
+  if (xcd_blocked) {
+    st = build_pr_xcd_layout(ctx, g);
+    if (st != GRX_SUCCESS) return st;
+  } else {
+    st = graph_build_transpose(ctx, g);
+    if (st != GRX_SUCCESS) return st;
+    st = build_pr_partition(g);
+    if (st != GRX_SUCCESS) return st;
+  }
 
   const size_t V = (size_t)g->V;
   const int n_partial = std::min<int>(2048, (int)((V + PR_BLOCK - 1) / PR_BLOCK));
   GRX_HIP(ctx->fbuf[0].reserve(V * sizeof(float)));  // x
   GRX_HIP(ctx->fbuf[1].reserve(V * sizeof(float)));  // iweights
   GRX_HIP(ctx->fbuf[2].reserve(((size_t)n_partial + 16) * sizeof(float)));
-  GRX_HIP(ctx->fbuf[3].reserve(((size_t)g->n_pr_pieces + 16) * sizeof(float)));
+  GRX_HIP(ctx->fbuf[3].reserve(((size_t)std::max(g->n_pr_pieces, g->n_xb_pieces) + 16) * sizeof(float)));
+  if (xcd_blocked) GRX_HIP(ctx->far[0].reserve((size_t)XB * V * sizeof(float)));  // partial sums (scratch reuse)
   GRX_HIP(ctx->misc.reserve(64));
 
   pr_args a;
@@ -327,6 +549,12 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   a.alpha = alpha; a.tol = tol;
   a.err_bits = ctx->misc.as<unsigned>();
   a.base = reinterpret_cast<float*>(ctx->misc.as<unsigned>() + 4);
+  a.xb_ro = g->xb_ro; a.xb_ci = g->xb_ci; a.xb_w = g->xb_w;
+  a.xb_blocks = reinterpret_cast<const int4*>(g->xb_blocks);
+  a.xb_piece = g->xb_piece; a.xb_long = g->xb_long;
+  for (int i = 0; i <= XB; ++i) a.xb_begin[i] = g->xb_begin[i];
+  a.n_xb_long = g->n_xb_long;
+  a.partial_y = xcd_blocked ? ctx->far[0].as<float>() : nullptr;
 
   // problem.reset() (pr.hxx:65-93), outside the timed region as in the reference
   GRX_HIP(fill_f32(s, d_p, (float)(1.0 / (double)g->V), g->V));
@@ -335,16 +563,23 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   GRX_HIP(hipEventRecord(ctx->ev_begin, s));
   hipLaunchKernelGGL(pr_init_kernel, dim3(1), dim3(64), 0, s, a);
 
-  const int pull_grid = std::max(1, std::min(g->n_pr_blocks, ctx->num_cus * 8));
+  const int pull_grid = std::max(1, std::min(std::max(1, g->n_pr_blocks), ctx->num_cus * 8));
   const int max_iter = opt.max_iterations > 0 ? opt.max_iterations : 0x7fffffff;
   int launched = 0, batch = 4;
   for (;;) {
     for (int i = 0; i < batch && launched < max_iter; ++i, ++launched) {
       hipLaunchKernelGGL(pr_prepare_kernel, dim3(n_partial), dim3(PR_BLOCK), 0, s, a);
       hipLaunchKernelGGL(pr_scalar_kernel, dim3(1), dim3(PR_BLOCK), 0, s, a, launched);
-      hipLaunchKernelGGL(pr_pull_kernel, dim3(pull_grid), dim3(PR_BLOCK), 0, s, a, launched);
-      if (g->n_pr_long > 0)
-        hipLaunchKernelGGL(pr_long_kernel, dim3((g->n_pr_long + 255) / 256), dim3(256), 0, s, a, launched);
+      if (xcd_blocked) {
+        hipLaunchKernelGGL(pr_pull_xcd_kernel, dim3(ctx->num_cus * 8), dim3(PR_BLOCK), 0, s, a);
+        if (g->n_xb_long > 0)
+          hipLaunchKernelGGL(pr_long_xcd_kernel, dim3((g->n_xb_long + 255) / 256), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(pr_combine_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, a, launched);
+      } else {
+        hipLaunchKernelGGL(pr_pull_kernel, dim3(pull_grid), dim3(PR_BLOCK), 0, s, a, launched);
+        if (g->n_pr_long > 0)
+          hipLaunchKernelGGL(pr_long_kernel, dim3((g->n_pr_long + 255) / 256), dim3(256), 0, s, a, launched);
+      }
     }
     GRX_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost, s));
     GRX_HIP(hipStreamSynchronize(s));

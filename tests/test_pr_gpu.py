@@ -23,13 +23,14 @@ ABS_TOL = 1e-6
 REL_TOL = 1e-4
 
 
-def run_pr(gr, ctx, g, alpha=0.85, tol=1e-6, weighted=True, max_iterations=0):
+def run_pr(gr, ctx, g, alpha=0.85, tol=1e-6, weighted=True, max_iterations=0, engine_flags=0):
     import torch
     csr = gr.csr_t.from_arrays(g.row_offsets, g.column_indices, g.values)
     G = gr.build_graph(gr.graph_properties_t(True, weighted, False), csr, ctx)
     p = torch.zeros(g.n_vertices, dtype=torch.float32, device="cuda:0")
     res = gr.pr_result_t(p)
-    ms = gr.pr_run(G, gr.pr_param_t(alpha, tol, gr.options_t(max_iterations=max_iterations)), res, ctx)
+    ms = gr.pr_run(G, gr.pr_param_t(alpha, tol, gr.options_t(max_iterations=max_iterations,
+                                                            engine_flags=engine_flags)), res, ctx)
     assert ms >= 0
     return p.cpu().numpy(), res.iterations
 
@@ -75,6 +76,21 @@ def test_alpha_tol_variants_and_iteration_cap(gr, gpu_ctx, golden):
     assert it == 3
     p64, _, _ = O.pr_f64(g, force_iterations=3)
     assert np.abs(p - p64).max() <= ABS_TOL
+
+
+def test_xcd_blocked_layout_equals_plain_layout(gr, gpu_ctx, golden):
+    """The XCD-blocked pull (in-edges bucketed by source block, 8 partial sums per row) is a
+    different summation order only: same iteration count, ranks within fp32 rounding."""
+    graphs = [O.Csr(golden["rmat_ro"], golden["rmat_ci"], np.ones(len(golden["rmat_ci"]), np.float32)),
+              O.Csr(golden["road_ro"], golden["road_ci"], golden["road_w"])]
+    _, c = gr.generate("rmat_sym", 1 << 15, 600_000, seed=13)  # hubs => long-row pieces in every bucket
+    graphs.append(O.Csr(c.row_offsets, c.column_indices, c.nonzero_values))
+    for g in graphs:
+        p_plain, it_plain = run_pr(gr, gpu_ctx, g, engine_flags=0x40)
+        p_xcd, it_xcd = run_pr(gr, gpu_ctx, g, engine_flags=0x80)
+        assert it_plain == it_xcd
+        assert np.abs(p_plain.astype(np.float64) - p_xcd).max() <= 2e-7 * max(1.0, float(p_plain.max()) * 1e3)
+        check(g, p_xcd, it_xcd)
 
 
 def test_hub_rows_are_split(gr, gpu_ctx):
