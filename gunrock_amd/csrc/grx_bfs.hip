@@ -22,6 +22,7 @@
 #include "grx_engine.hpp"
 
 #include <climits>
+#include <cstdlib>
 
 namespace grx {
 
@@ -109,11 +110,12 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
   }
 }
 
-// Level bookkeeping + direction choice.  <<<1, 1024>>>
+// Level bookkeeping + direction choice (one workgroup of PLAN_BLOCK threads).
 // The size of the frontier entering this level is reduced here from per-tile
 // (queue) or per-workgroup (bitmap) partials, so producers need no counter atomics.
-__global__ __launch_bounds__(PLAN_BLOCK) void bfs_decide_kernel(pipe_args a, dobfs_args d) {
-  __shared__ unsigned long long s_n, s_m, s_open, s_probe;
+// s_red: 4 LDS words, zeroed and synchronised on entry.  On return every thread may
+// read the decision from the control block.
+__device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_args& d, unsigned long long* s_red) {
   ctrl_t* c = a.ctrl;
   const int tid = threadIdx.x;
   const int done = c->done;
@@ -121,8 +123,6 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_decide_kernel(pipe_args a, dob
   const int p = level & 1;
   const int is_bitmap = c->frontier_bitmap;
   const int nt = c->n_tiles[p];
-  if (tid == 0) { s_n = 0; s_m = 0; s_open = 0; s_probe = 0; }
-  __syncthreads();
   if (done) return;
   long long n = 0, m = 0, op = 0, pr = 0;
   if (is_bitmap) {
@@ -146,44 +146,74 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_decide_kernel(pipe_args a, dob
     pr += __shfl_xor(pr, o, 64);
   }
   if (dev::lane_id() == 0) {
-    atomicAdd(&s_n, (unsigned long long)n);
-    atomicAdd(&s_m, (unsigned long long)m);
-    atomicAdd(&s_open, (unsigned long long)op);
-    atomicAdd(&s_probe, (unsigned long long)pr);
+    atomicAdd(&s_red[0], (unsigned long long)n);
+    atomicAdd(&s_red[1], (unsigned long long)m);
+    atomicAdd(&s_red[2], (unsigned long long)op);
+    atomicAdd(&s_red[3], (unsigned long long)pr);
   }
   __syncthreads();
-  if (tid != 0) return;
-  const long long n_f = (long long)s_n, m_f = (long long)s_m;
-  c->bu_open += (long long)s_open;
-  c->bu_probes += (long long)s_probe;
-  if (n_f == 0) {
-    c->done = 1;
-    c->level = level;
-    a.mailbox[1] = level;
-    a.mailbox[0] = 1;
-    return;
-  }
-  int mode = c->mode;
-  if (d.enabled) {
-    const long long m_u = (long long)d.n_edges - c->edges_visited;  // edges of still-unexpanded vertices
-    if (mode == 0) {
-      if (m_f > m_u / DO_ALPHA && n_f > 256) mode = 1;
+  if (tid == 0) {
+    const long long n_f = (long long)s_red[0], m_f = (long long)s_red[1];
+    c->bu_open += (long long)s_red[2];
+    c->bu_probes += (long long)s_red[3];
+    if (n_f == 0) {
+      c->done = 1;
+      c->level = level;
+      a.mailbox[1] = level;
+      a.mailbox[0] = 1;
     } else {
-      if (n_f < (long long)a.V / DO_BETA) mode = 0;
+      int mode = c->mode;
+      if (d.enabled) {
+        const long long m_u = (long long)d.n_edges - c->edges_visited;  // edges of still-unexpanded vertices
+        if (mode == 0) {
+          if (m_f > m_u / DO_ALPHA && n_f > 256) mode = 1;
+        } else {
+          if (n_f < (long long)a.V / DO_BETA) mode = 0;
+        }
+      }
+      c->convert = (mode == 0 && is_bitmap) ? 1 : ((mode == 1 && !is_bitmap) ? 2 : 0);
+      c->mode = mode;
+      c->level = level;
+      c->edges_visited += m_f;
+      c->vertices_visited += n_f;
+      c->n_items[p] = (int)n_f;
+      c->q_edges[p] = m_f;
+      c->n_tiles[p ^ 1] = 0;
+      if (c->convert == 1) c->n_tiles[p] = 0;  // the queue of this level is rebuilt from the bitmap
+      c->frontier_bitmap = mode;               // format of the frontier this level PRODUCES
+      if (c->convert == 1) c->total_chunks = -1;  // tile mode: no chunk map for the rebuilt queue
+      a.mailbox[1] = level;
+      a.mailbox[2] = (int)n_f;
     }
   }
-  c->convert = (mode == 0 && is_bitmap) ? 1 : ((mode == 1 && !is_bitmap) ? 2 : 0);
-  c->mode = mode;
-  c->level = level;
-  c->edges_visited += m_f;
-  c->vertices_visited += n_f;
-  c->n_items[p] = (int)n_f;
-  c->q_edges[p] = m_f;
-  c->n_tiles[p ^ 1] = 0;
-  if (c->convert == 1) c->n_tiles[p] = 0;  // the queue of this level is rebuilt from the bitmap
-  c->frontier_bitmap = mode;               // format of the frontier this level PRODUCES
-  a.mailbox[1] = level;
-  a.mailbox[2] = (int)n_f;
+  __syncthreads();
+}
+
+// Head of a level, ONE launch of one workgroup: as many tiny levels as there are
+// (tiny_levels_body), then level bookkeeping + direction choice, then the chunk map of a
+// top-down level.  (A trivial kernel costs ~4 us on this part: this used to be three.)
+// The level that switches back from bottom-up has no chunk map: its queue is rebuilt by
+// bfs_convert_kernel after this kernel, and advance_block walks it in tile mode.  <<<1, 1024>>>
+__global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs_args d, bfs_policy pol,
+                                                              int allow_tiny, int seq) {
+  __shared__ tiny_smem<bfs_policy> tsm;
+  __shared__ unsigned long long s_red[4];
+  __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
+  static_assert(TINY_THREADS == PLAN_BLOCK, "head kernel runs both bodies");
+  ctrl_t* c = a.ctrl;
+  if (threadIdx.x < 4) s_red[threadIdx.x] = 0ull;
+  if (threadIdx.x == 0) a.mailbox[3] = seq;  // host pacing: group `seq` has started
+  __syncthreads();
+  if (allow_tiny && tiny_levels_body(a, pol, d.enabled, (long long)d.n_edges, tsm)) return;
+  if (!d.enabled) {
+    plan_body<PLAN_BLOCK>(a, c, 0, s_wave, &s_red[0]);
+    return;
+  }
+  bfs_decide_body(a, d, s_red);
+  if (c->done || c->mode != 0 || c->convert == 1) return;
+  if (threadIdx.x == 0) s_red[0] = 0ull;
+  __syncthreads();
+  plan_body<PLAN_BLOCK>(a, c, 1, s_wave, &s_red[0]);
 }
 
 // Frontier format change at a direction switch.
@@ -260,13 +290,19 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_convert_kernel(pipe_args a, dob
 // BATCH chunks at a time so that the dependent load chain (visited word -> in-offsets
 // -> in-neighbour -> frontier word) of several chunks is in flight together.
 // `visited` already counts vertices without in-edges as closed (bfs_convert_kernel).
-__global__ __launch_bounds__(ADV_BLOCK) void bfs_bottomup_kernel(pipe_args a, dobfs_args d) {
-  __shared__ int s_cnt[ADV_BLOCK / 64];
-  __shared__ long long s_deg[ADV_BLOCK / 64];
-  __shared__ int s_open[ADV_BLOCK / 64];
-  __shared__ long long s_probe[ADV_BLOCK / 64];
-  ctrl_t* c = a.ctrl;
-  if (c->done || c->mode != 1) return;
+struct bottomup_smem {
+  int cnt[ADV_BLOCK / 64];
+  long long deg[ADV_BLOCK / 64];
+  int open[ADV_BLOCK / 64];
+  long long probe[ADV_BLOCK / 64];
+};
+
+__device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dobfs_args& d, ctrl_t* c,
+                                                   bottomup_smem& sm) {
+  int* s_cnt = sm.cnt;
+  long long* s_deg = sm.deg;
+  int* s_open = sm.open;
+  long long* s_probe = sm.probe;
   const int level = c->level;
   const int p = level & 1;
   const unsigned* __restrict__ fin = d.fbits[p];
@@ -313,25 +349,50 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_bottomup_kernel(pipe_args a, do
         if (open[j]) odeg[j] = a.ro[v + 1] - a.ro[v];
       }
     }
-    // phase A: up to SERIAL probes per lane, the BATCH chunks advance in lock step
-    for (int r = 0; r < SERIAL; ++r) {
-      int u[BATCH];
-      bool act[BATCH];
-      bool any = false;
+    // phase A: up to SERIAL probes per lane, the BATCH chunks advance in lock step.
+    // Probes are issued SPECULATIVELY in groups (2, 2, 4): a group's column indices are
+    // loaded together, then its frontier words together -- two dependent round trips per
+    // group instead of two per probe (the wave waits for its slowest lane, which nearly
+    // always runs all SERIAL probes).  A group's extra loads fall in the cache line its
+    // first probe fetches anyway.
+    {
+      auto probe_group = [&](auto r0_c, auto n_c) -> bool {
+        constexpr int R0 = decltype(r0_c)::value, N = decltype(n_c)::value;
+        int u[BATCH][N];
+        bool act[BATCH][N];
+        bool any = false;
 #pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        act[j] = open[j] && !found[j] && b[j] + r < e[j];
-        u[j] = act[j] ? d.t_ci[b[j] + r] : 0;
-        any |= act[j];
-      }
-      if (dev::ballot(any) == 0ull) break;
+        for (int j = 0; j < BATCH; ++j) {
+          const bool live = open[j] && !found[j];
 #pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        if (act[j]) {
-          ++my_probes;
-          if (fin[u[j] >> 5] & (1u << (u[j] & 31))) found[j] = true;
+          for (int q = 0; q < N; ++q) {
+            act[j][q] = live && b[j] + R0 + q < e[j];
+            u[j][q] = act[j][q] ? d.t_ci[b[j] + R0 + q] : 0;
+            any |= act[j][q];
+          }
         }
-      }
+        if (dev::ballot(any) == 0ull) return false;
+        unsigned w[BATCH][N];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+#pragma unroll
+          for (int q = 0; q < N; ++q) w[j][q] = act[j][q] ? fin[u[j][q] >> 5] : 0u;
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+#pragma unroll
+          for (int q = 0; q < N; ++q) {
+            if (act[j][q]) {
+              ++my_probes;
+              if (w[j][q] & (1u << (u[j][q] & 31))) found[j] = true;
+            }
+          }
+        return true;
+      };
+      using std::integral_constant;
+      static_assert(SERIAL == 8, "probe groups cover 8 probes");
+      if (probe_group(integral_constant<int, 0>{}, integral_constant<int, 2>{}))
+        if (probe_group(integral_constant<int, 2>{}, integral_constant<int, 2>{}))
+          (void)probe_group(integral_constant<int, 4>{}, integral_constant<int, 4>{});
     }
     // phase B: long in-lists are scanned by the whole wave, 64 edges per step
 #pragma unroll
@@ -399,9 +460,40 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_bottomup_kernel(pipe_args a, do
   }
 }
 
+// One level, ONE launch: top-down (advance + fused compaction) or bottom-up, as the
+// head kernel decided.
+__global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs_args d, bfs_policy pol) {
+  __shared__ advance_smem<bfs_policy> sm;
+  __shared__ bottomup_smem bsm;
+  ctrl_t* c = a.ctrl;
+  if (c->done) return;
+  if (c->mode == 0) {
+    pol.begin(c);
+    advance_block<bfs_policy, false>(a, c, pol, sm, c->level & 1, blockIdx.x, gridDim.x, c->total_chunks,
+                                     a.chunk_tile, a.chunk_prefix);
+  } else {
+    bfs_bottomup_block(a, d, c, bsm);
+  }
+}
+
 }  // namespace grx
 
 using namespace grx;
+
+// Workgroups of the per-level kernel: exactly what is RESIDENT (persistent workgroups
+// stride over the work with gridDim, so a partial second round would double the time),
+// one per CU on road-like graphs (advance_grid_for).
+static int level_grid(grx_context_t ctx, grx_graph_t g) {
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_level_kernel, ADV_BLOCK, 0) != hipSuccess || n < 1) n = 4;
+    per_cu = n > 8 ? 8 : n;
+  }
+  const int full = advance_grid_for(ctx, g);
+  const int resident = ctx->num_cus * per_cu;
+  return full < resident ? full : resident;
+}
 
 extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
                                 const grx_options_t* options, int32_t* d_dist,
@@ -447,7 +539,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     d.visited = ctx->bitmap[0].as<unsigned>();
     d.fbits[0] = ctx->bitmap[1].as<unsigned>();
     d.fbits[1] = d.fbits[0] + bm_words;
-    d.bu_grid = advance_grid_for(ctx, g);
+    d.bu_grid = level_grid(ctx, g);
     GRX_HIP(ctx->bu_part.reserve((size_t)d.bu_grid * 4 * sizeof(long long)));
     d.bu_part = ctx->bu_part.as<long long>();
   } else if (variant != 0) {
@@ -459,10 +551,13 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   GRX_HIP(fill_i32(s, d_dist, INT_MAX, g->V));
   if (visited) GRX_HIP(hipMemsetAsync(visited, 0, bm_words * sizeof(unsigned), s));
 
+  const bool dense = g->V > 0 && (long long)g->E >= 8ll * g->V;  // few fat levels: paced enqueueing
+  ctx->h_mailbox[0] = 0;
+  ctx->h_mailbox[3] = -1;
   GRX_HIP(hipEventRecord(ctx->ev_begin, s));
   hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, visited, src);
 
-  const int grid = advance_grid_for(ctx, g);
+  const int grid = (variant == 0) ? level_grid(ctx, g) : advance_grid_for(ctx, g);
   const bool profile = (opt.engine_flags & GRX_FLAG_PROFILE) != 0;
   ctx->levels.clear();
   hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
@@ -471,30 +566,28 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   hipError_t launch_err = hipSuccess;
   int64_t prof_v = 0, prof_e = 0, prof_open = 0, prof_probe = 0;
   int launches = 0;
-  st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
+  st = run_levels(ctx, opt, [&](hipStream_t stream, int seq) {
     if (profile) (void)hipEventRecord(pe[0], stream);
-    if (variant == 0 && !profile)  // tiny levels (the tail of a scale-free BFS, most of a road BFS) in one launch
-      hipLaunchKernelGGL((tiny_levels_kernel<bfs_policy>), dim3(1), dim3(TINY_THREADS), 0, stream, a,
-                         bfs_policy{d_dist, nullptr, 0, nullptr}, dopt ? 1 : 0, (long long)g->E);
-    if (dopt) {
-      hipLaunchKernelGGL(bfs_decide_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d);
-      hipLaunchKernelGGL(bfs_convert_kernel, dim3(grid / 4), dim3(ADV_BLOCK), 0, stream, a, d);
-      hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 1);
+    if (variant == 0) {
+      // head (tiny levels + decide + plan) -> [format conversion at a direction switch] -> level
+      hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d,
+                         bfs_policy{d_dist, nullptr, 0, nullptr}, profile ? 0 : 1, seq);
+      if (dopt) hipLaunchKernelGGL(bfs_convert_kernel, dim3(ctx->num_cus * 2), dim3(ADV_BLOCK), 0, stream, a, d);
+      if (profile) (void)hipEventRecord(pe[1], stream);
+      hipLaunchKernelGGL(bfs_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d,
+                         bfs_policy{d_dist, nullptr, 0, nullptr});
     } else {
       hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
+      if (profile) (void)hipEventRecord(pe[1], stream);
+      switch (variant) {
+        case 1: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<1>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
+                                   bfs_policy_t<1>{d_dist, visited, 0, nullptr}); break;
+        case 2: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<2>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
+                                   bfs_policy_t<2>{d_dist, visited, 0, nullptr}); break;
+        default: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<3>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
+                                    bfs_policy_t<3>{d_dist, visited, 0, nullptr});
+      }
     }
-    if (profile) (void)hipEventRecord(pe[1], stream);
-    switch (variant) {
-      case 1: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<1>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
-                                 bfs_policy_t<1>{d_dist, visited, 0, nullptr}); break;
-      case 2: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<2>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
-                                 bfs_policy_t<2>{d_dist, visited, 0, nullptr}); break;
-      case 3: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<3>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
-                                 bfs_policy_t<3>{d_dist, visited, 0, nullptr}); break;
-      default: hipLaunchKernelGGL((advance_kernel<bfs_policy>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
-                                  bfs_policy{d_dist, nullptr, 0, nullptr});
-    }
-    if (dopt) hipLaunchKernelGGL(bfs_bottomup_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d);
     ++launches;
     if (profile) {
       (void)hipEventRecord(pe[2], stream);
@@ -530,7 +623,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     r.bottom_up = h.mode;
     prof_v = h.vertices_visited;
     prof_e = h.edges_visited;
-  }, /*first_batch=*/(g->V > 0 && (long long)g->E >= 8ll * g->V) ? 8 : 4);
+  }, /*first_batch=*/dense ? 8 : 4, /*pace_depth=*/(dense && variant == 0) ? (getenv("GRX_PACE_DEPTH") ? atoi(getenv("GRX_PACE_DEPTH")) : 2) : 0);
   if (st != GRX_SUCCESS) return st;
   if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));
 

@@ -30,18 +30,54 @@ inline int advance_grid_for(grx_context_t ctx, grx_graph_t g) {
   return road_like ? ctx->num_cus : ctx->num_cus * 8;
 }
 
-// Generic host loop: `launch_level(stream)` enqueues one level (plan + advance
-// [+ extra]); levels are enqueued in growing batches and the host only reads
-// the control block between batches.  Returns after `done`.
+// Generic host loop: `launch_level(stream, i)` enqueues level group i (head + level kernels);
+// the host never passes a level-dependent size.  Two pacing modes:
+//  * batches (pace_depth == 0): groups are enqueued blindly in growing batches and the host
+//    reads the control block between batches -- right for thousands of short levels;
+//  * paced (pace_depth > 0): the head kernel of group i publishes i in the pinned mailbox
+//    (word 3) and `done` in word 0; the host keeps at most `pace_depth` groups queued behind
+//    the running one and stops enqueueing the moment `done` shows up.  No blocking round trip
+//    per level, and at most pace_depth wasted (no-op) groups at the end -- right for the few
+//    fat levels of a scale-free search, where a wasted full-grid group costs ~9 us.
+//    The caller resets mailbox words 0 and 3 (host side) before the first launch.
 template <class LaunchLevel, class AfterSync>
 grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel launch_level,
-                        AfterSync after_sync, int first_batch = 4) {
+                        AfterSync after_sync, int first_batch = 4, int pace_depth = 0) {
   const bool sync_each = (opt.engine_flags & (GRX_FLAG_SYNC_EACH_LEVEL | GRX_FLAG_PROFILE)) != 0;
   int batch = sync_each ? 1 : first_batch;
   int launched = 0;
   const int max_levels = opt.max_iterations > 0 ? opt.max_iterations : 0x7fffffff;
+  if (sync_each) pace_depth = 0;
   for (;;) {
-    for (int i = 0; i < batch && launched < max_levels; ++i, ++launched) launch_level(ctx->stream, launched);
+    if (pace_depth > 0) {
+      volatile int32_t* mb = ctx->h_mailbox;
+      unsigned spins = 0;
+      for (;;) {
+        if (mb[0] != 0) break;  // done
+        const int started = mb[3] + 1;
+        if (launched < max_levels && launched - started < pace_depth) {
+          launch_level(ctx->stream, launched);
+          ++launched;
+          spins = 0;
+          continue;
+        }
+        if (launched >= max_levels && started >= launched) break;
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffff) == 0) {
+          // no progress for a long time: if the stream drained without `done` (mailbox writes
+          // not visible to this host?), fall back to blind enqueueing
+          hipError_t q = hipStreamQuery(ctx->stream);
+          if (q == hipSuccess) {
+            if (mb[0] != 0) break;
+            for (int i = 0; i < pace_depth && launched < max_levels; ++i, ++launched) launch_level(ctx->stream, launched);
+            break;
+          }
+          if (q != hipErrorNotReady) GRX_HIP(q);
+        }
+      }
+    } else {
+      for (int i = 0; i < batch && launched < max_levels; ++i, ++launched) launch_level(ctx->stream, launched);
+    }
     GRX_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost, ctx->stream));
     GRX_HIP(hipStreamSynchronize(ctx->stream));
     after_sync(*ctx->h_ctrl);

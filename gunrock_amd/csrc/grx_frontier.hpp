@@ -60,18 +60,17 @@ struct pipe_args {
 // external_control != 0: level bookkeeping, termination and counters are done by
 // another kernel (direction-optimising BFS); this one only builds the chunk map of
 // a top-down level and leaves when the level runs bottom-up.
-static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, int external_control) {
-  __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
-  __shared__ unsigned long long s_esum;
-  ctrl_t* c = a.ctrl;
+// Body of the plan step for a workgroup of BLOCK threads; *s_esum must be 0 and the
+// workgroup synchronised on entry.  s_wave: BLOCK / 64 + 1 ints of LDS.
+template <int BLOCK>
+__device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int external_control, int* s_wave,
+                                          unsigned long long* s_esum) {
   const int tid = threadIdx.x;
   const int done = c->done;
   const int level = external_control ? c->level : c->level + 1;
   const int p = level & 1;
   const int nt = c->n_tiles[p];
   const int mode = c->mode;
-  if (tid == 0) s_esum = 0ull;
-  __syncthreads();
   if (done) return;
   if (external_control == 1 && mode != 0) return;
   if (!external_control && nt == 0) {
@@ -85,7 +84,7 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, in
   }
   long long esum = 0;
   int carry = 0;
-  for (int base = 0; base < nt; base += PLAN_BLOCK) {
+  for (int base = 0; base < nt; base += BLOCK) {
     const int i = base + tid;
     int ch = 0;
     if (i < nt) {
@@ -94,7 +93,7 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, in
       esum += (long long)a.tile_sums[i] + ((long long)a.tile_count[i] << 40);
     }
     int tot;
-    int ex = dev::block_exclusive_sum<PLAN_BLOCK>(ch, s_wave, &tot);
+    int ex = dev::block_exclusive_sum<BLOCK>(ch, s_wave, &tot);
     if (i < nt) {
       const int pre = carry + ex;
       a.chunk_prefix[i] = pre;
@@ -105,13 +104,13 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, in
   // 64-bit block reduction of the traversed-edge count
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
-  if (dev::lane_id() == 0) atomicAdd(&s_esum, (unsigned long long)esum);
+  if (dev::lane_id() == 0) atomicAdd(s_esum, (unsigned long long)esum);
   __syncthreads();
   if (tid == 0) {
     c->total_chunks = carry;
     if (external_control != 1) {
-      const long long edges = (long long)(s_esum & ((1ull << 40) - 1));
-      const int nitems = (int)(s_esum >> 40);
+      const long long edges = (long long)(*s_esum & ((1ull << 40) - 1));
+      const int nitems = (int)(*s_esum >> 40);
       c->edges_visited += edges;
       c->vertices_visited += nitems;
       c->n_items[p] = nitems;
@@ -124,6 +123,14 @@ static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, in
       }
     }
   }
+}
+
+static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, int external_control) {
+  __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
+  __shared__ unsigned long long s_esum;
+  if (threadIdx.x == 0) s_esum = 0ull;
+  __syncthreads();
+  plan_body<PLAN_BLOCK>(a, a.ctrl, external_control, s_wave, &s_esum);
 }
 
 // Emit n (<= TILE) vertices s_out[lo .. lo+n) as one tile of the frontier with
@@ -223,9 +230,16 @@ __device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Pol
   if (tid == 0) { sm.cnt = 0; sm.res[0] = 0; sm.res[1] = 0; sm.side_cnt = 0; }
   __syncthreads();
 
-  for (int chunk = chunk_first; chunk < total_chunks; chunk += chunk_stride) {
-    const int t = chunk_tile[chunk];
-    const int lc = chunk - chunk_prefix[t];
+  // total_chunks < 0: TILE MODE -- no chunk map was built for this level (the level after a
+  // bottom-up -> top-down switch: its queue is rebuilt by many workgroups, and a last-
+  // workgroup plan would need agent-scope fences, i.e. L2 write-backs on a multi-XCD part).
+  // Workgroup w takes tiles w, w + stride, ... and walks each tile's chunks itself.
+  const bool tile_mode = total_chunks < 0;
+  const int n_units = tile_mode ? c->n_tiles[p] : total_chunks;
+  for (int unit = chunk_first; unit < n_units; unit += chunk_stride)
+  for (int lc_t = 0, n_lc = tile_mode ? a.tile_chunks[unit] : 1; lc_t < n_lc; ++lc_t) {
+    const int t = tile_mode ? unit : chunk_tile[unit];
+    const int lc = tile_mode ? lc_t : unit - chunk_prefix[t];
     // ---- stage the tile -------------------------------------------------
     int v;
     if constexpr (FRESH)
@@ -362,43 +376,68 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
 // ---------------------------------------------------------------------------
 constexpr int TINY_CAP = 4096;
 constexpr int TINY_THREADS = 1024;
+constexpr int TINY_MAX_TILES = 256;  // tiles the tiny path is willing to gather from
 
 template <class Policy>
-__global__ __launch_bounds__(TINY_THREADS) void tiny_levels_kernel(pipe_args a, Policy pol, int do_enabled,
-                                                                   long long n_edges_total) {
-  __shared__ int s_buf[2][TINY_CAP];
-  __shared__ int s_seg[TINY_CAP + 1];
-  __shared__ int s_start[TINY_CAP];
-  __shared__ typename Policy::src_state s_state[TINY_CAP];
-  __shared__ int s_wave[TINY_THREADS / 64 + 1];
-  __shared__ int s_n;
+struct tiny_smem {
+  int buf[2][TINY_CAP];
+  int seg[TINY_CAP + 1];
+  int start[TINY_CAP];
+  typename Policy::src_state state[TINY_CAP];
+  int wave[TINY_THREADS / 64 + 1];
+  int n;
+  unsigned long long total;
+};
+
+// Returns 1 when the search finished inside (done is set), 0 when the regular per-level
+// path has to continue (nothing done, or frontier handed back as tiles).
+template <class Policy>
+__device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol, int do_enabled,
+                                                long long n_edges_total, tiny_smem<Policy>& sm) {
   ctrl_t* c = a.ctrl;
   const int tid = threadIdx.x;
-  if (c->done) return;
-  if (c->frontier_bitmap) return;  // direction-optimising BFS: the frontier is a bitmap right now
-  int level = c->level + 1;        // next level to run
+  if (c->done) return 1;
+  if (c->frontier_bitmap) return 0;  // direction-optimising BFS: the frontier is a bitmap right now
+  int level = c->level + 1;          // next level to run
   {
     const int p = level & 1;
     const int nt = c->n_tiles[p];
-    if (nt * TILE > TINY_CAP) return;
-    if (tid == 0) s_n = 0;
+    // sparse tiles are common (every producing workgroup leaves a partial tile and reserves
+    // tile ids four at a time): go by the VERTEX count, over a bounded number of tiles
+    if (nt > TINY_MAX_TILES) return 0;
+    if (tid == 0) sm.total = 0ull;
+    __syncthreads();
+    {
+      // vertices in the low 32 bits, out-edges (known per tile) in the high 32
+      unsigned long long cnt = 0;
+      for (int t = tid; t < nt; t += TINY_THREADS)
+        cnt += (unsigned long long)a.tile_count[t] + ((unsigned long long)a.tile_sums[t] << 32);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+      if (dev::lane_id() == 0 && cnt) atomicAdd(&sm.total, cnt);
+    }
+    __syncthreads();
+    const unsigned long long total = sm.total;
+    __syncthreads();
+    if ((int)(total & 0xffffffffull) > TINY_CAP || (int)(total >> 32) > TINY_CAP) return 0;
+    if (tid == 0) sm.n = 0;
     __syncthreads();
     const int32_t* in = a.frontier[p];
     for (int slot = tid; slot < nt * TILE; slot += TINY_THREADS) {
       if (a.tile_count[slot / TILE] == 0) continue;  // reserved-but-unused tile: stale slots
       const int v = in[slot];
-      if (v >= 0) s_buf[0][atomicAdd(&s_n, 1)] = v;
+      if (v >= 0) sm.buf[0][atomicAdd(&sm.n, 1)] = v;
     }
     __syncthreads();
   }
-  int n = s_n;
+  int n = sm.n;
   int sel = 0;
   long long edges_done = 0, vertices_done = 0;
   const long long edges_before = c->edges_visited;
   constexpr int PER = TINY_CAP / TINY_THREADS;  // frontier slots per thread in the degree scan
   for (;;) {
-    const int* cur = s_buf[sel];
-    int* nxt = s_buf[sel ^ 1];
+    const int* cur = sm.buf[sel];
+    int* nxt = sm.buf[sel ^ 1];
     if (n == 0) {
       if (tid == 0) {
         c->done = 1;
@@ -408,7 +447,7 @@ __global__ __launch_bounds__(TINY_THREADS) void tiny_levels_kernel(pipe_args a, 
         a.mailbox[1] = level;
         a.mailbox[0] = 1;
       }
-      return;
+      return 1;
     }
     // ---- degrees + exclusive scan (each thread owns PER consecutive slots) ----------
     int deg[PER], local = 0;
@@ -420,20 +459,20 @@ __global__ __launch_bounds__(TINY_THREADS) void tiny_levels_kernel(pipe_args a, 
         const int v = cur[i];
         const int rs = a.ro[v];
         deg[k] = a.ro[v + 1] - rs;
-        s_start[i] = rs;
-        s_state[i] = pol.load_source(v);
+        sm.start[i] = rs;
+        sm.state[i] = pol.load_source(v);
       }
       local += deg[k];
     }
     int m;
-    int ex = dev::block_exclusive_sum<TINY_THREADS>(local, s_wave, &m);
+    int ex = dev::block_exclusive_sum<TINY_THREADS>(local, sm.wave, &m);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int i = tid * PER + k;
-      if (i < n) s_seg[i] = ex;
+      if (i < n) sm.seg[i] = ex;
       ex += deg[k];
     }
-    if (tid == 0) { s_seg[n] = m; s_n = 0; }
+    if (tid == 0) { sm.seg[n] = m; sm.n = 0; }
     __syncthreads();
     const bool heavy = do_enabled && (long long)m > (n_edges_total - edges_before - edges_done) / 14 && n > 256;
     if (m > TINY_CAP || heavy) {
@@ -443,7 +482,7 @@ __global__ __launch_bounds__(TINY_THREADS) void tiny_levels_kernel(pipe_args a, 
       for (int slot = tid; slot < tiles * TILE; slot += TINY_THREADS) a.frontier[p][slot] = slot < n ? cur[slot] : -1;
       if (tid < tiles) {
         const int lo = tid * TILE, hi = min(n, lo + TILE);
-        const int sum = s_seg[hi] - s_seg[lo];
+        const int sum = sm.seg[hi] - sm.seg[lo];
         a.tile_sums[tid] = sum;
         a.tile_chunks[tid] = (sum + CHUNK - 1) / CHUNK;
         a.tile_count[tid] = hi - lo;
@@ -454,7 +493,8 @@ __global__ __launch_bounds__(TINY_THREADS) void tiny_levels_kernel(pipe_args a, 
         c->edges_visited = edges_before + edges_done;
         c->vertices_visited += vertices_done;
       }
-      return;
+      __syncthreads();  // a plan/decide step may follow in the same workgroup
+      return 0;
     }
     // ---- the level itself -----------------------------------------------------------
     pol.set_level(level);
@@ -462,20 +502,27 @@ __global__ __launch_bounds__(TINY_THREADS) void tiny_levels_kernel(pipe_args a, 
       int lo = 0;
 #pragma unroll
       for (int step = TINY_CAP / 2; step >= 1; step >>= 1)
-        if (lo + step < n && s_seg[lo + step] <= atom) lo += step;
-      const int e = s_start[lo] + (atom - s_seg[lo]);
+        if (lo + step < n && sm.seg[lo + step] <= atom) lo += step;
+      const int e = sm.start[lo] + (atom - sm.seg[lo]);
       const int nb = a.ci[e];
-      const auto st = s_state[lo];
-      if (pol.precheck(st, nb, e) && (int)pol.visit(cur[lo], st, nb, e) == 1) nxt[atomicAdd(&s_n, 1)] = nb;
+      const auto st = sm.state[lo];
+      if (pol.precheck(st, nb, e) && (int)pol.visit(cur[lo], st, nb, e) == 1) nxt[atomicAdd(&sm.n, 1)] = nb;
     }
     edges_done += m;
     vertices_done += n;
     __syncthreads();
-    n = s_n;
+    n = sm.n;
     sel ^= 1;
     ++level;
     __syncthreads();
   }
+}
+
+template <class Policy>
+__global__ __launch_bounds__(TINY_THREADS) void tiny_levels_kernel(pipe_args a, Policy pol, int do_enabled,
+                                                                   long long n_edges_total) {
+  __shared__ tiny_smem<Policy> sm;
+  (void)tiny_levels_body(a, pol, do_enabled, n_edges_total, sm);
 }
 
 }  // namespace grx

@@ -1,5 +1,5 @@
 """Tiny workload driver for profiling: run one algorithm a few times on a bench workload.
-    python tools/run_algo.py bfs|sssp|pr lj|kron|road|small [runs] [engine_flags] [lb]"""
+    python tools/run_algo.py bfs|sssp|pr lj|kron|road|small [runs] [engine_flags] [lb] [direction: forward|optimized]"""
 import os
 import sys
 
@@ -27,6 +27,8 @@ ctx = gr.multi_context_t(0)
 G = gr.build_graph(props, csr, ctx)
 V = G.get_number_of_vertices()
 o = gr.options_t(advance_load_balance=lb, engine_flags=flags)
+if len(sys.argv) > 6:
+    o.advance_direction = getattr(gr, sys.argv[6])
 times = []
 for _ in range(runs):
     if algo == "bfs":
