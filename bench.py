@@ -92,6 +92,11 @@ def main():
         bounds = D.vertex_bounds(V, world)
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         props, mine = gr.generate_rows(wl["kind"], V, entries, lo, hi, wl["a"], wl["b"], wl["c"], seed=42)
+        topdown_only = args.topdown_only
+        mine_in = None
+        if wl["kind"] == "rmat" and not topdown_only:  # directed: the bottom-up step needs the in-rows too
+            _, mine_in = gr.generate_rows(wl["kind"], V, entries, lo, hi, wl["a"], wl["b"], wl["c"], seed=42,
+                                          in_rows=True)
         deg = np.diff(mine.row_offsets)
         cdev = dev if dist.get_backend() == "nccl" else "cpu"
         best = torch.tensor([int(deg.max())], dtype=torch.int64, device=cdev)
@@ -100,10 +105,12 @@ def main():
         srct = torch.tensor([cand], dtype=torch.int64, device=cdev)
         dist.all_reduce(srct, op=dist.ReduceOp.MIN)
         src = int(srct.item())
-        eng = D.GrxEngine(props, mine, bounds, rank, dev)
         E = int(mine.number_of_nonzeros)
+        et = torch.tensor([E], dtype=torch.int64, device=cdev)
+        dist.all_reduce(et)
+        overlap = os.environ.get("GRX_BENCH_OVERLAP", "0") == "1"
+        eng = D.GrxEngine(props, mine, rank, world, dev, int(et.item()), in_rows=mine_in, overlap=overlap)
         dist_t = torch.empty(V, dtype=torch.int32, device=dev)
-        recv = torch.empty(max(hi - lo, 1) * max(world - 1, 1), dtype=torch.int32, device=dev)
         t_setup = time.time() - t0
 
         def barrier():
@@ -111,11 +118,11 @@ def main():
             torch.cuda.synchronize()
 
         for _ in range(args.warmup):
-            st = D.bfs(eng, dist, src, dist_t, bounds, rank, recv)
+            st = D.bfs(eng, dist, src, dist_t, optimized=not topdown_only)
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            st = D.bfs(eng, dist, src, dist_t, bounds, rank, recv)
+            st = D.bfs(eng, dist, src, dist_t, optimized=not topdown_only)
         barrier()
         elapsed = time.perf_counter() - t1
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -135,9 +142,13 @@ def main():
                 "config": {"workload": "BFS R-MAT(0.57,0.19,0.19,0.05), %d x the single-GPU size: %d V / %d E, "
                                        "src = max out-degree vertex" % (world, V, e_total),
                            "n_vertices": V, "n_edges": e_total, "source": src,
-                           "parallelism": "vertex-range partition over %d GPUs, RCCL all-to-all frontier exchange "
-                                          "per level, all-reduce termination" % world,
-                           "advance_direction": "forward (top-down on every rank)",
+                           "parallelism": "vertex-range partition over %d GPUs; per level one RCCL "
+                                          "all_to_all_single of fixed-size bitmaps (%d B per pair) + a 4-word "
+                                          "all_reduce; device-side direction choice; host polls once per batch "
+                                          "of levels%s" % (world, eng.S // 8,
+                                                           "; top-down halves overlapped" if overlap else ""),
+                           "advance_direction": "forward (top-down)" if topdown_only else "optimized (Beamer, "
+                                                "decided on the device from all-reduced statistics)",
                            "edges_visited_per_step": edges_total, "search_depth": st["search_depth"],
                            "setup_s": round(t_setup, 1)},
                 "roofline": None, "cpu_baseline": None}))

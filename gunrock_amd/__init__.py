@@ -416,14 +416,17 @@ def level_profile(context, capacity=65536):
             for i in range(min(n.value, capacity))]
 
 
-def generate_rows(kind, n_vertices, n_entries, row_lo, row_hi, a=0.57, b=0.19, c=0.19, seed=42):
+def generate_rows(kind, n_vertices, n_entries, row_lo, row_hi, a=0.57, b=0.19, c=0.19, seed=42, in_rows=False):
     """The rows [row_lo, row_hi) of generate(kind, ...): same edges, same order, global
-    column ids, n_vertices rows with the others empty -- the slice one rank owns."""
+    column ids, n_vertices rows with the others empty -- the slice one rank owns.
+    in_rows=True: the rows of the TRANSPOSE instead (in-edges of the owned vertices, global
+    source ids) -- what the bottom-up step of a partitioned directed graph needs."""
     kinds = {"rmat": 0, "rmat_sym": 1}
     L = _capi.lib()
     h = C.c_void_p()
-    _capi.check(L.grx_host_csr_generate_rows(kinds[kind], int(n_vertices), int(n_entries), float(a), float(b),
-                                             float(c), int(seed), int(row_lo), int(row_hi), C.byref(h)))
+    fn = L.grx_host_csr_generate_in_rows if in_rows else L.grx_host_csr_generate_rows
+    _capi.check(fn(kinds[kind], int(n_vertices), int(n_entries), float(a), float(b),
+                   float(c), int(seed), int(row_lo), int(row_hi), C.byref(h)))
     try:
         ro, ci, x, props = _host_csr_to_numpy(h)
     finally:

@@ -109,11 +109,15 @@ def lib():
         "grx_host_csr_destroy": (i32, [vp]),
         "grx_host_csr_generate": (i32, [i32, i32, i64, f32, f32, f32, C.c_uint64, P(vp)]),
         "grx_host_csr_generate_rows": (i32, [i32, i32, i64, f32, f32, f32, C.c_uint64, i32, i32, P(vp)]),
-        "grx_bfs_dist_begin": (i32, [vp, vp, i32, P(i32), i32, i32, vp, vp]),
-        "grx_bfs_dist_advance": (i32, [vp, vp]),
-        "grx_bfs_dist_apply": (i32, [vp, vp, C.c_longlong]),
-        "grx_bfs_dist_frontier": (i32, [vp, P(C.c_longlong), P(C.c_longlong)]),
+        "grx_host_csr_generate_in_rows": (i32, [i32, i32, i64, f32, f32, f32, C.c_uint64, i32, i32, P(vp)]),
+        "grx_bfs_dist_slice_bits": (i32, [i32, i32]),
+        "grx_bfs_dist_create": (i32, [vp, vp, vp, i32, i32, C.c_longlong, i32, vp, vp, vp, vp, P(vp)]),
+        "grx_bfs_dist_begin": (i32, [vp, i32, i32, vp]),
+        "grx_bfs_dist_pre": (i32, [vp, i32]),
+        "grx_bfs_dist_post": (i32, [vp]),
+        "grx_bfs_dist_poll": (i32, [vp, P(i32), P(i32)]),
         "grx_bfs_dist_end": (i32, [vp, P(grx_run_stats_t)]),
+        "grx_bfs_dist_destroy": (i32, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here == header/library mismatch

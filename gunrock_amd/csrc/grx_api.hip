@@ -130,7 +130,10 @@ grx_status_t grx_context_create(int32_t device, void* stream, grx_context_t* out
   GRX_HIP(hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_ctrl), sizeof(ctrl_t)));
-  GRX_HIP(hipMemset(c->d_ctrl, 0, sizeof(ctrl_t)));
+  // NOT hipMemset: that is queued on the null stream and may be submitted much later than
+  // work on this context's (non-blocking) stream -- it once zeroed a running search
+  GRX_HIP(hipMemsetAsync(c->d_ctrl, 0, sizeof(ctrl_t), c->stream));
+  GRX_HIP(hipStreamSynchronize(c->stream));
   GRX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ctrl), sizeof(ctrl_t), hipHostMallocDefault));
   memset(c->h_ctrl, 0, sizeof(ctrl_t));
   void* mb = nullptr;

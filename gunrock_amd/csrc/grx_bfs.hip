@@ -20,60 +20,12 @@
 //    and is taken ON THE DEVICE by bfs_decide_kernel, so the host still enqueues
 //    levels blindly.
 #include "grx_engine.hpp"
+#include "grx_bfs_kernels.hpp"
 
 #include <climits>
 #include <cstdlib>
 
 namespace grx {
-
-constexpr int DO_ALPHA = 14;
-constexpr int DO_BETA = 24;
-
-// VARIANT 0: the reference's claim, atomicMin on the label array with a stale
-// pre-check (fastest measured).  Tuning variants for A/B runs (engine_flags bits
-// 8-9): 1 = claim on a visited bitmap (atomicOr), 2 = same with an agent-scope
-// pre-check, 3 = variant 1 counting attempted atomics in ctrl->spare[0].
-template <int VARIANT>
-struct bfs_policy_t {
-  using src_state = int;
-  int32_t* dist;
-  unsigned* visited;
-  int next_depth;
-  ctrl_t* ctrl;
-
-  __device__ __forceinline__ void begin(ctrl_t* c) { next_depth = c->level + 1; ctrl = c; }
-  __device__ __forceinline__ void set_level(int level) { next_depth = level + 1; }
-  __device__ __forceinline__ src_state load_source(int) const { return 0; }
-  __device__ __forceinline__ bool precheck(src_state, int n, int) const {
-    if constexpr (VARIANT == 0) return dist[n] > next_depth;
-    if constexpr (VARIANT == 2)
-      return (__hip_atomic_load(&visited[n >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << (n & 31))) == 0u;
-    return (visited[n >> 5] & (1u << (n & 31))) == 0u;
-  }
-  __device__ __forceinline__ bool visit(int, src_state, int n, int) const {
-    if constexpr (VARIANT == 0) return next_depth < atomicMin(&dist[n], next_depth);
-    if constexpr (VARIANT == 3) atomicAdd(&ctrl->spare[0], 1);
-    const unsigned bit = 1u << (n & 31);
-    const unsigned old = atomicOr(&visited[n >> 5], bit);
-    if (old & bit) return false;
-    dist[n] = next_depth;
-    return true;
-  }
-};
-using bfs_policy = bfs_policy_t<0>;
-
-struct dobfs_args {
-  const int32_t* t_ro;   // in-edges (transpose; the CSR itself for symmetric graphs)
-  const int32_t* t_ci;
-  int32_t* dist;
-  unsigned* visited;     // bitmap, maintained only while running bottom-up
-  unsigned* fbits[2];    // frontier bitmaps by level parity
-  int32_t n_words;       // 32-bit words per bitmap (even)
-  int32_t n_edges;
-  int32_t enabled;       // direction optimisation on
-  long long* bu_part;    // per workgroup {found, out-degree sum, open, probes} of the last bottom-up launch
-  int32_t bu_grid;       // workgroups of the bottom-up launch
-};
 
 __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, int src) {
   const int tid = threadIdx.x;
@@ -221,10 +173,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
 //     coalesced reads: visited = (dist != INF), frontier = (dist == level).
 //   convert == 1 (bottom-up -> top-down): expand the frontier bitmap into tiles.
 __global__ __launch_bounds__(ADV_BLOCK) void bfs_convert_kernel(pipe_args a, dobfs_args d) {
-  __shared__ int s_out[TILE + ADV_BLOCK * 32];
-  __shared__ int s_wave[ADV_BLOCK / 64 + 1];
-  __shared__ int s_res[3];
-  __shared__ int s_cnt;
+  __shared__ words_smem sm;
   ctrl_t* c = a.ctrl;
   if (c->done) return;
   const int convert = c->convert;
@@ -254,210 +203,9 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_convert_kernel(pipe_args a, dob
     }
     return;
   }
-  // convert == 1: each thread takes one bitmap word per round
+  // convert == 1
   const unsigned* fin = d.fbits[p];
-  if (tid == 0) { s_cnt = 0; s_res[0] = 0; s_res[1] = 0; }
-  __syncthreads();
-  for (int base = blockIdx.x * ADV_BLOCK; base < d.n_words; base += gridDim.x * ADV_BLOCK) {
-    const int w = base + tid;
-    unsigned bits = w < d.n_words ? fin[w] : 0u;
-    int cnt = __popc(bits);
-    int tot;
-    int at = s_cnt + dev::block_exclusive_sum<ADV_BLOCK>(cnt, s_wave, &tot);
-    while (bits) {
-      const int b = __ffs(bits) - 1;
-      bits &= bits - 1;
-      s_out[at++] = w * 32 + b;
-    }
-    __syncthreads();
-    int have = s_cnt + tot;
-    __syncthreads();
-    while (have >= TILE) {
-      emit_tile(a, c, p, s_out, have - TILE, TILE, s_wave, s_res);
-      have -= TILE;
-      __syncthreads();
-    }
-    if (tid == 0) s_cnt = have;
-    __syncthreads();
-  }
-  const int rem = s_cnt;
-  if (rem > 0) emit_tile(a, c, p, s_out, 0, rem, s_wave, s_res);
-  __syncthreads();
-  release_tiles(a, s_res);
-}
-
-// Bottom-up level.  A wave owns 64 consecutive vertices (one "chunk") and works on
-// BATCH chunks at a time so that the dependent load chain (visited word -> in-offsets
-// -> in-neighbour -> frontier word) of several chunks is in flight together.
-// `visited` already counts vertices without in-edges as closed (bfs_convert_kernel).
-struct bottomup_smem {
-  int cnt[ADV_BLOCK / 64];
-  long long deg[ADV_BLOCK / 64];
-  int open[ADV_BLOCK / 64];
-  long long probe[ADV_BLOCK / 64];
-};
-
-__device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dobfs_args& d, ctrl_t* c,
-                                                   bottomup_smem& sm) {
-  int* s_cnt = sm.cnt;
-  long long* s_deg = sm.deg;
-  int* s_open = sm.open;
-  long long* s_probe = sm.probe;
-  const int level = c->level;
-  const int p = level & 1;
-  const unsigned* __restrict__ fin = d.fbits[p];
-  unsigned* fout = d.fbits[p ^ 1];
-  const int lane = dev::lane_id();
-  const int wid = threadIdx.x >> 6;
-  const int wave = (blockIdx.x * ADV_BLOCK + threadIdx.x) >> 6;
-  const int n_waves = (gridDim.x * ADV_BLOCK) >> 6;
-  const int n_chunks = d.n_words / 2;
-  const bool same_csr = d.t_ro == a.ro;  // symmetric graph: out-degree == in-degree
-  int my_cnt = 0;
-  long long my_deg = 0;
-  long long my_probes = 0;  // in-edges actually read (roofline accounting)
-  int my_open = 0;
-  constexpr int SERIAL = 8;
-  constexpr int BATCH = 4;
-  for (int ch0 = wave * BATCH; ch0 < n_chunks; ch0 += n_waves * BATCH) {
-    unsigned long long vis[BATCH];
-    int b[BATCH], e[BATCH], odeg[BATCH];
-    bool open[BATCH], found[BATCH];
-#pragma unroll
-    for (int j = 0; j < BATCH; ++j) {
-      const int ch = ch0 + j;
-      vis[j] = ~0ull;
-      if (ch < n_chunks)
-        vis[j] = (unsigned long long)d.visited[2 * ch] | ((unsigned long long)d.visited[2 * ch + 1] << 32);
-    }
-#pragma unroll
-    for (int j = 0; j < BATCH; ++j) {
-      const int v = (ch0 + j) * 64 + lane;
-      open[j] = v < a.V && !((vis[j] >> lane) & 1ull);
-      found[j] = false;
-      b[j] = e[j] = odeg[j] = 0;
-      if (open[j]) {
-        b[j] = d.t_ro[v];
-        e[j] = d.t_ro[v + 1];
-        ++my_open;
-      }
-    }
-    if (!same_csr) {
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        const int v = (ch0 + j) * 64 + lane;
-        if (open[j]) odeg[j] = a.ro[v + 1] - a.ro[v];
-      }
-    }
-    // phase A: up to SERIAL probes per lane, the BATCH chunks advance in lock step.
-    // Probes are issued SPECULATIVELY in groups (2, 2, 4): a group's column indices are
-    // loaded together, then its frontier words together -- two dependent round trips per
-    // group instead of two per probe (the wave waits for its slowest lane, which nearly
-    // always runs all SERIAL probes).  A group's extra loads fall in the cache line its
-    // first probe fetches anyway.
-    {
-      auto probe_group = [&](auto r0_c, auto n_c) -> bool {
-        constexpr int R0 = decltype(r0_c)::value, N = decltype(n_c)::value;
-        int u[BATCH][N];
-        bool act[BATCH][N];
-        bool any = false;
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-          const bool live = open[j] && !found[j];
-#pragma unroll
-          for (int q = 0; q < N; ++q) {
-            act[j][q] = live && b[j] + R0 + q < e[j];
-            u[j][q] = act[j][q] ? d.t_ci[b[j] + R0 + q] : 0;
-            any |= act[j][q];
-          }
-        }
-        if (dev::ballot(any) == 0ull) return false;
-        unsigned w[BATCH][N];
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j)
-#pragma unroll
-          for (int q = 0; q < N; ++q) w[j][q] = act[j][q] ? fin[u[j][q] >> 5] : 0u;
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j)
-#pragma unroll
-          for (int q = 0; q < N; ++q) {
-            if (act[j][q]) {
-              ++my_probes;
-              if (w[j][q] & (1u << (u[j][q] & 31))) found[j] = true;
-            }
-          }
-        return true;
-      };
-      using std::integral_constant;
-      static_assert(SERIAL == 8, "probe groups cover 8 probes");
-      if (probe_group(integral_constant<int, 0>{}, integral_constant<int, 2>{}))
-        if (probe_group(integral_constant<int, 2>{}, integral_constant<int, 2>{}))
-          (void)probe_group(integral_constant<int, 4>{}, integral_constant<int, 4>{});
-    }
-    // phase B: long in-lists are scanned by the whole wave, 64 edges per step
-#pragma unroll
-    for (int j = 0; j < BATCH; ++j) {
-      unsigned long long pend = dev::ballot(open[j] && !found[j] && e[j] > b[j] + SERIAL);
-      while (pend) {
-        const int src_lane = __builtin_ctzll(pend);
-        pend &= pend - 1;
-        const int bb = __shfl(b[j], src_lane, 64) + SERIAL, ee = __shfl(e[j], src_lane, 64);
-        bool hit = false;
-        for (int k = bb; k < ee; k += 64) {
-          const int kk = k + lane;
-          bool h = false;
-          if (kk < ee) {
-            const int u = d.t_ci[kk];
-            ++my_probes;
-            h = (fin[u >> 5] & (1u << (u & 31))) != 0u;
-          }
-          if (dev::ballot(h)) { hit = true; break; }
-        }
-        if (lane == src_lane) found[j] = hit;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < BATCH; ++j) {
-      const int ch = ch0 + j;
-      if (ch >= n_chunks) continue;
-      const unsigned long long nw = dev::ballot(found[j]);
-      if (lane == 0) {
-        fout[2 * ch] = (unsigned)nw;
-        fout[2 * ch + 1] = (unsigned)(nw >> 32);
-        if (nw) {
-          const unsigned long long nv = vis[j] | nw;
-          d.visited[2 * ch] = (unsigned)nv;
-          d.visited[2 * ch + 1] = (unsigned)(nv >> 32);
-        }
-      }
-      if (found[j]) {
-        d.dist[ch * 64 + lane] = level + 1;
-        my_cnt += 1;
-        my_deg += same_csr ? (e[j] - b[j]) : odeg[j];
-      }
-    }
-  }
-  // per-workgroup totals -> a handful of atomics per workgroup
-  my_cnt = dev::wave_sum(my_cnt);
-  my_open = dev::wave_sum(my_open);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    my_deg += __shfl_xor(my_deg, o, 64);
-    my_probes += __shfl_xor(my_probes, o, 64);
-  }
-  if (lane == 0) { s_cnt[wid] = my_cnt; s_deg[wid] = my_deg; s_open[wid] = my_open; s_probe[wid] = my_probes; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int tc = 0, to = 0;
-    long long td = 0, tp = 0;
-#pragma unroll
-    for (int i = 0; i < ADV_BLOCK / 64; ++i) { tc += s_cnt[i]; td += s_deg[i]; to += s_open[i]; tp += s_probe[i]; }
-    // plain stores; bfs_decide_kernel of the next level reduces them
-    d.bu_part[4 * blockIdx.x] = tc;
-    d.bu_part[4 * blockIdx.x + 1] = td;
-    d.bu_part[4 * blockIdx.x + 2] = to;
-    d.bu_part[4 * blockIdx.x + 3] = tp;
-  }
+  words_to_tiles(a, c, p, d.n_words, 0, [fin](int w) { return fin[w]; }, sm);
 }
 
 // One level, ONE launch: top-down (advance + fused compaction) or bottom-up, as the

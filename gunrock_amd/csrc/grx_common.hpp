@@ -92,6 +92,7 @@ struct ctrl_t {
   int32_t nf_phases;
   int64_t bu_open;          // bottom-up accounting: unvisited vertices examined (cumulative)
   int64_t bu_probes;        // bottom-up accounting: in-edges read (cumulative)
+  int64_t g_edges_visited;  // partitioned BFS: out-edges of all expanded vertices, whole graph
 };
 
 struct level_rec {

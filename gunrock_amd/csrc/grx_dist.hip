@@ -1,20 +1,31 @@
-// grx_dist.hip -- level-stepping interface of the BFS enactor for multi-GPU hosts.
+// grx_dist.hip -- partitioned (multi-GPU) BFS enactor: device side + level-group C ABI.
 //
 // The reference is single-GPU only: every operator throws when
 // `context.size() != 1` (advance/advance.hxx:129-132, filter/filter.hxx:96-99) and no
-// NCCL/RCCL/MPI call exists in its tree.  This file is the device side of the
-// MI355X multi-GPU design:
-//   * 1-D vertex-range partition: rank r owns vertices [bounds[r], bounds[r+1]) and the
-//     CSR rows of those vertices (GLOBAL column ids; rows of other ranks are empty), plus
-//     a full-size label array in which only the owned range is authoritative;
-//   * per level: advance (the same fused kernel as single-GPU) -> COLLECT the winners
-//     this rank does not own into one bucket per owner -> the host exchanges buckets with
-//     an RCCL all-to-all (one process per GPU, torch.distributed) -> APPLY the received
-//     candidates (claim with atomicMin, append winners to the next frontier);
-//   * termination: all-reduce of the next frontier sizes (host).
-// A rank marks every vertex it has ever sent in its own label copy, so a vertex crosses
-// a given link at most once per BFS.
+// NCCL/RCCL/MPI call exists in its tree.  This is the MI355X design:
+//
+//   * one process per GPU; rank r owns the vertex slice [r * S, min((r + 1) * S, V)), S a
+//     multiple of 2048, the OUT-rows of that slice (global column ids) and -- for the
+//     bottom-up step -- its IN-rows (the same rows when the graph is symmetric);
+//   * every level moves exactly one fixed-size message per pair of GPUs: an S-bit bitmap.
+//       top-down level : bit v of the slice sent to owner(v) = "I discovered v" (deduplicated
+//                        against everything this rank ever sent); the owner ORs the P - 1
+//                        slices it receives, claims the new ones and appends them to its queue;
+//       bottom-up level: every rank sends its frontier slice to everybody (the all-to-all
+//                        degenerates to an all-gather), so each rank holds the whole-graph
+//                        frontier bitmap and scans the in-edges of its unvisited vertices.
+//     Fixed sizes mean NO size exchange and no host round trip: like the single-GPU enactor
+//     the host enqueues level groups blindly (kernels + RCCL all_to_all_single + a 4-word
+//     all_reduce of the frontier statistics) and reads `done` once per batch.  A slice is
+//     S / 8 bytes (0.6 MB for a 4.85 M-vertex slice): ~4 us on one 153 GB/s xGMI link, and on
+//     the full mesh every pair has its own link.
+//   * the direction (Beamer) is chosen ON THE DEVICE from the all-reduced statistics, so all
+//     ranks take the same branch without talking to the host;
+//   * `parts = 2` cuts a top-down level in two halves with their own bitmaps: the exchange
+//     of the first half runs on the communication stream while the second half is still
+//     advancing on the compute stream (gunrock_amd/distributed.py).
 #include "grx_engine.hpp"
+#include "grx_bfs_kernels.hpp"
 
 #include <climits>
 
@@ -23,204 +34,46 @@ namespace grx {
 constexpr int DIST_MAX_RANKS = 64;
 
 struct dist_args {
-  int32_t bounds[DIST_MAX_RANKS + 1];
-  int32_t n_ranks;
-  int32_t my_rank;
-  int32_t* send;             // bucket of owner j starts at send + bounds[j] (capacity = its vertex count)
-  unsigned long long* cursor;  // [n_ranks], 16 words apart (own cache line each)
-  int32_t* dist;
+  int32_t n_ranks, my_rank;
+  int32_t lo, hi;            // owned vertices
+  int32_t slice_words;       // S / 32
+  int32_t parts;             // 1 or 2 top-down halves
+  unsigned* send;            // [parts][n_ranks][slice_words]
+  const unsigned* recv;      // [parts][n_ranks][slice_words]
+  unsigned* sent;            // [n_ranks * slice_words]: remote vertices this rank already reported
+  long long* stats_local;    // {frontier vertices, frontier out-edges, 0, 0} of the NEXT level (this rank)
+  const long long* stats_global;  // the same, summed over ranks (all_reduce by the host library)
+  long long e_global;        // edges of the whole graph
+  int32_t do_enabled;
 };
 
-constexpr int CURSOR_STRIDE = 16;
-
-// Same claim as single-GPU top-down BFS (grx_bfs.hip, variant 0).
+// Top-down claim on a partitioned graph: owned targets are claimed on the label like the
+// single-GPU policy; targets of other ranks are reported once through the outgoing bitmap.
 struct bfs_policy_dist {
   using src_state = int;
   int32_t* dist;
+  unsigned* sent;
+  unsigned* send;
+  int lo, hi;
   int next_depth;
   __device__ __forceinline__ void begin(ctrl_t* c) { next_depth = c->level + 1; }
   __device__ __forceinline__ src_state load_source(int) const { return 0; }
-  __device__ __forceinline__ bool precheck(src_state, int n, int) const { return dist[n] > next_depth; }
+  __device__ __forceinline__ bool precheck(src_state, int n, int) const {
+    if (n >= lo && n < hi) return dist[n] > next_depth;
+    return (sent[n >> 5] & (1u << (n & 31))) == 0u;
+  }
   __device__ __forceinline__ bool visit(int, src_state, int n, int) const {
-    return next_depth < atomicMin(&dist[n], next_depth);
+    if (n >= lo && n < hi) return next_depth < atomicMin(&dist[n], next_depth);
+    const unsigned bit = 1u << (n & 31);
+    const unsigned old = atomicOr(&sent[n >> 5], bit);
+    if (!(old & bit)) atomicOr(&send[n >> 5], bit);
+    return false;
   }
 };
 
-__global__ void dist_counts_kernel(const unsigned long long* cursor, int n_ranks, long long* out) {
-  if ((int)threadIdx.x < n_ranks) out[threadIdx.x] = (long long)cursor[threadIdx.x * CURSOR_STRIDE];
-}
-
-// Start of a level: level counter, statistics of the frontier entering it (owned
-// vertices only), reset of the output side.  Never sets `done`: another rank may
-// still feed this one.  <<<1, 1024>>>
-__global__ __launch_bounds__(PLAN_BLOCK) void dist_level_begin_kernel(pipe_args a, dist_args d) {
-  __shared__ unsigned long long s_n, s_m;
-  ctrl_t* c = a.ctrl;
+__global__ void dist_init_kernel(pipe_args a, dist_args x, int32_t* dist, int src_if_owned) {
   const int tid = threadIdx.x;
-  const int level = c->level + 1;
-  const int p = level & 1;
-  const int nt = c->n_tiles[p];
-  if (tid == 0) { s_n = 0; s_m = 0; }
-  __syncthreads();
-  long long n = 0, m = 0;
-  for (int i = tid; i < nt; i += PLAN_BLOCK) {
-    n += a.tile_count[i];
-    m += a.tile_sums[i];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    n += __shfl_xor(n, o, 64);
-    m += __shfl_xor(m, o, 64);
-  }
-  if (dev::lane_id() == 0) {
-    atomicAdd(&s_n, (unsigned long long)n);
-    atomicAdd(&s_m, (unsigned long long)m);
-  }
-  __syncthreads();
-  if (tid < d.n_ranks) d.cursor[tid * CURSOR_STRIDE] = 0ull;
-  if (tid != 0) return;
-  c->done = 0;
-  c->mode = 0;
-  c->level = level;
-  c->edges_visited += (long long)s_m;
-  c->vertices_visited += (long long)s_n;
-  c->n_items[p] = (int)s_n;
-  c->q_edges[p] = (long long)s_m;
-  c->n_tiles[p ^ 1] = 0;
-}
-
-__device__ __forceinline__ int owner_of(const dist_args& d, int v) {
-  int o = 0;
-  for (int j = 1; j < d.n_ranks; ++j) o += (v >= d.bounds[j]) ? 1 : 0;
-  return o;
-}
-
-// Move the winners this rank does not own out of the freshly produced frontier
-// (parity q = (level + 1) & 1) into per-owner buckets.  Two sweeps per workgroup over
-// its tiles: count (LDS histogram) -> one cursor atomic per owner per workgroup ->
-// write.  Removed slots become -1 and the tile's vertex count is corrected (their
-// local degree is 0, so degree sums and chunk counts are unaffected).
-__global__ __launch_bounds__(ADV_BLOCK) void dist_collect_kernel(pipe_args a, dist_args d) {
-  __shared__ int s_hist[DIST_MAX_RANKS];
-  __shared__ int s_base[DIST_MAX_RANKS];
-  __shared__ int s_removed;
-  ctrl_t* c = a.ctrl;
-  const int q = (c->level + 1) & 1;
-  const int nt = c->n_tiles[q];
-  const int tid = threadIdx.x;
-  int32_t* out = a.frontier[q];
-  const int lo = d.bounds[d.my_rank], hi = d.bounds[d.my_rank + 1];
-  if (tid < DIST_MAX_RANKS) s_hist[tid] = 0;
-  __syncthreads();
-  for (int t = blockIdx.x; t < nt; t += gridDim.x) {
-    if (a.tile_count[t] == 0) continue;  // reserved-but-unused tile: its slots are stale
-    const int v = out[(size_t)t * TILE + tid];
-    if (v >= 0 && (v < lo || v >= hi)) atomicAdd(&s_hist[owner_of(d, v)], 1);
-  }
-  __syncthreads();
-  if (tid < d.n_ranks) {
-    const int cnt = s_hist[tid];
-    s_base[tid] = cnt ? (int)atomicAdd(&d.cursor[tid * CURSOR_STRIDE], (unsigned long long)cnt) : 0;
-    s_hist[tid] = 0;  // becomes the running offset inside this workgroup's share
-  }
-  __syncthreads();
-  for (int t = blockIdx.x; t < nt; t += gridDim.x) {
-    if (a.tile_count[t] == 0) continue;
-    if (tid == 0) s_removed = 0;
-    __syncthreads();
-    const size_t slot = (size_t)t * TILE + tid;
-    const int v = out[slot];
-    if (v >= 0 && (v < lo || v >= hi)) {
-      const int o = owner_of(d, v);
-      const int at = s_base[o] + atomicAdd(&s_hist[o], 1);
-      d.send[d.bounds[o] + at] = v;
-      out[slot] = -1;
-      atomicAdd(&s_removed, 1);
-    }
-    __syncthreads();
-    if (tid == 0 && s_removed) a.tile_count[t] -= s_removed;
-    __syncthreads();
-  }
-}
-
-// Claim the candidates received from the other ranks (all owned by this rank) and
-// append the winners to the next frontier as tiles.
-__global__ __launch_bounds__(ADV_BLOCK) void dist_apply_kernel(pipe_args a, dist_args d, const int32_t* recv,
-                                                               long long n) {
-  __shared__ int s_out[2 * TILE];
-  __shared__ int s_wave[ADV_BLOCK / 64 + 1];
-  __shared__ int s_res[3];
-  __shared__ int s_cnt;
-  ctrl_t* c = a.ctrl;
-  const int depth = c->level + 1;
-  const int q = depth & 1;
-  const int tid = threadIdx.x;
-  const int lane = dev::lane_id();
-  if (tid == 0) { s_cnt = 0; s_res[0] = 0; s_res[1] = 0; }
-  __syncthreads();
-  for (long long base = (long long)blockIdx.x * ADV_BLOCK; base < n; base += (long long)gridDim.x * ADV_BLOCK) {
-    const long long i = base + tid;
-    bool win = false;
-    int v = -1;
-    if (i < n) {
-      v = recv[i];
-      if (d.dist[v] > depth) win = depth < atomicMin(&d.dist[v], depth);
-    }
-    const unsigned long long m = dev::ballot(win);
-    if (m) {
-      int at = 0;
-      if (lane == 0) at = atomicAdd(&s_cnt, __popcll(m));
-      at = __shfl(at, 0, 64);
-      if (win) s_out[at + dev::mask_rank(m)] = v;
-    }
-    __syncthreads();
-    int have = s_cnt;
-    __syncthreads();
-    if (have >= TILE) {
-      emit_tile(a, c, q, s_out, have - TILE, TILE, s_wave, s_res);
-      have -= TILE;
-      __syncthreads();
-    }
-    if (tid == 0) s_cnt = have;
-    __syncthreads();
-  }
-  const int rem = s_cnt;
-  if (rem > 0) emit_tile(a, c, q, s_out, 0, rem, s_wave, s_res);
-  __syncthreads();
-  release_tiles(a, s_res);
-}
-
-// Size of the frontier the next level will expand.  <<<1, 1024>>>
-__global__ __launch_bounds__(PLAN_BLOCK) void dist_frontier_size_kernel(pipe_args a, long long* out) {
-  __shared__ unsigned long long s_n, s_m;
-  ctrl_t* c = a.ctrl;
-  const int q = (c->level + 1) & 1;
-  const int nt = c->n_tiles[q];
-  if (threadIdx.x == 0) { s_n = 0; s_m = 0; }
-  __syncthreads();
-  long long n = 0, m = 0;
-  for (int i = threadIdx.x; i < nt; i += PLAN_BLOCK) {
-    n += a.tile_count[i];
-    m += a.tile_sums[i];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    n += __shfl_xor(n, o, 64);
-    m += __shfl_xor(m, o, 64);
-  }
-  if (dev::lane_id() == 0) {
-    atomicAdd(&s_n, (unsigned long long)n);
-    atomicAdd(&s_m, (unsigned long long)m);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    out[0] = (long long)s_n;
-    out[1] = (long long)s_m;
-  }
-}
-
-__global__ void dist_init_kernel(pipe_args a, int32_t* dist, int src) {
-  const int tid = threadIdx.x;
+  const int src = src_if_owned;
   a.frontier[0][tid] = (tid == 0 && src >= 0) ? src : -1;
   if (tid == 0) {
     ctrl_t* c = a.ctrl;
@@ -233,112 +86,393 @@ __global__ void dist_init_kernel(pipe_args a, int32_t* dist, int src) {
     c->mode = 0;
     c->n_tiles[0] = src >= 0 ? 1 : 0;
     c->n_tiles[1] = 0;
-    c->n_items[0] = c->n_items[1] = 0;
+    c->n_items[0] = src >= 0 ? 1 : 0;
+    c->n_items[1] = 0;
+    c->q_edges[0] = deg;
+    c->q_edges[1] = 0;
     c->total_chunks = 0;
     c->edges_visited = 0;
     c->vertices_visited = 0;
+    c->g_edges_visited = 0;
     c->frontier_bitmap = 0;
     c->convert = 0;
+    c->bu_open = 0;
+    c->bu_probes = 0;
     if (src >= 0) dist[src] = 0;
+    x.stats_local[0] = src >= 0 ? 1 : 0;
+    x.stats_local[1] = deg;
+    x.stats_local[2] = 0;
+    x.stats_local[3] = 0;
+    a.mailbox[0] = 0;
+    a.mailbox[1] = 0;
   }
 }
 
-struct dist_state {
-  pipe_args a;
-  dist_args d;
-  bool active = false;
-};
+// Head of a level group: global termination + direction choice from the all-reduced
+// statistics (identical on every rank), local bookkeeping, chunk map of a top-down level.
+// <<<1, 1024>>>
+__global__ __launch_bounds__(PLAN_BLOCK) void dist_head_kernel(pipe_args a, dist_args x) {
+  __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
+  __shared__ unsigned long long s_esum;
+  ctrl_t* c = a.ctrl;
+  const int tid = threadIdx.x;
+  if (c->done) return;
+  if (tid == 0) {
+    s_esum = 0ull;
+    const int level = c->level + 1;
+    const int p = level & 1;
+    const long long n_f = x.stats_global[0], m_f = x.stats_global[1];
+    if (n_f == 0) {
+      c->done = 1;
+      c->level = level;
+      a.mailbox[1] = level;
+      a.mailbox[0] = 1;
+    } else {
+      const int is_bitmap = c->frontier_bitmap;
+      int mode = c->mode;
+      if (x.do_enabled) {
+        const long long m_u = x.e_global - c->g_edges_visited;
+        if (mode == 0) {
+          if (m_f > m_u / DO_ALPHA && n_f > 256) mode = 1;
+        } else {
+          const long long v_global = (long long)x.n_ranks * x.slice_words * 32;
+          if (n_f < v_global / DO_BETA) mode = 0;
+        }
+      }
+      c->convert = (mode == 0 && is_bitmap) ? 1 : ((mode == 1 && !is_bitmap) ? 2 : 0);
+      c->mode = mode;
+      c->level = level;
+      c->g_edges_visited += m_f;
+      c->edges_visited += c->q_edges[p];      // this rank's share (dist_stats_kernel / init)
+      c->vertices_visited += c->n_items[p];
+      c->n_tiles[p ^ 1] = 0;
+      if (c->convert == 1) {
+        c->n_tiles[p] = 0;       // the queue of this level is rebuilt from the bitmap ...
+        c->total_chunks = -1;    // ... and walked in tile mode (no chunk map)
+      }
+      c->frontier_bitmap = mode;
+      a.mailbox[1] = level;
+    }
+  }
+  __syncthreads();
+  if (c->done || c->mode != 0 || c->convert == 1) return;
+  plan_body<PLAN_BLOCK>(a, c, 1, s_wave, &s_esum);
+}
 
-static dist_state& state_of(grx_context_t ctx) {
-  static thread_local dist_state st;  // one BFS in flight per host thread
-  (void)ctx;
-  return st;
+// Before the exchange.  Bottom-up level: publish this rank's frontier slice to every peer
+// (from the labels at the top-down -> bottom-up switch, which also builds the visited
+// slice).  Top-down level: clear the outgoing candidate bitmaps; at the switch back,
+// rebuild the queue from the frontier slice.
+__global__ __launch_bounds__(ADV_BLOCK) void dist_prep_kernel(pipe_args a, dobfs_args d, dist_args x) {
+  __shared__ words_smem sm;
+  ctrl_t* c = a.ctrl;
+  if (c->done) return;
+  const int convert = c->convert;
+  const int level = c->level;
+  const int p = level & 1;
+  const int tid = threadIdx.x;
+  const int lane = dev::lane_id();
+  if (c->mode == 1) {
+    unsigned* fcur = d.fbits[p];
+    const int n_chunks = d.n_words / 2;
+    const int wave = (blockIdx.x * ADV_BLOCK + tid) >> 6;
+    const int n_waves = (gridDim.x * ADV_BLOCK) >> 6;
+    for (int ch = wave; ch < n_chunks; ch += n_waves) {
+      unsigned w0, w1;
+      if (convert == 2) {
+        const int v = x.lo + ch * 64 + lane;
+        const bool in = v < x.hi;
+        const int dv = in ? d.dist[v] : INT_MAX;
+        const bool no_in = in ? (d.t_ro[v + 1] == d.t_ro[v]) : true;  // can never be found bottom-up
+        const unsigned long long vis = dev::ballot(dv != INT_MAX || no_in);
+        const unsigned long long fr = dev::ballot(dv == level);
+        w0 = (unsigned)fr;
+        w1 = (unsigned)(fr >> 32);
+        if (lane == 0) {
+          d.visited[2 * ch] = (unsigned)vis;
+          d.visited[2 * ch + 1] = (unsigned)(vis >> 32);
+          fcur[2 * ch] = w0;
+          fcur[2 * ch + 1] = w1;
+        }
+      } else {
+        w0 = fcur[2 * ch];
+        w1 = fcur[2 * ch + 1];
+      }
+      if (lane < x.n_ranks) {  // lane j addresses peer j
+        unsigned* dst = x.send + (size_t)lane * x.slice_words + 2 * ch;
+        dst[0] = w0;
+        dst[1] = w1;
+      }
+    }
+    return;
+  }
+  const size_t total = (size_t)x.parts * x.n_ranks * x.slice_words;
+  for (size_t i = (size_t)blockIdx.x * ADV_BLOCK + tid; i < total; i += (size_t)gridDim.x * ADV_BLOCK) x.send[i] = 0u;
+  if (convert == 1) {
+    const unsigned* fin = d.fbits[p];
+    words_to_tiles(a, c, p, d.n_words, x.lo, [fin](int w) { return fin[w]; }, sm);
+  }
+}
+
+// Top-down half `part` of `parts`: units part, part + parts, ... of the level.
+__global__ __launch_bounds__(ADV_BLOCK) void dist_advance_kernel(pipe_args a, bfs_policy_dist pol, int part,
+                                                                 int parts) {
+  __shared__ advance_smem<bfs_policy_dist> sm;
+  ctrl_t* c = a.ctrl;
+  if (c->done || c->mode != 0) return;
+  pol.begin(c);
+  advance_block<bfs_policy_dist, false>(a, c, pol, sm, c->level & 1, blockIdx.x * parts + part, gridDim.x * parts,
+                                        c->total_chunks, a.chunk_tile, a.chunk_prefix);
+}
+
+// After the exchange.  Top-down: claim what the peers discovered in this rank's slice.
+// Bottom-up: scan the in-edges of the unvisited owned vertices against the whole-graph
+// frontier bitmap the all-to-all assembled in `recv`.
+__global__ __launch_bounds__(ADV_BLOCK) void dist_post_kernel(pipe_args a, dobfs_args d, dist_args x) {
+  __shared__ words_smem sm;
+  __shared__ bottomup_smem bsm;
+  ctrl_t* c = a.ctrl;
+  if (c->done) return;
+  if (c->mode == 1) {
+    bfs_bottomup_block(a, d, c, bsm);
+    return;
+  }
+  const int depth = c->level + 1;
+  const int q = depth & 1;
+  words_to_tiles(a, c, q, x.slice_words, x.lo, [&](int w) {
+    unsigned cand = 0u;
+    for (int k = 0; k < x.parts; ++k)
+      for (int j = 0; j < x.n_ranks; ++j)
+        if (j != x.my_rank) cand |= x.recv[((size_t)k * x.n_ranks + j) * x.slice_words + w];
+    unsigned acc = 0u;
+    while (cand) {
+      const int b = __ffs(cand) - 1;
+      cand &= cand - 1;
+      const int v = x.lo + w * 32 + b;  // each owned vertex is looked at by exactly one thread
+      if (v < x.hi && d.dist[v] > depth) {
+        d.dist[v] = depth;
+        acc |= 1u << b;
+      }
+    }
+    return acc;
+  }, sm);
+}
+
+// Statistics of the frontier the next level expands (this rank's share): the input of the
+// all_reduce that drives termination and the direction choice.  <<<1, 1024>>>
+__global__ __launch_bounds__(PLAN_BLOCK) void dist_stats_kernel(pipe_args a, dobfs_args d, dist_args x) {
+  __shared__ unsigned long long s_red[4];
+  ctrl_t* c = a.ctrl;
+  const int tid = threadIdx.x;
+  if (tid < 4) s_red[tid] = 0ull;
+  __syncthreads();
+  if (c->done) {
+    if (tid < 4) x.stats_local[tid] = 0;
+    return;
+  }
+  const int q = (c->level + 1) & 1;
+  long long n = 0, m = 0, op = 0, pr = 0;
+  if (c->frontier_bitmap) {
+    for (int i = tid; i < d.bu_grid; i += PLAN_BLOCK) {
+      n += d.bu_part[4 * i];
+      m += d.bu_part[4 * i + 1];
+      op += d.bu_part[4 * i + 2];
+      pr += d.bu_part[4 * i + 3];
+    }
+  } else {
+    const int nt = c->n_tiles[q];
+    for (int i = tid; i < nt; i += PLAN_BLOCK) {
+      n += a.tile_count[i];
+      m += a.tile_sums[i];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    n += __shfl_xor(n, o, 64);
+    m += __shfl_xor(m, o, 64);
+    op += __shfl_xor(op, o, 64);
+    pr += __shfl_xor(pr, o, 64);
+  }
+  if (dev::lane_id() == 0) {
+    atomicAdd(&s_red[0], (unsigned long long)n);
+    atomicAdd(&s_red[1], (unsigned long long)m);
+    atomicAdd(&s_red[2], (unsigned long long)op);
+    atomicAdd(&s_red[3], (unsigned long long)pr);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    c->n_items[q] = (int)s_red[0];
+    c->q_edges[q] = (long long)s_red[1];
+    c->bu_open += (long long)s_red[2];
+    c->bu_probes += (long long)s_red[3];
+    x.stats_local[0] = (long long)s_red[0];
+    x.stats_local[1] = (long long)s_red[1];
+    x.stats_local[2] = 0;
+    x.stats_local[3] = 0;
+  }
+}
+
+template <class Kernel>
+static int resident_per_cu(Kernel k) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, ADV_BLOCK, 0) != hipSuccess || n < 1) n = 4;
+  return n > 8 ? 8 : n;
 }
 
 }  // namespace grx
 
 using namespace grx;
 
+struct grx_bfs_dist {
+  grx_context_t ctx = nullptr;
+  grx_graph_t g = nullptr;      // out-rows of the owned slice
+  grx_graph_t g_in = nullptr;   // in-rows (null: symmetric, or direction optimisation off)
+  pipe_args a{};
+  dobfs_args d{};
+  dist_args x{};
+  int grid_advance = 0, grid_post = 0;
+  bool active = false;
+};
+
 extern "C" {
 
-grx_status_t grx_bfs_dist_begin(grx_context_t ctx, grx_graph_t g, int32_t source_if_owned,
-                                const int32_t* bounds, int32_t n_ranks, int32_t my_rank, int32_t* d_send,
-                                int32_t* d_dist) {
-  if (!ctx || !g || !bounds || !d_send || !d_dist)
-    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_begin: null argument");
+int32_t grx_bfs_dist_slice_bits(int32_t n_vertices, int32_t n_ranks) {
+  if (n_vertices < 0 || n_ranks < 1) return 0;
+  const long long per = ((long long)n_vertices + n_ranks - 1) / n_ranks;
+  const long long s = ((per + 2047) / 2048) * 2048;
+  return (int32_t)(s < 2048 ? 2048 : s);
+}
+
+grx_status_t grx_bfs_dist_create(grx_context_t ctx, grx_graph_t out_rows, grx_graph_t in_rows, int32_t n_ranks,
+                                 int32_t my_rank, long long n_edges_global, int32_t parts, void* d_send,
+                                 void* d_recv, long long* d_stats_local, const long long* d_stats_global,
+                                 grx_bfs_dist_t* out) {
+  if (!ctx || !out_rows || !d_send || !d_recv || !d_stats_local || !d_stats_global || !out)
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_create: null argument");
   if (n_ranks < 1 || n_ranks > DIST_MAX_RANKS || my_rank < 0 || my_rank >= n_ranks)
-    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_begin: bad rank layout");
-  if (bounds[0] != 0 || bounds[n_ranks] != g->V)
-    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_begin: bounds must cover [0, V]");
-  if (source_if_owned >= 0 && (source_if_owned < bounds[my_rank] || source_if_owned >= bounds[my_rank + 1]))
-    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_begin: source not owned by this rank");
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_create: bad rank layout");
+  if (parts != 1 && parts != 2) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_create: parts must be 1 or 2");
+  if (in_rows && in_rows->V != out_rows->V)
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_create: in-rows and out-rows disagree on V");
   GRX_HIP(hipSetDevice(ctx->device));
-  dist_state& st = state_of(ctx);
-  grx_status_t rc = pipeline_prepare(ctx, g, &st.a);
-  if (rc != GRX_SUCCESS) return rc;
-  GRX_HIP(ctx->misc.reserve((size_t)DIST_MAX_RANKS * CURSOR_STRIDE * sizeof(unsigned long long) + 64));
-  for (int i = 0; i <= n_ranks; ++i) st.d.bounds[i] = bounds[i];
-  st.d.n_ranks = n_ranks;
-  st.d.my_rank = my_rank;
-  st.d.send = d_send;
-  st.d.cursor = ctx->misc.as<unsigned long long>() + 8;
-  st.d.dist = d_dist;
+  grx_bfs_dist* h = new grx_bfs_dist();
+  h->ctx = ctx;
+  h->g = out_rows;
+  h->g_in = in_rows;
+  const int32_t S = grx_bfs_dist_slice_bits(out_rows->V, n_ranks);
+  const long long lo = (long long)my_rank * S, hi = lo + S;
+  dist_args& x = h->x;
+  x.n_ranks = n_ranks;
+  x.my_rank = my_rank;
+  x.lo = (int32_t)(lo < out_rows->V ? lo : out_rows->V);
+  x.hi = (int32_t)(hi < out_rows->V ? hi : out_rows->V);
+  x.slice_words = S / 32;
+  x.parts = parts;
+  x.send = static_cast<unsigned*>(d_send);
+  x.recv = static_cast<const unsigned*>(d_recv);
+  x.stats_local = d_stats_local;
+  x.stats_global = d_stats_global;
+  x.e_global = n_edges_global;
+  grx_status_t rc = pipeline_prepare(ctx, out_rows, &h->a);
+  if (rc != GRX_SUCCESS) { delete h; return rc; }
+  static int per_cu_adv = 0, per_cu_post = 0;
+  if (!per_cu_adv) per_cu_adv = resident_per_cu(dist_advance_kernel);
+  if (!per_cu_post) per_cu_post = resident_per_cu(dist_post_kernel);
+  h->grid_advance = ctx->num_cus * per_cu_adv;
+  h->grid_post = ctx->num_cus * per_cu_post;
+  const size_t words = (size_t)n_ranks * x.slice_words;
+  GRX_HIP(ctx->bitmap[0].reserve((size_t)x.slice_words * sizeof(unsigned)));          // visited slice
+  GRX_HIP(ctx->bitmap[1].reserve((size_t)2 * x.slice_words * sizeof(unsigned)));      // frontier slices
+  GRX_HIP(ctx->labels.reserve(words * sizeof(unsigned)));                             // `sent`
+  GRX_HIP(ctx->bu_part.reserve((size_t)h->grid_post * 4 * sizeof(long long)));
+  x.sent = ctx->labels.as<unsigned>();
+  dobfs_args& d = h->d;
+  const bool can_bottom_up = in_rows != nullptr || out_rows->symmetric;
+  d.t_ro = in_rows ? in_rows->ro : out_rows->ro;
+  d.t_ci = in_rows ? in_rows->ci : out_rows->ci;
+  d.visited = ctx->bitmap[0].as<unsigned>();
+  d.fbits[0] = ctx->bitmap[1].as<unsigned>();
+  d.fbits[1] = d.fbits[0] + x.slice_words;
+  d.n_words = x.slice_words;
+  d.enabled = can_bottom_up ? 1 : 0;
+  d.bu_part = ctx->bu_part.as<long long>();
+  d.bu_grid = h->grid_post;
+  d.ch_lo = x.lo / 64;
+  d.fin_global = x.recv;
+  *out = h;
+  return GRX_SUCCESS;
+}
+
+// problem.reset() + frontier seed.  The caller all-reduces stats_local into stats_global
+// before the first grx_bfs_dist_pre.  advance_direction: GRX_DIR_FORWARD keeps every level
+// top-down; GRX_DIR_OPTIMIZED enables the bottom-up step (needs in-rows or symmetry).
+grx_status_t grx_bfs_dist_begin(grx_bfs_dist_t h, int32_t source, int32_t advance_direction, int32_t* d_dist) {
+  if (!h || !d_dist) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_begin: null argument");
+  if (source < 0 || source >= h->g->V) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_begin: source out of range");
+  grx_context_t ctx = h->ctx;
+  GRX_HIP(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  GRX_HIP(fill_i32(s, d_dist, INT_MAX, g->V));
+  dist_args& x = h->x;
+  x.do_enabled = (advance_direction == GRX_DIR_OPTIMIZED && h->d.enabled) ? 1 : 0;
+  h->d.dist = d_dist;
+  if (x.hi > x.lo) GRX_HIP(fill_i32(s, d_dist + x.lo, INT_MAX, x.hi - x.lo));  // only the owned range is used
+  GRX_HIP(hipMemsetAsync(x.sent, 0, (size_t)x.n_ranks * x.slice_words * sizeof(unsigned), s));
+  ctx->h_mailbox[0] = 0;
   GRX_HIP(hipEventRecord(ctx->ev_begin, s));
-  hipLaunchKernelGGL(dist_init_kernel, dim3(1), dim3(TILE), 0, s, st.a, d_dist, source_if_owned);
+  const int src_if_owned = (source >= x.lo && source < x.hi) ? source : -1;
+  hipLaunchKernelGGL(dist_init_kernel, dim3(1), dim3(TILE), 0, s, h->a, x, d_dist, src_if_owned);
   GRX_HIP(hipGetLastError());
-  st.active = true;
+  h->active = true;
   return GRX_SUCCESS;
 }
 
-// One level: expand the owned frontier, then bin the non-owned winners by owner.
-// d_counts[n_ranks] (device, int64) receives the bucket sizes.  Asynchronous.
-grx_status_t grx_bfs_dist_advance(grx_context_t ctx, long long* d_counts) {
-  dist_state& st = state_of(ctx);
-  if (!st.active || !d_counts) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_advance: no BFS in flight");
+// Enqueue the part of a level group that precedes the exchange of half `part`:
+//   part 0: head (termination, direction, chunk map) -> prep -> top-down advance of half 0
+//   part 1: top-down advance of half 1 (only with parts == 2)
+// After part k the caller exchanges send[k] -> recv[k] (all_to_all_single, n_ranks equal
+// splits of slice_words words).  Asynchronous.
+grx_status_t grx_bfs_dist_pre(grx_bfs_dist_t h, int32_t part) {
+  if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_pre: no BFS in flight");
+  if (part < 0 || part >= h->x.parts) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_pre: bad part");
+  grx_context_t ctx = h->ctx;
   hipStream_t s = ctx->stream;
-  const int grid = advance_grid(ctx);
-  hipLaunchKernelGGL(dist_level_begin_kernel, dim3(1), dim3(PLAN_BLOCK), 0, s, st.a, st.d);
-  hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, s, st.a, 1);
-  hipLaunchKernelGGL((advance_kernel<bfs_policy_dist>), dim3(grid), dim3(ADV_BLOCK), 0, s, st.a,
-                     bfs_policy_dist{st.d.dist, 0});
-  hipLaunchKernelGGL(dist_collect_kernel, dim3(grid / 4), dim3(ADV_BLOCK), 0, s, st.a, st.d);
-  hipLaunchKernelGGL(dist_counts_kernel, dim3(1), dim3(DIST_MAX_RANKS), 0, s, st.d.cursor, st.d.n_ranks, d_counts);
+  const dist_args& x = h->x;
+  if (part == 0) {
+    hipLaunchKernelGGL(dist_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, s, h->a, x);
+    hipLaunchKernelGGL(dist_prep_kernel, dim3(ctx->num_cus * 2), dim3(ADV_BLOCK), 0, s, h->a, h->d, x);
+  }
+  bfs_policy_dist pol{h->d.dist, x.sent, x.send + (size_t)part * x.n_ranks * x.slice_words, x.lo, x.hi, 0};
+  hipLaunchKernelGGL(dist_advance_kernel, dim3(h->grid_advance), dim3(ADV_BLOCK), 0, s, h->a, pol, part, x.parts);
   GRX_HIP(hipGetLastError());
   return GRX_SUCCESS;
 }
 
-// Claim `n` received candidates (global ids owned by this rank).  Asynchronous.
-grx_status_t grx_bfs_dist_apply(grx_context_t ctx, const int32_t* d_recv, long long n) {
-  dist_state& st = state_of(ctx);
-  if (!st.active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_apply: no BFS in flight");
-  if (n <= 0) return GRX_SUCCESS;
-  long long blocks = (n + ADV_BLOCK - 1) / ADV_BLOCK;
-  const long long cap = advance_grid(ctx) / 2;
-  if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(dist_apply_kernel, dim3((unsigned)blocks), dim3(ADV_BLOCK), 0, ctx->stream, st.a, st.d, d_recv, n);
+// Enqueue the part of a level group that follows the exchange(s): apply / bottom-up, then
+// the statistics kernel.  The caller then all-reduces stats_local into stats_global.
+grx_status_t grx_bfs_dist_post(grx_bfs_dist_t h) {
+  if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_post: no BFS in flight");
+  grx_context_t ctx = h->ctx;
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(dist_post_kernel, dim3(h->grid_post), dim3(ADV_BLOCK), 0, s, h->a, h->d, h->x);
+  hipLaunchKernelGGL(dist_stats_kernel, dim3(1), dim3(PLAN_BLOCK), 0, s, h->a, h->d, h->x);
   GRX_HIP(hipGetLastError());
   return GRX_SUCCESS;
 }
 
-// {vertices, out-edges} of the frontier the next level will expand.  Synchronises.
-grx_status_t grx_bfs_dist_frontier(grx_context_t ctx, long long* n_vertices, long long* n_edges) {
-  dist_state& st = state_of(ctx);
-  if (!st.active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_frontier: no BFS in flight");
-  long long* d_out = reinterpret_cast<long long*>(ctx->misc.as<unsigned long long>());
-  hipLaunchKernelGGL(dist_frontier_size_kernel, dim3(1), dim3(PLAN_BLOCK), 0, ctx->stream, st.a, d_out);
-  long long h[2] = {0, 0};
-  GRX_HIP(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+// Wait for everything enqueued so far and report the state of the search.
+grx_status_t grx_bfs_dist_poll(grx_bfs_dist_t h, int32_t* done, int32_t* level) {
+  if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_poll: no BFS in flight");
+  grx_context_t ctx = h->ctx;
+  GRX_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost, ctx->stream));
   GRX_HIP(hipStreamSynchronize(ctx->stream));
-  if (n_vertices) *n_vertices = h[0];
-  if (n_edges) *n_edges = h[1];
+  if (done) *done = ctx->h_ctrl->done;
+  if (level) *level = ctx->h_ctrl->level;
   return GRX_SUCCESS;
 }
 
-grx_status_t grx_bfs_dist_end(grx_context_t ctx, grx_run_stats_t* stats) {
-  dist_state& st = state_of(ctx);
-  if (!st.active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_end: no BFS in flight");
+grx_status_t grx_bfs_dist_end(grx_bfs_dist_t h, grx_run_stats_t* stats) {
+  if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_end: no BFS in flight");
+  grx_context_t ctx = h->ctx;
   hipStream_t s = ctx->stream;
   GRX_HIP(hipEventRecord(ctx->ev_end, s));
   GRX_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost, s));
@@ -348,11 +482,16 @@ grx_status_t grx_bfs_dist_end(grx_context_t ctx, grx_run_stats_t* stats) {
   GRX_HIP(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
   ctx->stats.edges_visited = ctx->h_ctrl->edges_visited;
   ctx->stats.vertices_visited = ctx->h_ctrl->vertices_visited;
-  ctx->stats.search_depth = ctx->h_ctrl->level + 1;
+  ctx->stats.search_depth = ctx->h_ctrl->level;
   ctx->stats.elapsed_ms = ms;
   ctx->stats.n_levels_recorded = 0;
   if (stats) *stats = ctx->stats;
-  st.active = false;
+  h->active = false;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_bfs_dist_destroy(grx_bfs_dist_t h) {
+  delete h;
   return GRX_SUCCESS;
 }
 

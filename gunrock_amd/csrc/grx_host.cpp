@@ -259,7 +259,8 @@ grx_status_t grx_host_csr_destroy(grx_host_csr_t h) {
 }
 
 static grx_status_t generate_impl(int32_t kind, int32_t V, int64_t n_entries, float a, float b, float c,
-                                  uint64_t seed, int32_t row_lo, int32_t row_hi, grx_host_csr_t* out);
+                                  uint64_t seed, int32_t row_lo, int32_t row_hi, grx_host_csr_t* out,
+                                  bool transposed = false);
 
 grx_status_t grx_host_csr_generate(int32_t kind, int32_t V, int64_t n_entries, float a, float b,
                                    float c, uint64_t seed, grx_host_csr_t* out) {
@@ -273,12 +274,20 @@ grx_status_t grx_host_csr_generate_rows(int32_t kind, int32_t V, int64_t n_entri
   return generate_impl(kind, V, n_entries, a, b, c, seed, row_lo, row_hi, out);
 }
 
+grx_status_t grx_host_csr_generate_in_rows(int32_t kind, int32_t V, int64_t n_entries, float a, float b, float c,
+                                           uint64_t seed, int32_t row_lo, int32_t row_hi, grx_host_csr_t* out) {
+  if (kind != 0 && kind != 1) return fail(GRX_ERROR_INVALID_ARGUMENT, "row slices: R-MAT kinds only");
+  if (row_lo < 0 || row_hi > V || row_lo > row_hi) return fail(GRX_ERROR_INVALID_ARGUMENT, "bad row range");
+  return generate_impl(kind, V, n_entries, a, b, c, seed, row_lo, row_hi, out, /*transposed=*/true);
+}
+
 }  // extern "C"
 
 static grx_status_t generate_impl(int32_t kind, int32_t V, int64_t n_entries, float a, float b, float c,
-                                  uint64_t seed, int32_t row_lo, int32_t row_hi, grx_host_csr_t* out) {
+                                  uint64_t seed, int32_t row_lo, int32_t row_hi, grx_host_csr_t* out,
+                                  bool transposed) {
   if (!out || V <= 0) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_host_csr_generate: bad argument");
-  const bool sliced = !(row_lo == 0 && row_hi == V);
+  const bool sliced = transposed || !(row_lo == 0 && row_hi == V);
   std::vector<int32_t> I, J;
   std::vector<float> X;
   grx_host_csr* h = new grx_host_csr();
@@ -345,6 +354,7 @@ static grx_status_t generate_impl(int32_t kind, int32_t V, int64_t n_entries, fl
           for (int64_t e = lo; e < hi; ++e) {
             int32_t u, w;
             endpoints(e, &u, &w);
+            if (transposed) std::swap(u, w);  // rows of the transpose: keyed by destination
             if (owned(u)) { PI[pi].push_back(u); PJ[pi].push_back(w); }
             if (kind == 1 && u != w && owned(w)) { PI[pi].push_back(w); PJ[pi].push_back(u); }
           }

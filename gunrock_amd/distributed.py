@@ -1,23 +1,36 @@
-"""Multi-GPU BFS: one process per GPU, vertex-range partition, RCCL all-to-all
-frontier exchange (torch.distributed; backend "nccl" is RCCL on ROCm).
+"""Multi-GPU BFS: one process per GPU, vertex-range partition, RCCL over xGMI
+(torch.distributed; backend "nccl" IS RCCL on ROCm).
 
 The reference has no multi-GPU path (every operator throws when
 `context.size() != 1`, framework/operators/advance/advance.hxx:129-132); this is
-the MI355X design of DESIGN.md section 6:
+the MI355X design of DESIGN.md section 7 (device side: csrc/grx_dist.hip):
 
-  rank r owns vertices [bounds[r], bounds[r+1]) and their CSR rows (global column
-  ids).  Per level:
-    1. local advance (the single-GPU fused kernel) over the owned frontier;
-    2. winners not owned by this rank are binned by owner on the device;
-    3. bucket sizes, then buckets, are exchanged with ALL-TO-ALL (each pair of GPUs
-       uses its own xGMI link, so the exchange is link-parallel);
-    4. received candidates are claimed (atomicMin) and appended to the next frontier;
-    5. the global next-frontier size is all-reduced for termination.
-  Depths are authoritative on the owned range of every rank.
+  rank r owns the vertex slice [r * S, min((r + 1) * S, V)) -- S = slice_bits(V, P), a
+  multiple of 2048 -- with its out-rows and, for the bottom-up step, its in-rows.
+  A level group is, per rank and entirely stream-ordered (no host round trip):
 
-`engine` abstracts the device side (grx_bfs_dist_* in include/grx.h) so that the
-protocol can also be exercised on CPU tensors with the gloo backend and a fake
-engine in tests (tests/test_distributed.py); the product engine is `GrxEngine`.
+    pre   head kernel (termination + Beamer direction from the all-reduced frontier
+          statistics, identical on every rank) -> prep -> top-down advance: owned
+          targets are claimed locally, targets of other ranks set a bit in the
+          outgoing bitmap (one S-bit slice per peer, deduplicated);
+          bottom-up level: the rank's frontier slice is replicated to every peer
+    a2a   all_to_all_single of the FIXED-SIZE bitmaps (P equal splits of S / 8 bytes;
+          each pair of GPUs has its own xGMI link, so the exchange is link-parallel)
+    post  top-down: OR of the received slices -> claim -> append to the queue;
+          bottom-up: scan in-edges of unvisited owned vertices against the
+          whole-graph frontier bitmap the all-to-all assembled; then frontier
+          statistics
+    ar    all_reduce of 4 int64 words (frontier vertices / out-edges)
+
+  Fixed message sizes mean the host never needs a size: it enqueues level groups
+  blindly in batches and polls `done` once per batch, like the single-GPU enactor.
+  `overlap=True` cuts a top-down level in two halves with their own bitmaps: the
+  all-to-all of the first half is issued asynchronously (RCCL runs it on its own HIP
+  stream) while the second half is still advancing on the compute stream.
+
+`engine` abstracts the device side so that the protocol can also be exercised on CPU
+tensors with the gloo backend and a numpy engine in tests (tests/test_distributed.py);
+the product engine is `GrxEngine` (C ABI grx_bfs_dist_*).
 """
 import ctypes as C
 
@@ -26,15 +39,23 @@ import numpy as np
 from . import _capi
 
 
+def slice_bits(n_vertices, n_ranks):
+    """Vertices per rank: ceil(V / P) rounded up to a multiple of 2048 (>= 2048)."""
+    per = (int(n_vertices) + n_ranks - 1) // n_ranks
+    return max(2048, ((per + 2047) // 2048) * 2048)
+
+
 def vertex_bounds(n_vertices, n_ranks):
-    """Contiguous, near-equal vertex ranges (vertex ids of the stand-in graphs are
-    randomly relabelled, so equal vertex counts give statistically equal edge counts)."""
-    b = [(n_vertices * r) // n_ranks for r in range(n_ranks + 1)]
-    return np.asarray(b, dtype=np.int32)
+    """Slice boundaries of the partition: bounds[r] = min(r * S, V).  (Vertex ids of the
+    stand-in graphs are randomly relabelled, so equal vertex counts give statistically
+    equal edge counts.)"""
+    S = slice_bits(n_vertices, n_ranks)
+    return np.asarray([min(r * S, int(n_vertices)) for r in range(n_ranks + 1)], dtype=np.int64).astype(np.int32)
 
 
 def edge_balanced_bounds(row_offsets, n_ranks):
-    """Contiguous vertex ranges with near-equal edge counts (prefix of degrees)."""
+    """Contiguous vertex ranges with near-equal edge counts (prefix of degrees); a helper
+    for callers that place their own data -- the bitmap exchange itself uses vertex_bounds."""
     ro = np.asarray(row_offsets, dtype=np.int64)
     total = int(ro[-1])
     cuts = [0]
@@ -45,13 +66,13 @@ def edge_balanced_bounds(row_offsets, n_ranks):
 
 
 class GrxEngine:
-    """Device side: the level-stepping C ABI (grx_bfs_dist_*).
+    """Device side: the level-group C ABI (grx_bfs_dist_*).
 
-    The engine context is created ON a torch stream, and every torch operation of the
-    exchange runs on that same stream, so kernels, bucket reads and collectives are
+    The engine context is created ON a torch stream and every torch operation of the
+    driver runs under that stream, so kernels, collectives and buffer reads are
     stream-ordered without extra synchronisation."""
 
-    def __init__(self, properties, csr_rows, bounds, rank, device):
+    def __init__(self, properties, out_rows, rank, n_ranks, device, n_edges_global, in_rows=None, overlap=False):
         import torch
         from . import build_graph, multi_context_t
         self.torch = torch
@@ -59,117 +80,121 @@ class GrxEngine:
         self.stream = torch.cuda.Stream(device=self.device)
         self.ctx = multi_context_t(self.device.index or 0, stream=self.stream)
         with torch.cuda.stream(self.stream):
-            self.g = build_graph(properties, csr_rows, self.ctx, device=device)
-        self.rank = rank
-        self.bounds = np.ascontiguousarray(bounds, dtype=np.int32)
-        self.P = len(self.bounds) - 1
+            self.g = build_graph(properties, out_rows, self.ctx, device=device)
+            self.g_in = build_graph(properties, in_rows, self.ctx, device=device) if in_rows is not None else None
+        self.rank, self.P = int(rank), int(n_ranks)
+        self.parts = 2 if overlap else 1
         V = self.g.get_number_of_vertices()
-        self.send = torch.empty(max(V, 1), dtype=torch.int32, device=device)
-        self.counts = torch.zeros(self.P, dtype=torch.int64, device=device)
+        self.V = V
+        self.S = slice_bits(V, self.P)
+        self.slice_words = self.S // 32
+        words = self.parts * self.P * self.slice_words
+        with torch.cuda.stream(self.stream):
+            self.send = torch.zeros(words, dtype=torch.int32, device=device)
+            self.recv = torch.zeros(words, dtype=torch.int32, device=device)
+            self.stats_local = torch.zeros(4, dtype=torch.int64, device=device)
+            self.stats_global = torch.zeros(4, dtype=torch.int64, device=device)
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().grx_bfs_dist_create(
+            self.ctx._h, self.g._h, self.g_in._h if self.g_in is not None else None, self.P, self.rank,
+            int(n_edges_global), self.parts, C.c_void_p(self.send.data_ptr()), C.c_void_p(self.recv.data_ptr()),
+            C.c_void_p(self.stats_local.data_ptr()), C.c_void_p(self.stats_global.data_ptr()), C.byref(self._h)))
 
-    def begin(self, source, dist):
-        lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
-        src = int(source) if lo <= source < hi else -1
-        _capi.check(_capi.lib().grx_bfs_dist_begin(
-            self.ctx._h, self.g._h, src, self.bounds.ctypes.data_as(C.POINTER(C.c_int32)), self.P, self.rank,
-            C.c_void_p(self.send.data_ptr()), C.c_void_p(dist.data_ptr())))
+    def part_buffers(self, part):
+        n = self.P * self.slice_words
+        return self.send[part * n:(part + 1) * n], self.recv[part * n:(part + 1) * n]
 
-    def advance(self):
-        """-> (send buffer, device int64[P] bucket sizes); bucket j at send[bounds[j]:]"""
-        _capi.check(_capi.lib().grx_bfs_dist_advance(self.ctx._h, C.c_void_p(self.counts.data_ptr())))
-        return self.send, self.counts
+    def begin(self, source, distances, optimized=True):
+        from . import forward, optimized as OPT
+        _capi.check(_capi.lib().grx_bfs_dist_begin(self._h, int(source), int(OPT if optimized else forward),
+                                                   C.c_void_p(distances.data_ptr())))
 
-    def apply(self, recv, n):
-        if n > 0:
-            _capi.check(_capi.lib().grx_bfs_dist_apply(self.ctx._h, C.c_void_p(recv.data_ptr()), int(n)))
+    def pre(self, part=0):
+        _capi.check(_capi.lib().grx_bfs_dist_pre(self._h, int(part)))
 
-    def frontier(self):
-        nv, ne = C.c_longlong(0), C.c_longlong(0)
-        _capi.check(_capi.lib().grx_bfs_dist_frontier(self.ctx._h, C.byref(nv), C.byref(ne)))
-        return nv.value, ne.value
+    def post(self):
+        _capi.check(_capi.lib().grx_bfs_dist_post(self._h))
+
+    def poll(self):
+        done, level = C.c_int32(0), C.c_int32(0)
+        _capi.check(_capi.lib().grx_bfs_dist_poll(self._h, C.byref(done), C.byref(level)))
+        return bool(done.value), level.value
 
     def end(self):
         s = _capi.grx_run_stats_t()
-        _capi.check(_capi.lib().grx_bfs_dist_end(self.ctx._h, C.byref(s)))
+        _capi.check(_capi.lib().grx_bfs_dist_end(self._h, C.byref(s)))
         return {"edges_visited": s.edges_visited, "vertices_visited": s.vertices_visited,
                 "search_depth": s.search_depth, "elapsed_ms": s.elapsed_ms}
 
     def sync(self):
         self.ctx.synchronize()
 
-
-def _exchange(dist, engine, send, counts, bounds, rank, P, recv):
-    """All-to-all of the per-owner buckets.  Returns the number of received ids,
-    packed at the front of `recv`."""
-    torch = engine.torch
-    counts_host = counts.to("cpu")  # the one host read of this level (bucket sizes)
-    backend = dist.get_backend()
-    if backend == "nccl":
-        got = torch.empty_like(counts)
-        dist.all_to_all_single(got, counts)
-        got_host = got.to("cpu").tolist()
-        sent = counts_host.tolist()
-        ins = [send[int(bounds[j]): int(bounds[j]) + int(sent[j])] for j in range(P)]
-        outs, at = [], 0
-        for j in range(P):
-            outs.append(recv[at: at + int(got_host[j])])
-            at += int(got_host[j])
-        dist.all_to_all(outs, ins)  # RCCL: one send/recv pair per peer, each on its own xGMI link
-        return at
-    # gloo (CPU tensors, tests): sizes by all_gather, payload by point-to-point
-    table = [torch.empty(P, dtype=torch.int64) for _ in range(P)]
-    dist.all_gather(table, counts_host)
-    sent = counts_host.tolist()
-    send_cpu = send.to("cpu")
-    reqs, pieces = [], []
-    at = 0
-    for j in range(P):
-        n_in = int(table[j][rank])
-        piece = torch.empty(n_in, dtype=torch.int32)
-        pieces.append(piece)
-        if j == rank:
-            continue
-        if n_in:
-            reqs.append(dist.irecv(piece, src=j))
-        n_out = int(sent[j])
-        if n_out:
-            reqs.append(dist.isend(send_cpu[int(bounds[j]): int(bounds[j]) + n_out].contiguous(), dst=j))
-    for r in reqs:
-        r.wait()
-    for j in range(P):
-        if j != rank and len(pieces[j]):
-            recv[at: at + len(pieces[j])] = pieces[j].to(recv.device)
-            at += len(pieces[j])
-    return at
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _capi.lib().grx_bfs_dist_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
-def bfs(engine, dist, source, distances, bounds, rank, recv=None):
+def _all_to_all(dist, send, recv, async_op=False):
+    """Fixed-size bitmap exchange: P equal splits.  nccl (= RCCL): device tensors, runs on
+    RCCL's own stream, ordered against the current stream by events.  gloo (tests): through
+    host copies."""
+    if dist is None or dist.get_world_size() == 1:
+        recv.copy_(send)
+        return None
+    if dist.get_backend() == "nccl":
+        return dist.all_to_all_single(recv, send, async_op=async_op)
+    s, r = send.cpu(), recv.cpu()
+    dist.all_to_all_single(r, s)
+    recv.copy_(r)
+    return None
+
+
+def _all_reduce_stats(dist, engine):
+    if dist is None or dist.get_world_size() == 1:
+        engine.stats_global.copy_(engine.stats_local)
+        return
+    if dist.get_backend() == "nccl":
+        engine.stats_global.copy_(engine.stats_local)
+        dist.all_reduce(engine.stats_global)
+        return
+    t = engine.stats_local.cpu()
+    dist.all_reduce(t)
+    engine.stats_global.copy_(t)
+
+
+def bfs(engine, dist, source, distances, optimized=True, first_batch=4):
     """Partitioned BFS driven by this rank.  `distances`: full-size int32 tensor on the
-    engine's device; on return its owned range holds the depths.  Returns run stats
-    (edges/vertices are this rank's share; search_depth is global)."""
+    engine's device; on return its owned slice holds the depths.  `dist`: the
+    torch.distributed module (or None for a single rank).  Returns run stats (edges /
+    vertices are this rank's share; search_depth is global)."""
     torch = engine.torch
-    P = len(bounds) - 1
-    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    if recv is None:
-        recv = torch.empty(max(hi - lo, 1) * max(P - 1, 1), dtype=torch.int32, device=distances.device)
     import contextlib
     on_stream = torch.cuda.stream(engine.stream) if getattr(engine, "stream", None) is not None \
         else contextlib.nullcontext()
     with on_stream:
-        engine.begin(source, distances)
-        levels = 0
+        engine.begin(source, distances, optimized)
+        _all_reduce_stats(dist, engine)
+        batch = first_batch
         while True:
-            send, counts = engine.advance()
-            n_recv = _exchange(dist, engine, send, counts, bounds, rank, P, recv) if P > 1 else 0
-            engine.apply(recv, n_recv)
-            nv, _ = engine.frontier()
-            total = torch.tensor([nv], dtype=torch.int64,
-                                 device=distances.device if dist.get_backend() == "nccl" else "cpu")
-            if P > 1:
-                dist.all_reduce(total)
-            levels += 1
-            if int(total.item()) == 0:
+            for _ in range(batch):
+                works = []
+                for part in range(engine.parts):
+                    engine.pre(part)  # part 0: head + prep + advance of half 0; part 1: advance of half 1
+                    send, recv = engine.part_buffers(part)
+                    # asynchronous: the compute stream goes on with the next half while RCCL
+                    # moves this half's bitmaps on its own stream
+                    works.append(_all_to_all(dist, send, recv, async_op=engine.parts > 1))
+                for w in works:
+                    if w is not None:
+                        w.wait()  # stream-level wait, the host does not block
+                engine.post()
+                _all_reduce_stats(dist, engine)
+            done, _ = engine.poll()
+            if done:
                 break
-        stats = engine.end()
-    stats["search_depth"] = levels
-    return stats
+            batch = min(batch * 2, 32)
+        return engine.end()

@@ -194,26 +194,43 @@ typedef struct grx_level_profile {
 grx_status_t grx_get_level_profile(grx_context_t ctx, grx_level_profile_t* out,
                                    int32_t capacity, int32_t* n_levels);
 
-/* ---- multi-GPU: level-stepping interface of the BFS enactor ------------------------
+/* ---- multi-GPU: level-group interface of the partitioned BFS enactor ------------------
  * The reference has no multi-GPU execution (every operator throws when
  * context.size() != 1: framework/operators/advance/advance.hxx:129-132).  One process
- * per GPU drives these calls and exchanges the buckets with RCCL (torch.distributed
- * all_to_all); see gunrock_amd/distributed.py and DESIGN.md section 6.
- * Rank r owns vertices [bounds[r], bounds[r+1]); `graph` holds the CSR rows of the
- * owned vertices with GLOBAL column ids (n_vertices = global V, other rows empty).
- * d_send: device int32[V]; the bucket for owner j starts at d_send + bounds[j].
- * d_distances: device int32[V]; authoritative on the owned range after the run. */
-grx_status_t grx_bfs_dist_begin(grx_context_t ctx, grx_graph_t graph, int32_t source_if_owned /* -1 if not */,
-                                const int32_t* bounds /* host, n_ranks + 1 */, int32_t n_ranks, int32_t my_rank,
-                                int32_t* d_send, int32_t* d_distances);
-/* expand the owned frontier by one level, then bin non-owned winners by owner;
- * d_counts: device int64[n_ranks] bucket sizes.  Asynchronous on the context stream. */
-grx_status_t grx_bfs_dist_advance(grx_context_t ctx, long long* d_counts);
-/* claim n received candidates (global ids owned by this rank); winners join the next frontier */
-grx_status_t grx_bfs_dist_apply(grx_context_t ctx, const int32_t* d_recv, long long n);
-/* size of the next frontier (owned vertices, their out-edges); synchronises the stream */
-grx_status_t grx_bfs_dist_frontier(grx_context_t ctx, long long* n_vertices, long long* n_edges);
-grx_status_t grx_bfs_dist_end(grx_context_t ctx, grx_run_stats_t* stats);
+ * per GPU drives these calls and runs the two collectives of a level group with RCCL
+ * (torch.distributed: all_to_all_single of fixed-size bitmaps, all_reduce of 4 words);
+ * see gunrock_amd/distributed.py, gunrock_amd/csrc/grx_dist.hip and DESIGN.md section 7.
+ *
+ * Partition: S = grx_bfs_dist_slice_bits(V, n_ranks) (a multiple of 2048); rank r owns
+ * vertices [r * S, min((r + 1) * S, V)).  `out_rows` holds the CSR rows of the owned
+ * vertices with GLOBAL column ids (n_vertices = global V, other rows empty); `in_rows`
+ * the same for the in-edges (NULL: the graph is symmetric, or no bottom-up step).
+ * Caller-owned device buffers (torch tensors in the Python driver):
+ *   d_send, d_recv : parts * n_ranks * (S / 32) 32-bit words each
+ *   d_stats_local, d_stats_global : int64[4]
+ * Per level group the caller enqueues, all asynchronously on the context's stream:
+ *   grx_bfs_dist_pre(h, 0); all_to_all_single(recv[0] <- send[0]);
+ *   [parts == 2: grx_bfs_dist_pre(h, 1); all_to_all_single(recv[1] <- send[1]);]
+ *   grx_bfs_dist_post(h); all_reduce(stats_global <- stats_local)
+ * -- blindly, several groups per grx_bfs_dist_poll; groups after `done` are no-ops. */
+typedef struct grx_bfs_dist* grx_bfs_dist_t;
+int32_t grx_bfs_dist_slice_bits(int32_t n_vertices, int32_t n_ranks);
+grx_status_t grx_bfs_dist_create(grx_context_t ctx, grx_graph_t out_rows, grx_graph_t in_rows_or_null,
+                                 int32_t n_ranks, int32_t my_rank, long long n_edges_global, int32_t parts,
+                                 void* d_send, void* d_recv, long long* d_stats_local,
+                                 const long long* d_stats_global, grx_bfs_dist_t* out);
+/* reset + seed; afterwards the caller all-reduces stats_local into stats_global once.
+ * advance_direction: GRX_DIR_FORWARD (top-down only) or GRX_DIR_OPTIMIZED.
+ * d_distances: device int32[V]; only the owned range is written (and authoritative). */
+grx_status_t grx_bfs_dist_begin(grx_bfs_dist_t h, int32_t source, int32_t advance_direction,
+                                int32_t* d_distances);
+grx_status_t grx_bfs_dist_pre(grx_bfs_dist_t h, int32_t part);
+grx_status_t grx_bfs_dist_post(grx_bfs_dist_t h);
+/* synchronises the stream; *done != 0 once the global frontier ran empty */
+grx_status_t grx_bfs_dist_poll(grx_bfs_dist_t h, int32_t* done, int32_t* level);
+/* run statistics: edges / vertices are this rank's share, search_depth is global */
+grx_status_t grx_bfs_dist_end(grx_bfs_dist_t h, grx_run_stats_t* stats);
+grx_status_t grx_bfs_dist_destroy(grx_bfs_dist_t h);
 
 /* ---- host-side ingest (same semantics as the reference) ---- */
 
@@ -254,6 +271,11 @@ grx_status_t grx_host_csr_generate(int32_t kind, int32_t n_vertices, int64_t n_e
 grx_status_t grx_host_csr_generate_rows(int32_t kind, int32_t n_vertices, int64_t n_entries,
                                         float a, float b, float c, uint64_t seed,
                                         int32_t row_lo, int32_t row_hi, grx_host_csr_t* out);
+/* The IN-rows [row_lo, row_hi) of the same graph (rows of its transpose, global source
+ * ids): what a rank needs for the bottom-up step of a directed graph. */
+grx_status_t grx_host_csr_generate_in_rows(int32_t kind, int32_t n_vertices, int64_t n_entries,
+                                           float a, float b, float c, uint64_t seed,
+                                           int32_t row_lo, int32_t row_hi, grx_host_csr_t* out);
 
 #ifdef __cplusplus
 }

@@ -26,62 +26,147 @@ def free_port():
     return p
 
 
+def _pack(bits):
+    """bool[n] (n % 32 == 0) -> int32 words, bit b of word w = vertex 32 w + b"""
+    return np.packbits(bits, bitorder="little").view(np.int32)
+
+
+def _unpack(words):
+    return np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little").astype(bool)
+
+
 class FakeEngine:
-    """Host stand-in for GrxEngine with the same contract (tests only)."""
+    """Host stand-in for GrxEngine with the same contract (tests only): numpy versions of
+    the head / prep / advance / apply / bottom-up / stats kernels of csrc/grx_dist.hip."""
+    stream = None
 
-    def __init__(self, ro, ci, bounds, rank):
+    def __init__(self, out_rows, in_rows, rank, n_ranks, n_edges_global, overlap=False):
         import torch
+        from gunrock_amd import distributed as D
         self.torch = torch
-        self.ro, self.ci, self.bounds, self.rank = ro, ci, np.asarray(bounds), rank
-        self.P = len(bounds) - 1
-        self.V = len(ro) - 1
-        self.send = torch.zeros(self.V, dtype=torch.int32)
-        self.counts = torch.zeros(self.P, dtype=torch.int64)
+        self.ro, self.ci = out_rows
+        self.iro, self.ici = in_rows
+        self.rank, self.P = rank, n_ranks
+        self.V = len(self.ro) - 1
+        self.S = D.slice_bits(self.V, n_ranks)
+        self.slice_words = self.S // 32
+        self.lo, self.hi = min(rank * self.S, self.V), min((rank + 1) * self.S, self.V)
+        self.parts = 2 if overlap else 1
+        n = self.parts * self.P * self.slice_words
+        self.send = torch.zeros(n, dtype=torch.int32)
+        self.recv = torch.zeros(n, dtype=torch.int32)
+        self.stats_local = torch.zeros(4, dtype=torch.int64)
+        self.stats_global = torch.zeros(4, dtype=torch.int64)
+        self.e_global = n_edges_global
+        self.modes = []
 
-    def begin(self, source, dist):
-        self.dist = dist.numpy()
-        self.dist[:] = INF
-        lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
-        self.frontier_v = []
-        self.level = -1
-        self.ev = 0
-        if lo <= source < hi:
+    def part_buffers(self, part):
+        n = self.P * self.slice_words
+        return self.send[part * n:(part + 1) * n], self.recv[part * n:(part + 1) * n]
+
+    def begin(self, source, distances, optimized=True):
+        self.dist = distances.numpy()
+        self.dist[self.lo:self.hi] = INF
+        self.sent = np.zeros(self.P * self.S, bool)
+        self.level, self.done, self.mode, self.optimized = -1, False, 0, optimized
+        self.g_edges = self.ev = self.vv = 0
+        self.frontier = []
+        self.modes = []
+        if self.lo <= source < self.hi:
             self.dist[source] = 0
-            self.frontier_v = [int(source)]
+            self.frontier = [int(source)]
+        self._stats()
 
-    def advance(self):
-        self.level += 1
-        lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
-        nxt, remote = [], [[] for _ in range(self.P)]
-        for u in self.frontier_v:
-            self.ev += self.ro[u + 1] - self.ro[u]
+    def _stats(self):
+        self.stats_local[0] = len(self.frontier)
+        self.stats_local[1] = int(sum(self.ro[v + 1] - self.ro[v] for v in self.frontier))
+        self.q_edges = int(self.stats_local[1])
+
+    def pre(self, part=0):
+        if part == 0:
+            if self.done:
+                return
+            n_f, m_f = int(self.stats_global[0]), int(self.stats_global[1])
+            if n_f == 0:
+                self.done = True
+                self.level += 1
+                return
+            if self.optimized:
+                m_u = self.e_global - self.g_edges
+                if self.mode == 0:
+                    if m_f > m_u // 14 and n_f > 256:
+                        self.mode = 1
+                elif n_f < (self.P * self.S) // 24:
+                    self.mode = 0
+            self.modes.append(self.mode)
+            self.level += 1
+            self.g_edges += m_f
+            self.ev += self.q_edges
+            self.vv += len(self.frontier)
+            self.next = []
+            self.send.zero_()
+            if self.mode == 1:
+                fr = np.zeros(self.S, bool)
+                fr[:self.hi - self.lo] = self.dist[self.lo:self.hi] == self.level
+                w = _pack(fr)
+                s0, _ = self.part_buffers(0)
+                for j in range(self.P):
+                    s0.numpy()[j * self.slice_words:(j + 1) * self.slice_words] = w
+                return
+        if self.done or self.mode == 1:
+            return
+        out = np.zeros(self.P * self.S, bool)
+        depth = self.level + 1
+        for u in self.frontier[part::self.parts]:
             for e in range(self.ro[u], self.ro[u + 1]):
                 n = int(self.ci[e])
-                if self.dist[n] > self.level + 1:
-                    self.dist[n] = self.level + 1
-                    if lo <= n < hi:
-                        nxt.append(n)
-                    else:
-                        remote[int(np.searchsorted(self.bounds, n, side="right") - 1)].append(n)
-        self.next_v = nxt
-        send = self.send.numpy()
-        for j in range(self.P):
-            self.counts[j] = len(remote[j])
-            send[self.bounds[j]: self.bounds[j] + len(remote[j])] = remote[j]
-        return self.send, self.counts
+                if self.lo <= n < self.hi:
+                    if self.dist[n] > depth:
+                        self.dist[n] = depth
+                        self.next.append(n)
+                elif not self.sent[n]:
+                    self.sent[n] = True
+                    out[n] = True
+        s, _ = self.part_buffers(part)
+        s.numpy()[:] = _pack(out)
 
-    def apply(self, recv, n):
-        for v in recv[:n].tolist():
-            if self.dist[v] > self.level + 1:
-                self.dist[v] = self.level + 1
-                self.next_v.append(v)
+    def post(self):
+        if self.done:
+            self.stats_local.zero_()
+            return
+        depth = self.level + 1
+        if self.mode == 0:
+            cand = np.zeros(self.S, bool)
+            for part in range(self.parts):
+                _, r = self.part_buffers(part)
+                bits = _unpack(r.numpy())
+                for j in range(self.P):
+                    if j != self.rank:
+                        cand |= bits[j * self.S:(j + 1) * self.S]
+            for i in np.flatnonzero(cand):
+                v = self.lo + int(i)
+                if v < self.hi and self.dist[v] > depth:
+                    self.dist[v] = depth
+                    self.next.append(v)
+        else:
+            _, r = self.part_buffers(0)
+            fr = _unpack(r.numpy())  # whole-graph frontier bitmap, indexed by global id
+            for v in range(self.lo, self.hi):
+                if self.dist[v] == INF:
+                    for e in range(self.iro[v], self.iro[v + 1]):
+                        if fr[self.ici[e]]:
+                            self.dist[v] = depth
+                            self.next.append(v)
+                            break
+        self.frontier = self.next
+        self._stats()
 
-    def frontier(self):
-        self.frontier_v = self.next_v
-        return len(self.frontier_v), 0
+    def poll(self):
+        return self.done, self.level
 
     def end(self):
-        return {"edges_visited": int(self.ev), "vertices_visited": 0, "search_depth": self.level + 1, "elapsed_ms": 0.0}
+        return {"edges_visited": int(self.ev), "vertices_visited": int(self.vv), "search_depth": self.level,
+                "elapsed_ms": 0.0}
 
 
 def _worker(rank, world, port, use_gpu, out_dir):
@@ -98,19 +183,29 @@ def _worker(rank, world, port, use_gpu, out_dir):
     results = {}
     for kind, seed in (("rmat", 5), ("rmat_sym", 9)):
         props, full = gr.generate(kind, V, E, seed=seed)
-        bounds = D.vertex_bounds(V, world) if kind == "rmat" else D.edge_balanced_bounds(full.row_offsets, world)
+        bounds = D.vertex_bounds(V, world)
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         _, mine = gr.generate_rows(kind, V, E, lo, hi, seed=seed)
+        mine_in = mine
+        if kind == "rmat":
+            _, mine_in = gr.generate_rows(kind, V, E, lo, hi, seed=seed, in_rows=True)
+        e_global = int(full.number_of_nonzeros)
         src = int(np.argmax(np.diff(full.row_offsets)))
-        if use_gpu:
-            eng = D.GrxEngine(props, mine, bounds, rank, "cuda:0")
-            d = torch.empty(V, dtype=torch.int32, device="cuda:0")
-        else:
-            eng = FakeEngine(mine.row_offsets, mine.column_indices, bounds, rank)
-            d = torch.empty(V, dtype=torch.int32)
-        for s in (src, 0, V - 1):
-            st = D.bfs(eng, dist, s, d, bounds, rank)
-            results["%s_%d" % (kind, s)] = (d.cpu().numpy()[lo:hi].copy(), lo, hi, st["edges_visited"], st["search_depth"])
+        for overlap in (False, True):
+            if use_gpu:
+                eng = D.GrxEngine(props, mine, rank, world, "cuda:0", e_global,
+                                  in_rows=mine_in if kind == "rmat" else None, overlap=overlap)
+                d = torch.empty(V, dtype=torch.int32, device="cuda:0")
+            else:
+                eng = FakeEngine((mine.row_offsets, mine.column_indices), (mine_in.row_offsets, mine_in.column_indices),
+                                 rank, world, e_global, overlap=overlap)
+                d = torch.empty(V, dtype=torch.int32)
+            for s, optimized in ((src, True), (src, False), (0, True), (V - 1, True)):
+                st = D.bfs(eng, dist, s, d, optimized=optimized)
+                key = "%s_%d_%d_%d" % (kind, s, int(optimized), int(overlap))
+                results[key] = (d.cpu().numpy()[lo:hi].copy(), lo, hi, st["edges_visited"], st["search_depth"],
+                                list(getattr(eng, "modes", [])))
+            del eng
     np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([results], dtype=object), allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -123,21 +218,28 @@ def _run(world, use_gpu, tmp_path):
     import gunrock_amd as gr
     per_rank = [np.load(os.path.join(str(tmp_path), "r%d.npy" % r), allow_pickle=True)[0] for r in range(world)]
     V, E = 20000, 160000
+    bottom_up_seen = False
     for kind, seed in (("rmat", 5), ("rmat_sym", 9)):
         _, full = gr.generate(kind, V, E, seed=seed)
         g = O.Csr(full.row_offsets, full.column_indices, full.nonzero_values)
         src = int(np.argmax(np.diff(full.row_offsets)))
-        for s in (src, 0, V - 1):
-            want, _, ev = O.bfs_queue(g, s)
-            got = np.full(V, -1, np.int32)
-            edges = 0
-            for r in range(world):
-                part, lo, hi, e_r, depth = per_rank[r]["%s_%d" % (kind, s)]
-                got[lo:hi] = part
-                edges += e_r
-            assert np.array_equal(got, want), (kind, s)
-            assert edges == ev  # every reached vertex is expanded exactly once, by its owner
-            assert depth == want[want != INF].max() + 1
+        for overlap in (0, 1):
+            for s, optimized in ((src, 1), (src, 0), (0, 1), (V - 1, 1)):
+                want, _, ev = O.bfs_queue(g, s)
+                got = np.full(V, -1, np.int32)
+                edges = 0
+                key = "%s_%d_%d_%d" % (kind, s, optimized, overlap)
+                for r in range(world):
+                    part, lo, hi, e_r, depth, modes = per_rank[r][key]
+                    got[lo:hi] = part
+                    edges += e_r
+                    bottom_up_seen |= 1 in modes
+                    assert optimized or 1 not in modes
+                assert np.array_equal(got, want), key
+                assert edges == ev, key  # every reached vertex is expanded exactly once, by its owner
+                assert depth == want[want != INF].max() + 1, key
+    if not use_gpu:
+        assert bottom_up_seen  # the direction switch is part of what this test covers
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -147,8 +249,9 @@ def test_protocol_on_cpu_with_gloo(world, tmp_path):
 
 def test_partition_helpers(gr):
     from gunrock_amd import distributed as D
-    b = D.vertex_bounds(10, 3)
-    assert b.tolist() == [0, 3, 6, 10]
+    assert D.slice_bits(10, 3) == 2048 and D.slice_bits(20000, 3) == 8192
+    assert D.vertex_bounds(10, 3).tolist() == [0, 10, 10, 10]
+    assert D.vertex_bounds(20000, 3).tolist() == [0, 8192, 16384, 20000]
     _, c = gr.generate("rmat", 5000, 60000, seed=1)
     e = D.edge_balanced_bounds(c.row_offsets, 4)
     assert e[0] == 0 and e[-1] == 5000 and np.all(np.diff(e) >= 0)
@@ -158,6 +261,16 @@ def test_partition_helpers(gr):
     _, a = gr.generate_rows("rmat", 5000, 60000, 0, int(e[2]), seed=1)
     _, b2 = gr.generate_rows("rmat", 5000, 60000, int(e[2]), 5000, seed=1)
     assert np.array_equal(np.concatenate([a.column_indices, b2.column_indices]), c.column_indices)
+    # in-row slices are the rows of the transpose
+    import scipy.sparse as sp
+    m = sp.csr_matrix((np.ones(len(c.column_indices)), c.column_indices, c.row_offsets), shape=(5000, 5000))
+    t = m.T.tocsr()
+    t.sum_duplicates()
+    _, ti = gr.generate_rows("rmat", 5000, 60000, 1000, 3000, seed=1, in_rows=True)
+    for v in (0, 999, 1000, 1500, 2999, 3000, 4999):
+        mine = np.sort(ti.column_indices[ti.row_offsets[v]:ti.row_offsets[v + 1]])
+        want = np.repeat(t.indices[t.indptr[v]:t.indptr[v + 1]], t.data[t.indptr[v]:t.indptr[v + 1]].astype(int))
+        assert np.array_equal(mine, np.sort(want) if 1000 <= v < 3000 else np.zeros(0, np.int32))
 
 
 @pytest.mark.gpu
@@ -169,21 +282,18 @@ def test_two_ranks_real_kernels_one_gpu(tmp_path):
 def test_single_rank_dist_path_equals_plain_bfs(gr, gpu_ctx):
     import torch
     from gunrock_amd import distributed as D
-
-    class NoDist:
-        @staticmethod
-        def get_backend():
-            return "none"
     V, E = 1 << 16, 1 << 20
     props, c = gr.generate("rmat", V, E, seed=2)
-    bounds = D.vertex_bounds(V, 1)
-    eng = D.GrxEngine(props, c, bounds, 0, "cuda:0")
-    d = torch.empty(V, dtype=torch.int32, device="cuda:0")
+    _, cin = gr.generate_rows("rmat", V, E, 0, V, seed=2, in_rows=True)
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
     src = int(np.argmax(np.diff(g.row_offsets)))
-    st = D.bfs(eng, NoDist, src, d, bounds, 0)
     want, _, ev = O.bfs_queue(g, src)
-    assert np.array_equal(d.cpu().numpy(), want) and st["edges_visited"] == ev
+    for overlap in (False, True):
+        eng = D.GrxEngine(props, c, 0, 1, "cuda:0", E, in_rows=cin, overlap=overlap)
+        d = torch.empty(V, dtype=torch.int32, device="cuda:0")
+        for optimized in (True, False):
+            st = D.bfs(eng, None, src, d, optimized=optimized)
+            assert np.array_equal(d.cpu().numpy(), want) and st["edges_visited"] == ev
 
 
 @pytest.mark.gpu
