@@ -52,6 +52,51 @@ struct cursor {
     *out = v;
     return true;
   }
+  // Clinger fast path: <= 15 significant digits and |10-exponent| <= 22 are exact in
+  // double arithmetic, i.e. identical to strtod; everything else goes to strtod.
+  bool read_f64_fast(double* out) {
+    skip_ws();
+    const char* s0 = p;
+    const char* q = p;
+    bool neg = false;
+    if (q < end && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
+    uint64_t mant = 0;
+    int digits = 0, frac = 0;
+    bool any = false;
+    while (q < end && *q >= '0' && *q <= '9') { if (mant || *q != '0') ++digits; mant = mant * 10 + (uint64_t)(*q - '0'); ++q; any = true; if (digits > 15) break; }
+    if (digits <= 15 && q < end && *q == '.') {
+      ++q;
+      while (q < end && *q >= '0' && *q <= '9') { if (mant || *q != '0') ++digits; mant = mant * 10 + (uint64_t)(*q - '0'); ++q; ++frac; any = true; if (digits > 15) break; }
+    }
+    int ex = 0;
+    bool simple = any && digits <= 15;
+    if (simple && q < end && (*q == 'e' || *q == 'E')) {
+      const char* r = q + 1;
+      bool eneg = false;
+      if (r < end && (*r == '-' || *r == '+')) { eneg = *r == '-'; ++r; }
+      int ed = 0;
+      if (r < end && *r >= '0' && *r <= '9') {
+        while (r < end && *r >= '0' && *r <= '9' && ed < 4) { ex = ex * 10 + (*r - '0'); ++r; ++ed; }
+        if (r < end && *r >= '0' && *r <= '9') simple = false;
+        if (eneg) ex = -ex;
+        q = r;
+      }
+    }
+    if (simple && (q >= end || *q == ' ' || *q == '\t' || *q == '\r' || *q == '\n')) {
+      static const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                   1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+      const int e10 = ex - frac;
+      if (e10 >= -22 && e10 <= 22) {
+        double v = (double)mant;
+        v = e10 < 0 ? v / p10[-e10] : v * p10[e10];
+        *out = neg ? -v : v;
+        p = q;
+        return true;
+      }
+    }
+    p = s0;
+    return read_f64(out);
+  }
   std::string line() {
     const char* s = p;
     while (p < end && *p != '\n') ++p;
@@ -66,23 +111,65 @@ std::string lowered(std::string s) {
   return s;
 }
 
+template <class F>
+void parallel_for(int64_t n, F f);
+unsigned host_threads();
+
 // Stable bucket-by-row conversion: keeps duplicates, self loops and the COO
-// order inside each row (formats/csr.hxx:104-133 semantics).
+// order inside each row (formats/csr.hxx:104-133 semantics).  `mirror`: every
+// off-diagonal entry (i, j) is followed by (j, i), the way the reference loader expands
+// symmetric files (io/matrix_market.hxx:225-240) -- done here instead of materialising
+// the doubled COO.  Parallel and still stable: each thread owns a contiguous range of ROWS
+// and streams the whole COO once per pass, so the order inside a row is the COO order.
 void coo_to_csr(int32_t rows, int64_t nnz, const int32_t* I, const int32_t* J, const float* X,
-                grx_host_csr* out) {
+                grx_host_csr* out, bool mirror = false) {
   out->ro.assign((size_t)rows + 1, 0);
-  out->ci.resize((size_t)nnz);
-  out->w.resize((size_t)nnz);
   std::vector<int32_t>& ro = out->ro;
-  for (int64_t k = 0; k < nnz; ++k) ++ro[(size_t)I[k] + 1];
-  for (int32_t r = 0; r < rows; ++r) ro[(size_t)r + 1] += ro[r];
-  std::vector<int32_t> fill(ro.begin(), ro.end() - 1);
-  for (int64_t k = 0; k < nnz; ++k) {
-    const int32_t pos = fill[I[k]]++;
-    out->ci[pos] = J[k];
-    out->w[pos] = X ? X[k] : 1.0f;
+  const unsigned nt = (nnz < (1 << 16) || rows < 1024) ? 1u : host_threads();
+  std::vector<int32_t> cut(nt + 1);
+  for (unsigned t = 0; t <= nt; ++t) cut[t] = (int32_t)(((int64_t)rows * t) / nt);
+  auto run = [&](auto body) {
+    if (nt == 1) { body(0u); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back([&, t] { body(t); });
+    for (auto& x : th) x.join();
+  };
+  // pass 1: degrees (row r counted at ro[r + 1] by the one thread that owns r)
+  run([&](unsigned t) {
+    const int32_t lo = cut[t], hi = cut[t + 1];
+    for (int64_t k = 0; k < nnz; ++k) {
+      const int32_t i = I[k], j = J[k];
+      if (i >= lo && i < hi) ++ro[(size_t)i + 1];
+      if (mirror && i != j && j >= lo && j < hi) ++ro[(size_t)j + 1];
+    }
+  });
+  int64_t total = 0;
+  for (int32_t r = 0; r < rows; ++r) {
+    total += ro[(size_t)r + 1];
+    ro[(size_t)r + 1] = (int32_t)total;
   }
-  out->E = (int32_t)nnz;
+  out->ci.resize((size_t)total);
+  out->w.resize((size_t)total);
+  std::vector<int32_t> fill(ro.begin(), ro.end() - 1);
+  // pass 2: placement
+  run([&](unsigned t) {
+    const int32_t lo = cut[t], hi = cut[t + 1];
+    for (int64_t k = 0; k < nnz; ++k) {
+      const int32_t i = I[k], j = J[k];
+      const float x = X ? X[k] : 1.0f;
+      if (i >= lo && i < hi) {
+        const int32_t pos = fill[i]++;
+        out->ci[pos] = j;
+        out->w[pos] = x;
+      }
+      if (mirror && i != j && j >= lo && j < hi) {
+        const int32_t pos = fill[j]++;
+        out->ci[pos] = i;
+        out->w[pos] = x;
+      }
+    }
+  });
+  out->E = (int32_t)total;
 }
 
 inline uint64_t mix64(uint64_t z) {
@@ -95,11 +182,17 @@ inline uint64_t rnd(uint64_t seed, uint64_t idx, uint64_t j) {
   return mix64(mix64(seed ^ (idx * 0xD1342543DE82EF95ull)) + j * 0xA24BAED4963EE407ull);
 }
 
-template <class F>
-void parallel_for(int64_t n, F f) {
+unsigned host_threads() {
   unsigned nt = std::thread::hardware_concurrency();
+  if (const char* e = getenv("GRX_HOST_THREADS")) nt = (unsigned)atoi(e);
   if (nt == 0) nt = 1;
   if (nt > 32) nt = 32;
+  return nt;
+}
+
+template <class F>
+void parallel_for(int64_t n, F f) {
+  unsigned nt = host_threads();
   if (n < 64) nt = 1;
   std::vector<std::thread> th;
   const int64_t per = (n + nt - 1) / nt;
@@ -156,27 +249,105 @@ grx_status_t grx_host_csr_load_mtx(const char* filename, grx_host_csr_t* out) {
   if (M >= (uint64_t)INT32_MAX || N >= (uint64_t)INT32_MAX) return fail(GRX_ERROR_IO, "vertex_t overflow");
   if (NZ >= (uint64_t)INT32_MAX) return fail(GRX_ERROR_IO, "edge_t overflow");
 
-  std::vector<int32_t> I, J;
-  std::vector<float> X;
-  const size_t reserve = (size_t)NZ * (symmetric ? 2 : 1);
-  I.reserve(reserve);
-  J.reserve(reserve);
-  X.reserve(reserve);
-  for (uint64_t k = 0; k < NZ; ++k) {
-    uint64_t r = 0, col = 0;
-    double val = 1.0;  // pattern entries carry weight 1.0
-    if (!c.read_u64(&r) || !c.read_u64(&col))
-      return fail(GRX_ERROR_IO, "Could not read edge from market file");
-    if (!pattern && !c.read_f64(&val))
-      return fail(GRX_ERROR_IO, "Could not read weighted edge from market file");
-    if (r == 0 || col == 0) return fail(GRX_ERROR_IO, "Market file is zero-indexed");
-    const int32_t i = (int32_t)r - 1, j = (int32_t)col - 1;
-    I.push_back(i); J.push_back(j); X.push_back((float)val);
-    if (symmetric && i != j) {  // mirrored entry sits right after its original
-      I.push_back(j); J.push_back(i); X.push_back((float)val);
+  // ---- entries.  Fast path: one entry per line (every Matrix-Market writer does that):
+  // the body is cut at newlines into one piece per host thread, lines are counted, then
+  // parsed in place in parallel (the reference runs one fscanf per entry,
+  // io/matrix_market.hxx:158-197).  Anything unusual -- entries wrapped over lines, too few
+  // lines, a malformed number -- falls back to the token-by-token parser below, which also
+  // produces the reference's error messages.
+  std::vector<int32_t> I((size_t)NZ), J((size_t)NZ);
+  std::vector<float> X(pattern ? 0 : (size_t)NZ);
+  bool parsed = false;
+  {
+    while (c.p < c.end && *c.p != '\n') ++c.p;  // rest of the size line
+    if (c.p < c.end) ++c.p;
+    const char* body = c.p;
+    const unsigned nt = (NZ < 4096) ? 1u : host_threads();
+    std::vector<const char*> cut(nt + 1);
+    cut[0] = body;
+    cut[nt] = c.end;
+    for (unsigned t = 1; t < nt; ++t) {
+      const char* q = body + ((size_t)(c.end - body) * t) / nt;
+      while (q < c.end && *q != '\n') ++q;
+      cut[t] = q < c.end ? q + 1 : c.end;
+      if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    }
+    auto blank = [](const char* a, const char* b) {
+      for (; a < b; ++a) if (*a != ' ' && *a != '\t' && *a != '\r') return false;
+      return true;
+    };
+    std::vector<int64_t> lines(nt + 1, 0);
+    std::vector<int> bad(nt, 0);
+    auto run = [&](auto body_fn) {
+      if (nt == 1) { body_fn(0u); return; }
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < nt; ++t) th.emplace_back([&, t] { body_fn(t); });
+      for (auto& x : th) x.join();
+    };
+    run([&](unsigned t) {
+      int64_t n = 0;
+      const char* a = cut[t];
+      const char* e = cut[t + 1];
+      while (a < e) {
+        const char* nl = (const char*)memchr(a, '\n', (size_t)(e - a));
+        const char* le = nl ? nl : e;
+        if (!blank(a, le)) ++n;
+        a = nl ? nl + 1 : e;
+      }
+      lines[t + 1] = n;
+    });
+    for (unsigned t = 0; t < nt; ++t) lines[t + 1] += lines[t];
+    if ((uint64_t)lines[nt] >= NZ) {  // surplus lines are ignored, like the reference's NZ-entry loop
+      run([&](unsigned t) {
+        int64_t k = lines[t];
+        const char* a = cut[t];
+        const char* e = cut[t + 1];
+        while (a < e && (uint64_t)k < NZ) {
+          const char* nl = (const char*)memchr(a, '\n', (size_t)(e - a));
+          const char* le = nl ? nl : e;
+          if (!blank(a, le)) {
+            cursor lc{a, le};
+            uint64_t r = 0, col = 0;
+            double val = 1.0;
+            bool ok = lc.read_u64(&r) && lc.read_u64(&col) && (pattern || lc.read_f64_fast(&val)) && lc.eof() &&
+                      r >= 1 && col >= 1 && r <= (uint64_t)INT32_MAX && col <= (uint64_t)INT32_MAX;
+            if (!ok) { bad[t] = 1; return; }
+            I[(size_t)k] = (int32_t)(r - 1);
+            J[(size_t)k] = (int32_t)(col - 1);
+            if (!pattern) X[(size_t)k] = (float)val;
+            ++k;
+          }
+          a = nl ? nl + 1 : e;
+        }
+      });
+      parsed = true;
+      for (unsigned t = 0; t < nt; ++t) parsed = parsed && !bad[t];
+    }
+    if (!parsed) c.p = body;
+  }
+  if (!parsed) {
+    for (uint64_t k = 0; k < NZ; ++k) {
+      uint64_t r = 0, col = 0;
+      double val = 1.0;  // pattern entries carry weight 1.0
+      if (!c.read_u64(&r) || !c.read_u64(&col))
+        return fail(GRX_ERROR_IO, "Could not read edge from market file");
+      if (!pattern && !c.read_f64(&val))
+        return fail(GRX_ERROR_IO, "Could not read weighted edge from market file");
+      if (r == 0 || col == 0) return fail(GRX_ERROR_IO, "Market file is zero-indexed");
+      I[(size_t)k] = (int32_t)r - 1;
+      J[(size_t)k] = (int32_t)col - 1;
+      if (!pattern) X[(size_t)k] = (float)val;
     }
   }
-  if ((uint64_t)I.size() >= (uint64_t)INT32_MAX) return fail(GRX_ERROR_IO, "edge_t overflow");
+  for (uint64_t k = 0; k < NZ; ++k)
+    if (I[(size_t)k] >= (int32_t)M || J[(size_t)k] < 0 || I[(size_t)k] < 0 ||
+        (symmetric && J[(size_t)k] >= (int32_t)M))
+      return fail(GRX_ERROR_IO, "Market file entry outside the declared matrix");
+  if (symmetric && 2 * NZ >= (uint64_t)INT32_MAX) {
+    uint64_t off = 0;
+    for (uint64_t k = 0; k < NZ; ++k) off += I[(size_t)k] != J[(size_t)k];
+    if (NZ + off >= (uint64_t)INT32_MAX) return fail(GRX_ERROR_IO, "edge_t overflow");
+  }
 
   grx_host_csr* h = new grx_host_csr();
   h->V = (int32_t)M;
@@ -184,7 +355,8 @@ grx_status_t grx_host_csr_load_mtx(const char* filename, grx_host_csr_t* out) {
   h->weighted = pattern ? 0 : 1;
   h->symmetric = symmetric ? 1 : 0;
   h->directed = symmetric ? 0 : 1;
-  coo_to_csr(h->V, (int64_t)I.size(), I.data(), J.data(), X.data(), h);
+  // symmetric files: the mirrored entry sits right after its original (expanded on the fly)
+  coo_to_csr(h->V, (int64_t)NZ, I.data(), J.data(), pattern ? nullptr : X.data(), h, symmetric);
   *out = h;
   return GRX_SUCCESS;
 }

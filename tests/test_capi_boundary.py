@@ -115,3 +115,78 @@ def test_generators_are_deterministic_and_well_formed(gr):
     assert pr.symmetric and pr.weighted
     assert r.nonzero_values.min() >= 1 and r.nonzero_values.max() <= 1000
     assert np.all(r.nonzero_values == np.round(r.nonzero_values))
+
+
+def _write_mtx(path, header, rows, cols, vals, sep="\n", extra_blank=False):
+    with open(path, "w", newline="") as f:
+        f.write(header + sep)
+        f.write("% a comment" + sep)
+        f.write("%d %d %d" % (rows.max() + 1 if len(rows) else 1, rows.max() + 1 if len(rows) else 1, len(rows)) + sep)
+        for k in range(len(rows)):
+            if extra_blank and k % 997 == 0:
+                f.write("   " + sep)
+            if vals is None:
+                f.write("%d %d" % (rows[k] + 1, cols[k] + 1) + sep)
+            else:
+                f.write("%d\t%d  %s " % (rows[k] + 1, cols[k] + 1, vals[k]) + sep)
+
+
+@pytest.mark.parametrize("kind", ["pattern general", "real symmetric", "integer general"])
+def test_parallel_ingest_equals_oracle_loader(gr, tmp_path, kind, monkeypatch):
+    """Files big enough for the multi-threaded line parser (>= 4096 entries), with the
+    formatting real files have: CRLF, tabs, trailing blanks, blank lines, exponents,
+    negative values, duplicates, self loops.  Checked against the oracle restatement of
+    the reference loader (and the reference loader itself when oracle/_ref is built)."""
+    rng = np.random.default_rng(7)
+    n, nnz = 3000, 50000
+    rows = rng.integers(0, n, nnz)
+    cols = rng.integers(0, n, nnz)
+    rows[-1] = n - 1  # make the declared size exact
+    if kind == "real symmetric":
+        lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
+        rows, cols = hi, lo
+        rows[-1] = n - 1
+    vals = None
+    if kind.startswith("real"):
+        pool = ["1", "0.5", "-3.25", "1e-3", "2.5E+2", "123456789.125", "7.", ".5", "1e22", "3.0000000000000001e-5",
+                "0.1234567890123456789", "-0"]
+        vals = [pool[i] for i in rng.integers(0, len(pool), nnz)]
+    elif kind.startswith("integer"):
+        vals = [str(int(v)) for v in rng.integers(-50, 1000, nnz)]
+    path = str(tmp_path / "big.mtx")
+    for sep, blank in (("\n", False), ("\r\n", True)):
+        _write_mtx(path, "%%MatrixMarket matrix coordinate " + kind, rows, cols, vals, sep=sep, extra_blank=blank)
+        want = O.load_mtx(path)
+        for threads in ("1", "5"):
+            monkeypatch.setenv("GRX_HOST_THREADS", threads)
+            props, coo = gr.matrix_market_t().load(path)
+            csr = gr.csr_t().from_coo(coo)
+            assert np.array_equal(csr.row_offsets, want.row_offsets)
+            assert np.array_equal(csr.column_indices, want.column_indices)
+            assert np.array_equal(csr.nonzero_values, want.values)  # bit-exact floats (strtod semantics)
+        if O.have_ref_cpu():
+            ref = O.ref_load_mtx(path)
+            assert np.array_equal(ref.row_offsets, want.row_offsets) and np.array_equal(ref.values, want.values)
+
+
+def test_parallel_ingest_falls_back_on_wrapped_entries(gr, tmp_path):
+    """Entries wrapped over lines are legal for the reference's fscanf loop: the line
+    parser must notice and hand over to the token parser."""
+    rng = np.random.default_rng(3)
+    n, nnz = 500, 6000
+    rows, cols = rng.integers(0, n, nnz), rng.integers(0, n, nnz)
+    rows[0] = n - 1
+    path = str(tmp_path / "wrapped.mtx")
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate pattern general\n%d %d %d\n" % (n, n, nnz))
+        for k in range(nnz):
+            f.write("%d\n%d " % (rows[k] + 1, cols[k] + 1) if k % 2 else "%d %d\n" % (rows[k] + 1, cols[k] + 1))
+    want = O.load_mtx(path)
+    _, coo = gr.matrix_market_t().load(path)
+    csr = gr.csr_t().from_coo(coo)
+    assert np.array_equal(csr.row_offsets, want.row_offsets) and np.array_equal(csr.column_indices, want.column_indices)
+    # an entry outside the declared matrix is an error, not an out-of-bounds write
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate pattern general\n3 3 2\n1 2\n4 1\n")
+    with pytest.raises(RuntimeError):
+        gr.matrix_market_t().load(path)
