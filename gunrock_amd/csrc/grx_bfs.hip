@@ -118,9 +118,12 @@ __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_
       if (d.enabled) {
         const long long m_u = (long long)d.n_edges - c->edges_visited;  // edges of still-unexpanded vertices
         if (mode == 0) {
-          if (m_f > m_u / DO_ALPHA && n_f > 256) mode = 1;
+          if (m_f > m_u / d.alpha && n_f > 256) mode = 1;
         } else {
-          if (n_f < (long long)a.V / DO_BETA) mode = 0;
+          // back to top-down: few frontier vertices (Beamer), or so few frontier out-edges that
+          // expanding them beats another sweep over every open vertex's in-edges
+          if (n_f < (long long)a.V / d.beta) mode = 0;
+          if (d.back_div > 0 && m_f < (long long)d.n_edges / d.back_div) mode = 0;
         }
       }
       c->convert = (mode == 0 && is_bitmap) ? 1 : ((mode == 1 && !is_bitmap) ? 2 : 0);
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_convert_kernel(pipe_args a, dob
 
 // One level, ONE launch: top-down (advance + fused compaction) or bottom-up, as the
 // head kernel decided.
+template <int BATCH>
 __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs_args d, bfs_policy pol) {
   __shared__ advance_smem<bfs_policy> sm;
   __shared__ bottomup_smem bsm;
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
     advance_block<bfs_policy, false>(a, c, pol, sm, c->level & 1, blockIdx.x, gridDim.x, c->total_chunks,
                                      a.chunk_tile, a.chunk_prefix);
   } else {
-    bfs_bottomup_block(a, d, c, bsm);
+    bfs_bottomup_block<BATCH>(a, d, c, bsm);
   }
 }
 
@@ -231,15 +235,33 @@ using namespace grx;
 // Workgroups of the per-level kernel: exactly what is RESIDENT (persistent workgroups
 // stride over the work with gridDim, so a partial second round would double the time),
 // one per CU on road-like graphs (advance_grid_for).
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+// bottom-up chunks in flight per wave (tuning knob GRX_BU_BATCH = 2 | 4 | 8)
+static int bu_batch() {
+  const int b = env_int("GRX_BU_BATCH", 4);
+  return (b == 2 || b == 8) ? b : 4;
+}
+
 static int level_grid(grx_context_t ctx, grx_graph_t g) {
-  static int per_cu = 0;
-  if (per_cu == 0) {
+  static int per_cu[3] = {0, 0, 0};
+  const int batch = bu_batch();
+  const int slot = batch == 2 ? 0 : (batch == 4 ? 1 : 2);
+  if (per_cu[slot] == 0) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_level_kernel, ADV_BLOCK, 0) != hipSuccess || n < 1) n = 4;
-    per_cu = n > 8 ? 8 : n;
+    hipError_t e = batch == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_level_kernel<2>, ADV_BLOCK, 0)
+                   : batch == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_level_kernel<4>, ADV_BLOCK, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_level_kernel<8>, ADV_BLOCK, 0);
+    if (e != hipSuccess || n < 1) n = 4;
+    per_cu[slot] = n > 8 ? 8 : n;
   }
+  const int cap = env_int("GRX_LEVEL_WG_PER_CU", 0);  // tuning knob: fewer resident workgroups
+  const int use = (cap > 0 && cap < per_cu[slot]) ? cap : per_cu[slot];
   const int full = advance_grid_for(ctx, g);
-  const int resident = ctx->num_cus * per_cu;
+  const int resident = ctx->num_cus * use;
   return full < resident ? full : resident;
 }
 
@@ -258,7 +280,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   pipe_args a;
   grx_status_t st = pipeline_prepare(ctx, g, &a);
   if (st != GRX_SUCCESS) return st;
-  const int variant = (opt.engine_flags >> 8) & 3;
+  const int variant = (opt.engine_flags >> 8) & 7;
   // bottom-up pays off on low-diameter graphs; with fewer than 4 edges per vertex the
   // frontier never gets heavy enough to switch and the extra per-level kernels only cost
   const bool dopt = opt.advance_direction == GRX_DIR_OPTIMIZED && variant == 0 && (long long)g->E >= 4ll * g->V;
@@ -270,7 +292,15 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   d.n_words = (int32_t)bm_words;
   d.n_edges = g->E;
   d.enabled = dopt ? 1 : 0;
+  d.alpha = env_int("GRX_DO_ALPHA", DO_ALPHA);
+  d.beta = env_int("GRX_DO_BETA", DO_BETA);
+  d.back_div = env_int("GRX_DO_BACK_DIV", 0);
+  if (d.alpha < 1) d.alpha = 1;
+  if (d.beta < 1) d.beta = 1;
+  const int batch = bu_batch();
   unsigned* visited = nullptr;
+  size_t visited_bytes = 0;
+  int xcd_words = 0;
   if (dopt) {
     // in-edges: the CSR itself when the graph is symmetric, else the cached transpose
     if (g->symmetric) {
@@ -290,14 +320,21 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     d.bu_grid = level_grid(ctx, g);
     GRX_HIP(ctx->bu_part.reserve((size_t)d.bu_grid * 4 * sizeof(long long)));
     d.bu_part = ctx->bu_part.as<long long>();
-  } else if (variant != 0) {
-    GRX_HIP(ctx->bitmap[0].reserve(bm_words * sizeof(unsigned)));
+  } else if (variant >= 4 && variant <= 6) {
+    // eight per-XCD filter bitmaps, each padded to whole 4 KB pages
+    xcd_words = (int)((((size_t)g->V + 31) / 32 + 1023) / 1024 * 1024);
+    visited_bytes = (size_t)8 * xcd_words * sizeof(unsigned);
+    GRX_HIP(ctx->bitmap[0].reserve(visited_bytes));
+    visited = ctx->bitmap[0].as<unsigned>();
+  } else if (variant != 0 && variant != 7) {
+    visited_bytes = bm_words * sizeof(unsigned);
+    GRX_HIP(ctx->bitmap[0].reserve(visited_bytes));
     visited = ctx->bitmap[0].as<unsigned>();
   }
 
   // problem.reset() -- outside the timed region, as in the reference
   GRX_HIP(fill_i32(s, d_dist, INT_MAX, g->V));
-  if (visited) GRX_HIP(hipMemsetAsync(visited, 0, bm_words * sizeof(unsigned), s));
+  if (visited) GRX_HIP(hipMemsetAsync(visited, 0, visited_bytes, s));
 
   const bool dense = g->V > 0 && (long long)g->E >= 8ll * g->V;  // few fat levels: paced enqueueing
   ctx->h_mailbox[0] = 0;
@@ -319,21 +356,29 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (variant == 0) {
       // head (tiny levels + decide + plan) -> [format conversion at a direction switch] -> level
       hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d,
-                         bfs_policy{d_dist, nullptr, 0, nullptr}, profile ? 0 : 1, seq);
+                         bfs_policy{d_dist, nullptr, 0, nullptr, 0, nullptr}, profile ? 0 : 1, seq);
       if (dopt) hipLaunchKernelGGL(bfs_convert_kernel, dim3(ctx->num_cus * 2), dim3(ADV_BLOCK), 0, stream, a, d);
       if (profile) (void)hipEventRecord(pe[1], stream);
-      hipLaunchKernelGGL(bfs_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d,
-                         bfs_policy{d_dist, nullptr, 0, nullptr});
+      const bfs_policy lp{d_dist, nullptr, 0, nullptr, 0, nullptr};
+      switch (batch) {
+        case 2: hipLaunchKernelGGL(bfs_level_kernel<2>, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp); break;
+        case 8: hipLaunchKernelGGL(bfs_level_kernel<8>, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp); break;
+        default: hipLaunchKernelGGL(bfs_level_kernel<4>, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
+      }
     } else {
       hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
       if (profile) (void)hipEventRecord(pe[1], stream);
+      auto adv = [&](auto pol) {
+        hipLaunchKernelGGL((advance_kernel<decltype(pol)>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
+      };
       switch (variant) {
-        case 1: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<1>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
-                                   bfs_policy_t<1>{d_dist, visited, 0, nullptr}); break;
-        case 2: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<2>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
-                                   bfs_policy_t<2>{d_dist, visited, 0, nullptr}); break;
-        default: hipLaunchKernelGGL((advance_kernel<bfs_policy_t<3>>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a,
-                                    bfs_policy_t<3>{d_dist, visited, 0, nullptr});
+        case 1: adv(bfs_policy_t<1>{d_dist, visited, 0, nullptr, 0, nullptr}); break;
+        case 2: adv(bfs_policy_t<2>{d_dist, visited, 0, nullptr, 0, nullptr}); break;
+        case 3: adv(bfs_policy_t<3>{d_dist, visited, 0, nullptr, 0, nullptr}); break;
+        case 4: adv(bfs_policy_t<4>{d_dist, visited, 0, nullptr, xcd_words, nullptr}); break;
+        case 5: adv(bfs_policy_t<5>{d_dist, visited, 0, nullptr, xcd_words, nullptr}); break;
+        case 6: adv(bfs_policy_t<6>{d_dist, visited, 0, nullptr, xcd_words, nullptr}); break;
+        default: adv(bfs_policy_t<7>{d_dist, nullptr, 0, nullptr, 0, nullptr});
       }
     }
     ++launches;

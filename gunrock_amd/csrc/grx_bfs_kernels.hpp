@@ -13,34 +13,84 @@ constexpr int DO_ALPHA = 14;
 constexpr int DO_BETA = 24;
 
 // VARIANT 0: the reference's claim, atomicMin on the label array with a stale
-// pre-check (fastest measured).  Tuning variants for A/B runs (engine_flags bits
-// 8-9): 1 = claim on a visited bitmap (atomicOr), 2 = same with an agent-scope
-// pre-check, 3 = variant 1 counting attempted atomics in ctrl->spare[0].
+// pre-check.  Tuning variants for A/B runs (engine_flags bits 8-10): 1 = claim on a
+// visited bitmap (atomicOr), 2 = same with an agent-scope pre-check, 3 = variant 1
+// counting attempted atomics in ctrl->spare[0].
+//
+// VARIANTS 4-6: PER-XCD FILTER BITMAPS.  What bounds variant 0 on a fat level is one
+// random label probe per edge: the labels (4 V bytes) do not fit an XCD's 4 MB L2, so the
+// probes run at HBM/MALL latency behind each CU's miss queue.  Here every XCD keeps a
+// PRIVATE V-bit bitmap "this XCD already tried vertex n" (V/8 bytes: L2 resident, and only
+// ever touched from that XCD, so the non-coherence of the eight L2s does not matter).  An
+// edge first tests the bit (L2 hit); a clear bit is set with a WORKGROUP-scope atomicOr,
+// which executes in the XCD's own L2 and keeps the line there (an agent-scope atomic goes to
+// memory and drops it); only the first edge per (XCD, vertex) goes on to the label -- at most
+// 8 label probes per vertex and search instead of one per in-edge.  The label atomicMin is
+// still the only arbiter, so exactly one thread wins a vertex, as in the reference.  Safety:
+// a set bit means "a thread of this XCD has issued, or is about to issue, atomicMin(label[n], d)
+// with d <= the current depth", so dropping the edge cannot change the final label; a LOST or
+// stale-clear bit only costs an extra probe.  The XCD id comes from HW_REG_XCC_ID; any other
+// placement would change speed only.  4 = plain bitmap loads (may hit the CU's L1),
+// 5 = L1-bypassing (sc1) loads, 6 = variant 4 without the plain label probe before atomicMin,
+// 7 = variant 0 on the stand-alone plan + advance kernels (control for variants 4-6).
 template <int VARIANT>
 struct bfs_policy_t {
   using src_state = int;
+  static constexpr bool xcd_filter = VARIANT >= 4 && VARIANT <= 6;
+  static constexpr int extra_stages = VARIANT == 6 ? 1 : (xcd_filter ? 2 : 0);
   int32_t* dist;
   unsigned* visited;
   int next_depth;
   ctrl_t* ctrl;
+  int xcd_words;   // variants 4-6: 32-bit words per per-XCD bitmap (the 8 bitmaps are consecutive)
+  unsigned* mine;  // variants 4-6: this XCD's bitmap (set by begin)
 
-  __device__ __forceinline__ void begin(ctrl_t* c) { next_depth = c->level + 1; ctrl = c; }
+  __device__ __forceinline__ void begin(ctrl_t* c) {
+    next_depth = c->level + 1;
+    ctrl = c;
+    if constexpr (xcd_filter) {
+      // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
+      const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(0x1814) & 7u;
+      mine = visited + (size_t)xcc * (size_t)xcd_words;
+    }
+  }
   __device__ __forceinline__ void set_level(int level) { next_depth = level + 1; }
   __device__ __forceinline__ src_state load_source(int) const { return 0; }
-  __device__ __forceinline__ bool precheck(src_state, int n, int) const {
-    if constexpr (VARIANT == 0) return dist[n] > next_depth;
+  __device__ __forceinline__ bool precheck(src_state, int n, int, int&) const {
+    if constexpr (VARIANT == 0 || VARIANT == 7) return dist[n] > next_depth;
     if constexpr (VARIANT == 2)
       return (__hip_atomic_load(&visited[n >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << (n & 31))) == 0u;
+    if constexpr (VARIANT == 5)
+      return (__hip_atomic_load(&mine[n >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << (n & 31))) == 0u;
+    if constexpr (VARIANT == 4 || VARIANT == 6) return (mine[n >> 5] & (1u << (n & 31))) == 0u;
     return (visited[n >> 5] & (1u << (n & 31))) == 0u;
   }
-  __device__ __forceinline__ bool visit(int, src_state, int n, int) const {
-    if constexpr (VARIANT == 0) return next_depth < atomicMin(&dist[n], next_depth);
+  // variants 4-6: first edge of this XCD to reach n?  (atomic executed in the XCD's own L2)
+  __device__ __forceinline__ unsigned stage1_issue(int n) const {
+    return __hip_atomic_fetch_or(&mine[n >> 5], 1u << (n & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ bool stage1_pass(unsigned raw, int n) const { return (raw & (1u << (n & 31))) == 0u; }
+  // variants 4-5: plain label probe, so that only potential winners pay for the memory-side atomic
+  __device__ __forceinline__ int stage2_issue(int n) const { return dist[n]; }
+  __device__ __forceinline__ bool stage2_pass(int raw) const { return raw > next_depth; }
+  __device__ __forceinline__ int claim(int n, int) const {
+    if constexpr (VARIANT == 0 || VARIANT >= 4) return atomicMin(&dist[n], next_depth);
     if constexpr (VARIANT == 3) atomicAdd(&ctrl->spare[0], 1);
-    const unsigned bit = 1u << (n & 31);
-    const unsigned old = atomicOr(&visited[n >> 5], bit);
-    if (old & bit) return false;
+    return (int)atomicOr(&visited[n >> 5], 1u << (n & 31));
+  }
+  __device__ __forceinline__ int code(int raw, int, int n, int) const {
+    if constexpr (VARIANT == 0 || VARIANT >= 4) return next_depth < raw ? 1 : 0;
+    if ((unsigned)raw & (1u << (n & 31))) return 0;
     dist[n] = next_depth;
-    return true;
+    return 1;
+  }
+  // the whole chain for one precheck survivor
+  __device__ __forceinline__ int visit(src_state, int n, int) const {
+    if constexpr (extra_stages >= 1)
+      if (!stage1_pass(stage1_issue(n), n)) return 0;
+    if constexpr (extra_stages >= 2)
+      if (!stage2_pass(stage2_issue(n))) return 0;
+    return code(claim(n, 0), 0, n, 0);
   }
 };
 using bfs_policy = bfs_policy_t<0>;
@@ -54,6 +104,8 @@ struct dobfs_args {
   int32_t n_words;       // 32-bit words per bitmap (even)
   int32_t n_edges;
   int32_t enabled;       // direction optimisation on
+  int32_t alpha, beta;   // Beamer switch: bottom-up when m_f > m_u / alpha, back when n_f < V / beta ...
+  int32_t back_div;      // ... or when the frontier's out-edges m_f drop below E / back_div (0: rule off)
   long long* bu_part;    // per workgroup {found, out-degree sum, open, probes} of the last bottom-up launch
   int32_t bu_grid;       // workgroups of the bottom-up launch
   // partitioned runs (grx_dist.hip): this rank owns the 64-vertex chunks [ch_lo, ch_lo + n_words / 2);
@@ -73,6 +125,7 @@ struct bottomup_smem {
   long long probe[ADV_BLOCK / 64];
 };
 
+template <int BATCH = 4>
 __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dobfs_args& d, ctrl_t* c,
                                                    bottomup_smem& sm) {
   int* s_cnt = sm.cnt;
@@ -95,7 +148,6 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
   long long my_probes = 0;  // in-edges actually read (roofline accounting)
   int my_open = 0;
   constexpr int SERIAL = 8;
-  constexpr int BATCH = 4;
   for (int ch0 = wave * BATCH; ch0 < n_chunks; ch0 += n_waves * BATCH) {
     unsigned long long vis[BATCH];
     int b[BATCH], e[BATCH], odeg[BATCH];
@@ -144,16 +196,22 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
 #pragma unroll
           for (int q = 0; q < N; ++q) {
             act[j][q] = live && b[j] + R0 + q < e[j];
-            u[j][q] = act[j][q] ? d.t_ci[b[j] + R0 + q] : 0;
             any |= act[j][q];
           }
         }
         if (dev::ballot(any) == 0ull) return false;
+        // UNCONDITIONAL loads from a clamped index (some lane has an in-edge, so entry 0 exists):
+        // a predicated load sits in its own basic block and the compiler then waits for each
+        // one before issuing the next -- 2 * BATCH * N serialized round trips instead of 2
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+#pragma unroll
+          for (int q = 0; q < N; ++q) u[j][q] = d.t_ci[act[j][q] ? b[j] + R0 + q : 0];
         unsigned w[BATCH][N];
 #pragma unroll
         for (int j = 0; j < BATCH; ++j)
 #pragma unroll
-          for (int q = 0; q < N; ++q) w[j][q] = act[j][q] ? fin[u[j][q] >> 5] : 0u;
+          for (int q = 0; q < N; ++q) w[j][q] = fin[(act[j][q] ? u[j][q] : 0) >> 5];
 #pragma unroll
         for (int j = 0; j < BATCH; ++j)
 #pragma unroll

@@ -58,16 +58,32 @@ struct bfs_policy_dist {
   int next_depth;
   __device__ __forceinline__ void begin(ctrl_t* c) { next_depth = c->level + 1; }
   __device__ __forceinline__ src_state load_source(int) const { return 0; }
-  __device__ __forceinline__ bool precheck(src_state, int n, int) const {
-    if (n >= lo && n < hi) return dist[n] > next_depth;
-    return (sent[n >> 5] & (1u << (n & 31))) == 0u;
+  static constexpr bool two_claims = true;
+  __device__ __forceinline__ bool owned(int n) const { return n >= lo && n < hi; }
+  // ONE load from a selected address (label of an owned target, `sent` word of a remote one)
+  // cand: 0 for an owned target, its bit in the 32-vertex word for a remote one
+  __device__ __forceinline__ bool precheck(src_state, int n, int, int& cand) const {
+    const bool own = owned(n);
+    cand = own ? 0 : (int)(1u << (n & 31));
+    const unsigned* p = own ? reinterpret_cast<const unsigned*>(dist + n) : sent + (n >> 5);
+    const unsigned v = *p;
+    return own ? (int)v > next_depth : (v & (1u << (n & 31))) == 0u;
   }
-  __device__ __forceinline__ bool visit(int, src_state, int n, int) const {
-    if (n >= lo && n < hi) return next_depth < atomicMin(&dist[n], next_depth);
-    const unsigned bit = 1u << (n & 31);
-    const unsigned old = atomicOr(&sent[n >> 5], bit);
-    if (!(old & bit)) atomicOr(&send[n >> 5], bit);
-    return false;
+  __device__ __forceinline__ int claim(int n, int) const {
+    if (owned(n)) return atomicMin(&dist[n], next_depth);
+    return (int)atomicOr(&sent[n >> 5], 1u << (n & 31));
+  }
+  // a remote target this rank reports for the first time goes into the outgoing bitmap
+  __device__ __forceinline__ bool need2(int raw1, int cand) const { return cand != 0 && ((unsigned)raw1 & (unsigned)cand) == 0u; }
+  __device__ __forceinline__ int claim2(int n) const { return (int)atomicOr(&send[n >> 5], 1u << (n & 31)); }
+  __device__ __forceinline__ int code(int raw1, int, int n, int) const {
+    return (owned(n) && next_depth < raw1) ? 1 : 0;
+  }
+  __device__ __forceinline__ int visit(src_state, int n, int) const {
+    const int r1 = claim(n, 0);
+    if (owned(n)) return next_depth < r1 ? 1 : 0;
+    if (((unsigned)r1 & (1u << (n & 31))) == 0u) (void)claim2(n);
+    return 0;
   }
 };
 

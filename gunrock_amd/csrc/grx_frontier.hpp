@@ -187,16 +187,44 @@ __device__ __forceinline__ void release_tiles(const pipe_args& a, const int* s_r
 // advance + fused compaction.  Policy interface (all __device__):
 //   void begin(ctrl_t*)                               once per workgroup
 //   src_state load_source(int v)                      per staged slot (e.g. dist[v])
-//   bool precheck(src_state, int nbr, int e)          cheap, read-only filter
-//   int  visit(int src, src_state, int nbr, int e)    1/true => nbr joins the output,
+//   bool precheck(src_state, int nbr, int e, int& cand)
+//        cheap READ-ONLY filter; called for every lane with a valid (nbr, e) -- lanes past
+//        the end of the chunk pass edge 0 -- so its loads are unconditional; `cand` carries a
+//        per-edge value (e.g. the tentative distance bits) to the later phases
+//   [extra_stages >= 1] unsigned stage1_issue(int nbr), bool stage1_pass(unsigned raw, int nbr)
+//   [extra_stages >= 2] int stage2_issue(int nbr), bool stage2_pass(int raw)
+//        further filters between precheck and claim, run only for surviving edges
+//   int  claim(int nbr, int cand)                     the claiming atomic; returns its raw result
+//   [two_claims] bool need2(int raw1, int cand), int claim2(int nbr)   a second, dependent atomic
+//   int  code(int raw1, int raw2, int nbr, int cand)  1 => nbr joins the output,
 //                                                     2 => nbr goes to the policy's SIDE pile
 //                                                     (policies with `has_side`), 0 => dropped
+//   int  visit(src_state, int nbr, int e)             precheck-survivor -> code, the whole chain for
+//                                                     one edge (tiny_levels_kernel)
 //   side pile (has_side): side_reserve(ctrl, n) -> base index or -1, side_store(i, v)
+//
+// WHY PHASES.  A memory operation under a per-lane condition lives in its own basic block, and
+// when its result is consumed in that block the compiler emits s_waitcnt vmcnt(0) right behind
+// it: the ADV_ITEMS probes of a lane, and then its ADV_ITEMS atomics, became 16 SERIAL round
+// trips per chunk (seen in the ISA of the first version of this kernel).  Here every phase
+// issues the operations of all ADV_ITEMS edges -- pure loads unconditionally from clamped
+// indices, atomics conditionally but with their raw result consumed only by the NEXT phase --
+// so a chunk costs one round trip per phase.
 // ---------------------------------------------------------------------------
 template <class Policy, class = void>
 struct policy_has_side : std::false_type {};
 template <class Policy>
 struct policy_has_side<Policy, std::void_t<decltype(Policy::has_side)>> : std::bool_constant<Policy::has_side> {};
+
+template <class Policy, class = void>
+struct policy_extra_stages : std::integral_constant<int, 0> {};
+template <class Policy>
+struct policy_extra_stages<Policy, std::void_t<decltype(Policy::extra_stages)>>
+    : std::integral_constant<int, Policy::extra_stages> {};
+template <class Policy, class = void>
+struct policy_two_claims : std::false_type {};
+template <class Policy>
+struct policy_two_claims<Policy, std::void_t<decltype(Policy::two_claims)>> : std::bool_constant<Policy::two_claims> {};
 
 // LDS of one advance workgroup.
 template <class Policy>
@@ -265,7 +293,7 @@ __device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Pol
     // ---- atoms of this chunk ---------------------------------------------
     const int a0 = lc * CHUNK;
     const int a_end = min(tot, a0 + CHUNK);
-    int e_k[ADV_ITEMS], slot_k[ADV_ITEMS], n_k[ADV_ITEMS];
+    int e_k[ADV_ITEMS], slot_k[ADV_ITEMS], n_k[ADV_ITEMS], cand_k[ADV_ITEMS];
 #pragma unroll
     for (int k = 0; k < ADV_ITEMS; ++k) {
       const int atom = a0 + k * ADV_BLOCK + tid;
@@ -280,16 +308,59 @@ __device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Pol
       }
       slot_k[k] = lo;
     }
+    // phase 0: column indices.  Lanes past the end of the chunk read edge 0 (the chunk has at
+    // least one atom, so the graph has an edge), which keeps every later pure load valid.
 #pragma unroll
-    for (int k = 0; k < ADV_ITEMS; ++k) n_k[k] = (e_k[k] >= 0) ? a.ci[e_k[k]] : -1;
+    for (int k = 0; k < ADV_ITEMS; ++k) n_k[k] = a.ci[e_k[k] >= 0 ? e_k[k] : 0];
+    // phase 1: read-only filter
     bool pre_k[ADV_ITEMS];
 #pragma unroll
-    for (int k = 0; k < ADV_ITEMS; ++k)
-      pre_k[k] = (e_k[k] >= 0) && pol.precheck(sm.state[slot_k[k]], n_k[k], e_k[k]);
+    for (int k = 0; k < ADV_ITEMS; ++k) {
+      const bool ok = e_k[k] >= 0;
+      cand_k[k] = 0;
+      const bool pass = pol.precheck(sm.state[slot_k[k]], n_k[k], ok ? e_k[k] : 0, cand_k[k]);
+      pre_k[k] = pass & ok;
+    }
+    constexpr int EXTRA = policy_extra_stages<Policy>::value;
+    if constexpr (EXTRA >= 1) {
+      unsigned s1[ADV_ITEMS];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) {
+        s1[k] = 0u;
+        if (pre_k[k]) s1[k] = pol.stage1_issue(n_k[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) pre_k[k] = pre_k[k] & pol.stage1_pass(s1[k], n_k[k]);
+    }
+    if constexpr (EXTRA >= 2) {
+      int s2[ADV_ITEMS];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) {
+        s2[k] = 0;
+        if (pre_k[k]) s2[k] = pol.stage2_issue(n_k[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) pre_k[k] = pre_k[k] & pol.stage2_pass(s2[k]);
+    }
+    // phase 2: the claiming atomics, all issued before any result is looked at
+    int r1_k[ADV_ITEMS], r2_k[ADV_ITEMS];
+#pragma unroll
+    for (int k = 0; k < ADV_ITEMS; ++k) {
+      r1_k[k] = 0;
+      r2_k[k] = 0;
+      if (pre_k[k]) r1_k[k] = pol.claim(n_k[k], cand_k[k]);
+    }
+    if constexpr (policy_two_claims<Policy>::value) {
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) {
+        const bool need = pre_k[k] & pol.need2(r1_k[k], cand_k[k]);
+        if (need) r2_k[k] = pol.claim2(n_k[k]);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < ADV_ITEMS; ++k) {
       int code = 0;
-      if (pre_k[k]) code = (int)pol.visit(sm.src[slot_k[k]], sm.state[slot_k[k]], n_k[k], e_k[k]);
+      if (pre_k[k]) code = pol.code(r1_k[k], r2_k[k], n_k[k], cand_k[k]);
       const bool keep = code == 1;
       const unsigned long long m = dev::ballot(keep);
       if (m) {
@@ -506,7 +577,8 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
       const int e = sm.start[lo] + (atom - sm.seg[lo]);
       const int nb = a.ci[e];
       const auto st = sm.state[lo];
-      if (pol.precheck(st, nb, e) && (int)pol.visit(cur[lo], st, nb, e) == 1) nxt[atomicAdd(&sm.n, 1)] = nb;
+      int cand = 0;
+      if (pol.precheck(st, nb, e, cand) && pol.visit(st, nb, e) == 1) nxt[atomicAdd(&sm.n, 1)] = nb;
     }
     edges_done += m;
     vertices_done += n;

@@ -45,16 +45,28 @@ struct sssp_policy {
     return __hip_atomic_load(&dist[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ float edge_weight(int e) const { return w ? w[e] : 1.0f; }
-  __device__ __forceinline__ bool precheck(src_state d_src, int n, int e) const {
+  static constexpr bool two_claims = true;
+  __device__ __forceinline__ bool precheck(src_state d_src, int n, int e, int& cand) const {
     // dist[] only decreases, so a possibly stale read can only be too large:
     // "cannot improve the stale value" implies "cannot improve the current one".
-    return d_src + edge_weight(e) < dist[n];
-  }
-  __device__ __forceinline__ bool visit(int, src_state d_src, int n, int e) const {
     const float nd = d_src + edge_weight(e);
-    const float old = dev::atomic_min_f32(&dist[n], nd);
-    if (!(nd < old)) return false;
-    return atomicExch(&stamp[n], level) != level;
+    cand = __float_as_int(nd);
+    return nd < dist[n];
+  }
+  __device__ __forceinline__ int claim(int n, int cand) const {
+    return __float_as_int(dev::atomic_min_f32(&dist[n], __int_as_float(cand)));
+  }
+  __device__ __forceinline__ bool need2(int raw1, int cand) const { return __int_as_float(cand) < __int_as_float(raw1); }
+  // once per level: the iteration stamp de-duplicates the output exactly
+  __device__ __forceinline__ int claim2(int n) const { return atomicExch(&stamp[n], level); }
+  __device__ __forceinline__ int code(int raw1, int raw2, int, int cand) const {
+    return (need2(raw1, cand) && raw2 != level) ? 1 : 0;
+  }
+  __device__ __forceinline__ int visit(src_state d_src, int n, int e) const {
+    const int cand = __float_as_int(d_src + edge_weight(e));
+    const int r1 = claim(n, cand);
+    if (!need2(r1, cand)) return 0;
+    return code(r1, claim2(n), n, cand);
   }
 };
 
@@ -83,20 +95,36 @@ struct sssp_nf_policy {
   }
   __device__ __forceinline__ src_state load_source(int v) const { return dist[v]; }
   __device__ __forceinline__ float edge_weight(int e) const { return w[e]; }
-  __device__ __forceinline__ bool precheck(src_state d_src, int n, int e) const {
-    return d_src + edge_weight(e) < dist[n];
-  }
-  __device__ __forceinline__ int visit(int, src_state d_src, int n, int e) const {
+  static constexpr bool two_claims = true;
+  __device__ __forceinline__ bool precheck(src_state d_src, int n, int e, int& cand) const {
     const float nd = d_src + edge_weight(e);
-    const float old = dev::atomic_min_f32(&dist[n], nd);
+    cand = __float_as_int(nd);
+    return nd < dist[n];
+  }
+  __device__ __forceinline__ int claim(int n, int cand) const {
+    return __float_as_int(dev::atomic_min_f32(&dist[n], __int_as_float(cand)));
+  }
+  // improved AND inside the bucket: joins the next frontier, once per level (stamp)
+  __device__ __forceinline__ bool need2(int raw1, int cand) const {
+    const float nd = __int_as_float(cand);
+    return nd < __int_as_float(raw1) && nd < hi;
+  }
+  __device__ __forceinline__ int claim2(int n) const { return atomicExch(&stamp[n], level); }
+  __device__ __forceinline__ int code(int raw1, int raw2, int, int cand) const {
+    const float nd = __int_as_float(cand), old = __int_as_float(raw1);
     if (!(nd < old)) return 0;
-    if (nd < hi) return atomicExch(&stamp[n], level) != level ? 1 : 0;  // next frontier, once per level
+    if (nd < hi) return raw2 != level ? 1 : 0;
     // beyond the bucket.  A finite previous label >= hi means the vertex already waits in
     // the far pile (it was appended when that label was set, and entries only leave the
     // pile once their label drops below a bucket bound): nothing to add.  Exactly one of
     // several concurrent first relaxations sees FLT_MAX and appends.
     if (old != FLT_MAX && old >= hi) return 0;
     return 2;
+  }
+  __device__ __forceinline__ int visit(src_state d_src, int n, int e) const {
+    const int cand = __float_as_int(d_src + edge_weight(e));
+    const int r1 = claim(n, cand);
+    return code(r1, need2(r1, cand) ? claim2(n) : 0, n, cand);
   }
   // one reservation atomic per flush of the workgroup's side buffer
   __device__ __forceinline__ int side_reserve(ctrl_t* c, int n) const {
