@@ -213,8 +213,8 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_convert_kernel(pipe_args a, dob
 
 // One level, ONE launch: top-down (advance + fused compaction) or bottom-up, as the
 // head kernel decided.
-template <int BATCH>
-__global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs_args d, bfs_policy pol) {
+template <int BATCH, int MINW>
+__global__ __launch_bounds__(ADV_BLOCK, MINW) void bfs_level_kernel(pipe_args a, dobfs_args d, bfs_policy pol) {
   __shared__ advance_smem<bfs_policy> sm;
   __shared__ bottomup_smem bsm;
   ctrl_t* c = a.ctrl;
@@ -240,26 +240,33 @@ static int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-// bottom-up chunks in flight per wave (tuning knob GRX_BU_BATCH = 2 | 4 | 8)
-static int bu_batch() {
-  const int b = env_int("GRX_BU_BATCH", 4);
-  return (b == 2 || b == 8) ? b : 4;
+// The per-level kernel comes in a few builds: bottom-up chunks in flight per wave
+// (GRX_BU_BATCH = 2 | 4) x minimum waves per SIMD the register allocator must leave room for
+// (GRX_LEVEL_MINW = 1 | 6 | 8).
+using level_kernel_fn = void (*)(pipe_args, dobfs_args, bfs_policy);
+struct level_build {
+  level_kernel_fn fn;
+  int per_cu;  // resident workgroups per CU (0: not queried yet)
+};
+static level_build* level_kernel_build() {
+  static level_build builds[2][3] = {
+      {{bfs_level_kernel<2, 1>, 0}, {bfs_level_kernel<2, 6>, 0}, {bfs_level_kernel<2, 8>, 0}},
+      {{bfs_level_kernel<4, 1>, 0}, {bfs_level_kernel<4, 6>, 0}, {bfs_level_kernel<4, 8>, 0}}};
+  const int batch = env_int("GRX_BU_BATCH", 4), minw = env_int("GRX_LEVEL_MINW", 1);
+  return &builds[batch == 2 ? 0 : 1][minw == 6 ? 1 : (minw == 8 ? 2 : 0)];
 }
 
-static int level_grid(grx_context_t ctx, grx_graph_t g) {
-  static int per_cu[3] = {0, 0, 0};
-  const int batch = bu_batch();
-  const int slot = batch == 2 ? 0 : (batch == 4 ? 1 : 2);
-  if (per_cu[slot] == 0) {
+// Workgroups of the per-level kernel: exactly what is RESIDENT (persistent workgroups
+// stride over the work with gridDim, so a partial second round would double the time),
+// one per CU on road-like graphs (advance_grid_for).
+static int level_grid(grx_context_t ctx, grx_graph_t g, level_build* lb) {
+  if (lb->per_cu == 0) {
     int n = 0;
-    hipError_t e = batch == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_level_kernel<2>, ADV_BLOCK, 0)
-                   : batch == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_level_kernel<4>, ADV_BLOCK, 0)
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_level_kernel<8>, ADV_BLOCK, 0);
-    if (e != hipSuccess || n < 1) n = 4;
-    per_cu[slot] = n > 8 ? 8 : n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lb->fn, ADV_BLOCK, 0) != hipSuccess || n < 1) n = 4;
+    lb->per_cu = n > 8 ? 8 : n;
   }
   const int cap = env_int("GRX_LEVEL_WG_PER_CU", 0);  // tuning knob: fewer resident workgroups
-  const int use = (cap > 0 && cap < per_cu[slot]) ? cap : per_cu[slot];
+  const int use = (cap > 0 && cap < lb->per_cu) ? cap : lb->per_cu;
   const int full = advance_grid_for(ctx, g);
   const int resident = ctx->num_cus * use;
   return full < resident ? full : resident;
@@ -297,10 +304,9 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   d.back_div = env_int("GRX_DO_BACK_DIV", 0);
   if (d.alpha < 1) d.alpha = 1;
   if (d.beta < 1) d.beta = 1;
-  const int batch = bu_batch();
+  level_build* lbuild = level_kernel_build();
   unsigned* visited = nullptr;
   size_t visited_bytes = 0;
-  int xcd_words = 0;
   if (dopt) {
     // in-edges: the CSR itself when the graph is symmetric, else the cached transpose
     if (g->symmetric) {
@@ -317,15 +323,9 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     d.visited = ctx->bitmap[0].as<unsigned>();
     d.fbits[0] = ctx->bitmap[1].as<unsigned>();
     d.fbits[1] = d.fbits[0] + bm_words;
-    d.bu_grid = level_grid(ctx, g);
+    d.bu_grid = level_grid(ctx, g, lbuild);
     GRX_HIP(ctx->bu_part.reserve((size_t)d.bu_grid * 4 * sizeof(long long)));
     d.bu_part = ctx->bu_part.as<long long>();
-  } else if (variant >= 4 && variant <= 6) {
-    // eight per-XCD filter bitmaps, each padded to whole 4 KB pages
-    xcd_words = (int)((((size_t)g->V + 31) / 32 + 1023) / 1024 * 1024);
-    visited_bytes = (size_t)8 * xcd_words * sizeof(unsigned);
-    GRX_HIP(ctx->bitmap[0].reserve(visited_bytes));
-    visited = ctx->bitmap[0].as<unsigned>();
   } else if (variant != 0 && variant != 7) {
     visited_bytes = bm_words * sizeof(unsigned);
     GRX_HIP(ctx->bitmap[0].reserve(visited_bytes));
@@ -342,7 +342,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   GRX_HIP(hipEventRecord(ctx->ev_begin, s));
   hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, visited, src);
 
-  const int grid = (variant == 0) ? level_grid(ctx, g) : advance_grid_for(ctx, g);
+  const int grid = (variant == 0) ? level_grid(ctx, g, lbuild) : advance_grid_for(ctx, g);
   const bool profile = (opt.engine_flags & GRX_FLAG_PROFILE) != 0;
   ctx->levels.clear();
   hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
@@ -356,15 +356,11 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (variant == 0) {
       // head (tiny levels + decide + plan) -> [format conversion at a direction switch] -> level
       hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d,
-                         bfs_policy{d_dist, nullptr, 0, nullptr, 0, nullptr}, profile ? 0 : 1, seq);
+                         bfs_policy{d_dist, nullptr, 0, nullptr}, profile ? 0 : 1, seq);
       if (dopt) hipLaunchKernelGGL(bfs_convert_kernel, dim3(ctx->num_cus * 2), dim3(ADV_BLOCK), 0, stream, a, d);
       if (profile) (void)hipEventRecord(pe[1], stream);
-      const bfs_policy lp{d_dist, nullptr, 0, nullptr, 0, nullptr};
-      switch (batch) {
-        case 2: hipLaunchKernelGGL(bfs_level_kernel<2>, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp); break;
-        case 8: hipLaunchKernelGGL(bfs_level_kernel<8>, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp); break;
-        default: hipLaunchKernelGGL(bfs_level_kernel<4>, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
-      }
+      const bfs_policy lp{d_dist, nullptr, 0, nullptr};
+      hipLaunchKernelGGL(lbuild->fn, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
     } else {
       hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
       if (profile) (void)hipEventRecord(pe[1], stream);
@@ -372,13 +368,10 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         hipLaunchKernelGGL((advance_kernel<decltype(pol)>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
       };
       switch (variant) {
-        case 1: adv(bfs_policy_t<1>{d_dist, visited, 0, nullptr, 0, nullptr}); break;
-        case 2: adv(bfs_policy_t<2>{d_dist, visited, 0, nullptr, 0, nullptr}); break;
-        case 3: adv(bfs_policy_t<3>{d_dist, visited, 0, nullptr, 0, nullptr}); break;
-        case 4: adv(bfs_policy_t<4>{d_dist, visited, 0, nullptr, xcd_words, nullptr}); break;
-        case 5: adv(bfs_policy_t<5>{d_dist, visited, 0, nullptr, xcd_words, nullptr}); break;
-        case 6: adv(bfs_policy_t<6>{d_dist, visited, 0, nullptr, xcd_words, nullptr}); break;
-        default: adv(bfs_policy_t<7>{d_dist, nullptr, 0, nullptr, 0, nullptr});
+        case 1: adv(bfs_policy_t<1>{d_dist, visited, 0, nullptr}); break;
+        case 2: adv(bfs_policy_t<2>{d_dist, visited, 0, nullptr}); break;
+        case 3: adv(bfs_policy_t<3>{d_dist, visited, 0, nullptr}); break;
+        default: adv(bfs_policy_t<7>{d_dist, nullptr, 0, nullptr});
       }
     }
     ++launches;

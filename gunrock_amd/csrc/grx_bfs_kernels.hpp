@@ -13,85 +13,46 @@ constexpr int DO_ALPHA = 14;
 constexpr int DO_BETA = 24;
 
 // VARIANT 0: the reference's claim, atomicMin on the label array with a stale
-// pre-check.  Tuning variants for A/B runs (engine_flags bits 8-10): 1 = claim on a
-// visited bitmap (atomicOr), 2 = same with an agent-scope pre-check, 3 = variant 1
-// counting attempted atomics in ctrl->spare[0].
-//
-// VARIANTS 4-6: PER-XCD FILTER BITMAPS.  What bounds variant 0 on a fat level is one
-// random label probe per edge: the labels (4 V bytes) do not fit an XCD's 4 MB L2, so the
-// probes run at HBM/MALL latency behind each CU's miss queue.  Here every XCD keeps a
-// PRIVATE V-bit bitmap "this XCD already tried vertex n" (V/8 bytes: L2 resident, and only
-// ever touched from that XCD, so the non-coherence of the eight L2s does not matter).  An
-// edge first tests the bit (L2 hit); a clear bit is set with a WORKGROUP-scope atomicOr,
-// which executes in the XCD's own L2 and keeps the line there (an agent-scope atomic goes to
-// memory and drops it); only the first edge per (XCD, vertex) goes on to the label -- at most
-// 8 label probes per vertex and search instead of one per in-edge.  The label atomicMin is
-// still the only arbiter, so exactly one thread wins a vertex, as in the reference.  Safety:
-// a set bit means "a thread of this XCD has issued, or is about to issue, atomicMin(label[n], d)
-// with d <= the current depth", so dropping the edge cannot change the final label; a LOST or
-// stale-clear bit only costs an extra probe.  The XCD id comes from HW_REG_XCC_ID; any other
-// placement would change speed only.  4 = plain bitmap loads (may hit the CU's L1),
-// 5 = L1-bypassing (sc1) loads, 6 = variant 4 without the plain label probe before atomicMin,
-// 7 = variant 0 on the stand-alone plan + advance kernels (control for variants 4-6).
+// pre-check (fastest measured).  Tuning variants for A/B runs (engine_flags bits 8-10):
+// 1 = claim on a visited bitmap (atomicOr), 2 = same with an agent-scope pre-check,
+// 3 = variant 1 counting attempted atomics in ctrl->spare[0], 7 = variant 0 on the
+// stand-alone plan + advance kernels.
+// Tried and rejected (round 1, LJ stand-in, top-down only): PER-XCD FILTER BITMAPS -- each
+// XCD keeps a private V-bit "already tried" bitmap in its own L2 (workgroup-scope atomicOr,
+// XCD id from HW_REG_XCC_ID) and only the first edge per (XCD, vertex) goes on to the label.
+// Correct, but the fat levels got SLOWER (31 M-edge level: 496 -> 951 us; plain or sc1
+// bitmap loads alike): one more dependent L2 round trip and one more atomic per surviving edge
+// cost more than the label probes they save.
 template <int VARIANT>
 struct bfs_policy_t {
   using src_state = int;
-  static constexpr bool xcd_filter = VARIANT >= 4 && VARIANT <= 6;
-  static constexpr int extra_stages = VARIANT == 6 ? 1 : (xcd_filter ? 2 : 0);
   int32_t* dist;
   unsigned* visited;
   int next_depth;
   ctrl_t* ctrl;
-  int xcd_words;   // variants 4-6: 32-bit words per per-XCD bitmap (the 8 bitmaps are consecutive)
-  unsigned* mine;  // variants 4-6: this XCD's bitmap (set by begin)
 
-  __device__ __forceinline__ void begin(ctrl_t* c) {
-    next_depth = c->level + 1;
-    ctrl = c;
-    if constexpr (xcd_filter) {
-      // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
-      const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(0x1814) & 7u;
-      mine = visited + (size_t)xcc * (size_t)xcd_words;
-    }
-  }
+  __device__ __forceinline__ void begin(ctrl_t* c) { next_depth = c->level + 1; ctrl = c; }
   __device__ __forceinline__ void set_level(int level) { next_depth = level + 1; }
   __device__ __forceinline__ src_state load_source(int) const { return 0; }
   __device__ __forceinline__ bool precheck(src_state, int n, int, int&) const {
     if constexpr (VARIANT == 0 || VARIANT == 7) return dist[n] > next_depth;
     if constexpr (VARIANT == 2)
       return (__hip_atomic_load(&visited[n >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << (n & 31))) == 0u;
-    if constexpr (VARIANT == 5)
-      return (__hip_atomic_load(&mine[n >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << (n & 31))) == 0u;
-    if constexpr (VARIANT == 4 || VARIANT == 6) return (mine[n >> 5] & (1u << (n & 31))) == 0u;
     return (visited[n >> 5] & (1u << (n & 31))) == 0u;
   }
-  // variants 4-6: first edge of this XCD to reach n?  (atomic executed in the XCD's own L2)
-  __device__ __forceinline__ unsigned stage1_issue(int n) const {
-    return __hip_atomic_fetch_or(&mine[n >> 5], 1u << (n & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  __device__ __forceinline__ bool stage1_pass(unsigned raw, int n) const { return (raw & (1u << (n & 31))) == 0u; }
-  // variants 4-5: plain label probe, so that only potential winners pay for the memory-side atomic
-  __device__ __forceinline__ int stage2_issue(int n) const { return dist[n]; }
-  __device__ __forceinline__ bool stage2_pass(int raw) const { return raw > next_depth; }
   __device__ __forceinline__ int claim(int n, int) const {
-    if constexpr (VARIANT == 0 || VARIANT >= 4) return atomicMin(&dist[n], next_depth);
+    if constexpr (VARIANT == 0 || VARIANT == 7) return atomicMin(&dist[n], next_depth);
     if constexpr (VARIANT == 3) atomicAdd(&ctrl->spare[0], 1);
     return (int)atomicOr(&visited[n >> 5], 1u << (n & 31));
   }
   __device__ __forceinline__ int code(int raw, int, int n, int) const {
-    if constexpr (VARIANT == 0 || VARIANT >= 4) return next_depth < raw ? 1 : 0;
+    if constexpr (VARIANT == 0 || VARIANT == 7) return next_depth < raw ? 1 : 0;
     if ((unsigned)raw & (1u << (n & 31))) return 0;
     dist[n] = next_depth;
     return 1;
   }
   // the whole chain for one precheck survivor
-  __device__ __forceinline__ int visit(src_state, int n, int) const {
-    if constexpr (extra_stages >= 1)
-      if (!stage1_pass(stage1_issue(n), n)) return 0;
-    if constexpr (extra_stages >= 2)
-      if (!stage2_pass(stage2_issue(n))) return 0;
-    return code(claim(n, 0), 0, n, 0);
-  }
+  __device__ __forceinline__ int visit(src_state, int n, int) const { return code(claim(n, 0), 0, n, 0); }
 };
 using bfs_policy = bfs_policy_t<0>;
 
@@ -171,13 +132,6 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
         ++my_open;
       }
     }
-    if (!same_csr) {
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        const int v = vbase + (ch0 + j) * 64 + lane;
-        if (open[j]) odeg[j] = a.ro[v + 1] - a.ro[v];
-      }
-    }
     // phase A: up to SERIAL probes per lane, the BATCH chunks advance in lock step.
     // Probes are issued SPECULATIVELY in groups (2, 2, 4): a group's column indices are
     // loaded together, then its frontier words together -- two dependent round trips per
@@ -249,6 +203,16 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
           if (dev::ballot(h)) { hit = true; break; }
         }
         if (lane == src_lane) found[j] = hit;
+      }
+    }
+    // out-degrees (next level's edge count) of the DISCOVERED vertices only, all chunks in one
+    // round trip; the other lanes read row 0 (one broadcast line).  Loading them up front for
+    // every open vertex cost a second 4 V-byte stream per bottom-up level on directed graphs.
+    if (!same_csr) {
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int v = found[j] ? vbase + (ch0 + j) * 64 + lane : 0;
+        odeg[j] = a.ro[v + 1] - a.ro[v];
       }
     }
 #pragma unroll

@@ -173,6 +173,61 @@ __device__ __forceinline__ void emit_tile(const pipe_args& a, ctrl_t* c, int q, 
   a.frontier[q][(size_t)s_res[2] * TILE + tid] = x;
 }
 
+// k (<= MAX_EMIT) FULL tiles s_out[lo .. lo + k * TILE) at once: all degree loads of the k
+// tiles are issued together, the k tile indices come from (at most) one global atomic, and
+// the block synchronises twice per CALL -- emit_tile costs two dependent round trips and
+// three barriers per TILE, which made a chunk that discovers 2000 vertices (the first level
+// from a hub) spend most of its time emitting.  Block-wide call.
+constexpr int MAX_EMIT = (CHUNK + TILE - 1) / TILE + 1;
+struct emit_smem {
+  int sum[MAX_EMIT][ADV_BLOCK / 64];
+  int tix[MAX_EMIT];
+};
+__device__ __forceinline__ void emit_full_tiles(const pipe_args& a, ctrl_t* c, int q, const int* s_out, int lo, int k,
+                                                emit_smem& es, int* s_res) {
+  const int tid = threadIdx.x;
+  const int lane = dev::lane_id();
+  const int wid = tid >> 6;
+  int x[MAX_EMIT], deg[MAX_EMIT];
+#pragma unroll
+  for (int j = 0; j < MAX_EMIT; ++j) x[j] = s_out[lo + (j < k ? j : 0) * TILE + tid];
+#pragma unroll
+  for (int j = 0; j < MAX_EMIT; ++j) deg[j] = a.ro[x[j] + 1] - a.ro[x[j]];  // unconditional: x[j] is a valid vertex
+#pragma unroll
+  for (int j = 0; j < MAX_EMIT; ++j) {
+    const int t = dev::wave_sum(j < k ? deg[j] : 0);
+    if (lane == 0) es.sum[j][wid] = t;
+  }
+  if (tid == 0) {
+    // tile indices: what is left of the current reservation first, then ONE new reservation
+    int have = s_res[1] - s_res[0];
+    int j = 0;
+    for (; j < k && have > 0; ++j, --have) es.tix[j] = s_res[0]++;
+    if (j < k) {
+      const int need = k - j;
+      const int take = (need + TILE_RESERVE - 1) / TILE_RESERVE * TILE_RESERVE;
+      int base = atomicAdd(&c->n_tiles[q], take);
+      s_res[1] = base + take;
+      for (; j < k; ++j) es.tix[j] = base++;
+      s_res[0] = base;
+    }
+  }
+  __syncthreads();
+  if (tid < k) {
+    int tot = 0;
+#pragma unroll
+    for (int i = 0; i < ADV_BLOCK / 64; ++i) tot += es.sum[tid][i];
+    const int tix = es.tix[tid];
+    a.tile_sums[tix] = tot;
+    a.tile_chunks[tix] = (tot + CHUNK - 1) / CHUNK;
+    a.tile_count[tix] = TILE;
+  }
+#pragma unroll
+  for (int j = 0; j < MAX_EMIT; ++j)
+    if (j < k) a.frontier[q][(size_t)es.tix[j] * TILE + tid] = x[j];
+  __syncthreads();
+}
+
 // Reserved but unused tile indices become empty tiles (never staged: 0 chunks).
 __device__ __forceinline__ void release_tiles(const pipe_args& a, const int* s_res) {
   const int t = s_res[0] + (int)threadIdx.x;
@@ -191,9 +246,6 @@ __device__ __forceinline__ void release_tiles(const pipe_args& a, const int* s_r
 //        cheap READ-ONLY filter; called for every lane with a valid (nbr, e) -- lanes past
 //        the end of the chunk pass edge 0 -- so its loads are unconditional; `cand` carries a
 //        per-edge value (e.g. the tentative distance bits) to the later phases
-//   [extra_stages >= 1] unsigned stage1_issue(int nbr), bool stage1_pass(unsigned raw, int nbr)
-//   [extra_stages >= 2] int stage2_issue(int nbr), bool stage2_pass(int raw)
-//        further filters between precheck and claim, run only for surviving edges
 //   int  claim(int nbr, int cand)                     the claiming atomic; returns its raw result
 //   [two_claims] bool need2(int raw1, int cand), int claim2(int nbr)   a second, dependent atomic
 //   int  code(int raw1, int raw2, int nbr, int cand)  1 => nbr joins the output,
@@ -201,7 +253,8 @@ __device__ __forceinline__ void release_tiles(const pipe_args& a, const int* s_r
 //                                                     (policies with `has_side`), 0 => dropped
 //   int  visit(src_state, int nbr, int e)             precheck-survivor -> code, the whole chain for
 //                                                     one edge (tiny_levels_kernel)
-//   side pile (has_side): side_reserve(ctrl, n) -> base index or -1, side_store(i, v)
+//   side pile (has_side): side_reserve(ctrl, n) -> base index or -1, side_store(i, v) -> key,
+//                         side_commit(min key of a wave)
 //
 // WHY PHASES.  A memory operation under a per-lane condition lives in its own basic block, and
 // when its result is consumed in that block the compiler emits s_waitcnt vmcnt(0) right behind
@@ -216,11 +269,6 @@ struct policy_has_side : std::false_type {};
 template <class Policy>
 struct policy_has_side<Policy, std::void_t<decltype(Policy::has_side)>> : std::bool_constant<Policy::has_side> {};
 
-template <class Policy, class = void>
-struct policy_extra_stages : std::integral_constant<int, 0> {};
-template <class Policy>
-struct policy_extra_stages<Policy, std::void_t<decltype(Policy::extra_stages)>>
-    : std::integral_constant<int, Policy::extra_stages> {};
 template <class Policy, class = void>
 struct policy_two_claims : std::false_type {};
 template <class Policy>
@@ -241,7 +289,19 @@ struct advance_smem {
   int wave[ADV_BLOCK / 64 + 1];
   int cnt;
   int res[3];
+  emit_smem emit;
 };
+
+// Store the sc side-pile entries of a workgroup at [sb, sb + sc) and commit the minimum of the
+// keys the policy returns with one atomic per wave.
+template <class Policy>
+__device__ __forceinline__ void side_flush(Policy& pol, const int* side, int sb, int sc) {
+  unsigned key = 0xffffffffu;
+  for (int i = threadIdx.x; i < sc; i += ADV_BLOCK) key = min(key, pol.side_store(sb + i, side[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o, 64));
+  if (dev::lane_id() == 0 && key != 0xffffffffu) pol.side_commit(key);
+}
 
 // The work of one advance workgroup on one level: chunks chunk_first, chunk_first +
 // chunk_stride, ... of the frontier with parity p; winners are emitted as tiles of parity
@@ -321,27 +381,6 @@ __device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Pol
       const bool pass = pol.precheck(sm.state[slot_k[k]], n_k[k], ok ? e_k[k] : 0, cand_k[k]);
       pre_k[k] = pass & ok;
     }
-    constexpr int EXTRA = policy_extra_stages<Policy>::value;
-    if constexpr (EXTRA >= 1) {
-      unsigned s1[ADV_ITEMS];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) {
-        s1[k] = 0u;
-        if (pre_k[k]) s1[k] = pol.stage1_issue(n_k[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) pre_k[k] = pre_k[k] & pol.stage1_pass(s1[k], n_k[k]);
-    }
-    if constexpr (EXTRA >= 2) {
-      int s2[ADV_ITEMS];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) {
-        s2[k] = 0;
-        if (pre_k[k]) s2[k] = pol.stage2_issue(n_k[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) pre_k[k] = pre_k[k] & pol.stage2_pass(s2[k]);
-    }
     // phase 2: the claiming atomics, all issued before any result is looked at
     int r1_k[ADV_ITEMS], r2_k[ADV_ITEMS];
 #pragma unroll
@@ -388,8 +427,7 @@ __device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Pol
         if (tid == 0) sm.side_base = pol.side_reserve(c, sc);
         __syncthreads();
         const int sb = sm.side_base;
-        if (sb >= 0)
-          for (int i = tid; i < sc; i += ADV_BLOCK) pol.side_store(sb + i, sm.side[i]);
+        if (sb >= 0) side_flush(pol, sm.side, sb, sc);
         __syncthreads();
         if (tid == 0) sm.side_cnt = 0;
         __syncthreads();
@@ -397,10 +435,11 @@ __device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Pol
     }
     // ---- flush full tiles --------------------------------------------------
     int cnt = sm.cnt;
-    while (cnt >= TILE) {
-      emit_tile(a, c, p ^ 1, sm.out, cnt - TILE, TILE, sm.wave, sm.res);
-      cnt -= TILE;
-      __syncthreads();
+    if (cnt >= TILE) {
+      // the LAST k * TILE entries leave; the first cnt % TILE stay for the next chunk
+      const int k = cnt / TILE;
+      emit_full_tiles(a, c, p ^ 1, sm.out, cnt - k * TILE, k, sm.emit, sm.res);
+      cnt -= k * TILE;
     }
     if (tid == 0) sm.cnt = cnt;
     __syncthreads();
@@ -415,8 +454,7 @@ __device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Pol
       if (tid == 0) sm.side_base = pol.side_reserve(c, sc);
       __syncthreads();
       const int sb = sm.side_base;
-      if (sb >= 0)
-        for (int i = tid; i < sc; i += ADV_BLOCK) pol.side_store(sb + i, sm.side[i]);
+      if (sb >= 0) side_flush(pol, sm.side, sb, sc);
     }
   }
   __syncthreads();

@@ -17,9 +17,9 @@
 //    as an empty stub, operators/advance/bucketing.hxx:30-35): improved vertices whose
 //    tentative distance falls in the current bucket [lo, hi) go to the next frontier, the
 //    others to a FAR pile (side output of the advance kernel, flushed through LDS with one
-//    reservation atomic per flush).  When the frontier drains, sssp_phase_kernel moves the
+//    reservation atomic per flush).  When the frontier drains, the head kernel moves the
 //    bucket on -- jumping over empty buckets with the tracked minimum of the pile -- and
-//    sssp_split_kernel pulls the new bucket out of the pile.  On weighted road-like graphs
+//    the level kernel pulls the new bucket out of the pile (sssp_split_body).  On weighted road-like graphs
 //    this cuts the relaxations of plain label-correcting by one to two orders of magnitude;
 //    the distances are identical.  Unit-weight graphs and engine_flags bit 4 use the plain
 //    schedule.
@@ -135,12 +135,15 @@ struct sssp_nf_policy {
     }
     return base;
   }
-  __device__ __forceinline__ void side_store(int i, int v) const {
+  // returns the ordered bits of the stored vertex's label; the caller reduces them over the
+  // wave and commits ONE atomicMin (a single word sustains only ~90 atomics/us)
+  __device__ __forceinline__ unsigned side_store(int i, int v) const {
     far_out[i] = v;
-    // lower bound of the labels waiting in the pile (may go stale; only steers how far
-    // the bucket jumps, never what is dropped)
-    atomicMin(min_far, __float_as_uint(dist[v]));
+    return __float_as_uint(dist[v]);
   }
+  // lower bound of the labels waiting in the pile (may go stale; only steers how far
+  // the bucket jumps, never what is dropped)
+  __device__ __forceinline__ void side_commit(unsigned key_min) const { atomicMin(min_far, key_min); }
 };
 
 __global__ void sssp_init_kernel(pipe_args a, float* dist, int src, float delta) {
@@ -178,73 +181,97 @@ __global__ void sssp_init_kernel(pipe_args a, float* dist, int src, float delta)
   }
 }
 
-// Start of an iteration of the near-far schedule.  <<<1, 1024>>>
-// Frontier non-empty: go on inside the current bucket.  Frontier empty: move to the next
-// bucket -- jumping over empty ones with the tracked lower bound of the waiting labels --
-// or finish when the far pile is empty too.
-__global__ __launch_bounds__(PLAN_BLOCK) void sssp_phase_kernel(pipe_args a, sssp_nf_args nf) {
+// Head of an iteration of the near-far schedule, ONE launch of one workgroup  <<<1, 1024>>>:
+// bucket bookkeeping, then the chunk map of the level (plan_body).
+//   frontier non-empty: go on inside the current bucket;
+//   frontier empty: move to the next bucket -- jumping over empty ones with the tracked lower
+//     bound of the waiting labels -- or finish when the far pile is empty too.  Moving on
+//     sets nf_split: THIS iteration's level kernel only pulls the new bucket out of the pile
+//     (sssp_split_body), and the next head (which finds nf_split set) plans that rebuilt
+//     frontier under the same level number.  A bucket change therefore costs one extra
+//     two-kernel group -- there are ~100 of them in a road-network search -- and every other
+//     iteration is two launches instead of four (phase, split, plan, advance).
+__global__ __launch_bounds__(PLAN_BLOCK) void sssp_nf_head_kernel(pipe_args a, sssp_nf_args nf) {
   __shared__ unsigned long long s_n;
+  __shared__ unsigned long long s_esum;
+  __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
+  __shared__ int s_go;
   ctrl_t* c = a.ctrl;
   const int tid = threadIdx.x;
   const int done = c->done;
-  const int level = c->level + 1;
+  const int resume = c->nf_split;  // the previous group rebuilt the frontier of c->level from the pile
+  const int level = resume ? c->level : c->level + 1;
   const int p = level & 1;
   const int nt = c->n_tiles[p];
-  if (tid == 0) s_n = 0;
+  if (tid == 0) { s_n = 0; s_esum = 0; s_go = 0; }
   __syncthreads();
   if (done) return;
-  long long n = 0;
-  for (int i = tid; i < nt; i += PLAN_BLOCK) n += a.tile_count[i];
+  if (!resume) {
+    long long n = 0;
+    for (int i = tid; i < nt; i += PLAN_BLOCK) n += a.tile_count[i];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-  if (dev::lane_id() == 0 && n) atomicAdd(&s_n, (unsigned long long)n);
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if (dev::lane_id() == 0 && n) atomicAdd(&s_n, (unsigned long long)n);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const long long n_f = (long long)s_n;
+    const int sel = c->nf_sel;
+    const int far_n = min(c->nf_far_n[sel], nf.capacity);
+    c->nf_split = 0;
+    if (resume) {
+      s_go = 1;
+    } else {
+      c->level = level;
+      c->n_tiles[p ^ 1] = 0;
+      a.mailbox[1] = level;
+      if (n_f > 0) {
+        s_go = 1;
+      } else if (far_n == 0) {
+        c->done = 1;
+        a.mailbox[0] = 1;
+      } else {
+        // New bucket [old hi, hi').  Everything in the pile whose label is below the OLD hi has
+        // been in a frontier since that label was set (the relaxation that produced it took the
+        // `nd < hi` branch), so it may be dropped; everything below hi' becomes the frontier.
+        const float delta = c->nf_delta;
+        const float closest = __uint_as_float(c->nf_min_far);
+        const float lo = c->nf_hi;
+        float hi = lo + delta;
+        if (closest >= hi && closest < FLT_MAX) {
+          hi = (floorf(closest / delta) + 1.0f) * delta;
+          if (!(hi > closest)) hi = nextafterf(closest, FLT_MAX);  // fp guard for huge labels
+        }
+        if (!(hi > lo)) hi = nextafterf(lo, FLT_MAX);
+        c->nf_lo = lo;
+        c->nf_hi = hi;
+        c->nf_min_far = 0x7f7fffffu;  // rebuilt by the split (kept entries) and by later appends
+        c->nf_split = 1;
+        c->nf_sel = sel ^ 1;
+        c->nf_far_n[sel ^ 1] = 0;
+        c->n_tiles[p] = 0;  // the frontier of this level is rebuilt from the pile
+        c->total_chunks = 0;
+        c->nf_phases += 1;
+      }
+    }
+  }
   __syncthreads();
-  if (tid != 0) return;
-  const long long n_f = (long long)s_n;
-  const int sel = c->nf_sel;
-  const int far_n = min(c->nf_far_n[sel], nf.capacity);
-  c->level = level;
-  c->n_tiles[p ^ 1] = 0;
-  c->nf_split = 0;
-  a.mailbox[1] = level;
-  if (n_f > 0) return;
-  if (far_n == 0) {
-    c->done = 1;
-    a.mailbox[0] = 1;
-    return;
-  }
-  // New bucket [old hi, hi').  Everything in the pile whose label is below the OLD hi has
-  // been in a frontier since that label was set (the relaxation that produced it took the
-  // `nd < hi` branch), so it may be dropped; everything below hi' becomes the frontier.
-  const float delta = c->nf_delta;
-  const float closest = __uint_as_float(c->nf_min_far);
-  const float lo = c->nf_hi;
-  float hi = lo + delta;
-  if (closest >= hi && closest < FLT_MAX) {
-    hi = (floorf(closest / delta) + 1.0f) * delta;
-    if (!(hi > closest)) hi = nextafterf(closest, FLT_MAX);  // fp guard for huge labels
-  }
-  if (!(hi > lo)) hi = nextafterf(lo, FLT_MAX);
-  c->nf_lo = lo;
-  c->nf_hi = hi;
-  c->nf_min_far = 0x7f7fffffu;  // rebuilt by the split (kept entries) and by later appends
-  c->nf_split = 1;
-  c->nf_sel = sel ^ 1;
-  c->nf_far_n[sel ^ 1] = 0;
-  c->n_tiles[p] = 0;  // the frontier of this level is rebuilt from the pile
-  c->nf_phases += 1;
+  if (s_go) plan_body<PLAN_BLOCK>(a, c, 2, s_wave, &s_esum);
 }
 
 // Pull the bucket [lo, hi) out of the far pile: entries whose CURRENT label lies in the
 // bucket become the frontier (once each), entries beyond it are kept, the rest are stale.
-__global__ __launch_bounds__(ADV_BLOCK) void sssp_split_kernel(pipe_args a, sssp_nf_args nf, float* dist) {
-  __shared__ int s_out[2 * TILE];
-  __shared__ int s_keep[2 * ADV_BLOCK];
-  __shared__ int s_wave[ADV_BLOCK / 64 + 1];
-  __shared__ int s_res[3];
-  __shared__ int s_cnt, s_kcnt, s_kbase;
+struct split_smem {
+  int out[2 * TILE];
+  int keep[2 * ADV_BLOCK];
+  int wave[ADV_BLOCK / 64 + 1];
+  int res[3];
+  int cnt, kcnt, kbase;
+};
+
+__device__ __forceinline__ void sssp_split_body(const pipe_args& a, const sssp_nf_args& nf, const float* dist,
+                                                split_smem& sm) {
   ctrl_t* c = a.ctrl;
-  if (c->done || !c->nf_split) return;
   const int level = c->level;
   const int p = level & 1;
   const int in_sel = c->nf_sel ^ 1;
@@ -255,7 +282,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_split_kernel(pipe_args a, sssp
   const int tid = threadIdx.x;
   const int lane = dev::lane_id();
   unsigned kept_min = 0x7f7fffffu;
-  if (tid == 0) { s_cnt = 0; s_kcnt = 0; s_res[0] = 0; s_res[1] = 0; }
+  if (tid == 0) { sm.cnt = 0; sm.kcnt = 0; sm.res[0] = 0; sm.res[1] = 0; }
   __syncthreads();
   for (int base = blockIdx.x * ADV_BLOCK; base < n; base += gridDim.x * ADV_BLOCK) {
     const int i = base + tid;
@@ -270,23 +297,23 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_split_kernel(pipe_args a, sssp
     const unsigned long long mn = dev::ballot(near);
     if (mn) {
       int at = 0;
-      if (lane == 0) at = atomicAdd(&s_cnt, __popcll(mn));
+      if (lane == 0) at = atomicAdd(&sm.cnt, __popcll(mn));
       at = __shfl(at, 0, 64);
-      if (near) s_out[at + dev::mask_rank(mn)] = v;
+      if (near) sm.out[at + dev::mask_rank(mn)] = v;
     }
     const unsigned long long mk = dev::ballot(keep);
     if (mk) {
       int at = 0;
-      if (lane == 0) at = atomicAdd(&s_kcnt, __popcll(mk));
+      if (lane == 0) at = atomicAdd(&sm.kcnt, __popcll(mk));
       at = __shfl(at, 0, 64);
-      if (keep) s_keep[at + dev::mask_rank(mk)] = v;
+      if (keep) sm.keep[at + dev::mask_rank(mk)] = v;
     }
     __syncthreads();
-    int have = s_cnt;
-    const int kc = s_kcnt;
+    int have = sm.cnt;
+    const int kc = sm.kcnt;
     __syncthreads();
     if (have >= TILE) {
-      emit_tile(a, c, p, s_out, have - TILE, TILE, s_wave, s_res);
+      emit_tile(a, c, p, sm.out, have - TILE, TILE, sm.wave, sm.res);
       have -= TILE;
       __syncthreads();
     }
@@ -294,37 +321,66 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_split_kernel(pipe_args a, sssp
       if (tid == 0) {
         int b = atomicAdd(&c->nf_far_n[in_sel ^ 1], kc);
         if (b + kc > nf.capacity) { c->nf_overflow = 1; b = -1; }
-        s_kbase = b;
+        sm.kbase = b;
       }
       __syncthreads();
-      if (s_kbase >= 0)
-        for (int k = tid; k < kc; k += ADV_BLOCK) fout[s_kbase + k] = s_keep[k];
+      if (sm.kbase >= 0)
+        for (int k = tid; k < kc; k += ADV_BLOCK) fout[sm.kbase + k] = sm.keep[k];
       __syncthreads();
     }
     if (tid == 0) {
-      s_cnt = have;
-      if (kc >= ADV_BLOCK) s_kcnt = 0;
+      sm.cnt = have;
+      if (kc >= ADV_BLOCK) sm.kcnt = 0;
     }
     __syncthreads();
   }
-  const int rem = s_cnt;
-  if (rem > 0) emit_tile(a, c, p, s_out, 0, rem, s_wave, s_res);
+  const int rem = sm.cnt;
+  if (rem > 0) emit_tile(a, c, p, sm.out, 0, rem, sm.wave, sm.res);
   __syncthreads();
-  release_tiles(a, s_res);
-  const int kc = s_kcnt;
+  release_tiles(a, sm.res);
+  const int kc = sm.kcnt;
   if (kc > 0) {
     if (tid == 0) {
       int b = atomicAdd(&c->nf_far_n[in_sel ^ 1], kc);
       if (b + kc > nf.capacity) { c->nf_overflow = 1; b = -1; }
-      s_kbase = b;
+      sm.kbase = b;
     }
     __syncthreads();
-    if (s_kbase >= 0)
-      for (int k = tid; k < kc; k += ADV_BLOCK) fout[s_kbase + k] = s_keep[k];
+    if (sm.kbase >= 0)
+      for (int k = tid; k < kc; k += ADV_BLOCK) fout[sm.kbase + k] = sm.keep[k];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) kept_min = min(kept_min, (unsigned)__shfl_xor((int)kept_min, o, 64));
   if (lane == 0 && kept_min != 0x7f7fffffu) atomicMin(&c->nf_min_far, kept_min);
+}
+
+// One near-far iteration, ONE launch: the advance (relax + far-pile side output), or -- when
+// the head moved to a new bucket -- the rebuild of the frontier from the pile.
+__global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, sssp_nf_args nf, sssp_nf_policy pol) {
+  __shared__ advance_smem<sssp_nf_policy> sm;
+  __shared__ split_smem ssm;
+  ctrl_t* c = a.ctrl;
+  if (c->done) return;
+  if (c->nf_split) {
+    sssp_split_body(a, nf, pol.dist, ssm);
+    return;
+  }
+  pol.begin(c);
+  advance_block<sssp_nf_policy, false>(a, c, pol, sm, c->level & 1, blockIdx.x, gridDim.x, c->total_chunks,
+                                       a.chunk_tile, a.chunk_prefix);
+}
+
+// Head of a plain (label-correcting) level, ONE launch of one workgroup: as many tiny levels
+// as there are (tiny_levels_body), then the bookkeeping + chunk map of the next regular level.
+__global__ __launch_bounds__(PLAN_BLOCK) void sssp_head_kernel(pipe_args a, sssp_policy pol, long long n_edges) {
+  __shared__ tiny_smem<sssp_policy> tsm;
+  __shared__ unsigned long long s_esum;
+  __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
+  static_assert(TINY_THREADS == PLAN_BLOCK, "head kernel runs both bodies");
+  if (tiny_levels_body(a, pol, 0, n_edges, tsm)) return;
+  if (threadIdx.x == 0) s_esum = 0ull;
+  __syncthreads();
+  plan_body<PLAN_BLOCK>(a, a.ctrl, 0, s_wave, &s_esum);
 }
 
 // out[0] = sum of weights; bits[0] / bits[1] = min / max weight as ordered uints (w >= 0)
@@ -387,19 +443,15 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
   if (near_far) {
     sssp_nf_policy pol{d_dist, stamp, g->w, nf, 0, 0.0f, nullptr, nullptr};
     st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
-      hipLaunchKernelGGL(sssp_phase_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, nf);
-      hipLaunchKernelGGL(sssp_split_kernel, dim3(std::max(64, grid / 4)), dim3(ADV_BLOCK), 0, stream, a, nf, d_dist);
-      hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 2);
-      hipLaunchKernelGGL((advance_kernel<sssp_nf_policy>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
+      hipLaunchKernelGGL(sssp_nf_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, nf);
+      hipLaunchKernelGGL(sssp_nf_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, nf, pol);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) launch_err = e;
     }, [&](const ctrl_t&) {});
   } else {
     sssp_policy pol{d_dist, stamp, g->w, 0};
     st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
-      hipLaunchKernelGGL((tiny_levels_kernel<sssp_policy>), dim3(1), dim3(TINY_THREADS), 0, stream, a, pol, 0,
-                         (long long)g->E);
-      hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
+      hipLaunchKernelGGL(sssp_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, pol, (long long)g->E);
       hipLaunchKernelGGL((advance_kernel<sssp_policy>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) launch_err = e;

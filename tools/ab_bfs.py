@@ -23,7 +23,7 @@ ctx = gr.multi_context_t(0)
 G = gr.build_graph(props, csr, ctx)
 V = G.get_number_of_vertices()
 d = torch.empty(V, dtype=torch.int32, device="cuda")
-KNOBS = ("GRX_BU_BATCH", "GRX_DO_ALPHA", "GRX_DO_BETA", "GRX_DO_BACK_DIV", "GRX_LEVEL_WG_PER_CU", "GRX_PACE_DEPTH")
+KNOBS = ("GRX_LEVEL_MINW", "GRX_BU_BATCH", "GRX_DO_ALPHA", "GRX_DO_BETA", "GRX_DO_BACK_DIV", "GRX_LEVEL_WG_PER_CU", "GRX_PACE_DEPTH")
 ref = None
 
 
@@ -74,23 +74,15 @@ def run(label, direction, variant=0, env=None, reps=15, profile=True):
 print("workload", name, "V", V, "E", G.get_number_of_edges(), "src", src, flush=True)
 if "do" in groups:
     run("DO default", gr.optimized)
-    run("DO batch2", gr.optimized, env={"GRX_BU_BATCH": 2})
-    run("DO batch8", gr.optimized, env={"GRX_BU_BATCH": 8})
-    run("DO wg/cu 4", gr.optimized, env={"GRX_LEVEL_WG_PER_CU": 4})
-    run("DO wg/cu 3", gr.optimized, env={"GRX_LEVEL_WG_PER_CU": 3})
+    for b in (2, 4):
+        for w in (1, 6, 8):
+            run("DO batch%d minw%d" % (b, w), gr.optimized, env={"GRX_BU_BATCH": b, "GRX_LEVEL_MINW": w})
 if "knobs" in groups:
-    for bd in (8, 16, 32, 64):
-        run("DO back_div %d" % bd, gr.optimized, env={"GRX_DO_BACK_DIV": bd})
-    for al in (6, 10, 20, 30):
+    for al in (6, 30):
         run("DO alpha %d" % al, gr.optimized, env={"GRX_DO_ALPHA": al})
-    for be in (8, 12, 48):
-        run("DO beta %d" % be, gr.optimized, env={"GRX_DO_BETA": be})
-    for pd in (1, 3, 4):
+    for pd in (1, 3):
         run("DO pace %d" % pd, gr.optimized, env={"GRX_PACE_DEPTH": pd}, profile=False)
 if "td" in groups:
     run("TD main path (v0)", gr.forward)
+    run("TD main batch2 minw8", gr.forward, env={"GRX_BU_BATCH": 2, "GRX_LEVEL_MINW": 8})
     run("TD v7 (v0, plan+advance kernels)", gr.forward, variant=7)
-    run("TD v4 xcd filter plain", gr.forward, variant=4)
-    run("TD v5 xcd filter sc1 loads", gr.forward, variant=5)
-    run("TD v6 xcd filter no label probe", gr.forward, variant=6)
-    run("TD v1 global bitmap atomicOr", gr.forward, variant=1)

@@ -1,7 +1,7 @@
 """All BASELINE.json single-GPU configs in one run: ours (engine) and, when
 oracle/_ref/libgunrock_ref_gpu.so is present, the reference's own GPU path on the same
 arrays (test infrastructure; reporting only).  Prints one JSON object per config.
-    python tools/bench_all.py [bfs_lj] [sssp_road] [pr_kron] [bfs_road] [sssp_lj] [bfs_kron]"""
+    python tools/bench_all.py [bfs_lj] [sssp_road] [ssspu_road] [pr_kron] [bfs_road] [sssp_lj] [bfs_kron]"""
 import json
 import os
 import sys
@@ -39,6 +39,8 @@ def med(xs):
 for item in which:
     algo, name = item.split("_")
     wl, props, csr = graph(name, weighted=(algo == "sssp"))
+    if algo == "ssspu":  # unit weights: what the reference loader makes of a pattern .mtx (road_usa)
+        algo = "sssp"
     g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
     V = g.n_vertices
     src = int(np.argmax(np.diff(g.row_offsets)))
