@@ -69,8 +69,7 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   GRX_HIP(ctx->tile_chunks.reserve(max_tiles * sizeof(int32_t)));
   GRX_HIP(ctx->tile_sums.reserve(max_tiles * sizeof(int32_t)));
   GRX_HIP(ctx->tile_count.reserve(max_tiles * sizeof(int32_t)));
-  GRX_HIP(ctx->chunk_prefix.reserve(max_tiles * sizeof(int32_t)));
-  GRX_HIP(ctx->chunk_tile.reserve(max_chunks * sizeof(int32_t)));
+  GRX_HIP(ctx->chunk_tile.reserve(max_chunks * 2 * sizeof(int32_t)));
   a->ro = g->ro;
   a->ci = g->ci;
   a->w = g->w;
@@ -82,7 +81,6 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   a->tile_chunks = ctx->tile_chunks.as<int32_t>();
   a->tile_sums = ctx->tile_sums.as<int32_t>();
   a->tile_count = ctx->tile_count.as<int32_t>();
-  a->chunk_prefix = ctx->chunk_prefix.as<int32_t>();
   a->chunk_tile = ctx->chunk_tile.as<int32_t>();
   return GRX_SUCCESS;
 }
@@ -166,7 +164,6 @@ grx_status_t grx_context_destroy(grx_context_t ctx) {
   ctx->bu_part.release();
   for (auto& b : ctx->far) b.release();
   ctx->chunk_tile.release();
-  ctx->chunk_prefix.release();
   for (auto& b : ctx->bitmap) b.release();
   ctx->labels.release();
   for (auto& b : ctx->fbuf) b.release();

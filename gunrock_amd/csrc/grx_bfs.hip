@@ -222,7 +222,7 @@ __global__ __launch_bounds__(ADV_BLOCK, MINW) void bfs_level_kernel(pipe_args a,
   if (c->mode == 0) {
     pol.begin(c);
     advance_block<bfs_policy, false>(a, c, pol, sm, c->level & 1, blockIdx.x, gridDim.x, c->total_chunks,
-                                     a.chunk_tile, a.chunk_prefix);
+                                     a.chunk_tile);
   } else {
     bfs_bottomup_block<BATCH>(a, d, c, bsm);
   }

@@ -26,6 +26,7 @@ constexpr int DO_BETA = 24;
 template <int VARIANT>
 struct bfs_policy_t {
   using src_state = int;
+  static constexpr bool stateless = true;  // load_source() carries nothing
   int32_t* dist;
   unsigned* visited;
   int next_depth;

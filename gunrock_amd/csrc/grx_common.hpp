@@ -126,8 +126,7 @@ struct grx_context {
   grx::dbuf tile_count;    // per tile: valid vertices
   grx::dbuf bu_part;       // per workgroup partial counters of the bottom-up kernel
   grx::dbuf far[2];        // near-far SSSP: far piles
-  grx::dbuf chunk_tile;    // per chunk: owning tile
-  grx::dbuf chunk_prefix;  // per tile: first chunk id
+  grx::dbuf chunk_tile;    // per chunk: int2 {owning tile, chunk index inside the tile}
   grx::dbuf bitmap[2];     // visited / scratch bitmaps
   grx::dbuf labels;        // int32 per vertex (SSSP stamps etc.)
   grx::dbuf fbuf[4];       // float per vertex (PR plast, iweights, x, ...)

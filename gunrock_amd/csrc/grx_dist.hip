@@ -238,7 +238,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void dist_advance_kernel(pipe_args a, bf
   if (c->done || c->mode != 0) return;
   pol.begin(c);
   advance_block<bfs_policy_dist, false>(a, c, pol, sm, c->level & 1, blockIdx.x * parts + part, gridDim.x * parts,
-                                        c->total_chunks, a.chunk_tile, a.chunk_prefix);
+                                        c->total_chunks, a.chunk_tile);
 }
 
 // After the exchange.  Top-down: claim what the peers discovered in this rank's slice.

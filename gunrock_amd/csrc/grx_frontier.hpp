@@ -50,8 +50,7 @@ struct pipe_args {
   int32_t* tile_chunks;   // chunks per tile of the CURRENT input frontier
   int32_t* tile_sums;     // degree sum per tile of the current input frontier
   int32_t* tile_count;    // valid vertices per tile
-  int32_t* chunk_prefix;  // first chunk id per tile
-  int32_t* chunk_tile;    // owning tile per chunk
+  int32_t* chunk_tile;    // per chunk: int2 {owning tile, chunk index inside the tile}
 };
 
 // ---------------------------------------------------------------------------
@@ -95,9 +94,10 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
     int tot;
     int ex = dev::block_exclusive_sum<BLOCK>(ch, s_wave, &tot);
     if (i < nt) {
+      // chunk -> {tile, chunk index inside the tile}: ONE 8-byte load per chunk in the level kernel
       const int pre = carry + ex;
-      a.chunk_prefix[i] = pre;
-      for (int j = 0; j < ch; ++j) a.chunk_tile[pre + j] = i;
+      int2* map = reinterpret_cast<int2*>(a.chunk_tile);
+      for (int j = 0; j < ch; ++j) map[pre + j] = make_int2(i, j);
     }
     carry += tot;
   }
@@ -310,7 +310,7 @@ __device__ __forceinline__ void side_flush(Policy& pol, const int* side, int sb,
 template <class Policy, bool FRESH>
 __device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Policy& pol, advance_smem<Policy>& sm,
                                               int p, int chunk_first, int chunk_stride, int total_chunks,
-                                              const int* chunk_tile, const int* chunk_prefix) {
+                                              const int* chunk_tile) {
   constexpr bool SIDE = policy_has_side<Policy>::value;
   const int tid = threadIdx.x;
   const int lane = dev::lane_id();
@@ -326,8 +326,12 @@ __device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Pol
   const int n_units = tile_mode ? c->n_tiles[p] : total_chunks;
   for (int unit = chunk_first; unit < n_units; unit += chunk_stride)
   for (int lc_t = 0, n_lc = tile_mode ? a.tile_chunks[unit] : 1; lc_t < n_lc; ++lc_t) {
-    const int t = tile_mode ? unit : chunk_tile[unit];
-    const int lc = tile_mode ? lc_t : unit - chunk_prefix[t];
+    int t = unit, lc = lc_t;
+    if (!tile_mode) {
+      const int2 tl = reinterpret_cast<const int2*>(chunk_tile)[unit];
+      t = tl.x;
+      lc = tl.y;
+    }
     // ---- stage the tile -------------------------------------------------
     int v;
     if constexpr (FRESH)
@@ -468,47 +472,110 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
   if (c->mode != 0) return;  // this level runs bottom-up
   const int p = c->level & 1;
   pol.begin(c);
-  advance_block<Policy, false>(a, c, pol, sm, p, blockIdx.x, gridDim.x, c->total_chunks, a.chunk_tile,
-                               a.chunk_prefix);
+  advance_block<Policy, false>(a, c, pol, sm, p, blockIdx.x, gridDim.x, c->total_chunks, a.chunk_tile);
 }
 
 // ---------------------------------------------------------------------------
 // Many TINY levels in one launch.  A single 1024-thread workgroup keeps the frontier in
-// LDS (<= TINY_CAP vertices, <= TINY_CAP out-edges per level) and plays plan + advance
-// itself, so a level costs three dependent global round trips (row offsets -> column
-// index -> claim) instead of a group of kernel launches (13.7 us per level measured).
-// High-diameter graphs (road networks: thousands of levels of a few hundred vertices)
-// live here; on scale-free graphs it absorbs the last few levels.  It starts from the
-// tiled queue the regular kernels left, and when a level is too big (or could switch
-// direction) it spills the frontier back as tiles and leaves the control block exactly
-// as plan_kernel / bfs_decide_kernel expect it.  <<<1, 1024>>>
+// LDS (<= 4096 vertices and <= 4096 out-edges per level) and plays plan + advance itself, so
+// a level costs a handful of dependent global round trips (row offsets -> column index ->
+// label probe -> claim) instead of a group of kernel launches (12.6 us per level measured for
+// head + level kernel).  It absorbs the first and last levels of scale-free searches and whole
+// chain-like searches.  It starts from the tiled queue the regular kernels left, and when a
+// level is too big (or could switch direction) it hands the frontier back as tiles and leaves
+// the control block exactly as plan_kernel / bfs_decide_kernel expect it.  <<<1, 1024>>>
+// The edges of a level are processed with the same phase structure as advance_block (all
+// loads of a phase in flight together).
+// SIZING (measured, road stand-in, 4.6 k vertices / 11 k edges per level on average): raising
+// the caps to 8192 vertices / 16384 edges made the search 2x SLOWER (26 us per level): one CU
+// retires about one scattered memory transaction every two clocks, so ~30 k transactions per
+// level belong on 256 CUs, not on one -- the single workgroup only wins while a level is a few
+// thousand transactions.
 // ---------------------------------------------------------------------------
-constexpr int TINY_CAP = 4096;
 constexpr int TINY_THREADS = 1024;
-constexpr int TINY_MAX_TILES = 256;  // tiles the tiny path is willing to gather from
+constexpr int TINY_EDGES = 4096;       // out-edges per level the workgroup is willing to take
+constexpr int TINY_MAX_TILES = 512;    // tiles the entry gather is willing to look at (a decline past
+                                       // this check costs the level a round trip over the tile counts)
+
+template <class Policy, class = void>
+struct policy_stateless : std::false_type {};
+template <class Policy>
+struct policy_stateless<Policy, std::void_t<decltype(Policy::stateless)>> : std::bool_constant<Policy::stateless> {};
 
 template <class Policy>
 struct tiny_smem {
-  int buf[2][TINY_CAP];
-  int seg[TINY_CAP + 1];
-  int start[TINY_CAP];
-  typename Policy::src_state state[TINY_CAP];
+  static constexpr bool STATELESS = policy_stateless<Policy>::value;
+  static constexpr int CAP = 4096;   // frontier vertices resident in LDS
+  static constexpr int ITEMS = 4;    // atoms per thread per pass: one pass covers TINY_EDGES
+  static_assert(CAP + 1 >= TINY_MAX_TILES + 1, "seg[] doubles as the tile-offset scratch of the entry gather");
+  int buf[2][CAP];
+  int seg[CAP + 1];
+  int start[CAP];
+  typename Policy::src_state state[STATELESS ? 1 : CAP];
   int wave[TINY_THREADS / 64 + 1];
   int n;
   unsigned long long total;
 };
+
+// Hand a frontier of n vertices back to the regular path as tiles of parity p: entries below
+// CAP come from LDS (`lds`), the others already sit in a.frontier[p] at their final slots
+// (written earlier in this launch by this workgroup: re-read past the L1).  Degrees are read
+// here.  Leaves c->level = level - 1 so that the next plan / decide step runs `level`.
+template <class Policy>
+__device__ __forceinline__ void tiny_hand_back(const pipe_args& a, ctrl_t* c, const int* lds, int n, int level,
+                                               long long edges_total, long long vertices_total,
+                                               tiny_smem<Policy>& sm) {
+  constexpr int CAP = tiny_smem<Policy>::CAP;
+  const int tid = threadIdx.x;
+  const int p = level & 1;
+  const int tiles = (n + TILE - 1) / TILE;
+  int32_t* out = a.frontier[p];
+  for (int base = 0; base < tiles * TILE; base += TINY_THREADS) {
+    const int slot = base + tid;
+    int v = -1;
+    if (slot < n) v = slot < CAP ? lds[slot] : __hip_atomic_load(&out[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int vv = v >= 0 ? v : lds[0];
+    int deg = a.ro[vv + 1] - a.ro[vv];
+    if (v < 0) deg = 0;
+    if (slot < tiles * TILE && (slot < CAP || slot >= n)) out[slot] = v;
+    const int wsum = dev::wave_sum(deg);
+    if (dev::lane_id() == 0) sm.wave[tid >> 6] = wsum;
+    __syncthreads();
+    if ((tid & (TILE - 1)) == 0 && slot < tiles * TILE) {
+      const int w0 = tid >> 6;
+      const int sum = sm.wave[w0] + sm.wave[w0 + 1] + sm.wave[w0 + 2] + sm.wave[w0 + 3];
+      const int t = slot / TILE;
+      a.tile_sums[t] = sum;
+      a.tile_chunks[t] = (sum + CHUNK - 1) / CHUNK;
+      a.tile_count[t] = min(TILE, n - t * TILE);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    c->n_tiles[p] = tiles;
+    c->level = level - 1;
+    c->edges_visited = edges_total;
+    c->vertices_visited += vertices_total;
+  }
+  __syncthreads();  // a plan/decide step may follow in the same workgroup
+}
 
 // Returns 1 when the search finished inside (done is set), 0 when the regular per-level
 // path has to continue (nothing done, or frontier handed back as tiles).
 template <class Policy>
 __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol, int do_enabled,
                                                 long long n_edges_total, tiny_smem<Policy>& sm) {
+  constexpr int CAP = tiny_smem<Policy>::CAP;
+  constexpr bool STATELESS = tiny_smem<Policy>::STATELESS;
+  constexpr int TINY_ITEMS = tiny_smem<Policy>::ITEMS;
   ctrl_t* c = a.ctrl;
   const int tid = threadIdx.x;
+  const int lane = dev::lane_id();
   if (c->done) return 1;
   if (c->frontier_bitmap) return 0;  // direction-optimising BFS: the frontier is a bitmap right now
   int level = c->level + 1;          // next level to run
   {
+    // ---- entry: gather the tiled queue into LDS ---------------------------------------
     const int p = level & 1;
     const int nt = c->n_tiles[p];
     // sparse tiles are common (every producing workgroup leaves a partial tile and reserves
@@ -516,34 +583,55 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
     if (nt > TINY_MAX_TILES) return 0;
     if (tid == 0) sm.total = 0ull;
     __syncthreads();
+    constexpr int TPT = (TINY_MAX_TILES + TINY_THREADS - 1) / TINY_THREADS;  // tiles per thread, consecutive
+    int cnt_k[TPT], mine = 0;
     {
       // vertices in the low 32 bits, out-edges (known per tile) in the high 32
       unsigned long long cnt = 0;
-      for (int t = tid; t < nt; t += TINY_THREADS)
-        cnt += (unsigned long long)a.tile_count[t] + ((unsigned long long)a.tile_sums[t] << 32);
+#pragma unroll
+      for (int k = 0; k < TPT; ++k) {
+        const int t = tid * TPT + k;
+        cnt_k[k] = t < nt ? a.tile_count[t] : 0;
+        const int es = t < nt ? a.tile_sums[t] : 0;
+        mine += cnt_k[k];
+        cnt += (unsigned long long)cnt_k[k] + ((unsigned long long)es << 32);
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-      if (dev::lane_id() == 0 && cnt) atomicAdd(&sm.total, cnt);
+      if (lane == 0 && cnt) atomicAdd(&sm.total, cnt);
     }
     __syncthreads();
     const unsigned long long total = sm.total;
     __syncthreads();
-    if ((int)(total & 0xffffffffull) > TINY_CAP || (int)(total >> 32) > TINY_CAP) return 0;
-    if (tid == 0) sm.n = 0;
+    if ((int)(total & 0xffffffffull) > CAP || (long long)(total >> 32) > TINY_EDGES) return 0;
+    // tiles are front-packed (tile_count valid slots, then -1): exclusive scan of the counts
+    // gives every tile its place in LDS, then one wave copies one tile
+    int tot;
+    int ex = dev::block_exclusive_sum<TINY_THREADS>(mine, sm.wave, &tot);
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+      const int t = tid * TPT + k;
+      if (t < nt) sm.seg[t] = ex;
+      ex += cnt_k[k];
+    }
     __syncthreads();
     const int32_t* in = a.frontier[p];
-    for (int slot = tid; slot < nt * TILE; slot += TINY_THREADS) {
-      if (a.tile_count[slot / TILE] == 0) continue;  // reserved-but-unused tile: stale slots
-      const int v = in[slot];
-      if (v >= 0) sm.buf[0][atomicAdd(&sm.n, 1)] = v;
+    for (int t = tid >> 6; t < nt; t += TINY_THREADS / 64) {
+      const int cnt = a.tile_count[t], off = sm.seg[t];
+#pragma unroll
+      for (int j = 0; j < TILE / 64; ++j) {
+        const int s_ = j * 64 + lane;
+        if (s_ < cnt) sm.buf[0][off + s_] = in[(size_t)t * TILE + s_];
+      }
     }
+    if (tid == 0) sm.n = tot;
     __syncthreads();
   }
   int n = sm.n;
   int sel = 0;
   long long edges_done = 0, vertices_done = 0;
   const long long edges_before = c->edges_visited;
-  constexpr int PER = TINY_CAP / TINY_THREADS;  // frontier slots per thread in the degree scan
+  constexpr int PER = CAP / TINY_THREADS;  // frontier slots per thread in the degree scan
   for (;;) {
     const int* cur = sm.buf[sel];
     int* nxt = sm.buf[sel ^ 1];
@@ -558,19 +646,31 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
       }
       return 1;
     }
+    if (n > CAP) {
+      // the level just finished discovered more than LDS holds (the overflow went straight to
+      // the tile array): back to the regular kernels
+      tiny_hand_back<Policy>(a, c, cur, n, level, edges_before + edges_done, vertices_done, sm);
+      return 0;
+    }
     // ---- degrees + exclusive scan (each thread owns PER consecutive slots) ----------
-    int deg[PER], local = 0;
+    // all row-offset loads of the thread in flight together: slots past n read vertex cur[0]
+    int rs[PER], deg[PER], local = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int i = tid * PER + k;
-      deg[k] = 0;
-      if (i < n) {
-        const int v = cur[i];
-        const int rs = a.ro[v];
-        deg[k] = a.ro[v + 1] - rs;
-        sm.start[i] = rs;
-        sm.state[i] = pol.load_source(v);
+      const int v = cur[i < n ? i : 0];
+      rs[k] = a.ro[v];
+      deg[k] = a.ro[v + 1];
+      if constexpr (!STATELESS) {
+        const auto st = pol.load_source(v);
+        if (i < n) sm.state[i] = st;
       }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid * PER + k;
+      deg[k] = i < n ? deg[k] - rs[k] : 0;
+      if (i < n) sm.start[i] = rs[k];
       local += deg[k];
     }
     int m;
@@ -584,8 +684,8 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
     if (tid == 0) { sm.seg[n] = m; sm.n = 0; }
     __syncthreads();
     const bool heavy = do_enabled && (long long)m > (n_edges_total - edges_before - edges_done) / 14 && n > 256;
-    if (m > TINY_CAP || heavy) {
-      // ---- too big for LDS (or the direction might switch): hand the frontier back as tiles
+    if (m > TINY_EDGES || heavy) {
+      // ---- too big for one workgroup (or the direction might switch): hand the frontier back
       const int p = level & 1;
       const int tiles = (n + TILE - 1) / TILE;
       for (int slot = tid; slot < tiles * TILE; slot += TINY_THREADS) a.frontier[p][slot] = slot < n ? cur[slot] : -1;
@@ -607,16 +707,64 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
     }
     // ---- the level itself -----------------------------------------------------------
     pol.set_level(level);
-    for (int atom = tid; atom < m; atom += TINY_THREADS) {
-      int lo = 0;
+    int32_t* spill = a.frontier[(level + 1) & 1];  // next-frontier entries beyond CAP
+    for (int base = 0; base < m; base += TINY_THREADS * TINY_ITEMS) {
+      int e_k[TINY_ITEMS], slot_k[TINY_ITEMS], n_k[TINY_ITEMS], cand_k[TINY_ITEMS];
 #pragma unroll
-      for (int step = TINY_CAP / 2; step >= 1; step >>= 1)
-        if (lo + step < n && sm.seg[lo + step] <= atom) lo += step;
-      const int e = sm.start[lo] + (atom - sm.seg[lo]);
-      const int nb = a.ci[e];
-      const auto st = sm.state[lo];
-      int cand = 0;
-      if (pol.precheck(st, nb, e, cand) && pol.visit(st, nb, e) == 1) nxt[atomicAdd(&sm.n, 1)] = nb;
+      for (int k = 0; k < TINY_ITEMS; ++k) {
+        const int atom = base + k * TINY_THREADS + tid;
+        int lo = 0;
+        e_k[k] = -1;
+        if (atom < m) {
+#pragma unroll
+          for (int step = CAP / 2; step >= 1; step >>= 1)
+            if (lo + step < n && sm.seg[lo + step] <= atom) lo += step;
+          e_k[k] = sm.start[lo] + (atom - sm.seg[lo]);
+        }
+        slot_k[k] = lo;
+      }
+#pragma unroll
+      for (int k = 0; k < TINY_ITEMS; ++k) n_k[k] = a.ci[e_k[k] >= 0 ? e_k[k] : 0];  // m > 0: edge 0 exists
+      bool pre_k[TINY_ITEMS];
+#pragma unroll
+      for (int k = 0; k < TINY_ITEMS; ++k) {
+        const bool ok = e_k[k] >= 0;
+        cand_k[k] = 0;
+        typename Policy::src_state st{};
+        if constexpr (!STATELESS) st = sm.state[slot_k[k]];
+        const bool pass = pol.precheck(st, n_k[k], ok ? e_k[k] : 0, cand_k[k]);
+        pre_k[k] = pass & ok;
+      }
+      int r1_k[TINY_ITEMS], r2_k[TINY_ITEMS];
+#pragma unroll
+      for (int k = 0; k < TINY_ITEMS; ++k) {
+        r1_k[k] = 0;
+        r2_k[k] = 0;
+        if (pre_k[k]) r1_k[k] = pol.claim(n_k[k], cand_k[k]);
+      }
+      if constexpr (policy_two_claims<Policy>::value) {
+#pragma unroll
+        for (int k = 0; k < TINY_ITEMS; ++k) {
+          const bool need = pre_k[k] & pol.need2(r1_k[k], cand_k[k]);
+          if (need) r2_k[k] = pol.claim2(n_k[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < TINY_ITEMS; ++k) {
+        int code = 0;
+        if (pre_k[k]) code = pol.code(r1_k[k], r2_k[k], n_k[k], cand_k[k]);
+        const bool keep = code == 1;
+        const unsigned long long mk = dev::ballot(keep);
+        if (mk) {
+          int at = 0;
+          if (lane == 0) at = atomicAdd(&sm.n, __popcll(mk));
+          at = __shfl(at, 0, 64) + dev::mask_rank(mk);
+          if (keep) {
+            if (at < CAP) nxt[at] = n_k[k];
+            else spill[at] = n_k[k];
+          }
+        }
+      }
     }
     edges_done += m;
     vertices_done += n;

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, s
   }
   pol.begin(c);
   advance_block<sssp_nf_policy, false>(a, c, pol, sm, c->level & 1, blockIdx.x, gridDim.x, c->total_chunks,
-                                       a.chunk_tile, a.chunk_prefix);
+                                       a.chunk_tile);
 }
 
 // Head of a plain (label-correcting) level, ONE launch of one workgroup: as many tiny levels
