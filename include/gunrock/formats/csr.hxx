@@ -18,6 +18,10 @@ namespace format {
 
 template <memory_space_t space, typename index_t, typename offset_t, typename value_t>
 struct csr_t {
+  using index_type = index_t;
+  using offset_type = offset_t;
+  using value_type = value_t;
+
   index_t number_of_rows = 0;
   index_t number_of_columns = 0;
   offset_t number_of_nonzeros = 0;

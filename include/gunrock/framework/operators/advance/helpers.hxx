@@ -51,10 +51,12 @@ __device__ __forceinline__ void expand_window(const graph_t& G, operator_t& op, 
 #pragma unroll
     for (int step = BLOCK / 2; step >= 1; step >>= 1)
       if (lo + step < nslots && s_seg[lo + step] <= atom) lo += step;
-    const edge_t e = (edge_t)(s_start[lo] + (atom - s_seg[lo]));
-    const vertex_t src = (vertex_t)s_src[lo];
-    const vertex_t nbr = G.get_destination_vertex(e);
-    const weight_t w = G.get_edge_weight(e);
+    // mutable lvalues: user operators may take (vertex_t&, vertex_t&, edge_t const&, weight_t const&)
+    // like the reference's hits.hxx:137
+    edge_t e = (edge_t)(s_start[lo] + (atom - s_seg[lo]));
+    vertex_t src = (vertex_t)s_src[lo];
+    vertex_t nbr = G.get_destination_vertex(e);
+    weight_t w = G.get_edge_weight(e);
     const bool keep = op(src, nbr, e, w);
     if constexpr (output_type != advance_io_type_t::none) {
       const type_t emitted = (output_type == advance_io_type_t::edges) ? (type_t)e : (type_t)nbr;

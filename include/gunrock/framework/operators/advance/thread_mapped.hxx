@@ -23,9 +23,12 @@ __global__ __launch_bounds__(256) void kernel(graph_t G, operator_t op, const ty
   const edge_t deg = G.get_number_of_neighbors((vertex_t)v);
   const edge_t base = segments[i];
   for (edge_t k = 0; k < deg; ++k) {
-    const edge_t e = first + k;
-    const vertex_t nbr = G.get_destination_vertex(e);
-    const bool keep = op((vertex_t)v, nbr, e, G.get_edge_weight(e));
+    // mutable lvalues: user operators may take (vertex_t&, vertex_t&, edge_t const&, weight_t const&)
+    // like the reference's hits.hxx:137
+    edge_t e = first + k;
+    vertex_t src = (vertex_t)v, nbr = G.get_destination_vertex(e);
+    auto w = G.get_edge_weight(e);
+    const bool keep = op(src, nbr, e, w);
     if constexpr (output_type != advance_io_type_t::none) {
       const type_t emitted = (output_type == advance_io_type_t::edges) ? (type_t)e : (type_t)nbr;
       output[base + k] = keep ? emitted : gunrock::numeric_limits<type_t>::invalid();

@@ -65,7 +65,8 @@ def test_drivers_build_and_help(binaries):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/include/gunrock"), reason="needs the reference tree")
 def test_reference_sources_compile_against_our_headers(binaries):
-    for name in ("ref_bfs", "ref_sssp", "ref_pr", "refalg_bfs", "refalg_sssp", "refalg_pr"):
+    for name in ("ref_bfs", "ref_sssp", "ref_pr", "refalg_bfs", "refalg_sssp", "refalg_pr",
+                 "refalg_kcore", "refalg_hits", "refalg_ppr", "refalg_spmv", "refalg_bc", "refalg_color"):
         assert os.path.exists(os.path.join(DROPIN, name)), name
 
 
@@ -173,3 +174,23 @@ def test_reference_sources_run_on_our_framework(gr, tmp_path):
     a = ranks(run([os.path.join(DROPIN, "refalg_pr"), "--market", CHES]).stdout)
     b = ranks(run([os.path.join(BIN, "pr"), "--market", CHES]).stdout)
     assert np.abs(a - b).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(DROPIN, "refalg_kcore")), reason="drop-in binaries not built")
+def test_other_reference_algorithms_run_on_our_operators(gr, tmp_path):
+    """the reference's OWN k-core, PPR, SpMV, HITS, BC and colouring (headers and
+    drivers, unmodified) on our enactor / frontier / advance / filter / parallel_for / batch;
+    those with a CPU oracle upstream validate against it."""
+    _, c = gr.generate("rmat_sym", 3000, 20000, seed=9)
+    g = str(tmp_path / "g.mtx")
+    write_mtx(g, c.row_offsets, c.column_indices)
+    # these four drivers take the file as argv[1] and always validate against their CPU oracle
+    for exe in ("refalg_kcore", "refalg_ppr", "refalg_spmv", "refalg_color"):
+        for mtx in (CHES, g):
+            r = run([os.path.join(DROPIN, exe), mtx], check=False)
+            assert r.returncode == 0, (exe, mtx, r.stdout[-600:], r.stderr[-600:])
+            assert "Number of errors : 0" in r.stdout, (exe, mtx, r.stdout[-600:])
+    for exe in ("refalg_hits", "refalg_bc"):
+        r = run([os.path.join(DROPIN, exe), "--market", CHES], check=False)
+        assert r.returncode == 0 and "GPU Elapsed Time" in r.stdout, (exe, r.stdout[-600:], r.stderr[-600:])
