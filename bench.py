@@ -230,12 +230,24 @@ def main():
         # in-edge (8), label + two out-offsets per discovered vertex (12)
         bu_bytes = lambda l, nxt: 3 * (V // 8) + 8 * l["bu_open"] + 8 * l["bu_probes"] + 12 * nxt
         prof_td = profile(gr.forward)
-        roofline_td = roof(prof_td, td_bytes, "advance_kernel<bfs_policy> (top-down only run)")
-        if pmc and args.workload == "lj":
-            k = pmc["advance_kernel"]
-            roofline_td["traffic"] = int((k["fetch_bytes_per_topdown_bfs_approx"] + k["write_bytes_per_topdown_bfs_approx"])
-                                         / max(1, len(prof_td)))
-            roofline_td["traffic_source"] = "profiles/r1_bench_pmc.json (FETCH_SIZE+WRITE_SIZE per launch, this workload)"
+        roofline_td = roof(prof_td, td_bytes, "bfs_level_kernel (top-down advance, forward-only run)")
+        def attach_traffic(r, cls):
+            # per-launch HBM-side bytes of the same launches from the committed rocprofv3 PMC passes
+            k = (pmc or {}).get("classes", {}).get(cls)
+            if not k or args.workload != "lj" or "fetch_bytes_per_launch" not in k:
+                return
+            r["traffic"] = int(k["fetch_bytes_per_launch"] + k.get("write_bytes_per_launch", 0.0))
+            r["traffic_source"] = ("profiles/r1_bench_pmc.json class '%s': FETCH_SIZE + WRITE_SIZE per launch, separate "
+                                   "--pmc passes of this command (raw counters; gfx950 tallies coalesced reads at 1/2)" % cls)
+            if "duration_us_per_launch" in k:
+                r["rocprof_avg_launch_us"] = round(k["duration_us_per_launch"], 2)
+
+        attach_traffic(roofline_td, "topdown_fat")
+        if roofline_td.get("traffic") is not None:
+            roofline_td["traffic_scope"] = "average of the two fat top-down levels (the launches that carry 99 % of the bytes)"
+            # the PMC class covers the two fat levels only: quote the event time of the same two launches
+            fat = sorted(prof_td, key=lambda l: -l["edges"])[:2]
+            roofline_td["fat_levels_avg_launch_us"] = round(sum(l["advance_ms"] for l in fat) * 1e3 / max(1, len(fat)), 2)
         roofline_td["levels"] = [[l["frontier_size"], l["edges"], round(l["advance_ms"], 4), round(l["other_ms"], 4)]
                                  for l in prof_td]
         if args.topdown_only:
@@ -247,14 +259,12 @@ def main():
             td = [l for l in prof_do if not l["bottom_up"]]
             t_bu = sum(l["advance_ms"] for l in bu)
             t_td = sum(l["advance_ms"] for l in td)
-            r_bu = roof(bu, lambda l: bu_bytes(l, l["nxt"]), "bfs_bottomup_kernel")
+            r_bu = roof(bu, lambda l: bu_bytes(l, l["nxt"]), "bfs_level_kernel (bottom-up launches)")
             r_bu["levels"] = [[l["frontier_size"], l["edges"], l["bu_open"], l["bu_probes"], round(l["advance_ms"], 4),
                                round(l["other_ms"], 4)] for l in bu]
             r_bu["share_of_step_kernel_time"] = round(t_bu / max(t_bu + t_td, 1e-9), 3)
-            if pmc and args.workload == "lj" and bu:
-                k = pmc["bfs_bottomup_kernel"]
-                r_bu["traffic"] = int((k["fetch_bytes_per_bfs"] + k["write_bytes_per_bfs"]) / len(bu))
-                r_bu["traffic_source"] = "profiles/r1_bench_pmc.json (FETCH_SIZE+WRITE_SIZE per launch, this workload)"
+            if bu:
+                attach_traffic(r_bu, "bottom_up")
             roofline, roofline_other = (r_bu, roofline_td) if t_bu >= t_td or not td else (roofline_td, r_bu)
             roofline["all_levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
                                        round(l["other_ms"], 4)] for l in prof_do]

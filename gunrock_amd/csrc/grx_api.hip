@@ -82,6 +82,7 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   a->tile_sums = ctx->tile_sums.as<int32_t>();
   a->tile_count = ctx->tile_count.as<int32_t>();
   a->chunk_tile = ctx->chunk_tile.as<int32_t>();
+  a->bu_part = nullptr;
   return GRX_SUCCESS;
 }
 
@@ -203,6 +204,7 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->t_ro) (void)hipFree(g->t_ro);
   if (g->t_ci) (void)hipFree(g->t_ci);
   if (g->t_w) (void)hipFree(g->t_w);
+  if (g->closed0) (void)hipFree(g->closed0);
   if (g->pr_blocks) (void)hipFree(g->pr_blocks);
   if (g->pr_piece) (void)hipFree(g->pr_piece);
   if (g->pr_long) (void)hipFree(g->pr_long);

@@ -17,8 +17,14 @@
 //    written with plain stores -- no atomics at all; the frontier bitmap is
 //    read-only during the level and stays L2 resident.  The switch follows Beamer's
 //    heuristic (frontier edges vs unexplored edges / alpha; frontier size vs V / beta)
-//    and is taken ON THE DEVICE by bfs_decide_kernel, so the host still enqueues
-//    levels blindly.
+//    and is taken ON THE DEVICE by the head kernel, so the host still enqueues levels blindly.
+//  * BOTH frontier formats are kept up to date all the time (queue of tiles + three rotating
+//    bitmaps + the visited bitmap): top-down discoveries set their bits (two fire-and-forget
+//    atomics per discovered vertex), bottom-up discoveries are also emitted as tiles.  A direction
+//    switch therefore needs no conversion pass, and a level is exactly two launches (head + level).
+//    Measured before this change (rocprofv3 kernel trace, LJ stand-in): the separate conversion
+//    kernel cost 52 of the 250 us of a search -- 19 us labels -> bitmaps, 10 us bitmap -> queue,
+//    and 4.5 us per level as a no-op launch the host had to enqueue blindly.
 #include "grx_engine.hpp"
 #include "grx_bfs_kernels.hpp"
 
@@ -27,7 +33,35 @@
 
 namespace grx {
 
-__global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, int src) {
+// problem.reset() of a direction-optimising run, ONE launch: labels = INT_MAX; visited = the
+// graph's static "no in-edges" bitmap; frontier bitmaps 0 and 1 empty (2 is cleared by level 0).
+__global__ void bfs_reset_kernel(int32_t* dist, int64_t V, dobfs_args d, const unsigned* closed0) {
+  const int64_t gsz = (int64_t)gridDim.x * blockDim.x, gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = gid; i < V; i += gsz) dist[i] = INT_MAX;
+  for (int64_t w = gid; w < d.n_words; w += gsz) {
+    d.visited[w] = closed0[w];
+    d.fbits[0][w] = 0u;
+    d.fbits[1][w] = 0u;
+  }
+}
+
+// closed0: bit v set <=> v has no in-edges (it can never be discovered bottom-up).  Once per graph.
+__global__ void bfs_closed0_kernel(const int32_t* t_ro, int32_t V, unsigned* out, int n_words) {
+  const int lane = dev::lane_id();
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t ch = wave; ch < n_words / 2; ch += n_waves) {
+    const int64_t v = ch * 64 + lane;
+    const bool no_in = v < V ? (t_ro[v + 1] == t_ro[v]) : true;
+    const unsigned long long m = dev::ballot(no_in);
+    if (lane == 0) {
+      out[2 * ch] = (unsigned)m;
+      out[2 * ch + 1] = (unsigned)(m >> 32);
+    }
+  }
+}
+
+__global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, int src, dobfs_args d) {
   const int tid = threadIdx.x;
   int32_t* f0 = a.frontier[0];
   f0[tid] = (tid == 0) ? src : -1;
@@ -54,8 +88,16 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
     c->q_edges[1] = 0;
     c->bu_open = 0;
     c->bu_probes = 0;
+    c->bu_R = 0;
+    c->bu_T = 0;
     dist[src] = 0;
-    if (visited) visited[src >> 5] = 1u << (src & 31);
+    if (d.enabled) {
+      const unsigned bit = 1u << (src & 31);
+      d.visited[src >> 5] |= bit;
+      d.fbits[0][src >> 5] = bit;
+    } else if (visited) {
+      visited[src >> 5] = 1u << (src & 31);
+    }
     a.mailbox[0] = 0;
     a.mailbox[1] = 0;
     a.mailbox[2] = 0;
@@ -63,8 +105,9 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
 }
 
 // Level bookkeeping + direction choice (one workgroup of PLAN_BLOCK threads).
-// The size of the frontier entering this level is reduced here from per-tile
-// (queue) or per-workgroup (bitmap) partials, so producers need no counter atomics.
+// The size of the frontier entering this level is reduced here from per-tile counts (after a
+// top-down level) or per-workgroup partials (after a bottom-up level), so producers need no
+// counter atomics.
 // s_red: 4 LDS words, zeroed and synchronised on entry.  On return every thread may
 // read the decision from the control block.
 __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_args& d, unsigned long long* s_red) {
@@ -73,13 +116,14 @@ __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_
   const int done = c->done;
   const int level = c->level + 1;
   const int p = level & 1;
-  const int is_bitmap = c->frontier_bitmap;
+  const int prev_bottom_up = c->mode;
   const int nt = c->n_tiles[p];
   if (done) return;
   long long n = 0, m = 0, op = 0, pr = 0;
-  if (is_bitmap) {
+  if (prev_bottom_up) {
+    // a bottom-up level leaves one record per workgroup (its tiles span a sparse static range)
     for (int i = tid; i < d.bu_grid; i += PLAN_BLOCK) {
-      n += d.bu_part[4 * i];
+      n += d.bu_part[4 * i] & ((1ll << 40) - 1);
       m += d.bu_part[4 * i + 1];
       op += d.bu_part[4 * i + 2];
       pr += d.bu_part[4 * i + 3];
@@ -114,19 +158,17 @@ __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_
       a.mailbox[1] = level;
       a.mailbox[0] = 1;
     } else {
-      int mode = c->mode;
-      if (d.enabled) {
-        const long long m_u = (long long)d.n_edges - c->edges_visited;  // edges of still-unexpanded vertices
-        if (mode == 0) {
-          if (m_f > m_u / d.alpha && n_f > 256) mode = 1;
-        } else {
-          // back to top-down: few frontier vertices (Beamer), or so few frontier out-edges that
-          // expanding them beats another sweep over every open vertex's in-edges
-          if (n_f < (long long)a.V / d.beta) mode = 0;
-          if (d.back_div > 0 && m_f < (long long)d.n_edges / d.back_div) mode = 0;
-        }
+      int mode = prev_bottom_up;
+      const long long m_u = (long long)d.n_edges - c->edges_visited;  // edges of still-unexpanded vertices
+      if (mode == 0) {
+        if (m_f > m_u / d.alpha && n_f > 256) mode = 1;
+      } else {
+        // back to top-down: few frontier vertices (Beamer), or so few frontier out-edges that
+        // expanding them beats another sweep over every open vertex's in-edges
+        if (n_f < (long long)a.V / d.beta) mode = 0;
+        if (d.back_div > 0 && m_f < (long long)d.n_edges / d.back_div) mode = 0;
       }
-      c->convert = (mode == 0 && is_bitmap) ? 1 : ((mode == 1 && !is_bitmap) ? 2 : 0);
+      if (!prev_bottom_up) c->bu_R = 0;  // the queue of this level is a dense run of tiles
       c->mode = mode;
       c->level = level;
       c->edges_visited += m_f;
@@ -134,9 +176,6 @@ __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_
       c->n_items[p] = (int)n_f;
       c->q_edges[p] = m_f;
       c->n_tiles[p ^ 1] = 0;
-      if (c->convert == 1) c->n_tiles[p] = 0;  // the queue of this level is rebuilt from the bitmap
-      c->frontier_bitmap = mode;               // format of the frontier this level PRODUCES
-      if (c->convert == 1) c->total_chunks = -1;  // tile mode: no chunk map for the rebuilt queue
       a.mailbox[1] = level;
       a.mailbox[2] = (int)n_f;
     }
@@ -146,9 +185,7 @@ __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_
 
 // Head of a level, ONE launch of one workgroup: as many tiny levels as there are
 // (tiny_levels_body), then level bookkeeping + direction choice, then the chunk map of a
-// top-down level.  (A trivial kernel costs ~4 us on this part: this used to be three.)
-// The level that switches back from bottom-up has no chunk map: its queue is rebuilt by
-// bfs_convert_kernel after this kernel, and advance_block walks it in tile mode.  <<<1, 1024>>>
+// top-down level.  (A trivial kernel costs ~4 us on this part: this used to be three.)  <<<1, 1024>>>
 __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs_args d, bfs_policy pol,
                                                               int allow_tiny, int seq) {
   __shared__ tiny_smem<bfs_policy> tsm;
@@ -165,66 +202,51 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
     return;
   }
   bfs_decide_body(a, d, s_red);
-  if (c->done || c->mode != 0 || c->convert == 1) return;
+  if (c->done || c->mode != 0) return;
   if (threadIdx.x == 0) s_red[0] = 0ull;
   __syncthreads();
   plan_body<PLAN_BLOCK>(a, c, 1, s_wave, &s_red[0]);
 }
 
-// Frontier format change at a direction switch.
-//   convert == 2 (top-down -> bottom-up): rebuild BOTH bitmaps from the labels with
-//     coalesced reads: visited = (dist != INF), frontier = (dist == level).
-//   convert == 1 (bottom-up -> top-down): expand the frontier bitmap into tiles.
-__global__ __launch_bounds__(ADV_BLOCK) void bfs_convert_kernel(pipe_args a, dobfs_args d) {
-  __shared__ words_smem sm;
+// One level, ONE launch: top-down (advance + fused compaction) or bottom-up, as the
+// head kernel decided.  Direction-optimising runs: every workgroup also clears its share of
+// the frontier bitmap the NEXT level will write into.
+template <int BATCH>
+__global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs_args d, bfs_policy pol) {
+  // a launch runs ONE of the two bodies: their LDS is overlaid (24 KB instead of 38: 6 workgroups per CU)
+  using td_smem = advance_smem<bfs_policy>;
+  using bu_smem = bottomup_smem<BATCH, true>;
+  constexpr size_t LDS_BYTES = sizeof(td_smem) > sizeof(bu_smem) ? sizeof(td_smem) : sizeof(bu_smem);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+  td_smem& sm = *reinterpret_cast<td_smem*>(lds_raw);
+  bu_smem& bsm = *reinterpret_cast<bu_smem*>(lds_raw);
   ctrl_t* c = a.ctrl;
   if (c->done) return;
-  const int convert = c->convert;
-  if (convert == 0) return;
   const int level = c->level;
-  const int p = level & 1;
-  const int tid = threadIdx.x;
-  const int lane = dev::lane_id();
-  if (convert == 2) {
-    unsigned* fin = d.fbits[p];
-    const int n_chunks = d.n_words / 2;
-    const int wave = (blockIdx.x * ADV_BLOCK + tid) >> 6;
-    const int n_waves = (gridDim.x * ADV_BLOCK) >> 6;
-    for (int ch = wave; ch < n_chunks; ch += n_waves) {
-      const int v = ch * 64 + lane;
-      const int dv = v < a.V ? d.dist[v] : INT_MAX;
-      // a vertex without in-edges can never be discovered bottom-up: close it
-      const bool no_in = v < a.V ? (d.t_ro[v + 1] == d.t_ro[v]) : true;
-      const unsigned long long vis = dev::ballot(dv != INT_MAX || no_in);
-      const unsigned long long fr = dev::ballot(dv == level);
-      if (lane == 0) {
-        d.visited[2 * ch] = (unsigned)vis;
-        d.visited[2 * ch + 1] = (unsigned)(vis >> 32);
-        fin[2 * ch] = (unsigned)fr;
-        fin[2 * ch + 1] = (unsigned)(fr >> 32);
+  if (d.enabled) {
+    uint4* z = reinterpret_cast<uint4*>(pick3(d.fbits, (level + 2) % 3));
+    const uint4* fc = reinterpret_cast<const uint4*>(pick3(d.fbits, level % 3));
+    uint4* vis = reinterpret_cast<uint4*>(d.visited);
+    const bool fold = c->mode == 0;  // top-down: the frontier being expanded joins `visited` here
+    const int n4 = d.n_words / 4;    // n_words is a multiple of 4 (bitmaps are padded)
+    for (int i = blockIdx.x * ADV_BLOCK + threadIdx.x; i < n4; i += gridDim.x * ADV_BLOCK) {
+      z[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (fold) {
+        const uint4 f = fc[i];
+        if (f.x | f.y | f.z | f.w) {
+          uint4 v = vis[i];
+          v.x |= f.x; v.y |= f.y; v.z |= f.z; v.w |= f.w;
+          vis[i] = v;
+        }
       }
     }
-    return;
   }
-  // convert == 1
-  const unsigned* fin = d.fbits[p];
-  words_to_tiles(a, c, p, d.n_words, 0, [fin](int w) { return fin[w]; }, sm);
-}
-
-// One level, ONE launch: top-down (advance + fused compaction) or bottom-up, as the
-// head kernel decided.
-template <int BATCH, int MINW>
-__global__ __launch_bounds__(ADV_BLOCK, MINW) void bfs_level_kernel(pipe_args a, dobfs_args d, bfs_policy pol) {
-  __shared__ advance_smem<bfs_policy> sm;
-  __shared__ bottomup_smem bsm;
-  ctrl_t* c = a.ctrl;
-  if (c->done) return;
   if (c->mode == 0) {
     pol.begin(c);
-    advance_block<bfs_policy, false>(a, c, pol, sm, c->level & 1, blockIdx.x, gridDim.x, c->total_chunks,
+    advance_block<bfs_policy, false>(a, c, pol, sm, level & 1, blockIdx.x, gridDim.x, c->total_chunks,
                                      a.chunk_tile);
   } else {
-    bfs_bottomup_block<BATCH>(a, d, c, bsm);
+    bfs_bottomup_block<BATCH, true>(a, d, c, bsm);
   }
 }
 
@@ -240,20 +262,17 @@ static int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-// The per-level kernel comes in a few builds: bottom-up chunks in flight per wave
-// (GRX_BU_BATCH = 2 | 4) x minimum waves per SIMD the register allocator must leave room for
-// (GRX_LEVEL_MINW = 1 | 6 | 8).
+// The per-level kernel comes in two builds: bottom-up chunks in flight per wave
+// (GRX_BU_BATCH = 2 | 4; measured equal on the LJ / kron stand-ins, 8 slower).  Forcing more
+// waves per SIMD through __launch_bounds__ only produced spills (measured slower).
 using level_kernel_fn = void (*)(pipe_args, dobfs_args, bfs_policy);
 struct level_build {
   level_kernel_fn fn;
   int per_cu;  // resident workgroups per CU (0: not queried yet)
 };
 static level_build* level_kernel_build() {
-  static level_build builds[2][3] = {
-      {{bfs_level_kernel<2, 1>, 0}, {bfs_level_kernel<2, 6>, 0}, {bfs_level_kernel<2, 8>, 0}},
-      {{bfs_level_kernel<4, 1>, 0}, {bfs_level_kernel<4, 6>, 0}, {bfs_level_kernel<4, 8>, 0}}};
-  const int batch = env_int("GRX_BU_BATCH", 4), minw = env_int("GRX_LEVEL_MINW", 1);
-  return &builds[batch == 2 ? 0 : 1][minw == 6 ? 1 : (minw == 8 ? 2 : 0)];
+  static level_build builds[2] = {{bfs_level_kernel<2>, 0}, {bfs_level_kernel<4>, 0}};
+  return &builds[env_int("GRX_BU_BATCH", 4) == 2 ? 0 : 1];
 }
 
 // Workgroups of the per-level kernel: exactly what is RESIDENT (persistent workgroups
@@ -291,7 +310,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   // bottom-up pays off on low-diameter graphs; with fewer than 4 edges per vertex the
   // frontier never gets heavy enough to switch and the extra per-level kernels only cost
   const bool dopt = opt.advance_direction == GRX_DIR_OPTIMIZED && variant == 0 && (long long)g->E >= 4ll * g->V;
-  const size_t bm_words = 2 * (((size_t)g->V + 63) / 64);
+  const size_t bm_words = 4 * (((size_t)g->V + 127) / 128);  // whole 16-byte groups: 64-vertex chunks, uint4 clears
   hipStream_t s = ctx->stream;
 
   dobfs_args d{};
@@ -319,13 +338,25 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       d.t_ci = g->t_ci;
     }
     GRX_HIP(ctx->bitmap[0].reserve(bm_words * sizeof(unsigned)));
-    GRX_HIP(ctx->bitmap[1].reserve(2 * bm_words * sizeof(unsigned)));
+    GRX_HIP(ctx->bitmap[1].reserve(3 * bm_words * sizeof(unsigned)));
     d.visited = ctx->bitmap[0].as<unsigned>();
     d.fbits[0] = ctx->bitmap[1].as<unsigned>();
     d.fbits[1] = d.fbits[0] + bm_words;
+    d.fbits[2] = d.fbits[1] + bm_words;
+    d.rot3 = 1;
+    if (!g->closed0 || g->closed0_words != (int32_t)bm_words) {
+      // static "no in-edges" bitmap, built once per graph and kept in the graph handle
+      if (g->closed0) GRX_HIP(hipFree(g->closed0));
+      g->closed0 = nullptr;
+      GRX_HIP(hipMalloc((void**)&g->closed0, bm_words * sizeof(unsigned)));
+      g->closed0_words = (int32_t)bm_words;
+      hipLaunchKernelGGL(bfs_closed0_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, d.t_ro, g->V, g->closed0,
+                         (int)bm_words);
+    }
     d.bu_grid = level_grid(ctx, g, lbuild);
     GRX_HIP(ctx->bu_part.reserve((size_t)d.bu_grid * 4 * sizeof(long long)));
     d.bu_part = ctx->bu_part.as<long long>();
+    a.bu_part = d.bu_part;
   } else if (variant != 0 && variant != 7) {
     visited_bytes = bm_words * sizeof(unsigned);
     GRX_HIP(ctx->bitmap[0].reserve(visited_bytes));
@@ -333,14 +364,18 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   }
 
   // problem.reset() -- outside the timed region, as in the reference
-  GRX_HIP(fill_i32(s, d_dist, INT_MAX, g->V));
-  if (visited) GRX_HIP(hipMemsetAsync(visited, 0, visited_bytes, s));
+  if (dopt) {
+    hipLaunchKernelGGL(bfs_reset_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, s, d_dist, (int64_t)g->V, d, g->closed0);
+  } else {
+    GRX_HIP(fill_i32(s, d_dist, INT_MAX, g->V));
+    if (visited) GRX_HIP(hipMemsetAsync(visited, 0, visited_bytes, s));
+  }
 
   const bool dense = g->V > 0 && (long long)g->E >= 8ll * g->V;  // few fat levels: paced enqueueing
   ctx->h_mailbox[0] = 0;
   ctx->h_mailbox[3] = -1;
   GRX_HIP(hipEventRecord(ctx->ev_begin, s));
-  hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, visited, src);
+  hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, visited, src, d);
 
   const int grid = (variant == 0) ? level_grid(ctx, g, lbuild) : advance_grid_for(ctx, g);
   const bool profile = (opt.engine_flags & GRX_FLAG_PROFILE) != 0;
@@ -348,18 +383,22 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
   if (profile) for (auto& e : pe) GRX_HIP(hipEventCreate(&e));
 
+  bfs_policy lp{};
+  lp.dist = d_dist;
+  if (dopt) {
+    lp.bm_visited = d.visited;
+    for (int i = 0; i < 3; ++i) lp.bm_f[i] = d.fbits[i];
+    lp.bm_words = d.n_words;
+  }
   hipError_t launch_err = hipSuccess;
   int64_t prof_v = 0, prof_e = 0, prof_open = 0, prof_probe = 0;
   int launches = 0;
   st = run_levels(ctx, opt, [&](hipStream_t stream, int seq) {
     if (profile) (void)hipEventRecord(pe[0], stream);
     if (variant == 0) {
-      // head (tiny levels + decide + plan) -> [format conversion at a direction switch] -> level
-      hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d,
-                         bfs_policy{d_dist, nullptr, 0, nullptr}, profile ? 0 : 1, seq);
-      if (dopt) hipLaunchKernelGGL(bfs_convert_kernel, dim3(ctx->num_cus * 2), dim3(ADV_BLOCK), 0, stream, a, d);
+      // head (tiny levels + decide + plan) -> level
+      hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, lp, profile ? 0 : 1, seq);
       if (profile) (void)hipEventRecord(pe[1], stream);
-      const bfs_policy lp{d_dist, nullptr, 0, nullptr};
       hipLaunchKernelGGL(lbuild->fn, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
     } else {
       hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
@@ -368,10 +407,10 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         hipLaunchKernelGGL((advance_kernel<decltype(pol)>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
       };
       switch (variant) {
-        case 1: adv(bfs_policy_t<1>{d_dist, visited, 0, nullptr}); break;
-        case 2: adv(bfs_policy_t<2>{d_dist, visited, 0, nullptr}); break;
-        case 3: adv(bfs_policy_t<3>{d_dist, visited, 0, nullptr}); break;
-        default: adv(bfs_policy_t<7>{d_dist, nullptr, 0, nullptr});
+        case 1: { bfs_policy_t<1> q{}; q.dist = d_dist; q.visited = visited; adv(q); break; }
+        case 2: { bfs_policy_t<2> q{}; q.dist = d_dist; q.visited = visited; adv(q); break; }
+        case 3: { bfs_policy_t<3> q{}; q.dist = d_dist; q.visited = visited; adv(q); break; }
+        default: { bfs_policy_t<7> q{}; q.dist = d_dist; adv(q); }
       }
     }
     ++launches;

@@ -9,6 +9,13 @@
 
 namespace grx {
 
+// element i (0..2) of a 3-array held in registers / kernel arguments WITHOUT dynamic indexing
+// (which would move the whole enclosing struct to scratch memory)
+template <class T>
+__device__ __forceinline__ T* pick3(T* const (&arr)[3], int i) {
+  return i == 0 ? arr[0] : (i == 1 ? arr[1] : arr[2]);
+}
+
 constexpr int DO_ALPHA = 14;
 constexpr int DO_BETA = 24;
 
@@ -31,9 +38,61 @@ struct bfs_policy_t {
   unsigned* visited;
   int next_depth;
   ctrl_t* ctrl;
+  // direction-optimising runs (variant 0): the top-down levels keep the bitmap view of the
+  // search up to date, so a switch to bottom-up needs no conversion pass -- every discovery sets
+  // its bit in the NEXT frontier bitmap (one fire-and-forget atomic per discovered vertex; top-down
+  // levels of such a run discover few), and the frontier being expanded is OR-ed into bm_visited.  bm_f[L % 3] is the frontier
+  // of level L; level L writes bm_f[(L + 1) % 3] and clears bm_f[(L + 2) % 3] for level L + 1.
+  unsigned* bm_visited;  // null: no bitmaps (forward-only runs)
+  unsigned* bm_f[3];
+  int bm_words;
+  unsigned* bm_next;     // set by begin / set_level
+  int in_tiny;           // set by tiny_levels_body: only bm_visited is maintained
 
-  __device__ __forceinline__ void begin(ctrl_t* c) { next_depth = c->level + 1; ctrl = c; }
-  __device__ __forceinline__ void set_level(int level) { next_depth = level + 1; }
+  __device__ __forceinline__ void set_level(int level) {
+    next_depth = level + 1;
+    if constexpr (VARIANT == 0)
+      if (bm_visited) bm_next = pick3(bm_f, (level + 1) % 3);
+  }
+  __device__ __forceinline__ void begin(ctrl_t* c) { ctrl = c; set_level(c->level); }
+  // a vertex joined the next frontier
+  __device__ __forceinline__ void on_accept(int n) const {
+    if constexpr (VARIANT == 0) {
+      if (bm_visited) {
+        const unsigned bit = 1u << (n & 31);
+        // regular top-down level: ONE atomic (next frontier); the level kernel folds each frontier
+        // bitmap into bm_visited with a streaming sweep when it is expanded.  Tiny levels: only
+        // bm_visited (tiny_hand_back rebuilds the frontier bitmap).
+        if (!in_tiny) (void)__hip_atomic_fetch_or(&bm_next[n >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else (void)__hip_atomic_fetch_or(&bm_visited[n >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  // tiny_levels_body keeps only `bm_visited` current while it runs levels inside one workgroup
+  // (nobody reads a frontier bitmap there); when it hands level `level` back to the regular
+  // kernels it restores their invariant: bm_f[level % 3] = exactly the frontier (n vertices:
+  // the first min(n, cap) in `lds`, the others at spill[cap ..], re-read past the L1),
+  // bm_f[(level + 1) % 3] empty.  Two 0.6 MB clears by one workgroup: a few us, once per
+  // hand-back, instead of bitmap upkeep in every tiny level.  Block-wide call.
+  __device__ __forceinline__ void tiny_enter() { in_tiny = 1; }
+  __device__ __forceinline__ void tiny_hand_back(int level, const int* lds, int n, int cap, const int* spill) {
+    if constexpr (VARIANT == 0) {
+      if (!bm_visited) return;
+      uint4* f0 = reinterpret_cast<uint4*>(pick3(bm_f, level % 3));
+      uint4* f1 = reinterpret_cast<uint4*>(pick3(bm_f, (level + 1) % 3));
+      for (int w = threadIdx.x; w < bm_words / 4; w += blockDim.x) {
+        f0[w] = make_uint4(0u, 0u, 0u, 0u);
+        f1[w] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      __syncthreads();
+      unsigned* f = pick3(bm_f, level % 3);
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int v = i < cap ? lds[i] : __hip_atomic_load(&spill[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_or(&f[v >> 5], 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+    }
+  }
   __device__ __forceinline__ src_state load_source(int) const { return 0; }
   __device__ __forceinline__ bool precheck(src_state, int n, int, int&) const {
     if constexpr (VARIANT == 0 || VARIANT == 7) return dist[n] > next_depth;
@@ -61,8 +120,9 @@ struct dobfs_args {
   const int32_t* t_ro;   // in-edges (transpose; the CSR itself for symmetric graphs)
   const int32_t* t_ci;
   int32_t* dist;
-  unsigned* visited;     // bitmap, maintained only while running bottom-up
-  unsigned* fbits[2];    // frontier bitmaps by level parity
+  unsigned* visited;     // bitmap of closed vertices (discovered, or without in-edges)
+  unsigned* fbits[3];    // frontier bitmaps: of level L at [L % 3] (rot3) or [L & 1] (partitioned runs)
+  int32_t rot3;          // single GPU: three rotating bitmaps, all formats always maintained
   int32_t n_words;       // 32-bit words per bitmap (even)
   int32_t n_edges;
   int32_t enabled;       // direction optimisation on
@@ -79,25 +139,72 @@ struct dobfs_args {
 // Bottom-up level.  A wave owns 64 consecutive vertices (one "chunk") and works on
 // BATCH chunks at a time so that the dependent load chain (visited word -> in-offsets
 // -> in-neighbour -> frontier word) of several chunks is in flight together.
-// `visited` already counts vertices without in-edges as closed (bfs_convert_kernel).
+// `visited` already counts vertices without in-edges as closed.
+// QUEUE: the discoveries are ALSO emitted as frontier tiles (wave-private LDS staging, one
+// tile per 256 discoveries of a wave, leftovers merged per workgroup), so a following top-down
+// level needs no bitmap -> queue conversion pass.  Tile indices come from a STATIC range per
+// workgroup -- workgroup b owns [b * T, (b + 1) * T), T = tiles its vertices could fill + 1 --
+// handed out through an LDS counter; unused indices are written as empty tiles.  (Reserving
+// them with atomics on the shared tile counter, as the top-down kernel does, made a fat bottom-up
+// level 35 us slower: 6144 waves hit one word that sustains ~90 atomics/us.)
+template <int BATCH = 4, bool QUEUE = false>
 struct bottomup_smem {
+  static constexpr int STAGE = QUEUE ? TILE + 64 * BATCH : 1;  // per wave
   int cnt[ADV_BLOCK / 64];
   long long deg[ADV_BLOCK / 64];
   int open[ADV_BLOCK / 64];
   long long probe[ADV_BLOCK / 64];
+  int sv[ADV_BLOCK / 64][STAGE];   // staged discoveries (vertex ids) of each wave
+  int sd[ADV_BLOCK / 64][STAGE];   // ... and their out-degrees
+  int bv[QUEUE ? ADV_BLOCK / 64 * TILE : 1];  // leftovers of the four waves, merged at the end
+  int bd[QUEUE ? ADV_BLOCK / 64 * TILE : 1];
+  int bcnt;
+  int tix_next;  // QUEUE: tiles of the workgroup's static range handed out so far
+  int tiles_out; // QUEUE: non-empty tiles of this workgroup (for its bu_part record)
 };
 
-template <int BATCH = 4>
+// One tile (index tix) of `n` (<= TILE) staged vertices sv[lo ..] with known degrees sd[lo ..],
+// written by ONE wave.
+__device__ __forceinline__ void wave_emit_tile(const pipe_args& a, int q, int tix, const int* sv, const int* sd,
+                                               int lo, int n) {
+  const int lane = dev::lane_id();
+  int dsum = 0;
+#pragma unroll
+  for (int i = 0; i < TILE / 64; ++i) {
+    const int k = i * 64 + lane;
+    const bool ok = k < n;
+    a.frontier[q][(size_t)tix * TILE + k] = ok ? sv[lo + k] : -1;
+    dsum += ok ? sd[lo + k] : 0;
+  }
+  dsum = dev::wave_sum(dsum);
+  if (lane == 0) {
+    a.tile_sums[tix] = dsum;
+    a.tile_chunks[tix] = (dsum + CHUNK - 1) / CHUNK;
+    a.tile_count[tix] = n;
+  }
+}
+
+template <int BATCH = 4, bool QUEUE = false>
 __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dobfs_args& d, ctrl_t* c,
-                                                   bottomup_smem& sm) {
+                                                   bottomup_smem<BATCH, QUEUE>& sm) {
   int* s_cnt = sm.cnt;
   long long* s_deg = sm.deg;
   int* s_open = sm.open;
   long long* s_probe = sm.probe;
   const int level = c->level;
   const int p = level & 1;
-  const unsigned* __restrict__ fin = d.fin_global ? d.fin_global : d.fbits[p];
-  unsigned* fout = d.fbits[p ^ 1];
+  const unsigned* __restrict__ fin = d.fin_global ? d.fin_global : pick3(d.fbits, d.rot3 ? level % 3 : p);
+  unsigned* fout = pick3(d.fbits, d.rot3 ? (level + 1) % 3 : (p ^ 1));
+  int wcnt = 0;  // QUEUE: staged discoveries of this wave
+  // QUEUE: static tile range of this workgroup (see above); every wave runs `iters` rounds of BATCH chunks
+  const int n_chunks_all = d.n_words / 2;
+  const int iters = (n_chunks_all + (int)gridDim.x * (ADV_BLOCK / 64) * BATCH - 1) / ((int)gridDim.x * (ADV_BLOCK / 64) * BATCH);
+  const int tiles_per_wg = BATCH * iters + 1;
+  const int tile_base = (int)blockIdx.x * tiles_per_wg;
+  if constexpr (QUEUE) {
+    if (threadIdx.x == 0) sm.tix_next = 0;
+    __syncthreads();
+  }
   const int vbase = d.ch_lo * 64;  // global id of local chunk 0
   const int lane = dev::lane_id();
   const int wid = threadIdx.x >> 6;
@@ -118,8 +225,12 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
     for (int j = 0; j < BATCH; ++j) {
       const int ch = ch0 + j;
       vis[j] = ~0ull;
-      if (ch < n_chunks)
+      if (ch < n_chunks) {
         vis[j] = (unsigned long long)d.visited[2 * ch] | ((unsigned long long)d.visited[2 * ch + 1] << 32);
+        // single GPU: the frontier of THIS level may not be in `visited` yet (the top-down levels
+        // fold a frontier in when they expand it): its own words are at hand
+        if (d.rot3) vis[j] |= (unsigned long long)fin[2 * ch] | ((unsigned long long)fin[2 * ch + 1] << 32);
+      }
     }
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
@@ -235,7 +346,55 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
         my_cnt += 1;
         my_deg += same_csr ? (e[j] - b[j]) : odeg[j];
       }
+      if constexpr (QUEUE) {
+        if (nw) {
+          if (found[j]) {
+            const int at = wcnt + dev::mask_rank(nw);
+            sm.sv[wid][at] = vbase + ch * 64 + lane;
+            sm.sd[wid][at] = same_csr ? (e[j] - b[j]) : odeg[j];
+          }
+          wcnt += __popcll(nw);
+        }
+      }
     }
+    if constexpr (QUEUE) {
+      if (wcnt >= TILE) {  // at most TILE - 1 + 64 * BATCH staged: one tile leaves, from the end
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&sm.tix_next, 1);
+        k = __shfl(k, 0, 64);
+        wave_emit_tile(a, p ^ 1, tile_base + k, sm.sv[wid], sm.sd[wid], wcnt - TILE, TILE);
+        wcnt -= TILE;
+      }
+    }
+  }
+  if constexpr (QUEUE) {
+    // leftovers (< TILE per wave) of the four waves -> as few tiles as possible
+    if (threadIdx.x == 0) sm.bcnt = 0;
+    __syncthreads();
+    int at = 0;
+    if (lane == 0 && wcnt) at = atomicAdd(&sm.bcnt, wcnt);
+    at = __shfl(at, 0, 64);
+    for (int i = lane; i < wcnt; i += 64) {
+      sm.bv[at + i] = sm.sv[wid][i];
+      sm.bd[at + i] = sm.sd[wid][i];
+    }
+    __syncthreads();
+    const int total = sm.bcnt;
+    const int used = sm.tix_next;  // full tiles emitted during the sweep
+    const int extra = (total + TILE - 1) / TILE;
+    if (wid < extra) wave_emit_tile(a, p ^ 1, tile_base + used + wid, sm.bv, sm.bd, wid * TILE, min(TILE, total - wid * TILE));
+    // the rest of the static range: empty tiles
+    for (int t = used + extra + (int)threadIdx.x; t < tiles_per_wg; t += ADV_BLOCK) {
+      a.tile_sums[tile_base + t] = 0;
+      a.tile_chunks[tile_base + t] = 0;
+      a.tile_count[tile_base + t] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      c->n_tiles[p ^ 1] = (int)gridDim.x * tiles_per_wg;
+      c->bu_R = (int)gridDim.x;
+      c->bu_T = tiles_per_wg;
+    }
+    if (threadIdx.x == 0) sm.tiles_out = used + extra;  // read after the barrier of the totals below
   }
   // per-workgroup totals -> a handful of atomics per workgroup
   my_cnt = dev::wave_sum(my_cnt);
@@ -253,7 +412,8 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
 #pragma unroll
     for (int i = 0; i < ADV_BLOCK / 64; ++i) { tc += s_cnt[i]; td += s_deg[i]; to += s_open[i]; tp += s_probe[i]; }
     // plain stores; bfs_decide_kernel of the next level reduces them
-    d.bu_part[4 * blockIdx.x] = tc;
+    // word 0: discoveries (low 40 bits) | non-empty tiles of this workgroup's static range (QUEUE)
+    d.bu_part[4 * blockIdx.x] = (long long)tc | (QUEUE ? ((long long)sm.tiles_out << 40) : 0ll);
     d.bu_part[4 * blockIdx.x + 1] = td;
     d.bu_part[4 * blockIdx.x + 2] = to;
     d.bu_part[4 * blockIdx.x + 3] = tp;

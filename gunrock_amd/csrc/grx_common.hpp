@@ -79,7 +79,9 @@ struct ctrl_t {
   int32_t mode;             // direction of the CURRENT level: 0 top-down (queue), 1 bottom-up (bitmap)
   int32_t frontier_bitmap;  // 1 if the frontier entering the next decide step is a bitmap
   int32_t convert;          // this level: 0 none, 1 bitmap -> queue, 2 labels -> bitmaps
-  int32_t pad2[3];
+  int32_t bu_R;             // > 0: the frontier entering the next plan step sits in bu_R static tile ranges ...
+  int32_t bu_T;             // ... of bu_T tile indices each (left by a bottom-up level); 0: dense tiles [0, n_tiles)
+  int32_t pad2[1];
   int64_t q_edges[2];       // out-degree sum of the frontier entering the level (set by plan/decide)
   // near-far (delta-stepping) SSSP
   float nf_lo, nf_hi;       // current bucket [lo, hi)
@@ -148,6 +150,8 @@ struct grx_graph {
   int32_t* t_ci = nullptr;
   float* t_w = nullptr;
   bool has_transpose = false;
+  unsigned* closed0 = nullptr;  // bitmap: vertices without in-edges (direction-optimising BFS), built lazily; owned
+  int32_t closed0_words = 0;
   double weight_sum = -1.0;  // sum of edge weights (lazy; near-far SSSP bucket width)
   bool uniform_weights = false;
   std::vector<int32_t> h_t_ro;  // host copy of the transpose offsets (for static partitions)

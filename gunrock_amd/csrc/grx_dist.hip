@@ -246,7 +246,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void dist_advance_kernel(pipe_args a, bf
 // frontier bitmap the all-to-all assembled in `recv`.
 __global__ __launch_bounds__(ADV_BLOCK) void dist_post_kernel(pipe_args a, dobfs_args d, dist_args x) {
   __shared__ words_smem sm;
-  __shared__ bottomup_smem bsm;
+  __shared__ bottomup_smem<4, false> bsm;
   ctrl_t* c = a.ctrl;
   if (c->done) return;
   if (c->mode == 1) {

@@ -51,6 +51,7 @@ struct pipe_args {
   int32_t* tile_sums;     // degree sum per tile of the current input frontier
   int32_t* tile_count;    // valid vertices per tile
   int32_t* chunk_tile;    // per chunk: int2 {owning tile, chunk index inside the tile}
+  const long long* bu_part;  // direction-optimising BFS: 4 words per bottom-up workgroup (word 0 >> 40 = its tiles)
 };
 
 // ---------------------------------------------------------------------------
@@ -82,24 +83,71 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
     return;
   }
   long long esum = 0;
-  int carry = 0;
-  for (int base = 0; base < nt; base += BLOCK) {
-    const int i = base + tid;
-    int ch = 0;
-    if (i < nt) {
-      ch = a.tile_chunks[i];
-      // {edges, vertices} packed: vertices in the top 24 bits of a 64-bit sum
-      esum += (long long)a.tile_sums[i] + ((long long)a.tile_count[i] << 40);
+  int mine = 0, carry;
+  const int R = external_control == 1 ? c->bu_R : 0;
+  if (R > 0) {
+    // The frontier was left by a bottom-up level: workgroup r of that launch filled the first
+    // n_r indices of its static tile range [r * T, (r + 1) * T) (n_r: bu_part word 0 >> 40).
+    // Walk the ranges, not the ~20 k mostly empty tile indices.
+    const int T = c->bu_T;
+    constexpr int RPT = 2;  // ranges per thread: the launch has at most 2 * BLOCK workgroups
+    int nr[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + q * BLOCK;
+      nr[q] = r < R ? (int)(a.bu_part[4 * r] >> 40) : 0;
     }
-    int tot;
-    int ex = dev::block_exclusive_sum<BLOCK>(ch, s_wave, &tot);
-    if (i < nt) {
-      // chunk -> {tile, chunk index inside the tile}: ONE 8-byte load per chunk in the level kernel
-      const int pre = carry + ex;
-      int2* map = reinterpret_cast<int2*>(a.chunk_tile);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int base = (tid + q * BLOCK) * T;
+      for (int k = 0; k < nr[q]; ++k) mine += a.tile_chunks[base + k];
+    }
+    int pre = dev::block_exclusive_sum<BLOCK>(mine, s_wave, &carry);
+    int2* map = reinterpret_cast<int2*>(a.chunk_tile);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int base = (tid + q * BLOCK) * T;
+      for (int k = 0; k < nr[q]; ++k) {
+        const int ch = a.tile_chunks[base + k];
+        for (int j = 0; j < ch; ++j) map[pre + j] = make_int2(base + k, j);
+        pre += ch;
+      }
+    }
+  } else {
+  // Thread t owns the contiguous tiles [t * K, (t + 1) * K), K = ceil(nt / BLOCK): all its loads
+  // are independent (issued G at a time), ONE block scan serves the whole level, and a second
+  // sweep over the same (now cached) counts writes the chunk map.
+  const int K = (nt + BLOCK - 1) / BLOCK;
+  const int t0 = tid * K, t1 = min(nt, t0 + K);
+  constexpr int G = 8;
+  for (int i0 = t0; i0 < t1; i0 += G) {
+    int ch[G], ts[G], tc[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const int i = min(i0 + k, t1 - 1);
+      ch[k] = a.tile_chunks[i];
+      ts[k] = a.tile_sums[i];
+      tc[k] = a.tile_count[i];
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      if (i0 + k < t1) {
+        mine += ch[k];
+        // {edges, vertices} packed: vertices in the top 24 bits of a 64-bit sum
+        esum += (long long)ts[k] + ((long long)tc[k] << 40);
+      }
+    }
+  }
+  int pre = dev::block_exclusive_sum<BLOCK>(mine, s_wave, &carry);
+  {
+    // chunk -> {tile, chunk index inside the tile}: ONE 8-byte load per chunk in the level kernel
+    int2* map = reinterpret_cast<int2*>(a.chunk_tile);
+    for (int i = t0; i < t1; ++i) {
+      const int ch = a.tile_chunks[i];
       for (int j = 0; j < ch; ++j) map[pre + j] = make_int2(i, j);
+      pre += ch;
     }
-    carry += tot;
+  }
   }
   // 64-bit block reduction of the traversed-edge count
 #pragma unroll
@@ -269,6 +317,12 @@ struct policy_has_side : std::false_type {};
 template <class Policy>
 struct policy_has_side<Policy, std::void_t<decltype(Policy::has_side)>> : std::bool_constant<Policy::has_side> {};
 
+// optional hooks: on_accept(nbr) for every vertex that joins the output; tiny_enter() /
+// tiny_hand_back(level, lds list, n, cap, spill) around tiny_levels_body
+template <class Policy, class = void>
+struct policy_has_accept : std::false_type {};
+template <class Policy>
+struct policy_has_accept<Policy, std::void_t<decltype(&Policy::on_accept)>> : std::true_type {};
 template <class Policy, class = void>
 struct policy_two_claims : std::false_type {};
 template <class Policy>
@@ -410,7 +464,10 @@ __device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Pol
         int base = 0;
         if (lane == 0) base = atomicAdd(&sm.cnt, __popcll(m));
         base = __shfl(base, 0, 64);
-        if (keep) sm.out[base + dev::mask_rank(m)] = n_k[k];
+        if (keep) {
+          sm.out[base + dev::mask_rank(m)] = n_k[k];
+          if constexpr (policy_has_accept<Policy>::value) pol.on_accept(n_k[k]);
+        }
       }
       if constexpr (SIDE) {
         const bool aside = code == 2;
@@ -572,7 +629,7 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
   const int tid = threadIdx.x;
   const int lane = dev::lane_id();
   if (c->done) return 1;
-  if (c->frontier_bitmap) return 0;  // direction-optimising BFS: the frontier is a bitmap right now
+  if (c->frontier_bitmap) return 0;  // partitioned BFS: the frontier is a bitmap right now
   int level = c->level + 1;          // next level to run
   {
     // ---- entry: gather the tiled queue into LDS ---------------------------------------
@@ -629,6 +686,7 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
   }
   int n = sm.n;
   int sel = 0;
+  if constexpr (policy_has_accept<Policy>::value) pol.tiny_enter();
   long long edges_done = 0, vertices_done = 0;
   const long long edges_before = c->edges_visited;
   constexpr int PER = CAP / TINY_THREADS;  // frontier slots per thread in the degree scan
@@ -649,6 +707,7 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
     if (n > CAP) {
       // the level just finished discovered more than LDS holds (the overflow went straight to
       // the tile array): back to the regular kernels
+      if constexpr (policy_has_accept<Policy>::value) pol.tiny_hand_back(level, cur, n, CAP, a.frontier[level & 1]);
       tiny_hand_back<Policy>(a, c, cur, n, level, edges_before + edges_done, vertices_done, sm);
       return 0;
     }
@@ -687,6 +746,9 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
     if (m > TINY_EDGES || heavy) {
       // ---- too big for one workgroup (or the direction might switch): hand the frontier back
       const int p = level & 1;
+      if constexpr (policy_has_accept<Policy>::value)
+        if (edges_done > 0 || vertices_done > 0)  // levels ran here: the frontier bitmaps are stale
+          pol.tiny_hand_back(level, cur, n, CAP, a.frontier[p]);
       const int tiles = (n + TILE - 1) / TILE;
       for (int slot = tid; slot < tiles * TILE; slot += TINY_THREADS) a.frontier[p][slot] = slot < n ? cur[slot] : -1;
       if (tid < tiles) {
@@ -707,6 +769,7 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
     }
     // ---- the level itself -----------------------------------------------------------
     pol.set_level(level);
+
     int32_t* spill = a.frontier[(level + 1) & 1];  // next-frontier entries beyond CAP
     for (int base = 0; base < m; base += TINY_THREADS * TINY_ITEMS) {
       int e_k[TINY_ITEMS], slot_k[TINY_ITEMS], n_k[TINY_ITEMS], cand_k[TINY_ITEMS];
@@ -762,6 +825,7 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
           if (keep) {
             if (at < CAP) nxt[at] = n_k[k];
             else spill[at] = n_k[k];
+            if constexpr (policy_has_accept<Policy>::value) pol.on_accept(n_k[k]);
           }
         }
       }

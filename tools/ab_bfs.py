@@ -75,8 +75,7 @@ print("workload", name, "V", V, "E", G.get_number_of_edges(), "src", src, flush=
 if "do" in groups:
     run("DO default", gr.optimized)
     for b in (2, 4):
-        for w in (1, 6, 8):
-            run("DO batch%d minw%d" % (b, w), gr.optimized, env={"GRX_BU_BATCH": b, "GRX_LEVEL_MINW": w})
+        run("DO batch%d" % b, gr.optimized, env={"GRX_BU_BATCH": b})
 if "knobs" in groups:
     for al in (6, 30):
         run("DO alpha %d" % al, gr.optimized, env={"GRX_DO_ALPHA": al})
@@ -84,5 +83,4 @@ if "knobs" in groups:
         run("DO pace %d" % pd, gr.optimized, env={"GRX_PACE_DEPTH": pd}, profile=False)
 if "td" in groups:
     run("TD main path (v0)", gr.forward)
-    run("TD main batch2 minw8", gr.forward, env={"GRX_BU_BATCH": 2, "GRX_LEVEL_MINW": 8})
     run("TD v7 (v0, plan+advance kernels)", gr.forward, variant=7)
