@@ -128,6 +128,10 @@ grx_status_t grx_context_create(int32_t device, void* stream, grx_context_t* out
   hipDeviceProp_t prop;
   GRX_HIP(hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_clock_khz = (double)khz;
+  }
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_ctrl), sizeof(ctrl_t)));
   // NOT hipMemset: that is queued on the null stream and may be submitted much later than
   // work on this context's (non-blocking) stream -- it once zeroed a running search

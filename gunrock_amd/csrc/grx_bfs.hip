@@ -90,6 +90,7 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
     c->bu_probes = 0;
     c->bu_R = 0;
     c->bu_T = 0;
+    c->t_start = (long long)wall_clock64();
     dist[src] = 0;
     if (d.enabled) {
       const unsigned bit = 1u << (src & 31);
@@ -155,8 +156,7 @@ __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_
     if (n_f == 0) {
       c->done = 1;
       c->level = level;
-      a.mailbox[1] = level;
-      a.mailbox[0] = 1;
+      publish_done(a, c, level);
     } else {
       int mode = prev_bottom_up;
       const long long m_u = (long long)d.n_edges - c->edges_visited;  // edges of still-unexpanded vertices
@@ -194,7 +194,9 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
   static_assert(TINY_THREADS == PLAN_BLOCK, "head kernel runs both bodies");
   ctrl_t* c = a.ctrl;
   if (threadIdx.x < 4) s_red[threadIdx.x] = 0ull;
-  if (threadIdx.x == 0) a.mailbox[3] = seq;  // host pacing: group `seq` has started
+  // host pacing: group `seq` has started (not after `done`: such a launch may still be in flight
+  // when the host has already begun the next search)
+  if (threadIdx.x == 0 && !c->done) a.mailbox[3] = seq;
   __syncthreads();
   if (allow_tiny && tiny_levels_body(a, pol, d.enabled, (long long)d.n_edges, tsm)) return;
   if (!d.enabled) {
@@ -391,6 +393,8 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     lp.bm_words = d.n_words;
   }
   hipError_t launch_err = hipSuccess;
+  bool returned_fast = false;
+  const int pace = (dense && variant == 0) ? env_int("GRX_PACE_DEPTH", 2) : 0;
   int64_t prof_v = 0, prof_e = 0, prof_open = 0, prof_probe = 0;
   int launches = 0;
   st = run_levels(ctx, opt, [&](hipStream_t stream, int seq) {
@@ -448,14 +452,21 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     r.bottom_up = h.mode;
     prof_v = h.vertices_visited;
     prof_e = h.edges_visited;
-  }, /*first_batch=*/dense ? 8 : 4, /*pace_depth=*/(dense && variant == 0) ? (getenv("GRX_PACE_DEPTH") ? atoi(getenv("GRX_PACE_DEPTH")) : 2) : 0);
+  }, /*first_batch=*/dense ? 8 : 4, /*pace_depth=*/pace, /*fast_return=*/pace > 0 && env_int("GRX_FAST_RETURN", 1) != 0,
+     &returned_fast);
   if (st != GRX_SUCCESS) return st;
   if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));
 
-  GRX_HIP(hipEventRecord(ctx->ev_end, s));
-  GRX_HIP(hipEventSynchronize(ctx->ev_end));
   float ms = 0;
-  GRX_HIP(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+  if (returned_fast) {
+    // enact() time on the device's own clock: seed (init kernel) -> the kernel that found the
+    // frontier empty; the reference brackets the same span with two events (enactor.hxx:270-282)
+    ms = (float)((double)ctx->h_ctrl->t_start / ctx->wall_clock_khz);
+  } else {
+    GRX_HIP(hipEventRecord(ctx->ev_end, s));
+    GRX_HIP(hipEventSynchronize(ctx->ev_end));
+    GRX_HIP(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+  }
   if (profile) for (auto& e : pe) (void)hipEventDestroy(e);
 
   ctx->stats.edges_visited = ctx->h_ctrl->edges_visited;

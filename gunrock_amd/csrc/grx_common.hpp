@@ -95,6 +95,7 @@ struct ctrl_t {
   int64_t bu_open;          // bottom-up accounting: unvisited vertices examined (cumulative)
   int64_t bu_probes;        // bottom-up accounting: in-edges read (cumulative)
   int64_t g_edges_visited;  // partitioned BFS: out-edges of all expanded vertices, whole graph
+  int64_t t_start;          // wall_clock64() at the seed of the search (init kernel)
 };
 
 struct level_rec {
@@ -118,7 +119,9 @@ struct grx_context {
 
   grx::ctrl_t* d_ctrl = nullptr;       // device control block
   grx::ctrl_t* h_ctrl = nullptr;       // pinned host mirror (written by memcpy)
-  volatile int32_t* h_mailbox = nullptr;  // pinned, device-visible: [0]=done,[1]=level,[2]=n_items
+  volatile int32_t* h_mailbox = nullptr;  // pinned, device-visible: [0]=done,[1]=level,[2]=n_items,[3]=group started,
+                                          // [4..9] = int64 {edges visited, vertices visited, wall-clock ticks} at `done`
+  double wall_clock_khz = 100000.0;       // rate of wall_clock64() on this device
   int32_t* d_mailbox = nullptr;        // device pointer aliasing h_mailbox
 
   // scratch

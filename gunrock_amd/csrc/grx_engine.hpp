@@ -40,9 +40,17 @@ inline int advance_grid_for(grx_context_t ctx, grx_graph_t g) {
 //    per level, and at most pace_depth wasted (no-op) groups at the end -- right for the few
 //    fat levels of a scale-free search, where a wasted full-grid group costs ~9 us.
 //    The caller resets mailbox words 0 and 3 (host side) before the first launch.
+//    fast_return (paced mode only): the kernel that finds the search finished publishes the final
+//    counters in the mailbox before the done flag (publish_done), so the host returns the moment
+//    it sees the flag -- no device-to-host copy, no stream synchronisation; the (at most
+//    pace_depth) groups still queued exit on `done` behind the caller's back, and anything the
+//    caller enqueues next on this stream is ordered after them.  *returned_fast tells the caller
+//    that ctx->h_ctrl was filled from the mailbox.
 template <class LaunchLevel, class AfterSync>
 grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel launch_level,
-                        AfterSync after_sync, int first_batch = 4, int pace_depth = 0) {
+                        AfterSync after_sync, int first_batch = 4, int pace_depth = 0, bool fast_return = false,
+                        bool* returned_fast = nullptr) {
+  if (returned_fast) *returned_fast = false;
   const bool sync_each = (opt.engine_flags & (GRX_FLAG_SYNC_EACH_LEVEL | GRX_FLAG_PROFILE)) != 0;
   int batch = sync_each ? 1 : first_batch;
   int launched = 0;
@@ -53,7 +61,20 @@ grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel
       volatile int32_t* mb = ctx->h_mailbox;
       unsigned spins = 0;
       for (;;) {
-        if (mb[0] != 0) break;  // done
+        if (mb[0] != 0) {  // done
+          if (fast_return) {
+            const volatile long long* mb64 = reinterpret_cast<const volatile long long*>(mb + 4);
+            ctx->h_ctrl->done = 1;
+            ctx->h_ctrl->level = mb[1];
+            ctx->h_ctrl->edges_visited = mb64[0];
+            ctx->h_ctrl->vertices_visited = mb64[1];
+            ctx->h_ctrl->t_start = mb64[2];  // elapsed wall-clock ticks, not a start stamp
+            if (returned_fast) *returned_fast = true;
+            after_sync(*ctx->h_ctrl);
+            return GRX_SUCCESS;
+          }
+          break;
+        }
         const int started = mb[3] + 1;
         if (launched < max_levels && launched - started < pace_depth) {
           launch_level(ctx->stream, launched);

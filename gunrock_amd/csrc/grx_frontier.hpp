@@ -54,6 +54,19 @@ struct pipe_args {
   const long long* bu_part;  // direction-optimising BFS: 4 words per bottom-up workgroup (word 0 >> 40 = its tiles)
 };
 
+// The search is over: final counters and the elapsed device time go to the host-pinned mailbox
+// BEFORE the done flag (system-scope fence in between), so a host that polls the flag can return
+// without a device round trip.  One thread; c->edges_visited / vertices_visited must be final.
+__device__ __forceinline__ void publish_done(const pipe_args& a, ctrl_t* c, int level) {
+  long long* mb64 = reinterpret_cast<long long*>(a.mailbox + 4);
+  mb64[0] = c->edges_visited;
+  mb64[1] = c->vertices_visited;
+  mb64[2] = (long long)wall_clock64() - c->t_start;
+  a.mailbox[1] = level;
+  __threadfence_system();
+  a.mailbox[0] = 1;
+}
+
 // ---------------------------------------------------------------------------
 // plan: per-level bookkeeping + chunk map.  <<<1, 1024>>>
 // ---------------------------------------------------------------------------
@@ -77,8 +90,7 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
     if (tid == 0) {
       c->done = 1;
       c->level = level;  // == number of advance iterations executed
-      a.mailbox[1] = level;
-      a.mailbox[0] = 1;
+      publish_done(a, c, level);
     }
     return;
   }
@@ -699,8 +711,7 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
         c->level = level;
         c->edges_visited = edges_before + edges_done;
         c->vertices_visited += vertices_done;
-        a.mailbox[1] = level;
-        a.mailbox[0] = 1;
+        publish_done(a, c, level);
       }
       return 1;
     }

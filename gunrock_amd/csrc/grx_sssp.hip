@@ -157,6 +157,7 @@ __global__ void sssp_init_kernel(pipe_args a, float* dist, int src, float delta)
     a.tile_count[0] = 1;
     c->level = -1;
     c->done = 0;
+    c->t_start = (long long)wall_clock64();
     c->n_tiles[0] = 1;
     c->n_items[0] = 1;
     c->n_tiles[1] = 0;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void sssp_nf_head_kernel(pipe_args a, s
         s_go = 1;
       } else if (far_n == 0) {
         c->done = 1;
-        a.mailbox[0] = 1;
+        publish_done(a, c, level);
       } else {
         // New bucket [old hi, hi').  Everything in the pile whose label is below the OLD hi has
         // been in a frontier since that label was set (the relaxation that produced it took the

@@ -4,7 +4,7 @@
 
 The single per-level kernel (bfs_level_kernel) runs a level top-down or bottom-up as the head
 kernel decided, so its dispatches are classified by POSITION inside a search: a search starts at
-a bfs_init_kernel dispatch; searches that contain bfs_convert_kernel dispatches are
+a bfs_init_kernel dispatch; searches whose reset was a bfs_reset_kernel (labels + bitmaps) are
 direction-optimising runs, whose level dispatches at the given 0-based positions ran bottom-up
 (bench.py's `all_levels` shows the same flags); searches without them are top-down-only runs,
 whose positions 1 and 2 are the two fat top-down levels of the LJ stand-in.
@@ -29,12 +29,14 @@ def classify(rows):
     """rows: (dispatch id, kernel name) in launch order -> {dispatch id: class}"""
     cls, cur = {}, None
     searches = []
+    reset_seen = False
     for did, name in rows:
-        if "bfs_init_kernel" in name:
-            cur = {"convert": False, "levels": []}
+        if "bfs_reset_kernel" in name:
+            reset_seen = True
+        elif "bfs_init_kernel" in name:
+            cur = {"convert": reset_seen, "levels": []}
             searches.append(cur)
-        elif cur is not None and "bfs_convert_kernel" in name:
-            cur["convert"] = True
+            reset_seen = False
         elif cur is not None and "bfs_level_kernel" in name:
             cur["levels"].append(did)
     for s in searches:
