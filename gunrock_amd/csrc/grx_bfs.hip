@@ -29,6 +29,7 @@
 #include "grx_bfs_kernels.hpp"
 
 #include <climits>
+#include <cstddef>
 #include <cstdlib>
 
 namespace grx {
@@ -109,17 +110,19 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
 // The size of the frontier entering this level is reduced here from per-tile counts (after a
 // top-down level) or per-workgroup partials (after a bottom-up level), so producers need no
 // counter atomics.
-// s_red: 4 LDS words, zeroed and synchronised on entry.  On return every thread may
-// read the decision from the control block.
-__device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_args& d, unsigned long long* s_red) {
+// s_red: 4 LDS words, zeroed and synchronised on entry.
+// s_dec (3 LDS ints) receives {done, direction of this level, level} for every thread.
+__device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_args& d, unsigned long long* s_red,
+                                                const ctrl_head& h, int* s_dec) {
   ctrl_t* c = a.ctrl;
   const int tid = threadIdx.x;
-  const int done = c->done;
-  const int level = c->level + 1;
+  const int done = h.done;
+  const int level = h.level + 1;
   const int p = level & 1;
-  const int prev_bottom_up = c->mode;
-  const int nt = c->n_tiles[p];
-  if (done) return;
+  const int prev_bottom_up = h.mode;
+  const int nt = h.nt(p);
+  if (tid == 0) { s_dec[0] = done; s_dec[1] = prev_bottom_up; s_dec[2] = level; }
+  if (done) { __syncthreads(); return; }
   long long n = 0, m = 0, op = 0, pr = 0;
   if (prev_bottom_up) {
     // a bottom-up level leaves one record per workgroup (its tiles span a sparse static range)
@@ -156,10 +159,11 @@ __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_
     if (n_f == 0) {
       c->done = 1;
       c->level = level;
+      s_dec[0] = 1;
       publish_done(a, c, level);
     } else {
       int mode = prev_bottom_up;
-      const long long m_u = (long long)d.n_edges - c->edges_visited;  // edges of still-unexpanded vertices
+      const long long m_u = (long long)d.n_edges - h.edges_visited;  // edges of still-unexpanded vertices
       if (mode == 0) {
         if (m_f > m_u / d.alpha && n_f > 256) mode = 1;
       } else {
@@ -169,6 +173,7 @@ __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_
         if (d.back_div > 0 && m_f < (long long)d.n_edges / d.back_div) mode = 0;
       }
       if (!prev_bottom_up) c->bu_R = 0;  // the queue of this level is a dense run of tiles
+      s_dec[1] = mode;
       c->mode = mode;
       c->level = level;
       c->edges_visited += m_f;
@@ -192,22 +197,36 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
   __shared__ unsigned long long s_red[4];
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
   static_assert(TINY_THREADS == PLAN_BLOCK, "head kernel runs both bodies");
+  __shared__ int s_dec[3];
   ctrl_t* c = a.ctrl;
+  const ctrl_head h0 = load_ctrl_head(c);
   if (threadIdx.x < 4) s_red[threadIdx.x] = 0ull;
   // host pacing: group `seq` has started (not after `done`: such a launch may still be in flight
   // when the host has already begun the next search)
-  if (threadIdx.x == 0 && !c->done) a.mailbox[3] = seq;
+  if (threadIdx.x == 0 && !h0.done) a.mailbox[3] = seq;
   __syncthreads();
-  if (allow_tiny && tiny_levels_body(a, pol, d.enabled, (long long)d.n_edges, tsm)) return;
+  const int t = allow_tiny ? tiny_levels_body(a, pol, d.enabled, (long long)d.n_edges, tsm, h0) : 0;
+  if (t == 1) return;
+  const ctrl_head h = t == 2 ? load_ctrl_head(c) : h0;  // tiny levels ran and handed back: fresh state
+  plan_in in;
+  in.done = h.done;
+  in.mode = 0;
+  in.R = 0;
+  in.T = h.bu_T;
   if (!d.enabled) {
-    plan_body<PLAN_BLOCK>(a, c, 0, s_wave, &s_red[0]);
+    in.level = h.level + 1;
+    in.nt = h.nt(in.level & 1);
+    plan_body<PLAN_BLOCK>(a, c, 0, s_wave, &s_red[0], in);
     return;
   }
-  bfs_decide_body(a, d, s_red);
-  if (c->done || c->mode != 0) return;
+  bfs_decide_body(a, d, s_red, h, s_dec);
+  if (s_dec[0] || s_dec[1] != 0) return;
   if (threadIdx.x == 0) s_red[0] = 0ull;
   __syncthreads();
-  plan_body<PLAN_BLOCK>(a, c, 1, s_wave, &s_red[0]);
+  in.level = s_dec[2];
+  in.nt = h.nt(in.level & 1);
+  in.R = h.mode ? h.bu_R : 0;  // the previous level ran bottom-up: its tiles sit in static ranges
+  plan_body<PLAN_BLOCK>(a, c, 1, s_wave, &s_red[0], in);
 }
 
 // One level, ONE launch: top-down (advance + fused compaction) or bottom-up, as the
@@ -223,13 +242,21 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
   td_smem& sm = *reinterpret_cast<td_smem*>(lds_raw);
   bu_smem& bsm = *reinterpret_cast<bu_smem*>(lds_raw);
   ctrl_t* c = a.ctrl;
-  if (c->done) return;
-  const int level = c->level;
+  // everything this launch needs from the control block in ONE batch of loads (read one by one
+  // behind the early-exit branches they were three to four dependent round trips, a third of a
+  // small level's kernel time)
+  const int4 h0 = *reinterpret_cast<const int4*>(c);        // level, done, n_tiles[0..1]
+  const int4 h1 = *(reinterpret_cast<const int4*>(c) + 1);  // n_items[0..1], total_chunks, pad
+  const int mode_now = c->mode;
+  static_assert(offsetof(ctrl_t, level) == 0 && offsetof(ctrl_t, done) == 4 && offsetof(ctrl_t, total_chunks) == 24,
+                "control block header layout");
+  if (h0.y) return;
+  const int level = h0.x;
   if (d.enabled) {
     uint4* z = reinterpret_cast<uint4*>(pick3(d.fbits, (level + 2) % 3));
     const uint4* fc = reinterpret_cast<const uint4*>(pick3(d.fbits, level % 3));
     uint4* vis = reinterpret_cast<uint4*>(d.visited);
-    const bool fold = c->mode == 0;  // top-down: the frontier being expanded joins `visited` here
+    const bool fold = mode_now == 0;  // top-down: the frontier being expanded joins `visited` here
     const int n4 = d.n_words / 4;    // n_words is a multiple of 4 (bitmaps are padded)
     for (int i = blockIdx.x * ADV_BLOCK + threadIdx.x; i < n4; i += gridDim.x * ADV_BLOCK) {
       z[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -243,10 +270,10 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
       }
     }
   }
-  if (c->mode == 0) {
-    pol.begin(c);
-    advance_block<bfs_policy, false>(a, c, pol, sm, level & 1, blockIdx.x, gridDim.x, c->total_chunks,
-                                     a.chunk_tile);
+  if (mode_now == 0) {
+    pol.ctrl = c;
+    pol.set_level(level);
+    advance_block<bfs_policy, false>(a, c, pol, sm, level & 1, blockIdx.x, gridDim.x, h1.z, a.chunk_tile);
   } else {
     bfs_bottomup_block<BATCH, true>(a, d, c, bsm);
   }

@@ -4,6 +4,8 @@
 
 #include "grx_frontier.hpp"
 
+#include <cstdlib>
+
 namespace grx {
 
 // Fill kernels (problem_t::reset(): algorithms/bfs.hxx:59-69, sssp.hxx:63-80).
@@ -54,6 +56,13 @@ grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel
   const bool sync_each = (opt.engine_flags & (GRX_FLAG_SYNC_EACH_LEVEL | GRX_FLAG_PROFILE)) != 0;
   int batch = sync_each ? 1 : first_batch;
   int launched = 0;
+  hipGraphExec_t graph_exec = nullptr;
+  bool graph_failed = false;
+  static const bool use_graph = [] { const char* v = getenv("GRX_USE_GRAPH"); return !(v && *v == '0'); }();
+  struct graph_guard {
+    hipGraphExec_t& e;
+    ~graph_guard() { if (e) (void)hipGraphExecDestroy(e); }
+  } guard{graph_exec};
   const int max_levels = opt.max_iterations > 0 ? opt.max_iterations : 0x7fffffff;
   if (sync_each) pace_depth = 0;
   for (;;) {
@@ -97,14 +106,48 @@ grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel
         }
       }
     } else {
-      for (int i = 0; i < batch && launched < max_levels; ++i, ++launched) launch_level(ctx->stream, launched);
+      // High-diameter searches (thousands of short levels) are bound by the HOST's launch rate:
+      // two launches per level at ~3.5-5 us each against ~10 us of device time.  No kernel takes a
+      // level-dependent argument, so once a search has outlived its first 64 groups the next
+      // GRAPH_GROUPS groups are captured into a hipGraph ONCE and every later batch is a few graph
+      // replays (one host call per 64 levels).  Capture + instantiate costs about what launching
+      // the same groups costs, so short searches never pay for it.
+      constexpr int GRAPH_GROUPS = 64;
+      if (!sync_each && use_graph && !graph_exec && !graph_failed && launched >= 64 &&
+          launched + GRAPH_GROUPS <= max_levels) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          for (int i = 0; i < GRAPH_GROUPS; ++i) launch_level(ctx->stream, launched + i);
+          if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || !graph ||
+              hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            graph_exec = nullptr;
+            graph_failed = true;
+          }
+          if (graph) (void)hipGraphDestroy(graph);
+        } else {
+          graph_failed = true;
+        }
+        (void)hipGetLastError();
+      }
+      if (graph_exec) {
+        int left = batch;
+        while (left >= GRAPH_GROUPS && launched + GRAPH_GROUPS <= max_levels) {
+          GRX_HIP(hipGraphLaunch(graph_exec, ctx->stream));
+          launched += GRAPH_GROUPS;
+          left -= GRAPH_GROUPS;
+        }
+        for (; left > 0 && launched < max_levels && launched + GRAPH_GROUPS > max_levels; --left, ++launched)
+          launch_level(ctx->stream, launched);
+      } else {
+        for (int i = 0; i < batch && launched < max_levels; ++i, ++launched) launch_level(ctx->stream, launched);
+      }
     }
     GRX_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost, ctx->stream));
     GRX_HIP(hipStreamSynchronize(ctx->stream));
     after_sync(*ctx->h_ctrl);
     if (ctx->h_ctrl->done) break;
     if (launched >= max_levels) break;
-    if (!sync_each && batch < 64) batch *= 2;
+    if (!sync_each && batch < (graph_exec ? 1024 : 64)) batch *= 2;
   }
   return GRX_SUCCESS;
 }

@@ -75,15 +75,50 @@ __device__ __forceinline__ void publish_done(const pipe_args& a, ctrl_t* c, int 
 // a top-down level and leaves when the level runs bottom-up.
 // Body of the plan step for a workgroup of BLOCK threads; *s_esum must be 0 and the
 // workgroup synchronised on entry.  s_wave: BLOCK / 64 + 1 ints of LDS.
+// What the single-workgroup kernels need from the control block, fetched in ONE batch of loads.
+// Read field by field behind early-exit branches these were four to five dependent round trips
+// at the start of every head kernel (seen in the ISA: s_load / s_waitcnt / branch, repeated) --
+// a third of the kernel on a level that is otherwise a handful of round trips.
+struct ctrl_head {
+  int level, done, nt0, nt1, total_chunks, mode, frontier_bitmap, bu_R, bu_T;
+  long long edges_visited;
+  __device__ __forceinline__ int nt(int parity) const { return parity ? nt1 : nt0; }
+};
+__device__ __forceinline__ ctrl_head load_ctrl_head(const ctrl_t* c) {
+  const int4 a0 = reinterpret_cast<const int4*>(c)[0];  // level, done, n_tiles[0..1]
+  const int4 a1 = reinterpret_cast<const int4*>(c)[1];  // n_items[0..1], total_chunks, pad
+  ctrl_head h;
+  h.mode = c->mode;
+  h.frontier_bitmap = c->frontier_bitmap;
+  h.bu_R = c->bu_R;
+  h.bu_T = c->bu_T;
+  h.edges_visited = c->edges_visited;
+  h.level = a0.x;
+  h.done = a0.y;
+  h.nt0 = a0.z;
+  h.nt1 = a0.w;
+  h.total_chunks = a1.z;
+  return h;
+}
+
+// state a plan step works from (already known to its caller, or taken from a ctrl_head)
+struct plan_in {
+  int done;
+  int level;  // the level being planned
+  int nt;     // tiles of its frontier
+  int mode;
+  int R, T;   // bottom-up tile ranges (external_control == 1), R == 0: dense tiles
+};
+
 template <int BLOCK>
 __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int external_control, int* s_wave,
-                                          unsigned long long* s_esum) {
+                                          unsigned long long* s_esum, const plan_in& in) {
   const int tid = threadIdx.x;
-  const int done = c->done;
-  const int level = external_control ? c->level : c->level + 1;
+  const int done = in.done;
+  const int level = in.level;
   const int p = level & 1;
-  const int nt = c->n_tiles[p];
-  const int mode = c->mode;
+  const int nt = in.nt;
+  const int mode = in.mode;
   if (done) return;
   if (external_control == 1 && mode != 0) return;
   if (!external_control && nt == 0) {
@@ -96,12 +131,12 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
   }
   long long esum = 0;
   int mine = 0, carry;
-  const int R = external_control == 1 ? c->bu_R : 0;
+  const int R = external_control == 1 ? in.R : 0;
   if (R > 0) {
     // The frontier was left by a bottom-up level: workgroup r of that launch filled the first
     // n_r indices of its static tile range [r * T, (r + 1) * T) (n_r: bu_part word 0 >> 40).
     // Walk the ranges, not the ~20 k mostly empty tile indices.
-    const int T = c->bu_T;
+    const int T = in.T;
     constexpr int RPT = 2;  // ranges per thread: the launch has at most 2 * BLOCK workgroups
     int nr[RPT];
 #pragma unroll
@@ -185,6 +220,20 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
   }
 }
 
+template <int BLOCK>
+__device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int external_control, int* s_wave,
+                                          unsigned long long* s_esum) {
+  const ctrl_head h = load_ctrl_head(c);
+  plan_in in;
+  in.done = h.done;
+  in.level = external_control ? h.level : h.level + 1;
+  in.nt = h.nt(in.level & 1);
+  in.mode = h.mode;
+  in.R = h.bu_R;
+  in.T = h.bu_T;
+  plan_body<BLOCK>(a, c, external_control, s_wave, s_esum, in);
+}
+
 static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, int external_control) {
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
   __shared__ unsigned long long s_esum;
@@ -207,6 +256,10 @@ __device__ __forceinline__ void emit_tile(const pipe_args& a, ctrl_t* c, int q, 
   const int tid = threadIdx.x;
   const int lane = dev::lane_id();
   const int wid = tid >> 6;
+  // the reservation atomic is issued FIRST so that it travels together with the degree loads
+  // (one round trip instead of two on the tail of every small level)
+  int fresh = -1;
+  if (tid == 0 && s_res[0] == s_res[1]) fresh = atomicAdd(&c->n_tiles[q], TILE_RESERVE);
   int x = -1, deg = 0;
   if (tid < n) {
     x = s_out[lo + tid];
@@ -219,9 +272,9 @@ __device__ __forceinline__ void emit_tile(const pipe_args& a, ctrl_t* c, int q, 
     int tot = 0;
 #pragma unroll
     for (int i = 0; i < ADV_BLOCK / 64; ++i) tot += s_wave[i];
-    if (s_res[0] == s_res[1]) {
-      s_res[0] = atomicAdd(&c->n_tiles[q], TILE_RESERVE);
-      s_res[1] = s_res[0] + TILE_RESERVE;
+    if (fresh >= 0) {
+      s_res[0] = fresh;
+      s_res[1] = fresh + TILE_RESERVE;
     }
     const int tix = s_res[0]++;
     a.tile_sums[tix] = tot;
@@ -249,6 +302,16 @@ __device__ __forceinline__ void emit_full_tiles(const pipe_args& a, ctrl_t* c, i
   const int lane = dev::lane_id();
   const int wid = tid >> 6;
   int x[MAX_EMIT], deg[MAX_EMIT];
+  // tile indices: what is left of the current reservation first, then ONE new reservation, whose
+  // atomic is issued before the degree loads so that both travel together
+  int fresh = -1, take = 0;
+  if (tid == 0) {
+    const int have = s_res[1] - s_res[0];
+    if (have < k) {
+      take = (k - have + TILE_RESERVE - 1) / TILE_RESERVE * TILE_RESERVE;
+      fresh = atomicAdd(&c->n_tiles[q], take);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < MAX_EMIT; ++j) x[j] = s_out[lo + (j < k ? j : 0) * TILE + tid];
 #pragma unroll
@@ -259,14 +322,11 @@ __device__ __forceinline__ void emit_full_tiles(const pipe_args& a, ctrl_t* c, i
     if (lane == 0) es.sum[j][wid] = t;
   }
   if (tid == 0) {
-    // tile indices: what is left of the current reservation first, then ONE new reservation
     int have = s_res[1] - s_res[0];
     int j = 0;
     for (; j < k && have > 0; ++j, --have) es.tix[j] = s_res[0]++;
     if (j < k) {
-      const int need = k - j;
-      const int take = (need + TILE_RESERVE - 1) / TILE_RESERVE * TILE_RESERVE;
-      int base = atomicAdd(&c->n_tiles[q], take);
+      int base = fresh;
       s_res[1] = base + take;
       for (; j < k; ++j) es.tix[j] = base++;
       s_res[0] = base;
@@ -629,24 +689,25 @@ __device__ __forceinline__ void tiny_hand_back(const pipe_args& a, ctrl_t* c, co
   __syncthreads();  // a plan/decide step may follow in the same workgroup
 }
 
-// Returns 1 when the search finished inside (done is set), 0 when the regular per-level
-// path has to continue (nothing done, or frontier handed back as tiles).
+// Returns 1 when the search finished inside (done is set); 0 when it declined without touching
+// anything; 2 when it ran levels and handed the frontier back as tiles (control block changed):
+// for 0 and 2 the regular per-level path has to continue.
 template <class Policy>
 __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol, int do_enabled,
-                                                long long n_edges_total, tiny_smem<Policy>& sm) {
+                                                long long n_edges_total, tiny_smem<Policy>& sm, const ctrl_head& h) {
   constexpr int CAP = tiny_smem<Policy>::CAP;
   constexpr bool STATELESS = tiny_smem<Policy>::STATELESS;
   constexpr int TINY_ITEMS = tiny_smem<Policy>::ITEMS;
   ctrl_t* c = a.ctrl;
   const int tid = threadIdx.x;
   const int lane = dev::lane_id();
-  if (c->done) return 1;
-  if (c->frontier_bitmap) return 0;  // partitioned BFS: the frontier is a bitmap right now
-  int level = c->level + 1;          // next level to run
+  if (h.done) return 1;
+  if (h.frontier_bitmap) return 0;  // partitioned BFS: the frontier is a bitmap right now
+  int level = h.level + 1;          // next level to run
   {
     // ---- entry: gather the tiled queue into LDS ---------------------------------------
     const int p = level & 1;
-    const int nt = c->n_tiles[p];
+    const int nt = h.nt(p);
     // sparse tiles are common (every producing workgroup leaves a partial tile and reserves
     // tile ids four at a time): go by the VERTEX count, over a bounded number of tiles
     if (nt > TINY_MAX_TILES) return 0;
@@ -700,7 +761,7 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
   int sel = 0;
   if constexpr (policy_has_accept<Policy>::value) pol.tiny_enter();
   long long edges_done = 0, vertices_done = 0;
-  const long long edges_before = c->edges_visited;
+  const long long edges_before = h.edges_visited;
   constexpr int PER = CAP / TINY_THREADS;  // frontier slots per thread in the degree scan
   for (;;) {
     const int* cur = sm.buf[sel];
@@ -720,7 +781,7 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
       // the tile array): back to the regular kernels
       if constexpr (policy_has_accept<Policy>::value) pol.tiny_hand_back(level, cur, n, CAP, a.frontier[level & 1]);
       tiny_hand_back<Policy>(a, c, cur, n, level, edges_before + edges_done, vertices_done, sm);
-      return 0;
+      return 2;
     }
     // ---- degrees + exclusive scan (each thread owns PER consecutive slots) ----------
     // all row-offset loads of the thread in flight together: slots past n read vertex cur[0]
@@ -776,7 +837,7 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
         c->vertices_visited += vertices_done;
       }
       __syncthreads();  // a plan/decide step may follow in the same workgroup
-      return 0;
+      return 2;
     }
     // ---- the level itself -----------------------------------------------------------
     pol.set_level(level);
@@ -855,7 +916,7 @@ template <class Policy>
 __global__ __launch_bounds__(TINY_THREADS) void tiny_levels_kernel(pipe_args a, Policy pol, int do_enabled,
                                                                    long long n_edges_total) {
   __shared__ tiny_smem<Policy> sm;
-  (void)tiny_levels_body(a, pol, do_enabled, n_edges_total, sm);
+  (void)tiny_levels_body(a, pol, do_enabled, n_edges_total, sm, load_ctrl_head(a.ctrl));
 }
 
 }  // namespace grx

@@ -199,11 +199,12 @@ __global__ __launch_bounds__(PLAN_BLOCK) void sssp_nf_head_kernel(pipe_args a, s
   __shared__ int s_go;
   ctrl_t* c = a.ctrl;
   const int tid = threadIdx.x;
-  const int done = c->done;
+  const ctrl_head h = load_ctrl_head(c);  // one batch of loads, together with nf_split
   const int resume = c->nf_split;  // the previous group rebuilt the frontier of c->level from the pile
-  const int level = resume ? c->level : c->level + 1;
+  const int done = h.done;
+  const int level = resume ? h.level : h.level + 1;
   const int p = level & 1;
-  const int nt = c->n_tiles[p];
+  const int nt = h.nt(p);
   if (tid == 0) { s_n = 0; s_esum = 0; s_go = 0; }
   __syncthreads();
   if (done) return;
@@ -257,7 +258,16 @@ __global__ __launch_bounds__(PLAN_BLOCK) void sssp_nf_head_kernel(pipe_args a, s
     }
   }
   __syncthreads();
-  if (s_go) plan_body<PLAN_BLOCK>(a, c, 2, s_wave, &s_esum);
+  if (s_go) {
+    plan_in in;
+    in.done = 0;
+    in.level = level;
+    in.nt = nt;  // resume: the tiles the split emitted last launch; otherwise the advance's output
+    in.mode = 0;
+    in.R = 0;
+    in.T = 0;
+    plan_body<PLAN_BLOCK>(a, c, 2, s_wave, &s_esum, in);
+  }
 }
 
 // Pull the bucket [lo, hi) out of the far pile: entries whose CURRENT label lies in the
@@ -378,10 +388,20 @@ __global__ __launch_bounds__(PLAN_BLOCK) void sssp_head_kernel(pipe_args a, sssp
   __shared__ unsigned long long s_esum;
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
   static_assert(TINY_THREADS == PLAN_BLOCK, "head kernel runs both bodies");
-  if (tiny_levels_body(a, pol, 0, n_edges, tsm)) return;
+  const ctrl_head h0 = load_ctrl_head(a.ctrl);
+  const int t = tiny_levels_body(a, pol, 0, n_edges, tsm, h0);
+  if (t == 1) return;
+  const ctrl_head h = t == 2 ? load_ctrl_head(a.ctrl) : h0;
   if (threadIdx.x == 0) s_esum = 0ull;
   __syncthreads();
-  plan_body<PLAN_BLOCK>(a, a.ctrl, 0, s_wave, &s_esum);
+  plan_in in;
+  in.done = h.done;
+  in.level = h.level + 1;
+  in.nt = h.nt(in.level & 1);
+  in.mode = 0;
+  in.R = 0;
+  in.T = 0;
+  plan_body<PLAN_BLOCK>(a, a.ctrl, 0, s_wave, &s_esum, in);
 }
 
 // out[0] = sum of weights; bits[0] / bits[1] = min / max weight as ordered uints (w >= 0)
