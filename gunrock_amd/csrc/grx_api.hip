@@ -218,6 +218,7 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->xb_blocks) (void)hipFree(g->xb_blocks);
   if (g->xb_piece) (void)hipFree(g->xb_piece);
   if (g->xb_long) (void)hipFree(g->xb_long);
+  if (g->xb_perm) (void)hipFree(g->xb_perm);
   delete g;
   return GRX_SUCCESS;
 }

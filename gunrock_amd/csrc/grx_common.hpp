@@ -171,6 +171,7 @@ struct grx_graph {
   void* xb_blocks = nullptr;    // int4 row blocks, the NB lists concatenated
   int32_t* xb_piece = nullptr;
   int32_t* xb_long = nullptr;   // {block-major row index, first piece, n pieces}
+  int32_t* xb_perm = nullptr;   // hub-first relabelling of the gathered vector (position of v's value in x[])
   int32_t xb_begin[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int32_t n_xb_pieces = 0, n_xb_long = 0;
   bool has_xb = false;

@@ -17,6 +17,7 @@
 #include <gunrock/hip/scan.hxx>
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace grx {
 
@@ -55,6 +56,7 @@ struct pr_args {
   int32_t xb_begin[9];
   int32_t n_xb_long;
   float* partial_y;      // NB * V partial sums, block-major
+  const int32_t* x_perm; // XCD-blocked variant: position of vertex v's value in x[] (null: v)
 };
 
 constexpr int XB = 8;  // source blocks == XCDs
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(PR_BLOCK) void pr_prepare_kernel(pr_args a) {
   float acc = 0.0f;
   for (int64_t v = lo + threadIdx.x; v < hi; v += PR_BLOCK) {
     const float pv = a.p[v], iwv = a.iw[v];
-    a.x[v] = pv * iwv;
+    a.x[a.x_perm ? a.x_perm[v] : v] = pv * iwv;
     acc += (iwv == 0.0f) ? a.alpha * pv : 0.0f;
   }
   acc = dev::wave_sum_f(acc);
@@ -325,29 +327,31 @@ __global__ __launch_bounds__(256) void pr_combine_kernel(pr_args a, int iter) {
 }
 
 // bucket in-edges by (source block, destination): counts, then fill with cursors
+// `perm` (may be null) relabels the SOURCES: in-edges are bucketed by, and store, perm[u].
 __global__ void xb_count_kernel(const int32_t* __restrict__ ro, const int32_t* __restrict__ ci, int32_t V,
-                                int32_t per_block, int32_t* cnt) {
+                                int32_t per_block, const int32_t* __restrict__ perm, int32_t* cnt) {
   const int lane = dev::lane_id();
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t u = wave; u < V; u += nwaves) {
-    const int s = (int)(u / per_block);
+    const int s = (int)((perm ? perm[u] : (int32_t)u) / per_block);
     const int b = ro[u], e = ro[u + 1];
     for (int k = b + lane; k < e; k += 64) atomicAdd(&cnt[(size_t)s * ((size_t)V + 1) + ci[k]], 1);
   }
 }
 __global__ void xb_fill_kernel(const int32_t* __restrict__ ro, const int32_t* __restrict__ ci,
-                               const float* __restrict__ w, int32_t V, int32_t per_block, int32_t* cursor,
-                               int32_t* out_ci, float* out_w) {
+                               const float* __restrict__ w, int32_t V, int32_t per_block,
+                               const int32_t* __restrict__ perm, int32_t* cursor, int32_t* out_ci, float* out_w) {
   const int lane = dev::lane_id();
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t u = wave; u < V; u += nwaves) {
-    const int s = (int)(u / per_block);
+    const int32_t pu = perm ? perm[u] : (int32_t)u;
+    const int s = (int)(pu / per_block);
     const int b = ro[u], e = ro[u + 1];
     for (int k = b + lane; k < e; k += 64) {
       const int pos = atomicAdd(&cursor[(size_t)s * ((size_t)V + 1) + ci[k]], 1);
-      out_ci[pos] = (int32_t)u;
+      out_ci[pos] = pu;
       if (out_w) out_w[pos] = w[k];
     }
   }
@@ -425,17 +429,38 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   const int32_t per_block = (V + XB - 1) / XB;
   hipStream_t s = ctx->stream;
   int32_t *cnt = nullptr, *bs = nullptr;
+  // HUB-FIRST RELABELLING OF THE SOURCES.  The gathers of a bucket go to one slice of x[] (V/8
+  // floats); on a scale-free graph most of them go to a few thousand hub vertices, which the
+  // Graph500 permutation scatters one per cache line.  Sources are ranked by out-degree (= how
+  // often they are gathered) and rank r goes to block r % 8, position r / 8: every block gets an
+  // equal share of the hubs, packed at the START of its slice, 32 hub values per 128-byte line --
+  // a hot set of a few KB that stays in the CU's 32 KB L1 instead of costing an L2 request per
+  // gather.  Only the position of x values changes; rows, and the result vector, keep their ids.
+  if (!getenv("GRX_PR_NOPERM")) {
+    std::vector<int32_t> h_ro((size_t)V + 1);
+    GRX_HIP(hipMemcpyAsync(h_ro.data(), g->ro, ((size_t)V + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    GRX_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t> order((size_t)V);
+    for (int32_t v = 0; v < V; ++v) order[(size_t)v] = v;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+      return h_ro[(size_t)x + 1] - h_ro[(size_t)x] > h_ro[(size_t)y + 1] - h_ro[(size_t)y];
+    });
+    std::vector<int32_t> perm((size_t)V);
+    for (int32_t r = 0; r < V; ++r) perm[(size_t)order[(size_t)r]] = (r % XB) * per_block + r / XB;
+    GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_perm), (size_t)V * sizeof(int32_t)));
+    GRX_HIP(hipMemcpy(g->xb_perm, perm.data(), (size_t)V * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ro), (n_off + 2) * sizeof(int32_t)));
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ci), (size_t)E * sizeof(int32_t)));
   if (g->w) GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_w), (size_t)E * sizeof(float)));
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&cnt), (n_off + 2) * sizeof(int32_t)));
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&bs), ((size_t)scan_num_blocks((int64_t)n_off) + 2) * sizeof(int32_t)));
   GRX_HIP(hipMemsetAsync(cnt, 0, (n_off + 2) * sizeof(int32_t), s));
-  hipLaunchKernelGGL(xb_count_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, V, per_block, cnt);
+  hipLaunchKernelGGL(xb_count_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, V, per_block, g->xb_perm, cnt);
   exclusive_scan_i32(s, cnt, (int64_t)n_off, g->xb_ro, bs);
   GRX_HIP(hipMemcpyAsync(cnt, g->xb_ro, n_off * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(xb_fill_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, g->w, V, per_block, cnt, g->xb_ci,
-                     g->xb_w);
+  hipLaunchKernelGGL(xb_fill_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, g->w, V, per_block, g->xb_perm, cnt,
+                     g->xb_ci, g->xb_w);
   std::vector<int32_t> off(n_off + 1);
   GRX_HIP(hipMemcpyAsync(off.data(), g->xb_ro, (n_off + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   GRX_HIP(hipStreamSynchronize(s));
@@ -526,7 +551,7 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
 
   const size_t V = (size_t)g->V;
   const int n_partial = std::min<int>(2048, (int)((V + PR_BLOCK - 1) / PR_BLOCK));
-  GRX_HIP(ctx->fbuf[0].reserve(V * sizeof(float)));  // x
+  GRX_HIP(ctx->fbuf[0].reserve(((V + XB - 1) / XB) * XB * sizeof(float)));  // x (permuted positions reach 8 * ceil(V / 8))
   GRX_HIP(ctx->fbuf[1].reserve(V * sizeof(float)));  // iweights
   GRX_HIP(ctx->fbuf[2].reserve(((size_t)n_partial + 16) * sizeof(float)));
   GRX_HIP(ctx->fbuf[3].reserve(((size_t)std::max(g->n_pr_pieces, g->n_xb_pieces) + 16) * sizeof(float)));
@@ -555,6 +580,7 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   for (int i = 0; i <= XB; ++i) a.xb_begin[i] = g->xb_begin[i];
   a.n_xb_long = g->n_xb_long;
   a.partial_y = xcd_blocked ? ctx->far[0].as<float>() : nullptr;
+  a.x_perm = xcd_blocked ? g->xb_perm : nullptr;
 
   // problem.reset() (pr.hxx:65-93), outside the timed region as in the reference
   GRX_HIP(fill_f32(s, d_p, (float)(1.0 / (double)g->V), g->V));
