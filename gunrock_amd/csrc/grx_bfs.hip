@@ -301,7 +301,7 @@ struct level_build {
 };
 static level_build* level_kernel_build() {
   static level_build builds[2] = {{bfs_level_kernel<2>, 0}, {bfs_level_kernel<4>, 0}};
-  return &builds[env_int("GRX_BU_BATCH", 4) == 2 ? 0 : 1];
+  return &builds[env_int("GRX_BU_BATCH", 2) == 4 ? 1 : 0];
 }
 
 // Workgroups of the per-level kernel: exactly what is RESIDENT (persistent workgroups

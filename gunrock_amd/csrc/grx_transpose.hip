@@ -10,6 +10,10 @@
 #include "grx_engine.hpp"
 #include <gunrock/hip/scan.hxx>
 
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
+
 namespace grx {
 
 __global__ void tr_count_kernel(const int32_t* __restrict__ ci, int64_t E, int32_t* cnt) {
@@ -23,12 +27,13 @@ __global__ void tr_count_kernel(const int32_t* __restrict__ ci, int64_t E, int32
 // claimed with an atomic cursor, so a per-column sort follows.
 __global__ void tr_fill_kernel(const int32_t* __restrict__ ro, const int32_t* __restrict__ ci,
                                const float* __restrict__ w, int32_t V, int32_t* cursor,
-                               int32_t* t_ci, float* t_w) {
+                               int32_t* t_ci, float* t_w, int32_t deg_lo, int32_t deg_hi) {
   const int lane = dev::lane_id();
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t v = wave; v < V; v += nwaves) {
     const int b = ro[v], e = ro[v + 1];
+    if (e - b < deg_lo || e - b >= deg_hi) continue;  // this pass places sources of another degree class
     for (int k = b + lane; k < e; k += 64) {
       const int dst = ci[k];
       const int pos = atomicAdd(&cursor[dst], 1);
@@ -58,9 +63,19 @@ grx_status_t grx::graph_build_transpose(grx_context_t ctx, grx_graph_t g) {
   if (E > 0) hipLaunchKernelGGL(tr_count_kernel, dim3(2048), dim3(256), 0, s, g->ci, E, cnt);
   exclusive_scan_i32(s, cnt, (int64_t)V, g->t_ro, bs);
   GRX_HIP(hipMemcpyAsync(cnt, g->t_ro, ((size_t)V + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-  if (E > 0)
-    hipLaunchKernelGGL(tr_fill_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, g->w, V, cnt, g->t_ci,
-                       g->t_w);
+  if (E > 0) {
+    // HUBS FIRST inside every in-list: three passes over the sources by out-degree class (>= 16x the
+    // mean, >= the mean, the rest) share the column cursors, so a bottom-up BFS level -- which
+    // stops at the first in-neighbour found in the frontier -- meets the likeliest parents first.
+    const int32_t mean = (int32_t)std::max<int64_t>(1, E / std::max(1, V));
+    const bool tiers = getenv("GRX_TR_NOTIERS") == nullptr;
+    const int32_t bounds[4] = {INT32_MAX, tiers ? 16 * mean : 0, tiers ? mean : 0, 0};
+    for (int t = 0; t < 3; ++t) {
+      if (bounds[t] == bounds[t + 1]) continue;
+      hipLaunchKernelGGL(tr_fill_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, g->w, V, cnt, g->t_ci, g->t_w,
+                         bounds[t + 1], bounds[t]);
+    }
+  }
   GRX_HIP(hipStreamSynchronize(s));
   std::vector<int32_t> h_ro((size_t)V + 1);
   GRX_HIP(hipMemcpy(h_ro.data(), g->t_ro, ((size_t)V + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
