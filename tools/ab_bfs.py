@@ -77,8 +77,10 @@ if "do" in groups:
     for b in (2, 4):
         run("DO batch%d" % b, gr.optimized, env={"GRX_BU_BATCH": b})
 if "knobs" in groups:
-    for al in (6, 30):
-        run("DO alpha %d" % al, gr.optimized, env={"GRX_DO_ALPHA": al})
+    for bd in (32, 64, 128):
+        run("DO back_div %d" % bd, gr.optimized, env={"GRX_DO_BACK_DIV": bd})
+    for be in (8, 12):
+        run("DO beta %d" % be, gr.optimized, env={"GRX_DO_BETA": be})
     for pd in (1, 3):
         run("DO pace %d" % pd, gr.optimized, env={"GRX_PACE_DEPTH": pd}, profile=False)
 if "td" in groups:
