@@ -1,7 +1,7 @@
 """All BASELINE.json single-GPU configs in one run: ours (engine) and, when
 oracle/_ref/libgunrock_ref_gpu.so is present, the reference's own GPU path on the same
 arrays (test infrastructure; reporting only).  Prints one JSON object per config.
-    python tools/bench_all.py [bfs_lj] [sssp_road] [ssspu_road] [pr_kron] [bfs_road] [sssp_lj] [bfs_kron]"""
+    python tests/tools/bench_all.py [bfs_lj] [sssp_road] [ssspu_road] [pr_kron] [bfs_road] [sssp_lj] [bfs_kron]"""
 import json
 import os
 import sys
@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gunrock_amd as gr  # noqa: E402

@@ -1,9 +1,9 @@
 """Ingest timing: write an R-MAT .mtx, load it with the engine's loader
 (parallel line parser + parallel stable COO->CSR) and with the reference's own loader
 (oracle/_ref/libgunrock_ref_cpu.so, compiled from /root/reference sources) when present.
-    python tools/bench_ingest.py [entries, default 8000000] [symmetric 0|1]"""
+    python tests/tools/bench_ingest.py [entries, default 8000000] [symmetric 0|1]"""
 import os, sys, time, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import gunrock_amd as gr
