@@ -27,6 +27,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 namespace grx {
 
@@ -508,7 +509,7 @@ extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
     return fail(GRX_ERROR_UNSUPPORTED, "Load balance type not supported.");
   GRX_HIP(hipSetDevice(ctx->device));
 
-  // bucket width: 32 x (mean weight) / (mean degree)  (Davidson et al.); unit-weight
+  // bucket width: 128 x (mean weight) / (mean degree)  (4 x Davidson et al.'s constant, see below); unit-weight
   // graphs (values == NULL) are already level-synchronous => plain schedule
   bool near_far = g->w != nullptr && g->E > 0 && !(opt.engine_flags & GRX_FLAG_SSSP_PLAIN);
   float delta = FLT_MAX;
@@ -533,7 +534,15 @@ extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (g->uniform_weights) near_far = false;
     const double mean_w = g->weight_sum / (double)g->E;
     const double mean_deg = std::max(1.0, (double)g->E / (double)std::max(1, g->V));
-    const double dlt = 32.0 * mean_w / mean_deg;
+    // GRX_NF_DELTA_SCALE: tuning knob (bucket width multiplier)
+    const char* dsc = getenv("GRX_NF_DELTA_SCALE");
+    // Width 128 x mean weight / mean degree: four times Davidson et al.'s constant.  Measured on the
+    // weighted road stand-in (tools/ab_sssp_delta.py), width / iterations / relaxations / time:
+    //   16: 10417 / 65 M / 192 ms   32: 8603 / 74 M / 164 ms   64: 7463 / 92 M / 150 ms
+    //   128: 6749 / 130 M / 143 ms   256: 6313 / 213 M / 144 ms
+    // -- an iteration is ~19 us of launch and latency, so fewer, fatter iterations win until the
+    // extra relaxations catch up.
+    const double dlt = 128.0 * mean_w / mean_deg * ((dsc && atof(dsc) > 0.0) ? atof(dsc) : 1.0);
     if (!(mean_w > 0.0) || !std::isfinite(dlt) || dlt <= 0.0) near_far = false;  // zero / negative weights
     // dense, low-diameter graphs finish in a dozen levels: label-correcting wastes little
     // there and the pile handling only costs (measured: LJ stand-in 4.8 ms plain vs 7.2 ms)
