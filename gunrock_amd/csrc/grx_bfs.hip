@@ -242,16 +242,10 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
   td_smem& sm = *reinterpret_cast<td_smem*>(lds_raw);
   bu_smem& bsm = *reinterpret_cast<bu_smem*>(lds_raw);
   ctrl_t* c = a.ctrl;
-  // everything this launch needs from the control block in ONE batch of loads (read one by one
-  // behind the early-exit branches they were three to four dependent round trips, a third of a
-  // small level's kernel time)
-  const int4 h0 = *reinterpret_cast<const int4*>(c);        // level, done, n_tiles[0..1]
-  const int4 h1 = *(reinterpret_cast<const int4*>(c) + 1);  // n_items[0..1], total_chunks, pad
-  const int mode_now = c->mode;
-  static_assert(offsetof(ctrl_t, level) == 0 && offsetof(ctrl_t, done) == 4 && offsetof(ctrl_t, total_chunks) == 24,
-                "control block header layout");
-  if (h0.y) return;
-  const int level = h0.x;
+  const level_head h = load_level_head(c);  // one batch of loads
+  if (h.done) return;
+  const int level = h.level;
+  const int mode_now = h.mode;
   if (d.enabled) {
     uint4* z = reinterpret_cast<uint4*>(pick3(d.fbits, (level + 2) % 3));
     const uint4* fc = reinterpret_cast<const uint4*>(pick3(d.fbits, level % 3));
@@ -273,7 +267,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
   if (mode_now == 0) {
     pol.ctrl = c;
     pol.set_level(level);
-    advance_block<bfs_policy, false>(a, c, pol, sm, level & 1, blockIdx.x, gridDim.x, h1.z, a.chunk_tile);
+    advance_block<bfs_policy, false>(a, c, pol, sm, level & 1, blockIdx.x, gridDim.x, h.total_chunks, a.chunk_tile);
   } else {
     bfs_bottomup_block<BATCH, true>(a, d, c, bsm);
   }

@@ -101,6 +101,31 @@ __device__ __forceinline__ ctrl_head load_ctrl_head(const ctrl_t* c) {
   return h;
 }
 
+// What a LEVEL kernel needs from the control block, as relaxed agent-scope atomic loads: unlike
+// plain loads the compiler may not sink them behind the early-exit branch, so all of them are in
+// flight at once (plain loads were split into {level, done} -> branch -> {total_chunks, mode}: two
+// dependent round trips in every workgroup of every level).
+struct level_head {
+  int level, done, nt0, nt1, total_chunks, mode;
+};
+__device__ __forceinline__ level_head load_level_head(const ctrl_t* c) {
+  const unsigned long long ld = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&c->level),
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long nt = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&c->n_tiles[0]),
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  level_head h;
+  const int tc = __hip_atomic_load(&c->total_chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int md = __hip_atomic_load(&c->mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the values are wave-uniform: hand them to the scalar unit (uniform branches, SGPR arithmetic)
+  h.total_chunks = __builtin_amdgcn_readfirstlane(tc);
+  h.mode = __builtin_amdgcn_readfirstlane(md);
+  h.level = __builtin_amdgcn_readfirstlane((int)(unsigned)ld);
+  h.done = __builtin_amdgcn_readfirstlane((int)(ld >> 32));
+  h.nt0 = __builtin_amdgcn_readfirstlane((int)(unsigned)nt);
+  h.nt1 = __builtin_amdgcn_readfirstlane((int)(nt >> 32));
+  return h;
+}
+
 // state a plan step works from (already known to its caller, or taken from a ctrl_head)
 struct plan_in {
   int done;
@@ -597,11 +622,12 @@ template <class Policy>
 __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy pol) {
   __shared__ advance_smem<Policy> sm;
   ctrl_t* c = a.ctrl;
-  if (c->done) return;
-  if (c->mode != 0) return;  // this level runs bottom-up
-  const int p = c->level & 1;
+  const level_head h = load_level_head(c);
+  if (h.done) return;
+  if (h.mode != 0) return;  // this level runs bottom-up
+  const int p = h.level & 1;
   pol.begin(c);
-  advance_block<Policy, false>(a, c, pol, sm, p, blockIdx.x, gridDim.x, c->total_chunks, a.chunk_tile);
+  advance_block<Policy, false>(a, c, pol, sm, p, blockIdx.x, gridDim.x, h.total_chunks, a.chunk_tile);
 }
 
 // ---------------------------------------------------------------------------

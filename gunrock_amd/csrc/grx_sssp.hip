@@ -372,13 +372,15 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, s
   __shared__ advance_smem<sssp_nf_policy> sm;
   __shared__ split_smem ssm;
   ctrl_t* c = a.ctrl;
-  if (c->done) return;
-  if (c->nf_split) {
+  const level_head h = load_level_head(c);  // one batch of loads, with nf_split
+  const int split = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&c->nf_split, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  if (h.done) return;
+  if (split) {
     sssp_split_body(a, nf, pol.dist, ssm);
     return;
   }
   pol.begin(c);
-  advance_block<sssp_nf_policy, false>(a, c, pol, sm, c->level & 1, blockIdx.x, gridDim.x, c->total_chunks,
+  advance_block<sssp_nf_policy, false>(a, c, pol, sm, h.level & 1, blockIdx.x, gridDim.x, h.total_chunks,
                                        a.chunk_tile);
 }
 
