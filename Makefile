@@ -15,7 +15,10 @@ bin/%: examples/algorithms/%/*.cu $(HDRS) | lib
 bin/test_operators: tests/cpp/test_operators.cu $(HDRS)
 	@mkdir -p bin
 	$(HIPCC) $(FLAGS) -DGUNROCK_HEADER_ONLY $< -o $@
-header_only: bin/bfs_generic bin/sssp_generic bin/pr_generic bin/test_operators
+bin/test_host_utils: tests/cpp/test_host_utils.cu $(HDRS)
+	@mkdir -p bin
+	$(HIPCC) $(FLAGS) $< -o $@ -lpthread
+header_only: bin/bfs_generic bin/sssp_generic bin/pr_generic bin/test_operators bin/test_host_utils
 bin/%_generic: examples/algorithms/%/*.cu $(HDRS)
 	@mkdir -p bin
 	$(HIPCC) $(FLAGS) -DGUNROCK_HEADER_ONLY $< -o $@

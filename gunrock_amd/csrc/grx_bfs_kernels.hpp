@@ -411,7 +411,7 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
     long long td = 0, tp = 0;
 #pragma unroll
     for (int i = 0; i < ADV_BLOCK / 64; ++i) { tc += s_cnt[i]; td += s_deg[i]; to += s_open[i]; tp += s_probe[i]; }
-    // plain stores; bfs_decide_kernel of the next level reduces them
+    // plain stores; the head kernel of the next level reduces them
     // word 0: discoveries (low 40 bits) | non-empty tiles of this workgroup's static range (QUEUE)
     d.bu_part[4 * blockIdx.x] = (long long)tc | (QUEUE ? ((long long)sm.tiles_out << 40) : 0ll);
     d.bu_part[4 * blockIdx.x + 1] = td;

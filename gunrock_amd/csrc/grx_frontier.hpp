@@ -397,7 +397,7 @@ __device__ __forceinline__ void release_tiles(const pipe_args& a, const int* s_r
 //                                                     2 => nbr goes to the policy's SIDE pile
 //                                                     (policies with `has_side`), 0 => dropped
 //   int  visit(src_state, int nbr, int e)             precheck-survivor -> code, the whole chain for
-//                                                     one edge (tiny_levels_kernel)
+//                                                     one edge (tiny_levels_body)
 //   side pile (has_side): side_reserve(ctrl, n) -> base index or -1, side_store(i, v) -> key,
 //                         side_commit(min key of a wave)
 //
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void advance_kernel(pipe_args a, Policy 
 // head + level kernel).  It absorbs the first and last levels of scale-free searches and whole
 // chain-like searches.  It starts from the tiled queue the regular kernels left, and when a
 // level is too big (or could switch direction) it hands the frontier back as tiles and leaves
-// the control block exactly as plan_kernel / bfs_decide_kernel expect it.  <<<1, 1024>>>
+// the control block exactly as the plan / decide step of the head kernels expects it.  <<<1, 1024>>>
 // The edges of a level are processed with the same phase structure as advance_block (all
 // loads of a phase in flight together).
 // SIZING (measured, road stand-in, 4.6 k vertices / 11 k edges per level on average): raising

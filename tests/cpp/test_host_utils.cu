@@ -1,0 +1,76 @@
+// Host-only checks of the header utilities that need no GPU: operators::batch::execute and
+// generate::random (reference: framework/operators/batch/batch.hxx:70-94,
+// algorithms/generate/random.hxx:20-52).  Built with hipcc, runs on the CPU.
+#include <gunrock/algorithms/generate/random.hxx>
+#include <gunrock/framework/operators/batch/batch.hxx>
+
+#include <atomic>
+#include <cstdio>
+#include <stdexcept>
+#include <vector>
+
+static int failures = 0;
+#define CHECK(cond)                                               \
+  do {                                                            \
+    if (!(cond)) {                                                \
+      std::printf("CHECK FAILED %s:%d %s\n", __FILE__, __LINE__, #cond); \
+      ++failures;                                                 \
+    } else {                                                      \
+      std::printf("CHECK ok: %s\n", #cond);                       \
+    }                                                             \
+  } while (0)
+
+int main() {
+  using namespace gunrock;
+  // every job runs exactly once, whatever the pool size
+  {
+    const std::size_t n = 1000;
+    std::vector<std::atomic<int>> hits(n);
+    for (auto& h : hits) h = 0;
+    float total = -1.0f;
+    operators::batch::execute([&](std::size_t j) -> float { ++hits[j]; return (float)j; }, n, &total);
+    bool once = true;
+    for (auto& h : hits) once = once && h.load() == 1;
+    CHECK(once);
+    CHECK(total >= 0.0f);
+  }
+  // zero jobs: returns, elapsed written
+  {
+    float total = -1.0f;
+    operators::batch::execute([](std::size_t) -> float { return 1.0f; }, 0, &total);
+    CHECK(total >= 0.0f);
+  }
+  // an exception in a job surfaces in the caller after the batch drained
+  {
+    float total = 0.0f;
+    bool thrown = false;
+    std::atomic<int> ran{0};
+    try {
+      operators::batch::execute(
+          [&](std::size_t j) -> float {
+            ++ran;
+            if (j == 3) throw std::runtime_error("job 3");
+            return 0.0f;
+          },
+          16, &total);
+    } catch (const std::runtime_error&) {
+      thrown = true;
+    }
+    CHECK(thrown);
+    CHECK(ran.load() == 16);
+  }
+  // uniform_distribution fills the whole vector inside [begin, end) and is reproducible
+  {
+    std::vector<float> a(4096), b(4096);
+    generate::random::uniform_distribution(a, 2.0f, 3.0f);
+    generate::random::uniform_distribution(b, 2.0f, 3.0f);
+    bool in_range = true;
+    for (float x : a) in_range = in_range && x >= 2.0f && x < 3.0f;
+    CHECK(in_range);
+    CHECK(a == b);
+    const float r = generate::random::get_random<float>(5.0f, 6.0f);
+    CHECK(r >= 5.0f && r <= 6.0f);
+  }
+  std::printf(failures ? "FAILED\n" : "ALL CHECKS PASSED\n");
+  return failures ? 1 : 0;
+}

@@ -63,6 +63,13 @@ def test_drivers_build_and_help(binaries):
     assert r.returncode != 0
 
 
+def test_host_utilities_batch_and_random(binaries):
+    """operators::batch::execute and generate::random need no GPU: every job runs once, an
+    exception surfaces after the batch drained, random fills are in range and reproducible."""
+    r = run([os.path.join(BIN, "test_host_utils")], check=False)
+    assert r.returncode == 0 and "ALL CHECKS PASSED" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/include/gunrock"), reason="needs the reference tree")
 def test_reference_sources_compile_against_our_headers(binaries):
     for name in ("ref_bfs", "ref_sssp", "ref_pr", "refalg_bfs", "refalg_sssp", "refalg_pr",
