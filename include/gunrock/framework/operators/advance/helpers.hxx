@@ -10,6 +10,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include <gunrock/cuda/context.hxx>
 #include <gunrock/framework/operators/configs.hxx>
 #include <gunrock/hip/scan.hxx>
@@ -114,6 +116,14 @@ std::size_t compute_output_length(graph_t& G, frontier_t* input, gcuda::standard
     edge_t* data() { return p; }
   } v{tmp, n + 2};
   return compute_output_offsets(G, input, v, context, false);
+}
+
+// reference spelling (helpers.hxx:127-131 takes the frontier by reference)
+template <typename graph_t, typename frontier_t,
+          typename = decltype(std::declval<frontier_t&>().get_number_of_elements())>
+std::size_t compute_output_length(graph_t& G, frontier_t& input, gcuda::standard_context_t& context,
+                                  bool graph_as_frontier = false) {
+  return compute_output_length(G, &input, context, graph_as_frontier);
 }
 
 }  // namespace advance
