@@ -217,7 +217,30 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
   long long my_probes = 0;  // in-edges actually read (roofline accounting)
   int my_open = 0;
   constexpr int SERIAL = 8;
+  // PREFILTER (single GPU): late bottom-up levels find most 64-vertex chunks completely closed, and
+  // walking them round by round costs one dependent round trip per round for nothing.  Lane l looks
+  // at chunk slot l of this wave (round l / BATCH, chunk l % BATCH) -- ONE round trip for all rounds
+  // -- and the ballot tells which rounds have an open vertex at all.  Closed chunks need no output:
+  // the next-frontier bitmap was cleared by the previous level's sweep.
+  unsigned long long live_slots = ~0ull;
+  if (d.rot3 && iters * BATCH <= 64) {
+    const int r = lane / BATCH, j = lane % BATCH;
+    const int ch = wave * BATCH + r * n_waves * BATCH + j;
+    bool live = false;
+    if (r < iters && ch < n_chunks) {
+      const unsigned long long v = *reinterpret_cast<const unsigned long long*>(d.visited + 2 * ch) |
+                                   *reinterpret_cast<const unsigned long long*>(fin + 2 * ch);
+      unsigned long long in_range = ~0ull;  // lanes of the last chunk beyond V are never open
+      const long long first = (long long)vbase + (long long)ch * 64;
+      if (first + 64 > (long long)a.V) in_range = first >= (long long)a.V ? 0ull : ((1ull << ((long long)a.V - first)) - 1ull);
+      live = (~v & in_range) != 0ull;
+    }
+    live_slots = dev::ballot(live);
+  }
+  int round = -1;
   for (int ch0 = wave * BATCH; ch0 < n_chunks; ch0 += n_waves * BATCH) {
+    ++round;
+    if (round * BATCH < 64 && ((live_slots >> (round * BATCH)) & ((1ull << BATCH) - 1ull)) == 0ull) continue;
     unsigned long long vis[BATCH];
     int b[BATCH], e[BATCH], odeg[BATCH];
     bool open[BATCH], found[BATCH];
