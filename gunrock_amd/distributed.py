@@ -166,6 +166,52 @@ def _all_reduce_stats(dist, engine):
     engine.stats_global.copy_(t)
 
 
+def _level_group(engine, dist):
+    """One level group: pre -> exchange -> post -> statistics all-reduce (all stream-ordered)."""
+    works = []
+    for part in range(engine.parts):
+        engine.pre(part)  # part 0: head + prep + advance of half 0; part 1: advance of half 1
+        send, recv = engine.part_buffers(part)
+        # asynchronous: the compute stream goes on with the next half while RCCL
+        # moves this half's bitmaps on its own stream
+        works.append(_all_to_all(dist, send, recv, async_op=engine.parts > 1))
+    for w in works:
+        if w is not None:
+            w.wait()  # stream-level wait, the host does not block
+    engine.post()
+    _all_reduce_stats(dist, engine)
+
+
+def _group_graph(engine, dist, key):
+    """A level group takes no level-dependent argument, so it can be captured ONCE into a HIP graph
+    -- five kernel launches and the two collectives (RCCL collectives are capturable) -- and every
+    later group is one graph launch: the host side of a level drops from seven Python / ctypes /
+    torch.distributed calls (~100 us) to one (~15 us), which is what bounds the search once the
+    exchange sits between the kernels.  Captured while no search is running (capture records, it does
+    not execute); the same on every rank.  Any failure falls back to eager calls for good."""
+    import os
+    torch = engine.torch
+    if getattr(engine, "_graph_failed", False) or os.environ.get("GRX_DIST_GRAPH", "1") == "0":
+        return None
+    if getattr(engine, "stream", None) is None or engine.parts != 1:
+        return None
+    if dist is not None and dist.get_world_size() > 1 and dist.get_backend() != "nccl":
+        return None
+    cached = getattr(engine, "_graph", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=engine.stream, capture_error_mode="thread_local"):
+            _level_group(engine, dist)
+        engine._graph = (key, g)
+        return g
+    except Exception:  # capture not possible here: eager from now on
+        engine._graph_failed = True
+        engine._graph = None
+        return None
+
+
 def bfs(engine, dist, source, distances, optimized=True, first_batch=4):
     """Partitioned BFS driven by this rank.  `distances`: full-size int32 tensor on the
     engine's device; on return its owned slice holds the depths.  `dist`: the
@@ -178,23 +224,22 @@ def bfs(engine, dist, source, distances, optimized=True, first_batch=4):
     with on_stream:
         engine.begin(source, distances, optimized)
         _all_reduce_stats(dist, engine)
+        key = (int(distances.data_ptr()), bool(optimized))
+        cached = getattr(engine, "_graph", None)
+        graph = cached[1] if (cached is not None and cached[0] == key) else None
         batch = first_batch
         while True:
             for _ in range(batch):
-                works = []
-                for part in range(engine.parts):
-                    engine.pre(part)  # part 0: head + prep + advance of half 0; part 1: advance of half 1
-                    send, recv = engine.part_buffers(part)
-                    # asynchronous: the compute stream goes on with the next half while RCCL
-                    # moves this half's bitmaps on its own stream
-                    works.append(_all_to_all(dist, send, recv, async_op=engine.parts > 1))
-                for w in works:
-                    if w is not None:
-                        w.wait()  # stream-level wait, the host does not block
-                engine.post()
-                _all_reduce_stats(dist, engine)
+                if graph is not None:
+                    graph.replay()
+                else:
+                    _level_group(engine, dist)
             done, _ = engine.poll()
             if done:
                 break
             batch = min(batch * 2, 32)
+        if graph is None:
+            # the search is over (every kernel of a further group would exit on `done`): record the
+            # group for the next search with the same label buffer and direction setting
+            _group_graph(engine, dist, key)
         return engine.end()

@@ -294,6 +294,16 @@ def test_single_rank_dist_path_equals_plain_bfs(gr, gpu_ctx):
         for optimized in (True, False):
             st = D.bfs(eng, None, src, d, optimized=optimized)
             assert np.array_equal(d.cpu().numpy(), want) and st["edges_visited"] == ev
+            # the first search recorded the level group as a HIP graph (overlap off): these replay it,
+            # from the same and from another source
+            st = D.bfs(eng, None, src, d, optimized=optimized)
+            assert np.array_equal(d.cpu().numpy(), want) and st["edges_visited"] == ev
+            src2 = int(np.argsort(np.diff(g.row_offsets))[-7])
+            want2, _, ev2 = O.bfs_queue(g, src2)
+            st = D.bfs(eng, None, src2, d, optimized=optimized)
+            assert np.array_equal(d.cpu().numpy(), want2) and st["edges_visited"] == ev2
+        if not overlap:
+            assert getattr(eng, "_graph", None) is not None or getattr(eng, "_graph_failed", False)
 
 
 @pytest.mark.gpu
