@@ -74,7 +74,18 @@ struct bfs_policy_t {
   // the first min(n, cap) in `lds`, the others at spill[cap ..], re-read past the L1),
   // bm_f[(level + 1) % 3] empty.  Two 0.6 MB clears by one workgroup: a few us, once per
   // hand-back, instead of bitmap upkeep in every tiny level.  Block-wide call.
-  __device__ __forceinline__ void tiny_enter() { in_tiny = 1; }
+  // entry: the frontier tiny levels start from (n vertices, in LDS) was produced by a regular level
+  // and would have been folded into bm_visited by the regular level kernel expanding it
+  __device__ __forceinline__ void tiny_enter(const int* lds, int n) {
+    in_tiny = 1;
+    if constexpr (VARIANT == 0) {
+      if (!bm_visited) return;
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int v = lds[i];
+        (void)__hip_atomic_fetch_or(&bm_visited[v >> 5], 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
   __device__ __forceinline__ void tiny_hand_back(int level, const int* lds, int n, int cap, const int* spill) {
     if constexpr (VARIANT == 0) {
       if (!bm_visited) return;
@@ -233,7 +244,10 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
       unsigned long long in_range = ~0ull;  // lanes of the last chunk beyond V are never open
       const long long first = (long long)vbase + (long long)ch * 64;
       if (first + 64 > (long long)a.V) in_range = first >= (long long)a.V ? 0ull : ((1ull << ((long long)a.V - first)) - 1ull);
-      live = (~v & in_range) != 0ull;
+      // live: an open vertex, OR frontier bits that `visited` does not hold yet (they are merged
+      // and written back by the round below)
+      const unsigned long long vm = *reinterpret_cast<const unsigned long long*>(d.visited + 2 * ch);
+      live = (~v & in_range) != 0ull || (v != vm);
     }
     live_slots = dev::ballot(live);
   }
@@ -241,17 +255,21 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
   for (int ch0 = wave * BATCH; ch0 < n_chunks; ch0 += n_waves * BATCH) {
     ++round;
     if (round * BATCH < 64 && ((live_slots >> (round * BATCH)) & ((1ull << BATCH) - 1ull)) == 0ull) continue;
-    unsigned long long vis[BATCH];
+    unsigned long long vis[BATCH], vis_mem[BATCH];
     int b[BATCH], e[BATCH], odeg[BATCH];
     bool open[BATCH], found[BATCH];
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
       const int ch = ch0 + j;
       vis[j] = ~0ull;
+      vis_mem[j] = ~0ull;
       if (ch < n_chunks) {
         vis[j] = (unsigned long long)d.visited[2 * ch] | ((unsigned long long)d.visited[2 * ch + 1] << 32);
+        vis_mem[j] = vis[j];
         // single GPU: the frontier of THIS level may not be in `visited` yet (the top-down levels
-        // fold a frontier in when they expand it): its own words are at hand
+        // fold a frontier in when they expand it): its own words are at hand -- and they are
+        // written back below even if this chunk discovers nothing, or the next bottom-up level
+        // would take these vertices for unvisited
         if (d.rot3) vis[j] |= (unsigned long long)fin[2 * ch] | ((unsigned long long)fin[2 * ch + 1] << 32);
       }
     }
@@ -358,8 +376,8 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
       if (lane == 0) {
         fout[2 * ch] = (unsigned)nw;
         fout[2 * ch + 1] = (unsigned)(nw >> 32);
-        if (nw) {
-          const unsigned long long nv = vis[j] | nw;
+        const unsigned long long nv = vis[j] | nw;
+        if (nv != vis_mem[j]) {
           d.visited[2 * ch] = (unsigned)nv;
           d.visited[2 * ch + 1] = (unsigned)(nv >> 32);
         }

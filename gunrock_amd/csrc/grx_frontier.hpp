@@ -414,7 +414,7 @@ struct policy_has_side : std::false_type {};
 template <class Policy>
 struct policy_has_side<Policy, std::void_t<decltype(Policy::has_side)>> : std::bool_constant<Policy::has_side> {};
 
-// optional hooks: on_accept(nbr) for every vertex that joins the output; tiny_enter() /
+// optional hooks: on_accept(nbr) for every vertex that joins the output; tiny_enter(list, n) /
 // tiny_hand_back(level, lds list, n, cap, spill) around tiny_levels_body
 template <class Policy, class = void>
 struct policy_has_accept : std::false_type {};
@@ -785,7 +785,7 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
   }
   int n = sm.n;
   int sel = 0;
-  if constexpr (policy_has_accept<Policy>::value) pol.tiny_enter();
+  if constexpr (policy_has_accept<Policy>::value) pol.tiny_enter(sm.buf[0], n);
   long long edges_done = 0, vertices_done = 0;
   const long long edges_before = h.edges_visited;
   constexpr int PER = CAP / TINY_THREADS;  // frontier slots per thread in the degree scan

@@ -158,3 +158,24 @@ def test_full_size_livejournal_standin_properties(gr, gpu_ctx):
         reached = d != INF
         assert st["vertices_visited"] == int(reached.sum())
         assert st["edges_visited"] == int(np.diff(g.row_offsets)[reached].sum())
+
+
+@pytest.mark.gpu
+def test_regression_frontier_merge_persisted_in_bottomup(gr, gpu_ctx):
+    """Found by tests/tools/fuzz_gpu.py: a vertex discovered top-down sits in the frontier bitmap
+    only; the bottom-up level that consumes that frontier must write the merged word back to
+    `visited` even when its 64-vertex chunk discovers nothing (here: the last, 2-vertex chunk),
+    or the next bottom-up level re-discovers the vertex at a greater depth."""
+    import torch
+    props, c = gr.generate("rmat_sym", 317250, 6588144, seed=716928211)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    G = gr.build_graph(props, c, gpu_ctx)
+    V = G.get_number_of_vertices()
+    dist = torch.empty(V, dtype=torch.int32, device="cuda")
+    for src in (133258, 194002, int(np.argmax(np.diff(g.row_offsets)))):
+        if src >= V:
+            continue
+        want, _ = O.bfs(g, src)
+        for _ in range(2):
+            gr.bfs(G, src, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.optimized))
+            assert np.array_equal(dist.cpu().numpy(), want), src
