@@ -12,7 +12,7 @@ cp gpurun_out/prof_bench_final/kt/p_kernel_stats.csv gpurun_out/final_kernel_sta
 rm -rf gpurun_out/prof_bench_final
 cp gpurun_out/final_bench_pmc.json profiles/r1_bench_pmc.json
 timeout 300 python bench.py > gpurun_out/final_bench.log 2>&1
-timeout 200 python bench.py --workload kron --no-cpu-baseline > gpurun_out/final_bench_kron.log 2>&1
-timeout 300 python bench.py --workload road --no-cpu-baseline --steps 5 --warmup 1 > gpurun_out/final_bench_road.log 2>&1
-timeout 600 python tests/tools/bench_all.py bfs_lj bfs_kron bfs_road sssp_lj sssp_road ssspu_road pr_kron > gpurun_out/final_bench_all.log 2>&1
+[ "${FINAL_SHORT:-0}" = 1 ] || timeout 200 python bench.py --workload kron --no-cpu-baseline > gpurun_out/final_bench_kron.log 2>&1
+[ "${FINAL_SHORT:-0}" = 1 ] || timeout 300 python bench.py --workload road --no-cpu-baseline --steps 5 --warmup 1 > gpurun_out/final_bench_road.log 2>&1
+[ "${FINAL_SHORT:-0}" = 1 ] || timeout 600 python tests/tools/bench_all.py bfs_lj bfs_kron bfs_road sssp_lj sssp_road ssspu_road pr_kron > gpurun_out/final_bench_all.log 2>&1
 tail -2 gpurun_out/final_pytest_gpu.log; tail -2 gpurun_out/final_smoke.log; tail -1 gpurun_out/final_bench.log | cut -c1-160
