@@ -482,7 +482,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   if (returned_fast) {
     // enact() time on the device's own clock: seed (init kernel) -> the kernel that found the
     // frontier empty; the reference brackets the same span with two events (enactor.hxx:270-282)
-    ms = (float)((double)ctx->h_ctrl->t_start / ctx->wall_clock_khz);
+    ms = (float)((double)ctx->mailbox_ticks / ctx->wall_clock_khz);
   } else {
     GRX_HIP(hipEventRecord(ctx->ev_end, s));
     GRX_HIP(hipEventSynchronize(ctx->ev_end));

@@ -122,6 +122,7 @@ struct grx_context {
   volatile int32_t* h_mailbox = nullptr;  // pinned, device-visible: [0]=done,[1]=level,[2]=n_items,[3]=group started,
                                           // [4..9] = int64 {edges visited, vertices visited, wall-clock ticks} at `done`
   double wall_clock_khz = 100000.0;       // rate of wall_clock64() on this device
+  int64_t mailbox_ticks = 0;              // elapsed wall-clock ticks of the last search that returned through the mailbox
   int32_t* d_mailbox = nullptr;        // device pointer aliasing h_mailbox
 
   // scratch

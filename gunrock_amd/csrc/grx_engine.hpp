@@ -77,7 +77,7 @@ grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel
             ctx->h_ctrl->level = mb[1];
             ctx->h_ctrl->edges_visited = mb64[0];
             ctx->h_ctrl->vertices_visited = mb64[1];
-            ctx->h_ctrl->t_start = mb64[2];  // elapsed wall-clock ticks, not a start stamp
+            ctx->mailbox_ticks = mb64[2];
             if (returned_fast) *returned_fast = true;
             after_sync(*ctx->h_ctrl);
             return GRX_SUCCESS;

@@ -133,7 +133,13 @@ int32_t grx_graph_number_of_edges(grx_graph_t graph);    /* graph_t::get_number_
  * include/gunrock/algorithms/bfs.hxx:162-182 (legacy overload :201-215).
  * d_distances[V] int32: depth, INT32_MAX if unreached (bfs.hxx:65-66).
  * d_predecessors may be NULL; like the reference it is accepted and never
- * written (bfs.hxx:29). */
+ * written (bfs.hxx:29).
+ * *elapsed_ms: enact() time, seed -> convergence, reset excluded (enactor.hxx:270-282).
+ * Completion: on return d_distances is final.  On scale-free graphs (E >= 8 V) the call returns as
+ * soon as the device publishes the end of the search in pinned host memory; at most two no-op
+ * kernel groups may still be draining on the context's stream (work enqueued on that stream
+ * afterwards is ordered behind them, grx_context_synchronize waits for them).  The environment
+ * variable GRX_FAST_RETURN=0 makes the call synchronise its stream before returning. */
 grx_status_t grx_bfs(grx_context_t ctx,
                      grx_graph_t graph,
                      int32_t single_source,
