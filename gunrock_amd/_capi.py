@@ -23,6 +23,7 @@ forward, backward, optimized = range(3)
 FLAG_UNFUSED = 0x1
 FLAG_PROFILE = 0x2
 FLAG_SYNC_EACH_LEVEL = 0x4
+FLAG_ASYNC_RETURN = 0x8
 
 
 class grx_options_t(C.Structure):
@@ -91,6 +92,7 @@ def lib():
         "grx_context_stream": (vp, [vp]),
         "grx_graph_create_csr": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, P(vp)]),
         "grx_graph_destroy": (i32, [vp]),
+        "grx_csr_fingerprint": (i32, [vp, i32, i32, vp, vp, vp, P(C.c_uint64)]),
         "grx_graph_number_of_vertices": (i32, [vp]),
         "grx_graph_number_of_edges": (i32, [vp]),
         "grx_bfs": (i32, [vp, vp, i32, P(grx_options_t), vp, vp, P(f32)]),

@@ -60,6 +60,32 @@ hipError_t fill_f32(hipStream_t s, float* p, float value, int64_t n) {
   return hipGetLastError();
 }
 
+// Sampled content fingerprint of a device CSR (grx_csr_fingerprint).  <<<1, 1024>>>
+__global__ void fingerprint_kernel(const int32_t* ro, const int32_t* ci, const float* w, int32_t V, int32_t E,
+                                   unsigned long long* out) {
+  auto mix = [](unsigned long long x) {
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+  };
+  const int t = threadIdx.x;
+  unsigned long long acc = 0ull;
+  // 1024 evenly spaced samples of each array (every element when it is shorter), position-keyed
+  const long long nr = (long long)V + 1, ne = (long long)E;
+  const long long ir = nr > 1024 ? (long long)t * nr / 1024 : t;
+  if (ir < nr) acc += mix(((unsigned long long)ir << 32) ^ (unsigned)ro[ir]);
+  const long long ie = ne > 1024 ? (long long)t * ne / 1024 : t;
+  if (ie < ne) {
+    acc += mix((1ull << 63) ^ ((unsigned long long)ie << 32) ^ (unsigned)ci[ie]);
+    if (w) acc += mix((1ull << 62) ^ ((unsigned long long)ie << 32) ^ (unsigned)__float_as_int(w[ie]));
+  }
+  if (t == 0) acc += mix((unsigned long long)(unsigned)ro[V] ^ 0xabcdull);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((t & 63) == 0) atomicAdd(out, acc);
+}
+
 grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   const size_t V = (size_t)g->V, E = (size_t)g->E;
   const size_t grid = (size_t)advance_grid(ctx);
@@ -220,6 +246,22 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->xb_long) (void)hipFree(g->xb_long);
   if (g->xb_perm) (void)hipFree(g->xb_perm);
   delete g;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_csr_fingerprint(grx_context_t ctx, int32_t V, int32_t E, const int32_t* ro, const int32_t* ci,
+                                 const float* w, uint64_t* out) {
+  if (!ctx || !ro || !out || V < 0 || E < 0 || (E > 0 && !ci))
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_csr_fingerprint: bad argument");
+  GRX_HIP(hipSetDevice(ctx->device));
+  GRX_HIP(ctx->misc.reserve(64));
+  unsigned long long* d = ctx->misc.as<unsigned long long>();
+  GRX_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(fingerprint_kernel, dim3(1), dim3(1024), 0, ctx->stream, ro, ci, w, V, E, d);
+  unsigned long long h = 0;
+  GRX_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  GRX_HIP(hipStreamSynchronize(ctx->stream));
+  *out = (uint64_t)h;
   return GRX_SUCCESS;
 }
 

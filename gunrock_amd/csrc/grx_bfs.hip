@@ -221,7 +221,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
   }
   bfs_decide_body(a, d, s_red, h, s_dec);
   if (s_dec[0] || s_dec[1] != 0) return;
-  if (threadIdx.x == 0) s_red[0] = 0ull;
+  if (threadIdx.x < 2) s_red[threadIdx.x] = 0ull;
   __syncthreads();
   in.level = s_dec[2];
   in.nt = h.nt(in.level & 1);
@@ -350,8 +350,14 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   unsigned* visited = nullptr;
   size_t visited_bytes = 0;
   if (dopt) {
-    // in-edges: the CSR itself when the graph is symmetric, else the cached transpose
+    // in-edges: the CSR itself when the graph is symmetric (the property is caller-supplied and
+    // defaults to true, so it is verified once per graph handle), else the cached transpose
+    bool symmetric = false;
     if (g->symmetric) {
+      st = graph_is_symmetric(ctx, g, &symmetric);
+      if (st != GRX_SUCCESS) return st;
+    }
+    if (symmetric) {
       d.t_ro = g->ro;
       d.t_ci = g->ci;
     } else {
@@ -473,7 +479,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     r.bottom_up = h.mode;
     prof_v = h.vertices_visited;
     prof_e = h.edges_visited;
-  }, /*first_batch=*/dense ? 8 : 4, /*pace_depth=*/pace, /*fast_return=*/pace > 0 && env_int("GRX_FAST_RETURN", 1) != 0,
+  }, /*first_batch=*/dense ? 8 : 4, /*pace_depth=*/pace, /*fast_return=*/pace > 0 && ((opt.engine_flags & GRX_FLAG_ASYNC_RETURN) != 0 || env_int("GRX_FAST_RETURN", 0) != 0),
      &returned_fast);
   if (st != GRX_SUCCESS) return st;
   if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));

@@ -149,6 +149,7 @@ struct grx_graph {
   const int32_t* ci = nullptr;
   const float* w = nullptr;  // may be null => 1.0
   int32_t directed = 1, weighted = 1, symmetric = 0;
+  int32_t sym_checked = 0;  // 0: `symmetric` not verified yet, 1: CSR == its transpose, 2: it is not
   // lazily built transpose (CSC) for pull operators; owned
   int32_t* t_ro = nullptr;
   int32_t* t_ci = nullptr;

@@ -129,12 +129,12 @@ __global__ void dist_init_kernel(pipe_args a, dist_args x, int32_t* dist, int sr
 // <<<1, 1024>>>
 __global__ __launch_bounds__(PLAN_BLOCK) void dist_head_kernel(pipe_args a, dist_args x) {
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
-  __shared__ unsigned long long s_esum;
+  __shared__ unsigned long long s_esum[2];
   ctrl_t* c = a.ctrl;
   const int tid = threadIdx.x;
   if (c->done) return;
   if (tid == 0) {
-    s_esum = 0ull;
+    s_esum[0] = s_esum[1] = 0ull;
     const int level = c->level + 1;
     const int p = level & 1;
     const long long n_f = x.stats_global[0], m_f = x.stats_global[1];
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void dist_head_kernel(pipe_args a, dist
   }
   __syncthreads();
   if (c->done || c->mode != 0 || c->convert == 1) return;
-  plan_body<PLAN_BLOCK>(a, c, 1, s_wave, &s_esum);
+  plan_body<PLAN_BLOCK>(a, c, 1, s_wave, s_esum);
 }
 
 // Before the exchange.  Bottom-up level: publish this rank's frontier slice to every peer

@@ -21,6 +21,11 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a);
 // Build (once) and cache the transpose of g in the graph handle.
 grx_status_t graph_build_transpose(grx_context_t ctx, grx_graph_t g);
 
+// Verify (once per graph handle, cached) that the CSR equals its transpose: the caller-supplied
+// `symmetric` property is only trusted after this check (direction-optimising BFS uses the CSR
+// itself as the in-edge list of a symmetric graph).
+grx_status_t graph_is_symmetric(grx_context_t ctx, grx_graph_t g, bool* result);
+
 // Launch configuration of the advance kernel (persistent workgroups striding over chunks).
 // Upper bound used for sizing scratch:
 inline int advance_grid(grx_context_t ctx) { return ctx->num_cus * 8; }

@@ -73,7 +73,7 @@ __device__ __forceinline__ void publish_done(const pipe_args& a, ctrl_t* c, int 
 // external_control != 0: level bookkeeping, termination and counters are done by
 // another kernel (direction-optimising BFS); this one only builds the chunk map of
 // a top-down level and leaves when the level runs bottom-up.
-// Body of the plan step for a workgroup of BLOCK threads; *s_esum must be 0 and the
+// Body of the plan step for a workgroup of BLOCK threads; s_esum[0..1] must be 0 and the
 // workgroup synchronised on entry.  s_wave: BLOCK / 64 + 1 ints of LDS.
 // What the single-workgroup kernels need from the control block, fetched in ONE batch of loads.
 // Read field by field behind early-exit branches these were four to five dependent round trips
@@ -154,7 +154,7 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
     }
     return;
   }
-  long long esum = 0;
+  long long esum = 0, vsum = 0;  // traversed edges / frontier vertices of the level (two 64-bit sums)
   int mine = 0, carry;
   const int R = external_control == 1 ? in.R : 0;
   if (R > 0) {
@@ -162,24 +162,21 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
     // n_r indices of its static tile range [r * T, (r + 1) * T) (n_r: bu_part word 0 >> 40).
     // Walk the ranges, not the ~20 k mostly empty tile indices.
     const int T = in.T;
-    constexpr int RPT = 2;  // ranges per thread: the launch has at most 2 * BLOCK workgroups
-    int nr[RPT];
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-      const int r = tid + q * BLOCK;
-      nr[q] = r < R ? (int)(a.bu_part[4 * r] >> 40) : 0;
-    }
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-      const int base = (tid + q * BLOCK) * T;
-      for (int k = 0; k < nr[q]; ++k) mine += a.tile_chunks[base + k];
+    // thread t owns the consecutive ranges [t * RPT, (t + 1) * RPT), RPT = ceil(R / BLOCK): any
+    // number of bottom-up workgroups is covered (the chunk map stays in range order)
+    const int RPT = (R + BLOCK - 1) / BLOCK;
+    const int r0 = tid * RPT, r1 = min(R, r0 + RPT);
+    for (int r = r0; r < r1; ++r) {
+      const int nr = (int)(a.bu_part[4 * r] >> 40);
+      const int base = r * T;
+      for (int k = 0; k < nr; ++k) mine += a.tile_chunks[base + k];
     }
     int pre = dev::block_exclusive_sum<BLOCK>(mine, s_wave, &carry);
     int2* map = reinterpret_cast<int2*>(a.chunk_tile);
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-      const int base = (tid + q * BLOCK) * T;
-      for (int k = 0; k < nr[q]; ++k) {
+    for (int r = r0; r < r1; ++r) {
+      const int nr = (int)(a.bu_part[4 * r] >> 40);
+      const int base = r * T;
+      for (int k = 0; k < nr; ++k) {
         const int ch = a.tile_chunks[base + k];
         for (int j = 0; j < ch; ++j) map[pre + j] = make_int2(base + k, j);
         pre += ch;
@@ -205,8 +202,8 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
     for (int k = 0; k < G; ++k) {
       if (i0 + k < t1) {
         mine += ch[k];
-        // {edges, vertices} packed: vertices in the top 24 bits of a 64-bit sum
-        esum += (long long)ts[k] + ((long long)tc[k] << 40);
+        esum += (long long)ts[k];
+        vsum += (long long)tc[k];
       }
     }
   }
@@ -221,16 +218,22 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
     }
   }
   }
-  // 64-bit block reduction of the traversed-edge count
+  // 64-bit block reductions of the traversed-edge and frontier-vertex counts (s_esum[0], [1])
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
-  if (dev::lane_id() == 0) atomicAdd(s_esum, (unsigned long long)esum);
+  for (int o = 32; o > 0; o >>= 1) {
+    esum += __shfl_xor(esum, o, 64);
+    vsum += __shfl_xor(vsum, o, 64);
+  }
+  if (dev::lane_id() == 0) {
+    atomicAdd(&s_esum[0], (unsigned long long)esum);
+    atomicAdd(&s_esum[1], (unsigned long long)vsum);
+  }
   __syncthreads();
   if (tid == 0) {
     c->total_chunks = carry;
     if (external_control != 1) {
-      const long long edges = (long long)(*s_esum & ((1ull << 40) - 1));
-      const int nitems = (int)(*s_esum >> 40);
+      const long long edges = (long long)s_esum[0];
+      const int nitems = (int)s_esum[1];
       c->edges_visited += edges;
       c->vertices_visited += nitems;
       c->n_items[p] = nitems;
@@ -261,10 +264,10 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
 
 static __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(pipe_args a, int external_control) {
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
-  __shared__ unsigned long long s_esum;
-  if (threadIdx.x == 0) s_esum = 0ull;
+  __shared__ unsigned long long s_esum[2];
+  if (threadIdx.x < 2) s_esum[threadIdx.x] = 0ull;
   __syncthreads();
-  plan_body<PLAN_BLOCK>(a, a.ctrl, external_control, s_wave, &s_esum);
+  plan_body<PLAN_BLOCK>(a, a.ctrl, external_control, s_wave, s_esum);
 }
 
 // Emit n (<= TILE) vertices s_out[lo .. lo+n) as one tile of the frontier with
@@ -729,6 +732,11 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
   const int lane = dev::lane_id();
   if (h.done) return 1;
   if (h.frontier_bitmap) return 0;  // partitioned BFS: the frontier is a bitmap right now
+  // the previous level ran bottom-up: its discoveries sit in static per-workgroup tile ranges and
+  // its counters in bu_part records, which only the decide / plan steps know how to read (and the
+  // hand-back paths below leave mode / bu_R untouched).  On a 256-CU part the ranges span more
+  // than TINY_MAX_TILES indices anyway; on a smaller grid they might not.
+  if (h.mode != 0 || h.bu_R > 0) return 0;
   int level = h.level + 1;          // next level to run
   {
     // ---- entry: gather the tiled queue into LDS ---------------------------------------

@@ -339,8 +339,13 @@ grx_status_t grx_host_csr_load_mtx(const char* filename, grx_host_csr_t* out) {
       if (!pattern) X[(size_t)k] = (float)val;
     }
   }
+  // Every index must lie inside the declared matrix.  A graph algorithm indexes its per-vertex
+  // arrays with COLUMN ids too, so the vertex count is max(M, N): a rectangular file with N > M
+  // gets N - M trailing vertices without out-edges (the reference takes M rows and then reads
+  // labels[col] out of bounds); square files -- every graph dataset -- are unaffected.
+  const uint64_t VV = std::max(M, N);
   for (uint64_t k = 0; k < NZ; ++k)
-    if (I[(size_t)k] >= (int32_t)M || J[(size_t)k] < 0 || I[(size_t)k] < 0 ||
+    if (I[(size_t)k] >= (int32_t)M || J[(size_t)k] < 0 || I[(size_t)k] < 0 || J[(size_t)k] >= (int32_t)N ||
         (symmetric && J[(size_t)k] >= (int32_t)M))
       return fail(GRX_ERROR_IO, "Market file entry outside the declared matrix");
   if (symmetric && 2 * NZ >= (uint64_t)INT32_MAX) {
@@ -350,7 +355,7 @@ grx_status_t grx_host_csr_load_mtx(const char* filename, grx_host_csr_t* out) {
   }
 
   grx_host_csr* h = new grx_host_csr();
-  h->V = (int32_t)M;
+  h->V = (int32_t)VV;
   h->cols = (int32_t)N;
   h->weighted = pattern ? 0 : 1;
   h->symmetric = symmetric ? 1 : 0;
@@ -366,12 +371,16 @@ grx_status_t grx_host_csr_from_coo(int32_t n_rows, int32_t n_cols, int64_t nnz, 
   if (!out || n_rows < 0 || nnz < 0 || (nnz > 0 && (!I || !J)))
     return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_host_csr_from_coo: bad argument");
   if (nnz >= (int64_t)INT32_MAX) return fail(GRX_ERROR_INVALID_ARGUMENT, "edge_t overflow");
-  for (int64_t k = 0; k < nnz; ++k)
+  // column ids index per-vertex arrays as well: they must be vertices (see grx_host_csr_load_mtx)
+  const int32_t VV = std::max(n_rows, n_cols);
+  for (int64_t k = 0; k < nnz; ++k) {
     if (I[k] < 0 || I[k] >= n_rows) return fail(GRX_ERROR_INVALID_ARGUMENT, "row index out of range");
+    if (J[k] < 0 || J[k] >= VV) return fail(GRX_ERROR_INVALID_ARGUMENT, "column index out of range");
+  }
   grx_host_csr* h = new grx_host_csr();
-  h->V = n_rows;
+  h->V = VV;
   h->cols = n_cols;
-  coo_to_csr(n_rows, nnz, I, J, X, h);
+  coo_to_csr(VV, nnz, I, J, X, h);
   *out = h;
   return GRX_SUCCESS;
 }

@@ -195,7 +195,7 @@ __global__ void sssp_init_kernel(pipe_args a, float* dist, int src, float delta)
 //     iteration is two launches instead of four (phase, split, plan, advance).
 __global__ __launch_bounds__(PLAN_BLOCK) void sssp_nf_head_kernel(pipe_args a, sssp_nf_args nf) {
   __shared__ unsigned long long s_n;
-  __shared__ unsigned long long s_esum;
+  __shared__ unsigned long long s_esum[2];
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
   __shared__ int s_go;
   ctrl_t* c = a.ctrl;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void sssp_nf_head_kernel(pipe_args a, s
   const int level = resume ? h.level : h.level + 1;
   const int p = level & 1;
   const int nt = h.nt(p);
-  if (tid == 0) { s_n = 0; s_esum = 0; s_go = 0; }
+  if (tid == 0) { s_n = 0; s_esum[0] = s_esum[1] = 0; s_go = 0; }
   __syncthreads();
   if (done) return;
   if (!resume) {
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void sssp_nf_head_kernel(pipe_args a, s
     in.mode = 0;
     in.R = 0;
     in.T = 0;
-    plan_body<PLAN_BLOCK>(a, c, 2, s_wave, &s_esum, in);
+    plan_body<PLAN_BLOCK>(a, c, 2, s_wave, s_esum, in);
   }
 }
 
@@ -388,14 +388,14 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, s
 // as there are (tiny_levels_body), then the bookkeeping + chunk map of the next regular level.
 __global__ __launch_bounds__(PLAN_BLOCK) void sssp_head_kernel(pipe_args a, sssp_policy pol, long long n_edges) {
   __shared__ tiny_smem<sssp_policy> tsm;
-  __shared__ unsigned long long s_esum;
+  __shared__ unsigned long long s_esum[2];
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
   static_assert(TINY_THREADS == PLAN_BLOCK, "head kernel runs both bodies");
   const ctrl_head h0 = load_ctrl_head(a.ctrl);
   const int t = tiny_levels_body(a, pol, 0, n_edges, tsm, h0);
   if (t == 1) return;
   const ctrl_head h = t == 2 ? load_ctrl_head(a.ctrl) : h0;
-  if (threadIdx.x == 0) s_esum = 0ull;
+  if (threadIdx.x < 2) s_esum[threadIdx.x] = 0ull;
   __syncthreads();
   plan_in in;
   in.done = h.done;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void sssp_head_kernel(pipe_args a, sssp
   in.mode = 0;
   in.R = 0;
   in.T = 0;
-  plan_body<PLAN_BLOCK>(a, a.ctrl, 0, s_wave, &s_esum, in);
+  plan_body<PLAN_BLOCK>(a, a.ctrl, 0, s_wave, s_esum, in);
 }
 
 // out[0] = sum of weights; bits[0] / bits[1] = min / max weight as ordered uints (w >= 0)

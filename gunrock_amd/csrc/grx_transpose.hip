@@ -43,9 +43,72 @@ __global__ void tr_fill_kernel(const int32_t* __restrict__ ro, const int32_t* __
   }
 }
 
+// ---- is the CSR its own transpose? ---------------------------------------------------------
+// graph_properties_t::symmetric is caller-supplied, defaults to true and is inert in the
+// reference (graph/properties.hxx:13-18); here it is LOAD-BEARING: a symmetric graph's CSR
+// doubles as its in-edge list in the bottom-up step.  So the claim is verified once per graph
+// handle: for every vertex the multiset of out-neighbours must equal the multiset of
+// in-neighbours, compared through 64-bit sums of a mixing hash of the neighbour ids (one pass
+// over the edges; a wrong "equal" needs a 2^-64 collision).
+__device__ __forceinline__ unsigned long long sym_mix(unsigned long long x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+__global__ void sym_hash_kernel(const int32_t* __restrict__ ro, const int32_t* __restrict__ ci, int32_t V,
+                                unsigned long long* h_in, unsigned long long* h_out, int32_t* bad) {
+  const int lane = dev::lane_id();
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t u = wave; u < V; u += nwaves) {
+    const int b = ro[u], e = ro[u + 1];
+    const unsigned long long hu = sym_mix((unsigned long long)u);
+    unsigned long long acc = 0ull;
+    for (int k = b + lane; k < e; k += 64) {
+      const int v = ci[k];
+      if (v < 0 || v >= V) { *bad = 1; continue; }
+      acc += sym_mix((unsigned long long)v);
+      atomicAdd(&h_in[v], hu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) h_out[u] = acc;
+  }
+}
+__global__ void sym_compare_kernel(const unsigned long long* h_in, const unsigned long long* h_out, int32_t V,
+                                   int32_t* bad) {
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x)
+    if (h_in[v] != h_out[v]) *bad = 1;
+}
+
 }  // namespace grx
 
 using namespace grx;
+
+grx_status_t grx::graph_is_symmetric(grx_context_t ctx, grx_graph_t g, bool* result) {
+  if (g->sym_checked == 0) {
+    const int32_t V = g->V;
+    hipStream_t s = ctx->stream;
+    unsigned long long* h = nullptr;
+    int32_t* bad = nullptr;
+    GRX_HIP(hipMalloc(reinterpret_cast<void**>(&h), (2 * (size_t)V + 2) * sizeof(unsigned long long)));
+    GRX_HIP(hipMalloc(reinterpret_cast<void**>(&bad), sizeof(int32_t)));
+    GRX_HIP(hipMemsetAsync(h, 0, (2 * (size_t)V + 2) * sizeof(unsigned long long), s));
+    GRX_HIP(hipMemsetAsync(bad, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(sym_hash_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, V, h, h + V, bad);
+    hipLaunchKernelGGL(sym_compare_kernel, dim3(1024), dim3(256), 0, s, h, h + V, V, bad);
+    int32_t hb = 0;
+    GRX_HIP(hipMemcpyAsync(&hb, bad, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    GRX_HIP(hipStreamSynchronize(s));
+    (void)hipFree(h);
+    (void)hipFree(bad);
+    GRX_HIP(hipGetLastError());
+    g->sym_checked = hb ? 2 : 1;
+  }
+  *result = g->sym_checked == 1;
+  return GRX_SUCCESS;
+}
 
 grx_status_t grx::graph_build_transpose(grx_context_t ctx, grx_graph_t g) {
   if (g->has_transpose) return GRX_SUCCESS;

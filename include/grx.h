@@ -92,6 +92,10 @@ typedef struct grx_options {
                                   reference pipeline does (frontier with -1 holes between them) */
 #define GRX_FLAG_PROFILE 0x2   /* record per-iteration operator timings (adds events + syncs) */
 #define GRX_FLAG_SYNC_EACH_LEVEL 0x4 /* host reads the frontier size after every level */
+#define GRX_FLAG_ASYNC_RETURN 0x8    /* grx_bfs may return as soon as the device has PUBLISHED the end
+                                        of the search (results final) instead of after its stream drained;
+                                        see grx_bfs.  Off by default: the reference's run() returns after a
+                                        stream synchronisation (enactor.hxx:280-282) */
 
 typedef struct grx_context* grx_context_t;
 typedef struct grx_graph* grx_graph_t;
@@ -114,7 +118,12 @@ void* grx_context_stream(grx_context_t ctx);
  * include/gunrock/graph/build.hxx:29-36 + graph/csr.hxx:218-226: a NON-OWNING
  * view over the caller's device CSR arrays.  d_values may be NULL (treated as
  * all 1.0, what the reference loader produces for pattern files,
- * io/matrix_market.hxx:170-171). */
+ * io/matrix_market.hxx:170-171).
+ * `symmetric` (graph_properties_t::symmetric, default true and inert in the reference) is
+ * load-bearing here -- a symmetric graph's CSR serves as its in-edge list in the bottom-up
+ * BFS step -- and therefore VERIFIED on the device the first time it is relied on (one pass
+ * over the edges, cached in the handle); a CSR that is not its own transpose gets a real
+ * transpose instead. */
 grx_status_t grx_graph_create_csr(grx_context_t ctx,
                                   int32_t n_vertices,
                                   int32_t n_edges,
@@ -126,6 +135,15 @@ grx_status_t grx_graph_create_csr(grx_context_t ctx,
                                   int32_t symmetric,
                                   grx_graph_t* out);
 grx_status_t grx_graph_destroy(grx_graph_t graph);
+/* A graph handle caches per-graph derived state (transpose, pull partitions, weight statistics),
+ * so the CSR arrays must not change under a live handle.  A caller that keys handles on array
+ * identity -- the C++ bridge include/gunrock/algorithms/engine.hxx does, because the reference's
+ * graph_t is a non-owning by-value view (graph/graph.hxx:187-214) -- compares this SAMPLED content
+ * fingerprint (1024 positions of each array + the edge count; one tiny kernel + one 8-byte
+ * read-back) to detect in-place edits or a different graph allocated at the same addresses. */
+grx_status_t grx_csr_fingerprint(grx_context_t ctx, int32_t n_vertices, int32_t n_edges,
+                                 const int32_t* d_row_offsets, const int32_t* d_column_indices,
+                                 const float* d_values, uint64_t* out);
 int32_t grx_graph_number_of_vertices(grx_graph_t graph); /* graph_t::get_number_of_vertices */
 int32_t grx_graph_number_of_edges(grx_graph_t graph);    /* graph_t::get_number_of_edges */
 
@@ -135,11 +153,12 @@ int32_t grx_graph_number_of_edges(grx_graph_t graph);    /* graph_t::get_number_
  * d_predecessors may be NULL; like the reference it is accepted and never
  * written (bfs.hxx:29).
  * *elapsed_ms: enact() time, seed -> convergence, reset excluded (enactor.hxx:270-282).
- * Completion: on return d_distances is final.  On scale-free graphs (E >= 8 V) the call returns as
- * soon as the device publishes the end of the search in pinned host memory; at most two no-op
- * kernel groups may still be draining on the context's stream (work enqueued on that stream
- * afterwards is ordered behind them, grx_context_synchronize waits for them).  The environment
- * variable GRX_FAST_RETURN=0 makes the call synchronise its stream before returning. */
+ * Completion: on return d_distances is final and the context's stream has drained, like the
+ * reference's run().  With GRX_FLAG_ASYNC_RETURN (opt-in; scale-free graphs, E >= 8 V) the call
+ * returns as soon as the device publishes the end of the search in pinned host memory -- the
+ * distances are final, but at most two no-op kernel groups may still be draining on the context's
+ * stream (work enqueued on that stream afterwards is ordered behind them,
+ * grx_context_synchronize waits for them). */
 grx_status_t grx_bfs(grx_context_t ctx,
                      grx_graph_t graph,
                      int32_t single_source,

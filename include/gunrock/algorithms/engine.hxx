@@ -27,33 +27,88 @@ inline void check(grx_status_t st) {
   if (st != GRX_SUCCESS) throw error::exception_t(std::string(grx_last_error_string()));
 }
 
-// one engine context per (device, stream); lives for the process
+struct graph_entry_t {
+  grx_graph_t handle;
+  uint64_t fingerprint;
+};
+using graph_key_t = std::tuple<grx_context_t, const void*, const void*, const void*, int, int>;
+inline std::map<graph_key_t, graph_entry_t>& graph_cache() {
+  static std::map<graph_key_t, graph_entry_t> cache;
+  return cache;
+}
+
+// The engine context belongs to the gunrock context it was created for: it is stored IN the
+// standard_context_t and destroyed by its destructor (before the stream it references goes
+// away), together with every cached graph handle of that context.  A temporary context -- the
+// default argument of run() -- therefore leaks nothing.
+inline void release_context(void* p) {
+  grx_context_t c = reinterpret_cast<grx_context_t>(p);
+  {
+    std::lock_guard<std::mutex> lock(guard());
+    auto& cache = graph_cache();
+    for (auto it = cache.begin(); it != cache.end();) {
+      if (std::get<0>(it->first) == c) {
+        grx_graph_destroy(it->second.handle);
+        it = cache.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  grx_context_destroy(c);
+}
+
 inline grx_context_t context_for(gcuda::multi_context_t& mc) {
-  static std::map<std::pair<int, void*>, grx_context_t> cache;
   auto* sc = mc.get_context(0);
   std::lock_guard<std::mutex> lock(guard());
-  auto key = std::make_pair((int)sc->ordinal(), (void*)sc->stream());
-  auto it = cache.find(key);
-  if (it != cache.end()) return it->second;
+  if (sc->attached()) return reinterpret_cast<grx_context_t>(sc->attached());
   grx_context_t c = nullptr;
   check(grx_context_create(sc->ordinal(), (void*)sc->stream(), &c));
-  cache[key] = c;
+  sc->attach(c, &release_context);
   return c;
 }
 
-// graph handles are cached by the identity of the CSR arrays so per-graph
-// preprocessing (the transpose behind pull PageRank) is paid once
+// Graph handles carry per-graph preprocessing (the transpose behind pull PageRank and the
+// bottom-up BFS step, weight statistics, pull partitions), so they are cached -- keyed on the
+// identity of the CSR arrays, because graph_t is a non-owning by-value view that cannot own a
+// handle.  Identity alone is not enough (arrays edited in place, or a different graph
+// allocated at the same addresses): every lookup re-takes a sampled content fingerprint
+// (grx_csr_fingerprint: one tiny kernel + an 8-byte read-back) and rebuilds the handle when it
+// changed.  An edit that misses all 1024 sampled positions per array needs engine::invalidate(G).
+template <typename graph_t>
+inline graph_key_t key_of(grx_context_t ctx, graph_t& G) {
+  return graph_key_t{ctx, (const void*)G.get_row_offsets(), (const void*)G.get_column_indices(),
+                     (const void*)G.get_nonzero_values(), (int)G.get_number_of_vertices(),
+                     (int)G.get_number_of_edges()};
+}
+
+template <typename graph_t>
+inline void invalidate(grx_context_t ctx, graph_t& G) {
+  std::lock_guard<std::mutex> lock(guard());
+  auto& cache = graph_cache();
+  auto it = cache.find(key_of(ctx, G));
+  if (it == cache.end()) return;
+  grx_graph_destroy(it->second.handle);
+  cache.erase(it);
+}
+
 template <typename graph_t>
 inline grx_graph_t graph_for(grx_context_t ctx, graph_t& G) {
-  using key_t = std::tuple<const void*, const void*, const void*, int, int>;
-  static std::map<key_t, grx_graph_t> cache;
+  uint64_t fp = 0;
+  check(grx_csr_fingerprint(ctx, (int32_t)G.get_number_of_vertices(), (int32_t)G.get_number_of_edges(),
+                            (const int32_t*)G.get_row_offsets(), (const int32_t*)G.get_column_indices(),
+                            (const float*)G.get_nonzero_values(), &fp));
   std::lock_guard<std::mutex> lock(guard());
-  key_t key{(const void*)G.get_row_offsets(), (const void*)G.get_column_indices(),
-            (const void*)G.get_nonzero_values(), (int)G.get_number_of_vertices(), (int)G.get_number_of_edges()};
+  auto& cache = graph_cache();
+  const graph_key_t key = key_of(ctx, G);
   auto it = cache.find(key);
-  if (it != cache.end()) return it->second;
+  if (it != cache.end()) {
+    if (it->second.fingerprint == fp) return it->second.handle;
+    grx_graph_destroy(it->second.handle);  // same arrays, different content: derived state is stale
+    cache.erase(it);
+  }
   if (cache.size() > 64) {  // bounded: drop everything rather than grow without limit
-    for (auto& kv : cache) grx_graph_destroy(kv.second);
+    for (auto& kv : cache) grx_graph_destroy(kv.second.handle);
     cache.clear();
   }
   grx_graph_t g = nullptr;
@@ -61,7 +116,7 @@ inline grx_graph_t graph_for(grx_context_t ctx, graph_t& G) {
                              (const int32_t*)G.get_row_offsets(), (const int32_t*)G.get_column_indices(),
                              (const float*)G.get_nonzero_values(), G.is_directed(), G.is_weighted(),
                              G.is_symmetric(), &g));
-  cache[key] = g;
+  cache[key] = graph_entry_t{g, fp};
   return g;
 }
 

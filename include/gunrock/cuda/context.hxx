@@ -36,6 +36,10 @@ class standard_context_t {
   int* _mailbox = nullptr;  // pinned host, 64 ints
   void* _scratch[4] = {nullptr, nullptr, nullptr, nullptr};  // growable device scratch slots
   std::size_t _scratch_bytes[4] = {0, 0, 0, 0};
+  // state another layer ties to THIS context's lifetime (the pre-compiled engine keeps its
+  // grx_context here: it references _stream and must die before it)
+  void* _attached = nullptr;
+  void (*_attached_free)(void*) = nullptr;
 
   void init() {
     error::throw_if_exception(hipSetDevice(_ordinal), "hipSetDevice");
@@ -53,6 +57,7 @@ class standard_context_t {
       : _ordinal(device), _stream(stream), _own_stream(false) { init(); }
   standard_context_t(const standard_context_t&) = delete;
   ~standard_context_t() {
+    if (_attached && _attached_free) _attached_free(_attached);
     if (_event) (void)hipEventDestroy(_event);
     if (_mailbox) (void)hipHostFree(_mailbox);
     for (auto* p : _scratch)
@@ -66,6 +71,11 @@ class standard_context_t {
   util::timer_t& timer() { return _timer; }
   device_id_t ordinal() { return _ordinal; }
   int* mailbox() { return _mailbox; }
+  void* attached() const { return _attached; }
+  void attach(void* state, void (*free_fn)(void*)) {
+    _attached = state;
+    _attached_free = free_fn;
+  }
 
   void synchronize() {
     error::throw_if_exception(_stream ? hipStreamSynchronize(_stream) : hipDeviceSynchronize(), "synchronize");

@@ -8,6 +8,11 @@
 // Copyable by value into kernels and lambdas (the copy shares the storage).
 // Storage is a plain hipMalloc'ed buffer grown geometrically; growth preserves
 // contents (reserve(size) allocates size * resizing_factor like the reference).
+// The host mutators (resize, fill, sequence, push_back, growth) are HOST-SYNCHRONOUS in
+// both directions like the reference's thrust calls: they wait for every stream of the
+// device first (operators here run asynchronously on the context's non-blocking stream,
+// which the null stream does not order against) and for their own kernel afterwards, so
+// `f.resize(n); advance::execute(...)` and `advance::execute(...); f.fill(x)` are safe.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -104,14 +109,18 @@ class frontier_t {
   void resize(std::size_t const& size, type_t const default_value = gunrock::numeric_limits<type_t>::invalid()) {
     const std::size_t old = num_elements;
     grow(size);
-    if (size > old)
+    if (size > old) {
+      quiesce();
       hipLaunchKernelGGL((detail::fill_kernel<type_t>), dim3(detail::grid_for(size - old)), dim3(256), 0, 0,
                          raw_ptr + old, default_value, size - old);
+      error::throw_if_exception(hipStreamSynchronize(0), "frontier resize");
+    }
     num_elements = size;
   }
 
   void push_back(type_t const& value) {
     if (num_elements + 1 > store->capacity) grow((num_elements + 1) * 2);
+    quiesce();
     error::throw_if_exception(hipMemcpy(raw_ptr + num_elements, &value, sizeof(type_t), hipMemcpyHostToDevice),
                               "frontier push_back");
     ++num_elements;
@@ -119,16 +128,20 @@ class frontier_t {
 
   void fill(type_t const value, hipStream_t stream = 0) {
     if (num_elements == 0) return;
+    quiesce();
     hipLaunchKernelGGL((detail::fill_kernel<type_t>), dim3(detail::grid_for(num_elements)), dim3(256), 0, stream,
                        raw_ptr, value, num_elements);
+    error::throw_if_exception(hipStreamSynchronize(stream), "frontier fill");
   }
 
   void sequence(type_t const initial_value, std::size_t const& size, hipStream_t stream = 0) {
     grow(size);
     num_elements = size;
     if (size == 0) return;
+    quiesce();
     hipLaunchKernelGGL((detail::sequence_kernel<type_t>), dim3(detail::grid_for(size)), dim3(256), 0, stream,
                        raw_ptr, initial_value, size);
+    error::throw_if_exception(hipStreamSynchronize(stream), "frontier sequence");
   }
 
   // Off the hot path (uniquify with full uniqueness only): vendor sort.
@@ -151,8 +164,12 @@ class frontier_t {
   }
 
  private:
+  // wait for pending operator work on every stream of the device (see the header comment)
+  static void quiesce() { error::throw_if_exception(hipDeviceSynchronize(), "frontier sync"); }
+
   void grow(std::size_t want) {
     if (want <= store->capacity) return;
+    quiesce();
     type_t* fresh = nullptr;
     error::throw_if_exception(hipMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(type_t)), "frontier alloc");
     if (store->ptr) {

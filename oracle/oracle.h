@@ -11,9 +11,10 @@
  * and against the chesapeake golden vector.
  * PageRank: "parity unpinned" by the reference (it ships no PR oracle, no
  * --validate for PR and no PR test); the restatement follows
- * include/gunrock/algorithms/pr.hxx:65-195 and is pinned only against the
- * reference GPU path when oracle/_ref/libgunrock_ref_gpu.so is run on a GPU
- * box (tests/test_ref_gpu.py).
+ * include/gunrock/algorithms/pr.hxx:65-195 and is cross-checked against the
+ * reference's own GPU path (oracle/_ref/libgunrock_ref_gpu.so, the reference
+ * compiled here) on a GPU box: tests/test_pr_gpu.py compares ours, the
+ * reference GPU result and this float64 evaluation side by side.
  *
  * Every function cites the reference file:line it follows
  * (paths relative to /root/reference).
@@ -123,6 +124,23 @@ double orc_bfs_queue(int32_t n_vertices,
                      int32_t source,
                      int32_t* distances,
                      int64_t* edges_visited);
+
+/* ---- N-core baselines (oracle_omp.c): the reference's bulk-synchronous operator loop on all
+ * host cores.  Same fixed points as the functions above; used by bench.py's cpu_baseline leg and
+ * cross-checked in tests, never as the parity yardstick. ---- */
+int orc_omp_threads(void);
+/* include/gunrock/algorithms/bfs.hxx:105-146 per level on host threads */
+double orc_bfs_omp(int32_t n_vertices, const int32_t* row_offsets, const int32_t* column_indices,
+                   int32_t source, int32_t* distances, int64_t* edges_visited);
+/* include/gunrock/algorithms/sssp.hxx:116-151 per iteration on host threads.  budget_ms > 0: stop
+ * after the iteration that exceeds it (*finished = 0, distances not final: rate sample only). */
+double orc_sssp_omp(int32_t n_vertices, const int32_t* row_offsets, const int32_t* column_indices,
+                    const float* nonzero_values, int32_t source, float* distances, double budget_ms,
+                    int64_t* edges_relaxed, int32_t* iterations, int32_t* finished);
+/* include/gunrock/algorithms/pr.hxx:107-152 as a pull over the transpose, exactly `iterations`
+ * loop() executions, fp32.  Returns the loop time in ms. */
+double orc_pr_omp(int32_t n_vertices, const int32_t* row_offsets, const int32_t* column_indices,
+                  const float* nonzero_values, float alpha, int iterations, float* p);
 
 #ifdef __cplusplus
 }

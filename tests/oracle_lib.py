@@ -36,8 +36,8 @@ class _Csr(C.Structure):
 
 
 def build_oracle():
-    if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
-            os.path.join(ORACLE_DIR, "oracle.c")):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle.c", "oracle_omp.c", "oracle.h")]
+    if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"],
                               stdout=subprocess.DEVNULL)
     return _LIB
@@ -75,6 +75,14 @@ def lib():
         L.orc_check_bfs.restype = C.c_int64
         L.orc_check_sssp.argtypes = [C.c_int32, i32p, i32p, f32p, C.c_int32, f32p]
         L.orc_check_sssp.restype = C.c_int64
+        L.orc_omp_threads.restype = C.c_int
+        L.orc_bfs_omp.argtypes = [C.c_int32, i32p, i32p, C.c_int32, i32p, C.POINTER(C.c_int64)]
+        L.orc_bfs_omp.restype = C.c_double
+        L.orc_sssp_omp.argtypes = [C.c_int32, i32p, i32p, C.c_void_p, C.c_int32, f32p, C.c_double,
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.orc_sssp_omp.restype = C.c_double
+        L.orc_pr_omp.argtypes = [C.c_int32, i32p, i32p, C.c_void_p, C.c_float, C.c_int, f32p]
+        L.orc_pr_omp.restype = C.c_double
         _lib = L
     return _lib
 
@@ -149,6 +157,36 @@ def pr_f64(g, alpha=0.85, tol=1e-6, max_iterations=0, force_iterations=0):
                           alpha, tol, max_iterations, force_iterations, p,
                           C.byref(ms))
     return p, it, ms.value
+
+
+def omp_threads():
+    return lib().orc_omp_threads()
+
+
+def bfs_omp(g, src):
+    """N-core level-synchronous BFS -> (depths, ms, edges visited)."""
+    d = np.empty(g.n_vertices, dtype=np.int32)
+    ev = C.c_int64(0)
+    ms = lib().orc_bfs_omp(g.n_vertices, g.row_offsets, g.column_indices, int(src), d, C.byref(ev))
+    return d, ms, ev.value
+
+
+def sssp_omp(g, src, budget_ms=0.0, unit_weights=False):
+    """N-core frontier Bellman-Ford -> (distances, ms, edges relaxed, iterations, finished)."""
+    d = np.empty(g.n_vertices, dtype=np.float32)
+    ev, it, fin = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+    w = None if unit_weights else g.values.ctypes.data_as(C.c_void_p)
+    ms = lib().orc_sssp_omp(g.n_vertices, g.row_offsets, g.column_indices, w, int(src), d,
+                            float(budget_ms), C.byref(ev), C.byref(it), C.byref(fin))
+    return d, ms, ev.value, it.value, bool(fin.value)
+
+
+def pr_omp(g, alpha=0.85, iterations=5, pattern=False):
+    """N-core pull PageRank, exactly `iterations` iterations -> (p, ms)."""
+    p = np.empty(g.n_vertices, dtype=np.float32)
+    w = None if pattern else g.values.ctypes.data_as(C.c_void_p)
+    ms = lib().orc_pr_omp(g.n_vertices, g.row_offsets, g.column_indices, w, alpha, int(iterations), p)
+    return p, ms
 
 
 def check_bfs(g, src, dist):
