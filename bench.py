@@ -1,23 +1,31 @@
 #!/usr/bin/env python
-"""bench.py -- MTEPS of the BFS hot path on the BASELINE.json configs[1] workload.
+"""bench.py -- MTEPS of the BFS / SSSP / PageRank hot path on the BASELINE.json workloads.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload lj|kron|road|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--only bfs,bfs_forward,sssp,pr] [--no-cpu-baseline]
 
-A "step" is one full pass of the hot path: problem reset + the enact loop
-(frontier seed -> convergence) of one BFS from the fixed source over the graph
-already resident in HBM.  value = traversed edges of all ranks / wall time of K
-steps (barrier + synchronize on both sides, max over ranks), in MTEPS
-(= edges_visited / (elapsed_ms * 1000), include/gunrock/util/performance.hxx:225-229
-of the reference).
+ONE JSON line.  Top level = BASELINE.json configs[1]: BFS on the soc-LiveJournal1 stand-in (C2'),
+direction-optimising; a "step" is one full pass of the hot path -- problem reset + the enact loop
+(frontier seed -> convergence) over the graph already resident in HBM; value = traversed edges /
+wall time of K steps (synchronize on both sides, max over ranks), in MTEPS
+(= edges_visited / (elapsed_ms * 1000), include/gunrock/util/performance.hxx:225-229 of the reference).
 
-Extra objects on the JSON line:
-  roofline      advance kernel: algorithmic bytes (12*|F| + 12*m_F per
-                launch, summed over the launches of one BFS) / HIP-event time of
-                those launches on the engine's stream, against 8 TB/s HBM.
-  cpu_baseline  the oracle (port of the reference's priority-queue CPU path)
-                timed on this box's host, rank 0, N=1 only, bounded sample.
+At N = 1 the same line carries the other single-GPU configurations of the metric ("BFS + SSSP", and
+PageRank), each measured in this run with its own roofline and CPU baselines:
+  bfs_forward  configs[1] as written: merge-path advance + compact filter, advance_direction = forward
+  sssp         configs[2]: road_usa stand-in (C3'), unit weights (what the reference loader makes of the
+               pattern file) and the U{1..1000} weighted variant (near-far / delta-stepping schedule)
+  pr           configs[3]: kron_g500-logn21 stand-in (C4') at full size, alpha 0.85, tol 1e-6
+
+roofline objects: algorithmic bytes (SURVEY.md 8d / BASELINE.md) of the launches of the dominant kernel
+divided by their HIP-event time on the engine's stream (GRX_FLAG_PROFILE), against 8 TB/s HBM.
+`traffic` = FETCH_SIZE + WRITE_SIZE per launch from the committed rocprofv3 --pmc passes of this
+command, attached only while the engine sources still hash to what those passes profiled
+(profiles/r2_bench_pmc.json: source_sha), else null.
+cpu_baseline = the oracle (port of the reference's CPU path), 1 core, bounded sample;
+cpu_baseline_ncore = the reference's operator loop on all host cores (oracle/oracle_omp.c).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,16 +39,92 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # BASELINE.json configs[1]: soc-LiveJournal1 stand-in (SURVEY.md 8d C2')
     "lj": dict(kind="rmat", V=4_847_571, entries=68_993_773, a=0.57, b=0.19, c=0.19,
-               name="BFS soc-LiveJournal1 stand-in: R-MAT(0.57,0.19,0.19,0.05) 4,847,571 V / 68,993,773 E, "
+               name="soc-LiveJournal1 stand-in C2': R-MAT(0.57,0.19,0.19,0.05) 4,847,571 V / 68,993,773 E, "
                     "src = max out-degree vertex"),
+    # configs[3]: kron_g500-logn21 stand-in C4'
     "kron": dict(kind="rmat_sym", V=1 << 21, entries=91_042_010, a=0.57, b=0.19, c=0.19,
-                 name="BFS kron_g500-logn21 stand-in"),
+                 name="kron_g500-logn21 stand-in C4': symmetric R-MAT(0.57,0.19,0.19,0.05) 2^21 V / 91,042,010 "
+                      "entries (~182 M edges)"),
+    # configs[2]: road_usa stand-in C3'
     "road": dict(kind="road", V=4894 * 4894, entries=0, a=0.602, b=0.0, c=0.0,
-                 name="BFS road_usa stand-in: 4894x4894 lattice p=0.602"),
+                 name="road_usa stand-in C3': 4894x4894 lattice, edges kept with p=0.602 (~57.7 M directed edges), "
+                      "src = centre vertex"),
+    # configs[4]: soc-twitter-2010 stand-in C5' (N = 8)
+    "twitter": dict(kind="rmat_sym", V=21_297_772, entries=265_025_809, a=0.57, b=0.19, c=0.19,
+                    name="soc-twitter-2010 stand-in C5': symmetric R-MAT(0.57,0.19,0.19,0.05) 21,297,772 V / "
+                         "265,025,809 entries (~530 M edges)"),
     "small": dict(kind="rmat", V=1 << 18, entries=4_000_000, a=0.57, b=0.19, c=0.19,
-                  name="BFS R-MAT 262,144 V / 4,000,000 E (smoke size)"),
+                  name="R-MAT 262,144 V / 4,000,000 E (smoke size)"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_FILE = os.path.join(ROOT, "profiles", "r2_bench_pmc.json")
+
+
+def source_sha():
+    """Hash of the engine sources: ties committed PMC traffic numbers to the kernels they were taken from."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gunrock_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    try:
+        pmc = json.load(open(PMC_FILE))
+    except Exception:
+        return None
+    return pmc if pmc.get("source_sha") == source_sha() else None
+
+
+def roof(levels, bytes_of, kernel, note=None):
+    ms = sum(l["advance_ms"] for l in levels)
+    byt = sum(bytes_of(l) for l in levels)
+    ach = byt / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+         "launches_per_step": len(levels), "alg_bytes_per_step": int(byt),
+         "kernel_ms_per_step": round(ms, 4), "avg_launch_us": round(ms * 1e3 / max(1, len(levels)), 2)}
+    if note:
+        r["alg_bytes_model"] = note
+    return r
+
+
+def attach_traffic(r, pmc, cls):
+    k = (pmc or {}).get("classes", {}).get(cls)
+    if not k or "fetch_bytes_per_launch" not in k:
+        r["traffic_note"] = ("no PMC passes committed for the current engine sources (profiles/r2_bench_pmc.json "
+                             "missing or taken from other sources)")
+        return
+    r["traffic"] = int(k["fetch_bytes_per_launch"] + k.get("write_bytes_per_launch", 0.0))
+    r["traffic_source"] = ("profiles/r2_bench_pmc.json class '%s': FETCH_SIZE + WRITE_SIZE per launch, separate --pmc "
+                           "passes of this command on these sources (raw counters; gfx950 tallies wide coalesced "
+                           "reads at 1/2)" % cls)
+    if "duration_us_per_launch" in k:
+        r["rocprof_avg_launch_us"] = round(k["duration_us_per_launch"], 2)
+
+
+def best_profile(run, profile_of, tries=3):
+    best = None
+    for _ in range(tries):
+        run()
+        prof = profile_of()
+        t = sum(l["advance_ms"] for l in prof)
+        if best is None or t < best[0]:
+            best = (t, prof)
+    return best[1]
+
+
+def timed(run, sync, steps, warmup):
+    for _ in range(warmup):
+        run()
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    sync()
+    return (time.perf_counter() - t1) * 1e3 / max(1, steps)
 
 
 def main():
@@ -48,12 +132,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lj", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="lj", choices=sorted(WORKLOADS),
+                    help="graph of the top-level BFS line (default: BASELINE configs[1])")
+    ap.add_argument("--only", default="bfs,bfs_forward,sssp,pr",
+                    help="comma list of the sections to run at N = 1 (bfs is always run)")
     ap.add_argument("--lb", default="merge_path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--topdown-only", action="store_true",
-                    help="advance_direction=forward: every level runs the top-down advance kernel")
+                    help="top-level line with advance_direction=forward (every level runs the top-down advance)")
     args = ap.parse_args()
+    only = set(x for x in args.only.split(",") if x)
 
     import torch
     import gunrock_amd as gr
@@ -61,247 +149,368 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist_on = world > 1
-    if dist_on:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # GRX_BENCH_BACKEND=gloo lets the N > 1 path be exercised with several ranks sharing
-        # one GPU (tests); the driver's multi-GPU runs use nccl (= RCCL), one rank per GPU
-        backend = os.environ.get("GRX_BENCH_BACKEND", "nccl")
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+    if world > 1:
+        return bench_multi_gpu(args, gr, torch, rank, local_rank, world)
+
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
+    ctx = gr.multi_context_t(local_rank)
+    pmc = load_pmc()
+    cpu_on = not args.no_cpu_baseline
+    if cpu_on:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O  # checker / timed CPU baseline only
+        ncore = O.omp_threads()
 
+    def sync():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    lb = getattr(gr, args.lb)
+
+    # ------------------------------------------------------------------ BFS (top level) + bfs_forward
     wl = WORKLOADS[args.workload]
     t0 = time.time()
-    if dist_on:
-        # ---- N > 1: ONE graph, N times the single-GPU size (weak scaling), vertex-range
-        # partitioned; per level an RCCL all-to-all of the non-owned discoveries
-        # (gunrock_amd/distributed.py).  At N = 8 this is BASELINE.json configs[4] scale
-        # (soc-twitter-2010: 21 M V / 530 M E) -- here 38.8 M V / 552 M E.
-        from gunrock_amd import distributed as D
-        if wl["kind"] not in ("rmat", "rmat_sym"):
-            raise SystemExit("multi-GPU bench supports the R-MAT workloads")
-        V = wl["V"] * world
-        entries = wl["entries"] * world
-        bounds = D.vertex_bounds(V, world)
-        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-        props, mine = gr.generate_rows(wl["kind"], V, entries, lo, hi, wl["a"], wl["b"], wl["c"], seed=42)
-        topdown_only = args.topdown_only
-        mine_in = None
-        if wl["kind"] == "rmat" and not topdown_only:  # directed: the bottom-up step needs the in-rows too
-            _, mine_in = gr.generate_rows(wl["kind"], V, entries, lo, hi, wl["a"], wl["b"], wl["c"], seed=42,
-                                          in_rows=True)
-        deg = np.diff(mine.row_offsets)
-        cdev = dev if dist.get_backend() == "nccl" else "cpu"
-        best = torch.tensor([int(deg.max())], dtype=torch.int64, device=cdev)
-        dist.all_reduce(best, op=dist.ReduceOp.MAX)
-        cand = int(np.argmax(deg)) if int(deg.max()) == int(best.item()) else V
-        srct = torch.tensor([cand], dtype=torch.int64, device=cdev)
-        dist.all_reduce(srct, op=dist.ReduceOp.MIN)
-        src = int(srct.item())
-        E = int(mine.number_of_nonzeros)
-        et = torch.tensor([E], dtype=torch.int64, device=cdev)
-        dist.all_reduce(et)
-        overlap = os.environ.get("GRX_BENCH_OVERLAP", "0") == "1"
-        eng = D.GrxEngine(props, mine, rank, world, dev, int(et.item()), in_rows=mine_in, overlap=overlap)
-        dist_t = torch.empty(V, dtype=torch.int32, device=dev)
-        t_setup = time.time() - t0
-
-        def barrier():
-            dist.barrier()
-            torch.cuda.synchronize()
-
-        for _ in range(args.warmup):
-            st = D.bfs(eng, dist, src, dist_t, optimized=not topdown_only)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            st = D.bfs(eng, dist, src, dist_t, optimized=not topdown_only)
-        barrier()
-        elapsed = time.perf_counter() - t1
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        ee = torch.tensor([st["edges_visited"], E], dtype=torch.int64, device=cdev)
-        dist.all_reduce(ee, op=dist.ReduceOp.SUM)
-        edges_total, e_total = int(ee[0].item()), int(ee[1].item())
-        ms_per_step = elapsed * 1e3 / args.steps
-        mteps = edges_total / (ms_per_step * 1e3)
-        if rank == 0:
-            print(json.dumps({
-                "metric": "MTEPS (million traversed edges/sec) BFS", "value": round(mteps, 1), "unit": "MTEPS",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
-                "data": "synthetic",
-                "config": {"workload": "BFS R-MAT(0.57,0.19,0.19,0.05), %d x the single-GPU size: %d V / %d E, "
-                                       "src = max out-degree vertex" % (world, V, e_total),
-                           "n_vertices": V, "n_edges": e_total, "source": src,
-                           "parallelism": "vertex-range partition over %d GPUs; per level one RCCL "
-                                          "all_to_all_single of fixed-size bitmaps (%d B per pair) + a 4-word "
-                                          "all_reduce; device-side direction choice; host polls once per batch "
-                                          "of levels%s" % (world, eng.S // 8,
-                                                           "; top-down halves overlapped" if overlap else ""),
-                           "advance_direction": "forward (top-down)" if topdown_only else "optimized (Beamer, "
-                                                "decided on the device from all-reduced statistics)",
-                           "edges_visited_per_step": edges_total, "search_depth": st["search_depth"],
-                           "setup_s": round(t_setup, 1)},
-                "roofline": None, "cpu_baseline": None}))
-        dist.barrier()
-        dist.destroy_process_group()
-        return
-
     props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], wl["c"], seed=42)
     deg = np.diff(csr.row_offsets)
     src = int(np.argmax(deg))
-    ctx = gr.multi_context_t(local_rank)
+    if wl["kind"] == "road":
+        src = (4894 // 2) * 4894 + 4894 // 2
     G = gr.build_graph(props, csr, ctx, device=dev)
     V, E = G.get_number_of_vertices(), G.get_number_of_edges()
     dist_t = torch.empty(V, dtype=torch.int32, device=dev)
     t_setup = time.time() - t0
 
-    lb = getattr(gr, args.lb)
+    def bfs_opts(direction, flags=0):
+        return gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact,
+                            advance_direction=direction, engine_flags=flags)
+
+    def bfs_section(direction):
+        o = bfs_opts(direction, gr.FLAG_ASYNC_RETURN)
+        ms_step = timed(lambda: gr.bfs(G, src, dist_t, None, ctx, o), sync, args.steps, args.warmup)
+        st = gr.run_stats(ctx)
+        return ms_step, st
+
+    td_bytes = lambda l: 12 * l["frontier_size"] + 12 * l["edges"]
+    # bottom-up kernel: visited r/w + next-frontier bitmap (3 V/8), two in-offsets per open vertex (8), column
+    # index + frontier-bitmap word per probed in-edge (8), label + two out-offsets per discovered vertex (12)
+    bu_bytes = lambda l, nxt: 3 * (V // 8) + 8 * l["bu_open"] + 8 * l["bu_probes"] + 12 * nxt
+
+    def bfs_profile(direction):
+        po = bfs_opts(direction, gr.FLAG_PROFILE)
+        return best_profile(lambda: gr.bfs(G, src, dist_t, None, ctx, po), lambda: gr.level_profile(ctx))
+
+    def forward_roofline():
+        prof = bfs_profile(gr.forward)
+        r = roof(prof, td_bytes, "bfs level kernels, forward-only run: claim-per-edge advance (advance_block) on the "
+                 "thin levels, binned advance (scatter + claim kernels, grx_bin.hpp) on the fat ones",
+                 "12 B per frontier slot + 12 B per traversed edge (SURVEY 8d)")
+        attach_traffic(r, pmc, "topdown_fat")
+        fat = sorted(prof, key=lambda l: -l["edges"])[:2]
+        r["fat_levels_avg_launch_us"] = round(sum(l["advance_ms"] for l in fat) * 1e3 / max(1, len(fat)), 2)
+        r["fat_levels_frac"] = round(sum(td_bytes(l) for l in fat) / max(1e-9, sum(l["advance_ms"] for l in fat) * 1e-3)
+                                     / 1e9 / HBM_PEAK_GBS, 4)
+        r["levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
+                        round(l["other_ms"], 4)] for l in prof]
+        r["levels_columns"] = "frontier vertices, out-edges, mode (2 = binned), level kernel(s) ms, head kernel ms"
+        return r
+
     direction = gr.forward if args.topdown_only else gr.optimized
-    opts = gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact,
-                        advance_direction=direction)
+    ms_per_step, st = bfs_section(direction)
+    edges_rank = st["edges_visited"]
+    mteps = edges_rank / (ms_per_step * 1e3)
+    bfs_gpu_depths = dist_t.cpu().numpy().copy()
+
+    roofline_td = forward_roofline()
+    if args.topdown_only:
+        roofline, roofline_other = roofline_td, None
+    else:
+        prof_do = bfs_profile(gr.optimized)
+        sizes = [l["frontier_size"] for l in prof_do] + [0]
+        bu = [dict(l, nxt=sizes[i + 1]) for i, l in enumerate(prof_do) if l["bottom_up"] == 1]
+        td = [l for l in prof_do if l["bottom_up"] != 1]
+        t_bu = sum(l["advance_ms"] for l in bu)
+        t_td = sum(l["advance_ms"] for l in td)
+        r_bu = roof(bu, lambda l: bu_bytes(l, l["nxt"]), "bfs_level_kernel (bottom-up launches)",
+                    "3 V/8 + 8 open + 8 probes + 12 found (DESIGN.md 5)")
+        r_bu["levels"] = [[l["frontier_size"], l["edges"], l["bu_open"], l["bu_probes"], round(l["advance_ms"], 4),
+                           round(l["other_ms"], 4)] for l in bu]
+        r_bu["share_of_step_kernel_time"] = round(t_bu / max(t_bu + t_td, 1e-9), 3)
+        if bu:
+            attach_traffic(r_bu, pmc, "bottom_up")
+        roofline, roofline_other = (r_bu, roofline_td) if t_bu >= t_td or not td else (roofline_td, r_bu)
+        roofline["all_levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
+                                   round(l["other_ms"], 4)] for l in prof_do]
+
+    cpu = cpu_n = None
+    if cpu_on:
+        g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
+        t_cpu, runs = 0.0, 0
+        while t_cpu < 8e3 and runs < 64:
+            d_cpu, ms = O.bfs(g, src)
+            t_cpu += ms
+            runs += 1
+        cpu = {"value": round(runs * edges_rank / (t_cpu * 1e3), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+               "sample": "%d full BFS runs of the same workload/source with oracle/oracle.c orc_bfs (priority-queue "
+                         "search of examples/algorithms/bfs/bfs_cpu.hxx), %.1f s" % (runs, t_cpu / 1e3),
+               "matches_gpu": bool(np.array_equal(d_cpu, bfs_gpu_depths))}
+        t_n, runs_n, ev_n = 0.0, 0, 0
+        while t_n < 3e3 and runs_n < 64:
+            d_n, ms, ev = O.bfs_omp(g, src)
+            t_n += ms
+            runs_n += 1
+            ev_n += ev
+        cpu_n = {"value": round(ev_n / (t_n * 1e3), 2), "unit": "MTEPS", "cores": ncore, "kind": "port",
+                 "sample": "%d full level-synchronous BFS runs on %d host threads (oracle/oracle_omp.c orc_bfs_omp: the "
+                           "reference's advance with atomicMin, bfs.hxx:105-146, per level), %.1f s"
+                           % (runs_n, ncore, t_n / 1e3),
+                 "matches_gpu": bool(np.array_equal(d_n, bfs_gpu_depths))}
+
+    out = {"metric": "MTEPS (million traversed edges/sec) BFS", "value": round(mteps, 1), "unit": "MTEPS",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+           "config": {"workload": "BFS on " + wl["name"], "n_vertices": V, "n_edges": E, "source": src,
+                      "advance_load_balance": args.lb + " (engine: tile/chunk merge-path decomposition; a per-level "
+                                              "choice between claim-per-edge, binned and bottom-up bodies is made on "
+                                              "the device)",
+                      "filter": "compact (fused into advance)",
+                      "advance_direction": "forward" if args.topdown_only else "optimized",
+                      "completion": "GRX_FLAG_ASYNC_RETURN (return when the device publishes the end of the search; "
+                                    "the K steps are bracketed by stream synchronisation)",
+                      "kernel_launch_groups_per_step": int(st["aux"]), "parallelism": "single GPU",
+                      "edges_visited_per_step": edges_rank, "search_depth": st["search_depth"],
+                      "enact_ms_last": round(st["elapsed_ms"], 4), "setup_s": round(t_setup, 1),
+                      "engine_source_sha": source_sha()},
+           "roofline": roofline, "roofline_topdown_advance": roofline_other,
+           "cpu_baseline": cpu, "cpu_baseline_ncore": cpu_n}
+
+    if "bfs_forward" in only and not args.topdown_only:
+        ms_f, st_f = bfs_section(gr.forward)
+        ok = bool(np.array_equal(dist_t.cpu().numpy(), bfs_gpu_depths))
+        out["bfs_forward"] = {
+            "config": "BASELINE configs[1] as written: merge-path advance + compact filter, advance_direction=forward, "
+                      "same graph/source",
+            "ms_per_step": round(ms_f, 4), "mteps": round(st_f["edges_visited"] / (ms_f * 1e3), 1),
+            "steps": args.steps, "edges_visited_per_step": st_f["edges_visited"], "search_depth": st_f["search_depth"],
+            "enact_ms_last": round(st_f["elapsed_ms"], 4), "equal_to_direction_optimized_depths": ok,
+            "roofline": roofline_td, "cpu_baseline": cpu, "cpu_baseline_ncore": cpu_n}
+    del G, dist_t
+
+    # ------------------------------------------------------------------ SSSP on the road stand-in
+    if "sssp" in only:
+        out["sssp"] = bench_sssp(gr, torch, ctx, dev, sync, pmc, cpu_on, args)
+    # ------------------------------------------------------------------ PageRank on the kron stand-in
+    if "pr" in only:
+        out["pr"] = bench_pr(gr, torch, ctx, dev, sync, pmc, cpu_on, args)
+    print(json.dumps(out))
+
+
+def bench_sssp(gr, torch, ctx, dev, sync, pmc, cpu_on, args):
+    if cpu_on:
+        import oracle_lib as O
+        ncore = O.omp_threads()
+    wl = WORKLOADS["road"]
+    res = {"workload": "SSSP on " + wl["name"]}
+    src = (4894 // 2) * 4894 + 4894 // 2
+    for label, weighted in (("unit_weights", False), ("weighted_1_1000", True)):
+        t0 = time.time()
+        props, csr = gr.generate("road", wl["V"], 0, wl["a"], 0.0, 1.0 if weighted else 0.0, seed=42)
+        G = gr.build_graph(props, csr, ctx, device=dev)
+        V, E = G.get_number_of_vertices(), G.get_number_of_edges()
+        d = torch.empty(V, dtype=torch.float32, device=dev)
+        t_setup = time.time() - t0
+        o = gr.options_t(advance_load_balance=gr.merge_path)
+        steps = 3 if weighted else 5
+        ms_step = timed(lambda: gr.sssp(G, src, d, None, ctx, o), sync, steps, 1)
+        st = gr.run_stats(ctx)
+        po = gr.options_t(advance_load_balance=gr.merge_path, engine_flags=gr.FLAG_PROFILE)
+        prof = best_profile(lambda: gr.sssp(G, src, d, None, ctx, po), lambda: gr.level_profile(ctx), tries=1)
+        adv = [l for l in prof if l["bottom_up"] != 2]  # 2: iterations that only pull a bucket out of the far pile
+        per_edge = 16 if weighted else 12  # weighted: + 4 B weight; all-1.0 weights are never read
+        r = roof(adv, lambda l: 12 * l["frontier_size"] + per_edge * l["edges"],
+                 "sssp_nf_level_kernel (near-far advance)" if weighted else "advance_kernel<sssp_policy>",
+                 "12 B per frontier slot + %d B per relaxed edge (SURVEY 8d)" % per_edge)
+        attach_traffic(r, pmc, "sssp_" + label)
+        r["head_kernel_ms_per_step"] = round(sum(l["other_ms"] for l in prof), 3)
+        r["bucket_pull_launches"] = len(prof) - len(adv)
+        r["bucket_pull_ms_per_step"] = round(sum(l["advance_ms"] for l in prof if l["bottom_up"] == 2), 3)
+        r["note"] = ("profile run: one record per two-launch iteration (levels absorbed by the LDS-resident tiny-level "
+                     "body of the head kernel are accounted to the iteration that ran them)")
+        item = {"schedule": "near-far (delta-stepping)" if weighted else "level-synchronous (all weights equal)",
+                "n_vertices": V, "n_edges": E, "source": src, "steps": steps, "ms_per_step": round(ms_step, 3),
+                "mteps": round(st["edges_visited"] / (ms_step * 1e3), 1),
+                "edges_relaxed_per_step": st["edges_visited"], "iterations": st["search_depth"],
+                "us_per_iteration": round(ms_step * 1e3 / max(1, st["search_depth"]), 2),
+                "setup_s": round(t_setup, 1), "roofline": r, "cpu_baseline": None, "cpu_baseline_ncore": None}
+        if cpu_on:
+            g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
+            mine = d.cpu().numpy()
+            item["property_check_violations"] = int(O.check_sssp(g, src, mine))
+            d1, ms1, ev1, fin1 = O.sssp_budget(g, src, 12e3)
+            item["cpu_baseline"] = {
+                "value": round(ev1 / (ms1 * 1e3), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+                "sample": "oracle/oracle.c orc_sssp (priority-queue Dijkstra of examples/algorithms/sssp/sssp_cpu.hxx) "
+                          "from the same source, %s after %.1f s: %d edges scanned"
+                          % ("finished" if fin1 else "stopped", ms1 / 1e3, ev1),
+                "matches_gpu": bool(np.array_equal(d1, mine)) if fin1 else None}
+            dn, msn, evn, itn, finn = O.sssp_omp(g, src, budget_ms=10e3)
+            item["cpu_baseline_ncore"] = {
+                "value": round(evn / (msn * 1e3), 2), "unit": "MTEPS", "cores": ncore, "kind": "port",
+                "sample": "oracle/oracle_omp.c orc_sssp_omp (the reference's frontier relaxation, sssp.hxx:116-151, on "
+                          "%d host threads), %s after %.1f s: %d iterations, %d edges relaxed"
+                          % (ncore, "finished" if finn else "stopped", msn / 1e3, itn, evn),
+                "matches_gpu": bool(np.array_equal(dn, mine)) if finn else None}
+        res[label] = item
+        del G, d
+    return res
+
+
+def bench_pr(gr, torch, ctx, dev, sync, pmc, cpu_on, args):
+    if cpu_on:
+        import oracle_lib as O
+        ncore = O.omp_threads()
+    wl = WORKLOADS["kron"]
+    t0 = time.time()
+    props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], wl["c"], seed=42)
+    G = gr.build_graph(props, csr, ctx, device=dev)
+    V, E = G.get_number_of_vertices(), G.get_number_of_edges()
+    p = torch.empty(V, dtype=torch.float32, device=dev)
+    result = gr.pr_result_t(p)
+    par = gr.pr_param_t(0.85, 1e-6)
+    t1 = time.time()
+    gr.pr_run(G, par, result, ctx)  # first call: builds the pull layout (graph preparation, untimed like the CSR build)
+    sync()
+    t_first = time.time() - t1
+    t_setup = time.time() - t0
+    steps = 5
+    ms_step = timed(lambda: gr.pr_run(G, par, result, ctx), sync, steps, 1)
+    iters = result.iterations
+    ppar = gr.pr_param_t(0.85, 1e-6, gr.options_t(engine_flags=gr.FLAG_PROFILE))
+    prof = best_profile(lambda: gr.pr_run(G, ppar, result, ctx), lambda: gr.level_profile(ctx))
+    per_iter = 8 * E + 16 * V  # pattern graph: column index + gathered x per edge; offsets, p, x, iweights per vertex
+    r = roof(prof, lambda l: per_iter, "pr pull iteration (pr_pull_xcd_kernel + long-row pieces + pr_combine_kernel)",
+             "8 E + 16 V per iteration on a pattern graph (weights all 1.0 are not read); SURVEY 8d")
+    attach_traffic(r, pmc, "pr_pull")
+    r["prepare_scalar_ms_per_step"] = round(sum(l["other_ms"] for l in prof), 4)
+    r["ms_per_iteration_pull"] = round(sum(l["advance_ms"] for l in prof) / max(1, len(prof)), 4)
+    item = {"workload": "PageRank on " + wl["name"], "alpha": 0.85, "tol": 1e-6, "n_vertices": V, "n_edges": E,
+            "steps": steps, "ms_per_step": round(ms_step, 4), "iterations": iters,
+            "ms_per_iteration": round(ms_step / max(1, iters), 4),
+            "mteps": round(E * iters / (ms_step * 1e3), 1), "first_call_s_incl_layout_build": round(t_first, 2),
+            "setup_s": round(t_setup, 1), "roofline": r, "cpu_baseline": None, "cpu_baseline_ncore": None}
+    if cpu_on:
+        g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
+        mine = p.cpu().numpy()
+        delta, err, _ = O.pr_f64_trace(g, max(iters + 1, 8), [mine], pattern=True)
+        item["max_abs_diff_to_float64_same_iterations"] = float(err[0][iters - 1])
+        item["float64_iterations"] = O.pr_iterations_from_trace(delta)
+        _, it1, ms1 = O.pr_f32(g, max_iterations=3)
+        item["cpu_baseline"] = {
+            "value": round(E * it1 / (ms1 * 1e3), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+            "sample": "oracle/oracle.c orc_pr_f32 (the reference's push iteration, pr.hxx:107-152, fp32), first %d "
+                      "iterations, %.1f s" % (it1, ms1 / 1e3)}
+        _, msn = O.pr_omp(g, iterations=5, pattern=True)
+        item["cpu_baseline_ncore"] = {
+            "value": round(E * 5 / (msn * 1e3), 2), "unit": "MTEPS", "cores": ncore, "kind": "port",
+            "sample": "oracle/oracle_omp.c orc_pr_omp (the same recurrence as a pull over the transpose on %d host "
+                      "threads), 5 iterations, %.1f s" % (ncore, msn / 1e3)}
+    del G, p
+    return item
+
+
+def bench_multi_gpu(args, gr, torch, rank, local_rank, world):
+    """N > 1: ONE graph, vertex-range partitioned over the ranks (gunrock_amd/distributed.py).
+    N = 8: BASELINE.json configs[4], the soc-twitter-2010 stand-in C5'.  N = 2, 4: N x the single-GPU C2' size
+    (weak scaling: per-GPU work fixed; 8 x C2' = 38.8 M V / 552 M E is within 4 % of C5' in edges)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # GRX_BENCH_BACKEND=gloo lets the N > 1 path be exercised with several ranks sharing one GPU (tests);
+    # the driver's multi-GPU runs use nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("GRX_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    dev = "cuda:%d" % local_rank
+    from gunrock_amd import distributed as D
+    name = os.environ.get("GRX_BENCH_MULTI_WORKLOAD", "twitter" if world == 8 else args.workload)
+    wl = WORKLOADS[name]
+    if wl["kind"] not in ("rmat", "rmat_sym"):
+        raise SystemExit("multi-GPU bench supports the R-MAT workloads")
+    t0 = time.time()
+    scale = 1 if name == "twitter" else world
+    V = wl["V"] * scale
+    entries = wl["entries"] * scale
+    bounds = D.vertex_bounds(V, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    props, mine = gr.generate_rows(wl["kind"], V, entries, lo, hi, wl["a"], wl["b"], wl["c"], seed=42)
+    topdown_only = args.topdown_only
+    mine_in = None
+    if wl["kind"] == "rmat" and not topdown_only:  # directed: the bottom-up step needs the in-rows too
+        _, mine_in = gr.generate_rows(wl["kind"], V, entries, lo, hi, wl["a"], wl["b"], wl["c"], seed=42, in_rows=True)
+    deg = np.diff(mine.row_offsets)
+    cdev = dev if dist.get_backend() == "nccl" else "cpu"
+    best = torch.tensor([int(deg.max())], dtype=torch.int64, device=cdev)
+    dist.all_reduce(best, op=dist.ReduceOp.MAX)
+    cand = int(np.argmax(deg)) if int(deg.max()) == int(best.item()) else V
+    srct = torch.tensor([cand], dtype=torch.int64, device=cdev)
+    dist.all_reduce(srct, op=dist.ReduceOp.MIN)
+    src = int(srct.item())
+    E = int(mine.number_of_nonzeros)
+    et = torch.tensor([E], dtype=torch.int64, device=cdev)
+    dist.all_reduce(et)
+    overlap = os.environ.get("GRX_BENCH_OVERLAP", "0") == "1"
+    eng = D.GrxEngine(props, mine, rank, world, dev, int(et.item()), in_rows=mine_in, overlap=overlap)
+    dist_t = eng.new_labels()
+    t_setup = time.time() - t0
 
     def barrier():
+        dist.barrier()
         torch.cuda.synchronize()
-        ctx.synchronize()
 
     for _ in range(args.warmup):
-        gr.bfs(G, src, dist_t, None, ctx, opts)
+        st = D.bfs(eng, dist, src, dist_t, optimized=not topdown_only)
     barrier()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        gr.bfs(G, src, dist_t, None, ctx, opts)
+        st = D.bfs(eng, dist, src, dist_t, optimized=not topdown_only)
     barrier()
     elapsed = time.perf_counter() - t1
-    st = gr.run_stats(ctx)
-    edges_rank = st["edges_visited"]
-    enact_ms = st["elapsed_ms"]
-    edges_total = edges_rank
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    ee = torch.tensor([st["edges_visited"], E], dtype=torch.int64, device=cdev)
+    dist.all_reduce(ee, op=dist.ReduceOp.SUM)
+    edges_total, e_total = int(ee[0].item()), int(ee[1].item())
     ms_per_step = elapsed * 1e3 / args.steps
     mteps = edges_total / (ms_per_step * 1e3)
-
-    out = None
     if rank == 0:
-        # ---- rooflines, HIP events on the engine stream (GRX_FLAG_PROFILE records per-level
-        # kernel times with events on ctx's stream and syncs after every level)
-        def profile(direction_):
-            popts = gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact,
-                                 advance_direction=direction_, engine_flags=gr.FLAG_PROFILE)
-            best_ = None
-            for _ in range(3):
-                gr.bfs(G, src, dist_t, None, ctx, popts)
-                prof_ = gr.level_profile(ctx)
-                t_ = sum(l["advance_ms"] for l in prof_)
-                if best_ is None or t_ < best_[0]:
-                    best_ = (t_, prof_)
-            return best_[1]
-
-        # HBM traffic of the same kernels from the committed rocprofv3 PMC passes of this round
-        # (FETCH_SIZE / WRITE_SIZE, separate --pmc runs; tools/profile.sh, profiles/r1_bench_pmc.json)
-        pmc = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_pmc.json")))
-        except Exception:
-            pass
-
-        def roof(levels, bytes_of, kernel):
-            ms = sum(l["advance_ms"] for l in levels)
-            byt = sum(bytes_of(l) for l in levels)
-            ach = byt / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
-                    "launches_per_step": len(levels), "alg_bytes_per_step": int(byt),
-                    "kernel_ms_per_step": round(ms, 4),
-                    "avg_launch_us": round(ms * 1e3 / max(1, len(levels)), 2)}
-
-        # top-down advance kernel: BASELINE.md / SURVEY 8d, 12 B per frontier slot + 12 B per edge
-        td_bytes = lambda l: 12 * l["frontier_size"] + 12 * l["edges"]
-        # bottom-up kernel: bytes it must touch -- visited r/w + next-frontier bitmap (3 * V/8),
-        # two in-offsets per open vertex (8), column index + frontier-bitmap word per probed
-        # in-edge (8), label + two out-offsets per discovered vertex (12)
-        bu_bytes = lambda l, nxt: 3 * (V // 8) + 8 * l["bu_open"] + 8 * l["bu_probes"] + 12 * nxt
-        prof_td = profile(gr.forward)
-        roofline_td = roof(prof_td, td_bytes, "bfs_level_kernel (top-down advance, forward-only run)")
-        def attach_traffic(r, cls):
-            # per-launch HBM-side bytes of the same launches from the committed rocprofv3 PMC passes
-            k = (pmc or {}).get("classes", {}).get(cls)
-            if not k or args.workload != "lj" or "fetch_bytes_per_launch" not in k:
-                return
-            r["traffic"] = int(k["fetch_bytes_per_launch"] + k.get("write_bytes_per_launch", 0.0))
-            r["traffic_source"] = ("profiles/r1_bench_pmc.json class '%s': FETCH_SIZE + WRITE_SIZE per launch, separate "
-                                   "--pmc passes of this command (raw counters; gfx950 tallies coalesced reads at 1/2)" % cls)
-            if "duration_us_per_launch" in k:
-                r["rocprof_avg_launch_us"] = round(k["duration_us_per_launch"], 2)
-
-        attach_traffic(roofline_td, "topdown_fat")
-        if roofline_td.get("traffic") is not None:
-            roofline_td["traffic_scope"] = "average of the two fat top-down levels (the launches that carry 99 % of the bytes)"
-            # the PMC class covers the two fat levels only: quote the event time of the same two launches
-            fat = sorted(prof_td, key=lambda l: -l["edges"])[:2]
-            roofline_td["fat_levels_avg_launch_us"] = round(sum(l["advance_ms"] for l in fat) * 1e3 / max(1, len(fat)), 2)
-        roofline_td["levels"] = [[l["frontier_size"], l["edges"], round(l["advance_ms"], 4), round(l["other_ms"], 4)]
-                                 for l in prof_td]
-        if args.topdown_only:
-            roofline, roofline_other = roofline_td, None
+        if name == "twitter":
+            wname = "BFS on " + wl["name"] + " (BASELINE.json configs[4]), src = max out-degree vertex"
         else:
-            prof_do = profile(gr.optimized)
-            sizes = [l["frontier_size"] for l in prof_do] + [0]
-            bu = [dict(l, nxt=sizes[i + 1]) for i, l in enumerate(prof_do) if l["bottom_up"]]
-            td = [l for l in prof_do if not l["bottom_up"]]
-            t_bu = sum(l["advance_ms"] for l in bu)
-            t_td = sum(l["advance_ms"] for l in td)
-            r_bu = roof(bu, lambda l: bu_bytes(l, l["nxt"]), "bfs_level_kernel (bottom-up launches)")
-            r_bu["levels"] = [[l["frontier_size"], l["edges"], l["bu_open"], l["bu_probes"], round(l["advance_ms"], 4),
-                               round(l["other_ms"], 4)] for l in bu]
-            r_bu["share_of_step_kernel_time"] = round(t_bu / max(t_bu + t_td, 1e-9), 3)
-            if bu:
-                attach_traffic(r_bu, "bottom_up")
-            roofline, roofline_other = (r_bu, roofline_td) if t_bu >= t_td or not td else (roofline_td, r_bu)
-            roofline["all_levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
-                                       round(l["other_ms"], 4)] for l in prof_do]
-        # ---- CPU baseline: the oracle (port of the reference's PQ CPU path), bounded sample
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib as O
-            g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
-            t_cpu, runs, ev_cpu, budget = 0.0, 0, 0, 12.0
-            while t_cpu < budget * 1e3 and runs < 64:
-                d_cpu, ms = O.bfs(g, src)
-                t_cpu += ms
-                runs += 1
-                ev_cpu += edges_rank
-            ok = bool(np.array_equal(d_cpu, dist_t.cpu().numpy()))
-            cpu = {"value": round(ev_cpu / (t_cpu * 1e3), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
-                   "sample": "%d full BFS runs of the same workload/source with oracle/oracle.c orc_bfs "
-                             "(priority-queue search of examples/algorithms/bfs/bfs_cpu.hxx), %.1f s"
-                             % (runs, t_cpu / 1e3),
-                   "matches_gpu": ok}
-        out = {"metric": "MTEPS (million traversed edges/sec) BFS", "value": round(mteps, 1), "unit": "MTEPS",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-               "config": {"workload": wl["name"], "n_vertices": V, "n_edges": E, "source": src,
-                          "advance_load_balance": args.lb, "filter": "compact (fused into advance)",
-                          "advance_direction": "forward" if args.topdown_only else "optimized",
-                          "kernel_launch_groups_per_step": int(st["aux"]),
-                          "parallelism": "single GPU",
-                          "edges_visited_per_step": edges_rank, "search_depth": st["search_depth"],
-                          "enact_ms_last": round(enact_ms, 4), "setup_s": round(t_setup, 1)},
-               "roofline": roofline, "roofline_topdown_advance": roofline_other, "cpu_baseline": cpu}
-        print(json.dumps(out))
-    if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
+            wname = ("BFS on %d x the single-GPU C2' size: R-MAT(0.57,0.19,0.19,0.05) %d V / %d E, src = max out-degree "
+                     "vertex (weak scaling)" % (world, V, e_total))
+        print(json.dumps({
+            "metric": "MTEPS (million traversed edges/sec) BFS", "value": round(mteps, 1), "unit": "MTEPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": wname, "n_vertices": V, "n_edges": e_total, "source": src,
+                       "per_gpu_edges": e_total // world,
+                       "parallelism": "vertex-range partition over %d GPUs, labels sharded (V/P per rank); per level "
+                                      "one all-to-all of fixed-size bitmaps (%d B per pair) + a 4-word all-reduce over "
+                                      "RCCL; device-side direction choice; %s%s"
+                                      % (world, eng.S // 8, eng.transport_description(),
+                                         "; top-down halves overlapped" if overlap else ""),
+                       "advance_direction": "forward (top-down)" if topdown_only else "optimized (Beamer, decided on "
+                                            "the device from all-reduced statistics)",
+                       "edges_visited_per_step": edges_total, "search_depth": st["search_depth"],
+                       "setup_s": round(t_setup, 1)},
+            "roofline": None, "cpu_baseline": None}))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -235,6 +235,9 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->t_ci) (void)hipFree(g->t_ci);
   if (g->t_w) (void)hipFree(g->t_w);
   if (g->closed0) (void)hipFree(g->closed0);
+  if (g->bins) (void)hipFree(g->bins);
+  if (g->bin_off) (void)hipFree(g->bin_off);
+  if (g->bin_fill) (void)hipFree(g->bin_fill);
   if (g->pr_blocks) (void)hipFree(g->pr_blocks);
   if (g->pr_piece) (void)hipFree(g->pr_piece);
   if (g->pr_long) (void)hipFree(g->pr_long);

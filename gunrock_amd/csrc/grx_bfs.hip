@@ -27,6 +27,7 @@
 //    and 4.5 us per level as a no-op launch the host had to enqueue blindly.
 #include "grx_engine.hpp"
 #include "grx_bfs_kernels.hpp"
+#include "grx_bin.hpp"
 
 #include <climits>
 #include <cstddef>
@@ -192,7 +193,7 @@ __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_
 // (tiny_levels_body), then level bookkeeping + direction choice, then the chunk map of a
 // top-down level.  (A trivial kernel costs ~4 us on this part: this used to be three.)  <<<1, 1024>>>
 __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs_args d, bfs_policy pol,
-                                                              int allow_tiny, int seq) {
+                                                              int allow_tiny, int seq, bin_args bn) {
   __shared__ tiny_smem<bfs_policy> tsm;
   __shared__ unsigned long long s_red[4];
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
@@ -216,6 +217,10 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
   if (!d.enabled) {
     in.level = h.level + 1;
     in.nt = h.nt(in.level & 1);
+    in.bin_min = bn.min_edges;  // > 0: fat levels run binned (mode 2), see grx_bin.hpp
+    in.bin_fill = bn.fill;
+    in.bin_nb = bn.nb;
+    in.bin_pad = BIN_PAD;
     plan_body<PLAN_BLOCK>(a, c, 0, s_wave, &s_red[0], in);
     return;
   }
@@ -273,9 +278,78 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
   }
 }
 
+// Forward-only runs with binned fat levels: one level is this kernel (the claim-per-edge advance, or
+// the SCATTER phase of a binned level) followed by bfs_claim_kernel (a no-op unless the level is
+// binned).  Separate from bfs_level_kernel so that the 38 KB of LDS the scatter phase sorts in do
+// not cost the direction-optimising path its resident workgroups.
+__global__ __launch_bounds__(ADV_BLOCK) void bfs_level_bin_kernel(pipe_args a, bin_args bn, bfs_policy pol) {
+  using td_smem = advance_smem<bfs_policy>;
+  constexpr size_t LDS_BYTES = sizeof(td_smem) > sizeof(bin_scatter_smem) ? sizeof(td_smem) : sizeof(bin_scatter_smem);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+  ctrl_t* c = a.ctrl;
+  const level_head h = load_level_head(c);
+  if (h.done) return;
+  if (h.mode == 2) {
+    bin_scatter_block(a, bn, *reinterpret_cast<bin_scatter_smem*>(lds_raw), h.level & 1, h.total_chunks, a.chunk_tile);
+  } else {
+    pol.ctrl = c;
+    pol.set_level(h.level);
+    advance_block<bfs_policy, false>(a, c, pol, *reinterpret_cast<td_smem*>(lds_raw), h.level & 1, blockIdx.x,
+                                     gridDim.x, h.total_chunks, a.chunk_tile);
+  }
+}
+
+__global__ __launch_bounds__(ADV_BLOCK) void bfs_claim_kernel(pipe_args a, bin_args bn, bfs_policy pol) {
+  __shared__ bin_claim_smem sm;
+  ctrl_t* c = a.ctrl;
+  const level_head h = load_level_head(c);
+  if (h.done || h.mode != 2) return;
+  pol.ctrl = c;
+  pol.set_level(h.level);
+  bin_claim_block(a, bn, c, pol, sm, h.level & 1);
+}
+
 }  // namespace grx
 
 using namespace grx;
+
+// Per-graph static part of the binned levels (cached in the graph handle): bin width, capacities
+// (= in-edges of each bin's vertex range), the E-entry bin array and the fill counters.
+static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
+  if (g->bin_state != 0) return GRX_SUCCESS;
+  g->bin_state = 2;  // unusable until proven otherwise
+  if (g->V <= 0 || g->E <= 0) return GRX_SUCCESS;
+  int shift = 5;
+  while (shift < 31 && (((long long)g->V + (1ll << shift) - 1) >> shift) > BIN_MAX) ++shift;
+  if (shift > BIN_SHIFT_MAX) return GRX_SUCCESS;  // a bin's bitmap slice would not fit the claim kernel's LDS
+  const int nb = (int)(((long long)g->V + (1ll << shift) - 1) >> shift);
+  hipStream_t s = ctx->stream;
+  int32_t* d_cnt = nullptr;
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt), BIN_MAX * sizeof(int32_t)));
+  GRX_HIP(hipMemsetAsync(d_cnt, 0, BIN_MAX * sizeof(int32_t), s));
+  hipLaunchKernelGGL(bin_count_kernel, dim3(ctx->num_cus * 8), dim3(BIN_MAX), 0, s, g->ci, (int64_t)g->E, shift, d_cnt);
+  int32_t h_cnt[BIN_MAX];
+  GRX_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+  GRX_HIP(hipStreamSynchronize(s));
+  (void)hipFree(d_cnt);
+  int32_t h_off[BIN_MAX + 1];
+  long long acc = 0;
+  for (int b = 0; b <= BIN_MAX; ++b) {
+    h_off[b] = (int32_t)acc;
+    if (b < BIN_MAX) acc += h_cnt[b];
+  }
+  if (acc != (long long)g->E) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: a column index lies outside [0, V)");
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_off), (BIN_MAX + 1) * sizeof(int32_t)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_fill), (size_t)BIN_MAX * BIN_PAD * sizeof(int32_t)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bins), (size_t)g->E * sizeof(int32_t)));
+  GRX_HIP(hipMemcpyAsync(g->bin_off, h_off, sizeof(h_off), hipMemcpyHostToDevice, s));
+  GRX_HIP(hipMemsetAsync(g->bin_fill, 0, (size_t)BIN_MAX * BIN_PAD * sizeof(int32_t), s));
+  GRX_HIP(hipStreamSynchronize(s));
+  g->bin_shift = shift;
+  g->bin_nb = nb;
+  g->bin_state = 1;
+  return GRX_SUCCESS;
+}
 
 // Workgroups of the per-level kernel: exactly what is RESIDENT (persistent workgroups
 // stride over the work with gridDim, so a partial second round would double the time),
@@ -296,6 +370,12 @@ struct level_build {
 static level_build* level_kernel_build() {
   static level_build builds[2] = {{bfs_level_kernel<2>, 0}, {bfs_level_kernel<4>, 0}};
   return &builds[env_int("GRX_BU_BATCH", 2) == 4 ? 1 : 0];
+}
+using bin_kernel_fn = void (*)(pipe_args, bin_args, bfs_policy);
+static int resident_per_cu(bin_kernel_fn fn) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, ADV_BLOCK, 0) != hipSuccess || n < 1) n = 2;
+  return n > 8 ? 8 : n;
 }
 
 // Workgroups of the per-level kernel: exactly what is RESIDENT (persistent workgroups
@@ -335,6 +415,17 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   const bool dopt = opt.advance_direction == GRX_DIR_OPTIMIZED && variant == 0 && (long long)g->E >= 4ll * g->V;
   const size_t bm_words = 4 * (((size_t)g->V + 127) / 128);  // whole 16-byte groups: 64-vertex chunks, uint4 clears
   hipStream_t s = ctx->stream;
+  // Forward-only runs on dense graphs keep a visited bitmap too: it pre-filters the label probes of
+  // the claim-per-edge advance and carries the binned fat levels (grx_bin.hpp).
+  // Tuning knobs: GRX_TD_BITMAP=0 (no bitmap at all), GRX_TD_PRE=0 (no pre-filter), GRX_TD_BIN=0 (no
+  // binned levels), GRX_BIN_MIN_EDGES (out-edges of a frontier from which a level is binned).
+  const bool fwd_bm = !dopt && variant == 0 && (long long)g->E >= 4ll * g->V && env_int("GRX_TD_BITMAP", 1) != 0;
+  bool use_bins = fwd_bm && env_int("GRX_TD_BIN", 1) != 0;
+  if (use_bins) {
+    st = graph_build_bins(ctx, g);
+    if (st != GRX_SUCCESS) return st;
+    use_bins = g->bin_state == 1;
+  }
 
   dobfs_args d{};
   d.dist = d_dist;
@@ -386,7 +477,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     GRX_HIP(ctx->bu_part.reserve((size_t)d.bu_grid * 4 * sizeof(long long)));
     d.bu_part = ctx->bu_part.as<long long>();
     a.bu_part = d.bu_part;
-  } else if (variant != 0 && variant != 7) {
+  } else if (fwd_bm || (variant != 0 && variant != 7)) {
     visited_bytes = bm_words * sizeof(unsigned);
     GRX_HIP(ctx->bitmap[0].reserve(visited_bytes));
     visited = ctx->bitmap[0].as<unsigned>();
@@ -418,6 +509,30 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     lp.bm_visited = d.visited;
     for (int i = 0; i < 3; ++i) lp.bm_f[i] = d.fbits[i];
     lp.bm_words = d.n_words;
+  } else if (fwd_bm) {
+    lp.bm_visited = visited;
+    for (int i = 0; i < 3; ++i) lp.bm_f[i] = visited;  // every discovery sets its bit in `visited` itself
+    lp.bm_words = (int)bm_words;
+    lp.fwd_bitmap = 1;
+    lp.pre_bm = env_int("GRX_TD_PRE", 1) != 0 ? visited : nullptr;
+  }
+  bin_args bn{};
+  int grid_scatter = 0, grid_claim = 0;
+  if (use_bins) {
+    bn.bins = g->bins;
+    bn.off = g->bin_off;
+    bn.fill = g->bin_fill;
+    bn.shift = g->bin_shift;
+    bn.nb = g->bin_nb;
+    bn.min_edges = (long long)env_int("GRX_BIN_MIN_EDGES", 1 << 20);
+    if (bn.min_edges < 1) bn.min_edges = 1;
+    bn.visited = visited;
+    bn.visited_words = (int32_t)bm_words;
+    bn.dist = d_dist;
+    static const int per_cu_scatter = resident_per_cu(bfs_level_bin_kernel);
+    static const int per_cu_claim = resident_per_cu(bfs_claim_kernel);
+    grid_scatter = ctx->num_cus * per_cu_scatter;
+    grid_claim = ctx->num_cus * per_cu_claim;
   }
   hipError_t launch_err = hipSuccess;
   bool returned_fast = false;
@@ -428,9 +543,15 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (profile) (void)hipEventRecord(pe[0], stream);
     if (variant == 0) {
       // head (tiny levels + decide + plan) -> level
-      hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, lp, profile ? 0 : 1, seq);
+      hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, lp, profile ? 0 : 1, seq, bn);
       if (profile) (void)hipEventRecord(pe[1], stream);
-      hipLaunchKernelGGL(lbuild->fn, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
+      if (use_bins) {
+        // level = claim-per-edge advance or SCATTER phase; the CLAIM phase is a no-op unless the head binned the level
+        hipLaunchKernelGGL(bfs_level_bin_kernel, dim3(grid_scatter), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
+        hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_claim), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
+      } else {
+        hipLaunchKernelGGL(lbuild->fn, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
+      }
     } else {
       hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
       if (profile) (void)hipEventRecord(pe[1], stream);

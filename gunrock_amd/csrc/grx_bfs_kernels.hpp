@@ -48,6 +48,14 @@ struct bfs_policy_t {
   int bm_words;
   unsigned* bm_next;     // set by begin / set_level
   int in_tiny;           // set by tiny_levels_body: only bm_visited is maintained
+  // forward-only runs with a visited bitmap (grx_bin.hpp): bm_f[0..2] all alias bm_visited, so
+  // every discovery sets its bit there directly and nothing is ever cleared or folded
+  int fwd_bitmap;
+  // read-only bitmap pre-filter of the label probe (null: off).  The bitmap is 32 x denser than
+  // the labels (V / 8 bytes: L2-resident), and a neighbour it already shows as visited -- most
+  // of them on the fat levels -- costs no label sector at all; it may lag behind (it is a hint,
+  // the atomicMin on the label decides).
+  const unsigned* pre_bm;
 
   __device__ __forceinline__ void set_level(int level) {
     next_depth = level + 1;
@@ -88,7 +96,7 @@ struct bfs_policy_t {
   }
   __device__ __forceinline__ void tiny_hand_back(int level, const int* lds, int n, int cap, const int* spill) {
     if constexpr (VARIANT == 0) {
-      if (!bm_visited) return;
+      if (!bm_visited || fwd_bitmap) return;
       uint4* f0 = reinterpret_cast<uint4*>(pick3(bm_f, level % 3));
       uint4* f1 = reinterpret_cast<uint4*>(pick3(bm_f, (level + 1) % 3));
       for (int w = threadIdx.x; w < bm_words / 4; w += blockDim.x) {
@@ -106,6 +114,15 @@ struct bfs_policy_t {
   }
   __device__ __forceinline__ src_state load_source(int) const { return 0; }
   __device__ __forceinline__ bool precheck(src_state, int n, int, int&) const {
+    if constexpr (VARIANT == 0) {
+      if (pre_bm) {
+        // the label load stays unconditional (a visited neighbour reads label 0: one broadcast
+        // line), so the probes of a lane's edges still travel together -- see WHY PHASES
+        const bool vis = (pre_bm[n >> 5] >> (n & 31)) & 1u;
+        const int d = dist[vis ? 0 : n];
+        return !vis && d > next_depth;
+      }
+    }
     if constexpr (VARIANT == 0 || VARIANT == 7) return dist[n] > next_depth;
     if constexpr (VARIANT == 2)
       return (__hip_atomic_load(&visited[n >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << (n & 31))) == 0u;

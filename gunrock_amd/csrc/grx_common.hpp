@@ -157,8 +157,15 @@ struct grx_graph {
   bool has_transpose = false;
   unsigned* closed0 = nullptr;  // bitmap: vertices without in-edges (direction-optimising BFS), built lazily; owned
   int32_t closed0_words = 0;
+  // binned top-down levels (grx_bin.hpp), built lazily; owned
+  int32_t* bins = nullptr;      // E entries
+  int32_t* bin_off = nullptr;   // static bin offsets (in-edges per vertex range)
+  int32_t* bin_fill = nullptr;  // per-level fill counters
+  int32_t bin_shift = 0, bin_nb = 0;
+  int32_t bin_state = 0;        // 0: not built, 1: usable, 2: not applicable to this graph
   double weight_sum = -1.0;  // sum of edge weights (lazy; near-far SSSP bucket width)
   bool uniform_weights = false;
+  float weight_min = 0.0f, weight_max = 0.0f;
   std::vector<int32_t> h_t_ro;  // host copy of the transpose offsets (for static partitions)
   // static PageRank pull partition (built once per graph)
   void* pr_blocks = nullptr;    // int4 {row0, nrows, e0, e1}; nrows == 0 => piece of a long row

@@ -26,6 +26,14 @@ grx_status_t graph_build_transpose(grx_context_t ctx, grx_graph_t g);
 // itself as the in-edge list of a symmetric graph).
 grx_status_t graph_is_symmetric(grx_context_t ctx, grx_graph_t g, bool* result);
 
+// Edge-weight statistics, once per graph handle (weight_sum / weight_min / weight_max / uniform_weights).
+grx_status_t graph_weight_stats(grx_context_t ctx, grx_graph_t g);
+// true when the graph needs no weight stream: no values array, or every weight exactly 1.0
+// (graph_weight_stats must have run)
+inline bool graph_unit_weights(grx_graph_t g) {
+  return !g->w || (g->weight_sum >= 0.0 && g->uniform_weights && g->weight_min == 1.0f);
+}
+
 // Launch configuration of the advance kernel (persistent workgroups striding over chunks).
 // Upper bound used for sizing scratch:
 inline int advance_grid(grx_context_t ctx) { return ctx->num_cus * 8; }

@@ -133,6 +133,11 @@ struct plan_in {
   int nt;     // tiles of its frontier
   int mode;
   int R, T;   // bottom-up tile ranges (external_control == 1), R == 0: dense tiles
+  // binned top-down levels (grx_bin.hpp; external_control == 0 only): a level whose frontier has at
+  // least bin_min out-edges runs as mode 2; the head zeroes the nb fill counters (bin_pad ints apart)
+  long long bin_min = 0;
+  int32_t* bin_fill = nullptr;
+  int bin_nb = 0, bin_pad = 0;
 };
 
 template <int BLOCK>
@@ -154,6 +159,7 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
     }
     return;
   }
+  if (in.bin_min > 0 && tid < in.bin_nb) in.bin_fill[tid * in.bin_pad] = 0;
   long long esum = 0, vsum = 0;  // traversed edges / frontier vertices of the level (two 64-bit sums)
   int mine = 0, carry;
   const int R = external_control == 1 ? in.R : 0;
@@ -238,6 +244,7 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
       c->vertices_visited += nitems;
       c->n_items[p] = nitems;
       c->q_edges[p] = edges;
+      if (in.bin_min > 0) c->mode = edges >= in.bin_min ? 2 : 0;
       if (!external_control) {
         c->level = level;
         c->n_tiles[p ^ 1] = 0;
@@ -735,8 +742,9 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
   // the previous level ran bottom-up: its discoveries sit in static per-workgroup tile ranges and
   // its counters in bu_part records, which only the decide / plan steps know how to read (and the
   // hand-back paths below leave mode / bu_R untouched).  On a 256-CU part the ranges span more
-  // than TINY_MAX_TILES indices anyway; on a smaller grid they might not.
-  if (h.mode != 0 || h.bu_R > 0) return 0;
+  // than TINY_MAX_TILES indices anyway; on a smaller grid they might not.  (mode 2, a binned
+  // top-down level, leaves ordinary dense tiles.)
+  if (h.mode == 1 || h.bu_R > 0) return 0;
   int level = h.level + 1;          // next level to run
   {
     // ---- entry: gather the tiled queue into LDS ---------------------------------------

@@ -456,15 +456,16 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   }
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ro), (n_off + 2) * sizeof(int32_t)));
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ci), (size_t)E * sizeof(int32_t)));
-  if (g->w) GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_w), (size_t)E * sizeof(float)));
+  const bool unit = graph_unit_weights(g);  // no weight stream needed (graph_weight_stats ran)
+  if (!unit) GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_w), (size_t)E * sizeof(float)));
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&cnt), (n_off + 2) * sizeof(int32_t)));
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&bs), ((size_t)scan_num_blocks((int64_t)n_off) + 2) * sizeof(int32_t)));
   GRX_HIP(hipMemsetAsync(cnt, 0, (n_off + 2) * sizeof(int32_t), s));
   hipLaunchKernelGGL(xb_count_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, V, per_block, g->xb_perm, cnt);
   exclusive_scan_i32(s, cnt, (int64_t)n_off, g->xb_ro, bs);
   GRX_HIP(hipMemcpyAsync(cnt, g->xb_ro, n_off * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(xb_fill_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, g->w, V, per_block, g->xb_perm, cnt,
-                     g->xb_ci, g->xb_w);
+  hipLaunchKernelGGL(xb_fill_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, unit ? nullptr : g->w, V, per_block,
+                     g->xb_perm, cnt, g->xb_ci, g->xb_w);
   std::vector<int32_t> off(n_off + 1);
   GRX_HIP(hipMemcpyAsync(off.data(), g->xb_ro, (n_off + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   GRX_HIP(hipStreamSynchronize(s));
@@ -542,7 +543,11 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   const bool xcd_blocked = (opt.engine_flags & 0x80) != 0 ||
                            ((long long)g->E >= 16ll * g->V && (size_t)g->V * sizeof(float) > ((size_t)3 << 20) &&
                             !(opt.engine_flags & 0x40));
-  grx_status_t st;
+  grx_status_t st = graph_weight_stats(ctx, g);
+  if (st != GRX_SUCCESS) return st;
+  // all weights exactly 1.0 (a pattern .mtx as the reference loads it): x * 1.0f == x, so the
+  // weight streams are neither built nor read -- 8 E instead of 12 E bytes per iteration
+  const bool unit = graph_unit_weights(g);
   if (xcd_blocked) {
     st = build_pr_xcd_layout(ctx, g);
     if (st != GRX_SUCCESS) return st;
@@ -563,8 +568,8 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   GRX_HIP(ctx->misc.reserve(64));
 
   pr_args a;
-  a.ro = g->ro; a.w = g->w;
-  a.t_ro = g->t_ro; a.t_ci = g->t_ci; a.t_w = g->t_w;
+  a.ro = g->ro; a.w = unit ? nullptr : g->w;
+  a.t_ro = g->t_ro; a.t_ci = g->t_ci; a.t_w = unit ? nullptr : g->t_w;
   a.V = g->V; a.ctrl = ctx->d_ctrl;
   a.p = d_p;
   a.x = ctx->fbuf[0].as<float>();
@@ -578,7 +583,7 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   a.alpha = alpha; a.tol = tol;
   a.err_bits = ctx->misc.as<unsigned>();
   a.base = reinterpret_cast<float*>(ctx->misc.as<unsigned>() + 4);
-  a.xb_ro = g->xb_ro; a.xb_ci = g->xb_ci; a.xb_w = g->xb_w;
+  a.xb_ro = g->xb_ro; a.xb_ci = g->xb_ci; a.xb_w = unit ? nullptr : g->xb_w;
   a.xb_blocks = reinterpret_cast<const int4*>(g->xb_blocks);
   a.xb_piece = g->xb_piece; a.xb_long = g->xb_long;
   for (int i = 0; i <= XB; ++i) a.xb_begin[i] = g->xb_begin[i];
@@ -595,11 +600,19 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
 
   const int pull_grid = std::max(1, std::min(std::max(1, g->n_pr_blocks), ctx->num_cus * 8));
   const int max_iter = opt.max_iterations > 0 ? opt.max_iterations : 0x7fffffff;
-  int launched = 0, batch = 4;
+  // GRX_FLAG_PROFILE: one record per iteration from events on this stream -- advance_ms = the pull
+  // (the SpMV-shaped gather incl. long-row pieces and the combine), other_ms = prepare + scalar
+  const bool profile = (opt.engine_flags & GRX_FLAG_PROFILE) != 0;
+  hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
+  if (profile) for (auto& e : pe) GRX_HIP(hipEventCreate(&e));
+  ctx->levels.clear();
+  int launched = 0, batch = profile ? 1 : 4;
   for (;;) {
     for (int i = 0; i < batch && launched < max_iter; ++i, ++launched) {
+      if (profile) (void)hipEventRecord(pe[0], s);
       hipLaunchKernelGGL(pr_prepare_kernel, dim3(n_partial), dim3(PR_BLOCK), 0, s, a);
       hipLaunchKernelGGL(pr_scalar_kernel, dim3(1), dim3(PR_BLOCK), 0, s, a, launched);
+      if (profile) (void)hipEventRecord(pe[1], s);
       if (xcd_blocked) {
         hipLaunchKernelGGL(pr_pull_xcd_kernel, dim3(ctx->num_cus * 8), dim3(PR_BLOCK), 0, s, a);
         if (g->n_xb_long > 0)
@@ -610,12 +623,25 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
         if (g->n_pr_long > 0)
           hipLaunchKernelGGL(pr_long_kernel, dim3((g->n_pr_long + 255) / 256), dim3(256), 0, s, a, launched);
       }
+      if (profile) {
+        (void)hipEventRecord(pe[2], s);
+        (void)hipEventSynchronize(pe[2]);
+        level_rec r{};
+        (void)hipEventElapsedTime(&r.other_ms, pe[0], pe[1]);
+        (void)hipEventElapsedTime(&r.advance_ms, pe[1], pe[2]);
+        r.frontier_size = g->V;
+        r.edges = g->E;
+        ctx->levels.push_back(r);
+      }
     }
     GRX_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost, s));
     GRX_HIP(hipStreamSynchronize(s));
+    if (profile && ctx->h_ctrl->done && !ctx->levels.empty() && (int)ctx->levels.size() > ctx->h_ctrl->pr_iter)
+      ctx->levels.pop_back();  // the group that only detected convergence
     if (ctx->h_ctrl->done || launched >= max_iter) break;
-    if (batch < 16) batch *= 2;
+    if (!profile && batch < 16) batch *= 2;
   }
+  if (profile) for (auto& e : pe) (void)hipEventDestroy(e);
   GRX_HIP(hipGetLastError());
   GRX_HIP(hipEventRecord(ctx->ev_end, s));
   GRX_HIP(hipEventSynchronize(ctx->ev_end));
@@ -626,7 +652,7 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   ctx->stats.vertices_visited = (int64_t)g->V * iters;
   ctx->stats.search_depth = iters;
   ctx->stats.elapsed_ms = ms;
-  ctx->stats.n_levels_recorded = 0;
+  ctx->stats.n_levels_recorded = (int32_t)ctx->levels.size();
   if (iterations) *iterations = iters;
   if (elapsed_ms) *elapsed_ms = ms;
   return GRX_SUCCESS;

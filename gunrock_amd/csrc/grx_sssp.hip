@@ -437,11 +437,36 @@ using namespace grx;
 
 #define GRX_FLAG_SSSP_PLAIN 0x10
 
+// Sum / min / max of the edge weights, once per graph handle (near-far bucket width; graphs whose
+// weights are all 1.0 -- what the reference loader makes of a pattern .mtx, io/matrix_market.hxx:170-171
+// -- need no weight stream at all).
+grx_status_t grx::graph_weight_stats(grx_context_t ctx, grx_graph_t g) {
+  if (g->weight_sum >= 0.0 || !g->w || g->E <= 0) return GRX_SUCCESS;
+  GRX_HIP(ctx->misc.reserve(64));
+  double* d_sum = reinterpret_cast<double*>(ctx->misc.as<unsigned char>());
+  unsigned* d_bits = reinterpret_cast<unsigned*>(d_sum + 1);
+  const unsigned init[4] = {0u, 0u, 0xffffffffu, 0u};  // sum = 0.0, min, max
+  GRX_HIP(hipMemcpyAsync(d_sum, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(weight_sum_kernel, dim3(1024), dim3(256), 0, ctx->stream, g->w, (int64_t)g->E, d_sum, d_bits);
+  unsigned char h[16];
+  GRX_HIP(hipMemcpyAsync(h, d_sum, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  GRX_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(&g->weight_sum, h, sizeof(double));
+  unsigned lohi[2];
+  memcpy(lohi, h + 8, sizeof(lohi));
+  g->uniform_weights = lohi[0] == lohi[1];
+  memcpy(&g->weight_min, &lohi[0], sizeof(float));
+  memcpy(&g->weight_max, &lohi[1], sizeof(float));
+  return GRX_SUCCESS;
+}
+
 static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, const grx_options_t& opt,
                              float* d_dist, bool near_far, float delta, float* elapsed_ms, bool* overflow) {
   pipe_args a;
   grx_status_t st = pipeline_prepare(ctx, g, &a);
   if (st != GRX_SUCCESS) return st;
+  // all weights exactly 1.0: nd = d + 1.0f needs no weight stream (4 bytes per relaxed edge less)
+  const float* w_eff = graph_unit_weights(g) ? nullptr : g->w;
   GRX_HIP(ctx->labels.reserve((size_t)g->V * sizeof(int32_t)));
   int32_t* stamp = ctx->labels.as<int32_t>();
   hipStream_t s = ctx->stream;
@@ -464,23 +489,55 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
   const int grid = advance_grid_for(ctx, g);
   ctx->levels.clear();
   hipError_t launch_err = hipSuccess;
+  // GRX_FLAG_PROFILE: one record per iteration -- head / level kernel times from events on this
+  // stream (run_levels synchronises after every group in that mode), frontier size and relaxed
+  // edges from the control block's running totals
+  const bool profile = (opt.engine_flags & GRX_FLAG_PROFILE) != 0;
+  hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
+  if (profile) for (auto& e : pe) GRX_HIP(hipEventCreate(&e));
+  int64_t prof_v = 0, prof_e = 0;
+  auto group = [&](hipStream_t stream, auto&& head, auto&& level) {
+    if (profile) (void)hipEventRecord(pe[0], stream);
+    head();
+    if (profile) (void)hipEventRecord(pe[1], stream);
+    level();
+    if (profile) {
+      (void)hipEventRecord(pe[2], stream);
+      (void)hipEventSynchronize(pe[2]);
+      level_rec r{};
+      (void)hipEventElapsedTime(&r.other_ms, pe[0], pe[1]);
+      (void)hipEventElapsedTime(&r.advance_ms, pe[1], pe[2]);
+      ctx->levels.push_back(r);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) launch_err = e;
+  };
+  auto after = [&](const ctrl_t& h) {
+    if (!profile || ctx->levels.empty()) return;
+    level_rec& r = ctx->levels.back();
+    r.frontier_size = h.vertices_visited - prof_v;
+    r.edges = h.edges_visited - prof_e;
+    r.bottom_up = near_far ? 2 * h.nf_split : 0;  // 2: this iteration only pulled a bucket out of the far pile
+    prof_v = h.vertices_visited;
+    prof_e = h.edges_visited;
+    if (h.done) ctx->levels.pop_back();  // the group that only detected the end
+  };
   if (near_far) {
-    sssp_nf_policy pol{d_dist, stamp, g->w, nf, 0, 0.0f, nullptr, nullptr};
+    sssp_nf_policy pol{d_dist, stamp, w_eff ? w_eff : g->w, nf, 0, 0.0f, nullptr, nullptr};
     st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
-      hipLaunchKernelGGL(sssp_nf_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, nf);
-      hipLaunchKernelGGL(sssp_nf_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, nf, pol);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess) launch_err = e;
-    }, [&](const ctrl_t&) {});
+      group(stream,
+            [&] { hipLaunchKernelGGL(sssp_nf_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, nf); },
+            [&] { hipLaunchKernelGGL(sssp_nf_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, nf, pol); });
+    }, after);
   } else {
-    sssp_policy pol{d_dist, stamp, g->w, 0};
+    sssp_policy pol{d_dist, stamp, w_eff, 0};
     st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
-      hipLaunchKernelGGL(sssp_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, pol, (long long)g->E);
-      hipLaunchKernelGGL((advance_kernel<sssp_policy>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess) launch_err = e;
-    }, [&](const ctrl_t&) {});
+      group(stream,
+            [&] { hipLaunchKernelGGL(sssp_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, pol, (long long)g->E); },
+            [&] { hipLaunchKernelGGL((advance_kernel<sssp_policy>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol); });
+    }, after);
   }
+  if (profile) for (auto& e : pe) (void)hipEventDestroy(e);
   if (st != GRX_SUCCESS) return st;
   if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));
 
@@ -492,7 +549,7 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
   ctx->stats.vertices_visited = ctx->h_ctrl->vertices_visited;
   ctx->stats.search_depth = ctx->h_ctrl->level;
   ctx->stats.elapsed_ms = ms;
-  ctx->stats.n_levels_recorded = 0;
+  ctx->stats.n_levels_recorded = (int32_t)ctx->levels.size();
   ctx->stats.reserved = near_far ? (float)ctx->h_ctrl->nf_phases : 0.0f;
   if (overflow) *overflow = near_far && ctx->h_ctrl->nf_overflow != 0;
   if (elapsed_ms) *elapsed_ms = ms;
@@ -515,22 +572,11 @@ extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
   // graphs (values == NULL) are already level-synchronous => plain schedule
   bool near_far = g->w != nullptr && g->E > 0 && !(opt.engine_flags & GRX_FLAG_SSSP_PLAIN);
   float delta = FLT_MAX;
+  {
+    grx_status_t wst = graph_weight_stats(ctx, g);
+    if (wst != GRX_SUCCESS) return wst;
+  }
   if (near_far) {
-    if (g->weight_sum < 0.0) {
-      GRX_HIP(ctx->misc.reserve(64));
-      double* d_sum = reinterpret_cast<double*>(ctx->misc.as<unsigned char>());
-      unsigned* d_bits = reinterpret_cast<unsigned*>(d_sum + 1);
-      const unsigned init[4] = {0u, 0u, 0xffffffffu, 0u};  // sum = 0.0, min, max
-      GRX_HIP(hipMemcpyAsync(d_sum, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-      hipLaunchKernelGGL(weight_sum_kernel, dim3(1024), dim3(256), 0, ctx->stream, g->w, (int64_t)g->E, d_sum, d_bits);
-      unsigned char h[16];
-      GRX_HIP(hipMemcpyAsync(h, d_sum, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-      GRX_HIP(hipStreamSynchronize(ctx->stream));
-      memcpy(&g->weight_sum, h, sizeof(double));
-      unsigned lohi[2];
-      memcpy(lohi, h + 8, sizeof(lohi));
-      g->uniform_weights = lohi[0] == lohi[1];
-    }
     // all weights equal (e.g. a pattern .mtx loaded with 1.0 everywhere): the search is
     // level-synchronous already, nothing is ever re-relaxed
     if (g->uniform_weights) near_far = false;

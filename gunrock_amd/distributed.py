@@ -100,6 +100,14 @@ class GrxEngine:
             int(n_edges_global), self.parts, C.c_void_p(self.send.data_ptr()), C.c_void_p(self.recv.data_ptr()),
             C.c_void_p(self.stats_local.data_ptr()), C.c_void_p(self.stats_global.data_ptr()), C.byref(self._h)))
 
+    def new_labels(self):
+        """Label buffer for bfs(): int32[V] on the engine's device; only the owned slice is written."""
+        return self.torch.empty(self.V, dtype=self.torch.int32, device=self.device)
+
+    def transport_description(self):
+        return ("level groups (kernels + both collectives) enqueued through torch.distributed and replayed as one "
+                "HIP graph per level after the first search; the host polls once per batch of levels")
+
     def part_buffers(self, part):
         n = self.P * self.slice_words
         return self.send[part * n:(part + 1) * n], self.recv[part * n:(part + 1) * n]

@@ -324,6 +324,41 @@ double orc_sssp(int32_t nv, const int32_t* ro, const int32_t* ci,
   return t1 - t0;
 }
 
+/* orc_sssp with a time budget, for bench.py's bounded CPU sample: the same loop (sssp_cpu.hxx:49-67),
+ * left after the pop that finds budget_ms exceeded (checked every 4096 pops).  *edges_scanned counts
+ * the edges the loop looked at; *finished = 0 means the distances are NOT final. */
+double orc_sssp_budget(int32_t nv, const int32_t* ro, const int32_t* ci,
+                       const float* w, int32_t src, float* dist, double budget_ms,
+                       int64_t* edges_scanned, int32_t* finished) {
+  for (int32_t i = 0; i < nv; ++i) dist[i] = FLT_MAX;
+  double t0 = now_ms();
+  dist[src] = 0.0f;
+  heap_f pq = {0, 0, 0};
+  heap_f_push(&pq, src, 0.0f);
+  int64_t scanned = 0, pops = 0;
+  int32_t fin = 1;
+  while (pq.n) {
+    if (budget_ms > 0 && (++pops & 4095) == 0 && now_ms() - t0 > budget_ms) { fin = 0; break; }
+    ent_f cur = heap_f_pop(&pq);
+    int32_t u = cur.v;
+    float du = cur.d;
+    scanned += ro[u + 1] - ro[u];
+    for (int32_t e = ro[u]; e < ro[u + 1]; ++e) {
+      int32_t nb = ci[e];
+      volatile float nd = du + w[e];
+      if (nd < dist[nb]) {
+        dist[nb] = nd;
+        heap_f_push(&pq, nb, nd);
+      }
+    }
+  }
+  double t1 = now_ms();
+  free(pq.a);
+  if (edges_scanned) *edges_scanned = scanned;
+  if (finished) *finished = fin;
+  return t1 - t0;
+}
+
 double orc_bfs_queue(int32_t nv, const int32_t* ro, const int32_t* ci,
                      int32_t src, int32_t* dist, int64_t* edges_visited) {
   for (int32_t i = 0; i < nv; ++i) dist[i] = INT32_MAX;

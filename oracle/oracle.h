@@ -71,6 +71,17 @@ double orc_sssp(int32_t n_vertices,
                 int32_t source,
                 float* distances);
 
+/* orc_sssp with a time budget (bench.py's bounded CPU sample).  *finished = 0: distances NOT final. */
+double orc_sssp_budget(int32_t n_vertices,
+                       const int32_t* row_offsets,
+                       const int32_t* column_indices,
+                       const float* nonzero_values,
+                       int32_t source,
+                       float* distances,
+                       double budget_ms,
+                       int64_t* edges_scanned,
+                       int32_t* finished);
+
 /* include/gunrock/algorithms/pr.hxx:65-93 (reset), :107-152 (iteration),
  * :172-195 (convergence), framework/enactor.hxx:274-277 (loop order).
  * fp32 throughout, edge updates applied in CSR edge order.  Returns the
@@ -141,6 +152,12 @@ double orc_sssp_omp(int32_t n_vertices, const int32_t* row_offsets, const int32_
  * loop() executions, fp32.  Returns the loop time in ms. */
 double orc_pr_omp(int32_t n_vertices, const int32_t* row_offsets, const int32_t* column_indices,
                   const float* nonzero_values, float alpha, int iterations, float* p);
+
+/* float64 pull evaluation of the PageRank recurrence with a per-iteration trace: see oracle_omp.c.
+ * delta[n_iter], err[n_cmp * n_iter]; returns 0, or -1 when out of memory. */
+int orc_pr_f64_trace(int32_t n_vertices, const int32_t* row_offsets, const int32_t* column_indices,
+                     const float* nonzero_values, double alpha, int n_iter, int n_cmp,
+                     const float* const* cmp, double* delta, double* err, double* p_final);
 
 #ifdef __cplusplus
 }

@@ -232,3 +232,80 @@ double orc_pr_omp(int32_t nv, const int32_t* ro, const int32_t* ci, const float*
   free(pn);
   return ms;
 }
+
+/* float64 evaluation of the PageRank recurrence (pr.hxx:65-152) as a pull over the transpose on all
+ * host cores, n_iter iterations exactly.  After iteration k (1-based) it records
+ *   delta[k - 1]            = max |p_k - p_{k-1}|   (what is_converged compares with tol, pr.hxx:189-194)
+ *   err[c * n_iter + k - 1] = max |cmp[c] - p_k|    for each of the n_cmp fp32 vectors handed in
+ * so one pass yields the iteration at which the float64 recurrence converges, the distance of an fp32
+ * result from the float64 iterate of ITS iteration count, and the best-matching iterate of a result
+ * whose iteration count is unknown (the reference GPU path).  p_final (may be NULL) receives p_{n_iter}.
+ * Differs from orc_pr_f64 only in summation order (in-edge order instead of CSR edge order). */
+int orc_pr_f64_trace(int32_t nv, const int32_t* ro, const int32_t* ci, const float* w, double alpha, int n_iter,
+                     int n_cmp, const float* const* cmp, double* delta, double* err, double* p_final) {
+  const int64_t ne = ro[nv];
+  int32_t* t_ro = (int32_t*)calloc((size_t)nv + 2, sizeof(int32_t));
+  int32_t* t_ci = (int32_t*)malloc((size_t)(ne > 0 ? ne : 1) * sizeof(int32_t));
+  float* t_w = (float*)malloc((size_t)(ne > 0 ? ne : 1) * sizeof(float));
+  double* iw = (double*)malloc((size_t)nv * sizeof(double));
+  double* x = (double*)malloc((size_t)nv * sizeof(double));
+  double* p = (double*)malloc((size_t)nv * sizeof(double));
+  double* pn = (double*)malloc((size_t)nv * sizeof(double));
+  if (!t_ro || !t_ci || !t_w || !iw || !x || !p || !pn) return -1;
+  for (int64_t e = 0; e < ne; ++e) t_ro[ci[e] + 2]++;
+  for (int32_t v = 0; v < nv; ++v) t_ro[v + 2] += t_ro[v + 1];
+  for (int32_t v = 0; v < nv; ++v)
+    for (int32_t e = ro[v]; e < ro[v + 1]; ++e) {
+      const int32_t at = t_ro[ci[e] + 1]++;
+      t_ci[at] = v;
+      t_w[at] = w ? w[e] : 1.0f;
+    }
+#pragma omp parallel for schedule(static)
+  for (int32_t v = 0; v < nv; ++v) {
+    double s = 0.0;
+    for (int32_t e = ro[v]; e < ro[v + 1]; ++e) s += w ? (double)w[e] : 1.0;
+    iw[v] = s != 0.0 ? alpha / s : 0.0;
+    p[v] = 1.0 / (double)nv;
+  }
+  for (int it = 0; it < n_iter; ++it) {
+    double dsum = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : dsum)
+    for (int32_t v = 0; v < nv; ++v) {
+      x[v] = p[v] * iw[v];
+      if (iw[v] == 0.0) dsum += alpha * p[v];
+    }
+    const double base = (1.0 - alpha + dsum) / (double)nv;
+    double dmax = 0.0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(max : dmax)
+    for (int32_t v = 0; v < nv; ++v) {
+      double acc = 0.0;
+      for (int32_t e = t_ro[v]; e < t_ro[v + 1]; ++e) acc += x[t_ci[e]] * (double)t_w[e];
+      pn[v] = base + acc;
+      const double d = fabs(pn[v] - p[v]);
+      if (d > dmax) dmax = d;
+    }
+    delta[it] = dmax;
+    for (int c = 0; c < n_cmp; ++c) {
+      const float* q = cmp[c];
+      double emax = 0.0;
+#pragma omp parallel for schedule(static) reduction(max : emax)
+      for (int32_t v = 0; v < nv; ++v) {
+        const double d = fabs((double)q[v] - pn[v]);
+        if (d > emax) emax = d;
+      }
+      err[(size_t)c * (size_t)n_iter + (size_t)it] = emax;
+    }
+    double* t = p;
+    p = pn;
+    pn = t;
+  }
+  if (p_final) memcpy(p_final, p, (size_t)nv * sizeof(double));
+  free(t_ro);
+  free(t_ci);
+  free(t_w);
+  free(iw);
+  free(x);
+  free(p);
+  free(pn);
+  return 0;
+}

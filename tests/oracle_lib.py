@@ -64,6 +64,9 @@ def lib():
         L.orc_bfs_queue.restype = C.c_double
         L.orc_sssp.argtypes = [C.c_int32, i32p, i32p, f32p, C.c_int32, f32p]
         L.orc_sssp.restype = C.c_double
+        L.orc_sssp_budget.argtypes = [C.c_int32, i32p, i32p, f32p, C.c_int32, f32p, C.c_double,
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        L.orc_sssp_budget.restype = C.c_double
         L.orc_pr_f32.argtypes = [C.c_int32, i32p, i32p, f32p, C.c_float,
                                  C.c_float, C.c_int, f32p, C.POINTER(C.c_double)]
         L.orc_pr_f32.restype = C.c_int
@@ -83,6 +86,9 @@ def lib():
         L.orc_sssp_omp.restype = C.c_double
         L.orc_pr_omp.argtypes = [C.c_int32, i32p, i32p, C.c_void_p, C.c_float, C.c_int, f32p]
         L.orc_pr_omp.restype = C.c_double
+        L.orc_pr_f64_trace.argtypes = [C.c_int32, i32p, i32p, C.c_void_p, C.c_double, C.c_int, C.c_int,
+                                       C.POINTER(C.c_void_p), f64p, f64p, C.c_void_p]
+        L.orc_pr_f64_trace.restype = C.c_int
         _lib = L
     return _lib
 
@@ -142,6 +148,15 @@ def sssp(g, src):
     return d, ms
 
 
+def sssp_budget(g, src, budget_ms):
+    """orc_sssp stopped after budget_ms -> (distances, ms, edges scanned, finished)."""
+    d = np.empty(g.n_vertices, dtype=np.float32)
+    ev, fin = C.c_int64(0), C.c_int32(0)
+    ms = lib().orc_sssp_budget(g.n_vertices, g.row_offsets, g.column_indices, g.values, int(src), d,
+                               float(budget_ms), C.byref(ev), C.byref(fin))
+    return d, ms, ev.value, bool(fin.value)
+
+
 def pr_f32(g, alpha=0.85, tol=1e-6, max_iterations=0):
     p = np.empty(g.n_vertices, dtype=np.float32)
     ms = C.c_double(0)
@@ -187,6 +202,31 @@ def pr_omp(g, alpha=0.85, iterations=5, pattern=False):
     w = None if pattern else g.values.ctypes.data_as(C.c_void_p)
     ms = lib().orc_pr_omp(g.n_vertices, g.row_offsets, g.column_indices, w, alpha, int(iterations), p)
     return p, ms
+
+
+def pr_f64_trace(g, n_iter, cmp=(), alpha=0.85, pattern=False, want_final=False):
+    """float64 pull PageRank for n_iter iterations -> (delta[n_iter], err[len(cmp)][n_iter], p_final or None):
+    delta[k-1] = max|p_k - p_{k-1}|, err[c][k-1] = max|cmp[c] - p_k| (cmp: float32 vectors)."""
+    cmp = [np.ascontiguousarray(c, dtype=np.float32) for c in cmp]
+    ptrs = (C.c_void_p * max(1, len(cmp)))(*[c.ctypes.data for c in cmp])
+    delta = np.zeros(n_iter, dtype=np.float64)
+    err = np.zeros(max(1, len(cmp)) * n_iter, dtype=np.float64)
+    pf = np.empty(g.n_vertices, dtype=np.float64) if want_final else None
+    w = None if pattern else g.values.ctypes.data_as(C.c_void_p)
+    rc = lib().orc_pr_f64_trace(g.n_vertices, g.row_offsets, g.column_indices, w, alpha, int(n_iter), len(cmp),
+                                ptrs, delta, err, pf.ctypes.data_as(C.c_void_p) if want_final else None)
+    if rc != 0:
+        raise MemoryError("orc_pr_f64_trace")
+    return delta, err.reshape(max(1, len(cmp)), n_iter)[:len(cmp)], pf
+
+
+def pr_iterations_from_trace(delta, tol=1e-6):
+    """loop() executions of the float64 recurrence: the first k >= 1 with max|p_k - p_{k-1}| < tol
+    (is_converged skips the check at iteration 0 and then compares the previous loop's norm: pr.hxx:172-195)."""
+    for k, d in enumerate(delta, start=1):
+        if d < tol:
+            return k
+    return None
 
 
 def check_bfs(g, src, dist):

@@ -179,3 +179,61 @@ def test_regression_frontier_merge_persisted_in_bottomup(gr, gpu_ctx):
         for _ in range(2):
             gr.bfs(G, src, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.optimized))
             assert np.array_equal(dist.cpu().numpy(), want), src
+
+
+def test_binned_forward_levels(gr, gpu_ctx, monkeypatch, golden):
+    """Forward-only BFS with its fat levels run as the binned scatter + claim kernels (grx_bin.hpp):
+    GRX_BIN_MIN_EDGES=1 forces EVERY level through them, the default threshold mixes them with the
+    claim-per-edge advance and the LDS-resident tiny levels; depths and counters must not change.
+    Covers bins of one bitmap word (V = 39), ragged last bins, hubs split over many chunks, duplicate
+    edges and self loops, and the A/B knobs (no pre-filter bitmap, no bins, no bitmap at all)."""
+    import torch
+    cases = []
+    props, coo = gr.matrix_market_t().load(os.path.join(GOLDEN, "chesapeake.mtx"))
+    cs = gr.csr_t().from_coo(coo)
+    cases.append((O.Csr(cs.row_offsets, cs.column_indices, cs.nonzero_values), [0, 5, 38]))
+    for kind, V, E, seed in (("rmat", 1 << 17, 3_000_000, 5), ("rmat_sym", 100_003, 1_200_000, 6),
+                             ("rmat", 8191, 200_000, 7), ("rmat_sym", 1 << 18, 6_000_000, 8)):
+        _, c = gr.generate(kind, V, E, seed=seed)
+        g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+        cases.append((g, [int(np.argmax(np.diff(g.row_offsets))), 1, g.n_vertices - 1]))
+    for g, sources in cases:
+        assert g.n_edges >= 4 * g.n_vertices  # dense enough for the forward bitmap path
+        for src in sources:
+            want, _, ev = O.bfs_queue(g, src)
+            for env in ({"GRX_BIN_MIN_EDGES": "1"}, {}, {"GRX_BIN_MIN_EDGES": "1", "GRX_TD_PRE": "0"},
+                        {"GRX_TD_BIN": "0"}, {"GRX_TD_BITMAP": "0"}):
+                for k in ("GRX_BIN_MIN_EDGES", "GRX_TD_PRE", "GRX_TD_BIN", "GRX_TD_BITMAP"):
+                    monkeypatch.delenv(k, raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                for flags in (0, gr.FLAG_PROFILE):
+                    d, st = run_bfs(gr, gpu_ctx, g.row_offsets, g.column_indices, src,
+                                    gr.options_t(advance_direction=gr.forward, engine_flags=flags))
+                    assert np.array_equal(d, want), (g.n_vertices, src, env, flags)
+                    assert st["edges_visited"] == ev and st["vertices_visited"] == int((want != INF).sum())
+                    if flags and env.get("GRX_BIN_MIN_EDGES") == "1" and "GRX_TD_BIN" not in env:
+                        prof = gr.level_profile(gpu_ctx)
+                        assert all(l["bottom_up"] == 2 for l in prof if l["edges"] > 0), "a level did not run binned"
+
+
+def test_symmetric_property_is_verified(gr, gpu_ctx):
+    """graph_properties_t defaults to symmetric=true (inert in the reference).  Here it lets the
+    bottom-up step use the CSR as its own in-edge list -- so the engine must notice a DIRECTED CSR
+    that claims to be symmetric and fall back to a real transpose."""
+    import torch
+    _, c = gr.generate("rmat", 1 << 16, 1_500_000, seed=21)  # directed
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    src = int(np.argmax(np.diff(g.row_offsets)))
+    want, _ = O.bfs(g, src)
+    G = gr.build_graph(gr.graph_properties_t(), c, gpu_ctx)  # default properties: symmetric = True
+    dist = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda:0")
+    gr.bfs(G, src, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.optimized, engine_flags=gr.FLAG_PROFILE))
+    assert np.array_equal(dist.cpu().numpy(), want)
+    assert any(l["bottom_up"] == 1 for l in gr.level_profile(gpu_ctx))
+    # and a directed cycle, whose in- and out-degrees all agree
+    n = 4096
+    ro = np.arange(n + 1, dtype=np.int32)
+    ci = ((np.arange(n) + 1) % n).astype(np.int32)
+    d, _ = run_bfs(gr, gpu_ctx, ro, ci, 0, gr.options_t(advance_direction=gr.optimized))
+    assert np.array_equal(d, np.arange(n))

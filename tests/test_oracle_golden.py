@@ -122,3 +122,32 @@ def test_pr_restatement_selfconsistent(golden):
     q64, _, _ = O.pr_f64(r, force_iterations=itq)
     assert abs(q32.sum() - 1.0) < 1e-4
     assert np.abs(q32 - q64).max() < 1e-6
+
+
+def test_ncore_baselines_equal_the_oracle(golden):
+    """oracle/oracle_omp.c (the N-core CPU baselines of bench.py) reach the same fixed points as the
+    restatements of the reference's CPU path; the float64 trace equals orc_pr_f64 up to summation order."""
+    import gunrock_amd as gr
+    for kind, V, E, seed in (("rmat", 30_000, 400_000, 3), ("rmat_sym", 20_001, 150_000, 4)):
+        _, c = gr.generate(kind, V, E, seed=seed)
+        g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+        src = int(np.argmax(np.diff(g.row_offsets)))
+        want, _ = O.bfs(g, src)
+        got, _, ev = O.bfs_omp(g, src)
+        assert np.array_equal(got, want)
+        assert ev == O.bfs_queue(g, src)[2]
+    _, c = gr.generate("road", 200 * 200, 0, 0.7, 0.0, 1.0, seed=5)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    want, _ = O.sssp(g, 17)
+    got, _, _, _, fin = O.sssp_omp(g, 17)
+    assert fin and np.array_equal(got, want)
+    part, _, scanned, fin = O.sssp_budget(g, 17, 0.0)
+    assert fin and np.array_equal(part, want) and scanned > 0
+    g = O.Csr(golden["rmat_ro"], golden["rmat_ci"], np.ones(len(golden["rmat_ci"]), np.float32))
+    p64, it64, _ = O.pr_f64(g)
+    delta, err, pf = O.pr_f64_trace(g, it64 + 2, [p64.astype(np.float32)], want_final=True)
+    assert O.pr_iterations_from_trace(delta) == it64
+    assert err[0][it64 - 1] < 1e-9  # only the fp32 rounding of the vector handed in
+    assert np.abs(O.pr_f64(g, force_iterations=it64 + 2)[0] - pf).max() < 1e-14
+    p32, _ = O.pr_omp(g, iterations=it64)
+    assert np.abs(p32 - O.pr_f64(g, force_iterations=it64)[0]).max() < 1e-6

@@ -128,3 +128,21 @@ def test_full_size_road_standin_properties(gr, gpu_ctx):
     d, st = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src)
     assert (d < FMAX).sum() > g.n_vertices // 2
     assert O.check_sssp(g, src, d) == 0
+
+
+def test_full_size_road_standin_unit_weights(gr, gpu_ctx):
+    """BASELINE.json configs[2] as the reference loader produces it from the pattern file road_usa.mtx:
+    every weight 1.0 (io/matrix_market.hxx:170-171).  Full size; distances must equal the BFS depths of
+    the same run (bit-exact, as floats) and pass the oracle's exact fixed-point check."""
+    import torch
+    props, c = gr.generate("road", 4894 * 4894, a=0.602, c=0.0, seed=42)
+    assert np.all(c.nonzero_values == 1.0)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    src = (4894 // 2) * 4894 + 4894 // 2
+    d, st = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src)
+    assert O.check_sssp(g, src, d) == 0
+    depths, _, ev = O.bfs_queue(g, src)
+    reached = depths != np.iinfo(np.int32).max
+    assert np.array_equal(d[reached], depths[reached].astype(np.float32))
+    assert np.all(d[~reached] == FMAX)
+    assert st["edges_visited"] == ev  # level-synchronous: every reached vertex relaxed exactly once

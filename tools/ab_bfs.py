@@ -1,5 +1,5 @@
 """A/B runs of the BFS engine's tuning knobs in ONE process (one graph build):
-    python tools/ab_bfs.py [lj|kron] [group ...]      groups: do td knobs
+    python tools/ab_bfs.py [lj|kron] [group ...]      groups: do td knobs bin
 Every configuration is checked against the first one's depths.  Prints one line per
 configuration: wall ms per BFS (reset + enact, median), enact ms (events), per-level profile."""
 import os
@@ -23,7 +23,7 @@ ctx = gr.multi_context_t(0)
 G = gr.build_graph(props, csr, ctx)
 V = G.get_number_of_vertices()
 d = torch.empty(V, dtype=torch.int32, device="cuda")
-KNOBS = ("GRX_LEVEL_MINW", "GRX_BU_BATCH", "GRX_DO_ALPHA", "GRX_DO_BETA", "GRX_DO_BACK_DIV", "GRX_LEVEL_WG_PER_CU", "GRX_PACE_DEPTH")
+KNOBS = ("GRX_TD_BITMAP", "GRX_TD_PRE", "GRX_TD_BIN", "GRX_BIN_MIN_EDGES", "GRX_LEVEL_MINW", "GRX_BU_BATCH", "GRX_DO_ALPHA", "GRX_DO_BETA", "GRX_DO_BACK_DIV", "GRX_LEVEL_WG_PER_CU", "GRX_PACE_DEPTH")
 ref = None
 
 
@@ -62,7 +62,7 @@ def run(label, direction, variant=0, env=None, reps=15, profile=True):
             t = sum(l["advance_ms"] for l in prof)
             if best is None or t < best[0]:
                 best = (t, prof)
-        lv = " ".join("%d/%d:%s%.0f" % (l["frontier_size"], l["edges"], "B" if l.get("bottom_up") else "T",
+        lv = " ".join("%d/%d:%s%.0f" % (l["frontier_size"], l["edges"], {0: "T", 1: "B", 2: "N"}.get(l.get("bottom_up"), "?"),
                                         l["advance_ms"] * 1e3) for l in best[1])
     walls.sort()
     enacts.sort()
@@ -86,3 +86,13 @@ if "knobs" in groups:
 if "td" in groups:
     run("TD main path (v0)", gr.forward)
     run("TD v7 (v0, plan+advance kernels)", gr.forward, variant=7)
+if "bin" in groups:
+    # forward-only run: round-1 body, bitmap pre-filter alone, binned fat levels (with / without the pre-filter
+    # on the thin levels), binning thresholds
+    run("TD round-1 body (no bitmap)", gr.forward, env={"GRX_TD_BITMAP": 0})
+    run("TD bitmap pre-filter, no bins", gr.forward, env={"GRX_TD_BIN": 0})
+    run("TD bins (default 1M) + pre-filter", gr.forward)
+    run("TD bins, no pre-filter", gr.forward, env={"GRX_TD_PRE": 0})
+    for m in (1 << 17, 1 << 18, 1 << 22):
+        run("TD bins min_edges %d" % m, gr.forward, env={"GRX_BIN_MIN_EDGES": m})
+    run("DO default (reference point)", gr.optimized)
