@@ -69,8 +69,6 @@ struct problem_t : gunrock::problem_t<graph_t> {
   void reset() override {
     const std::size_t n = (std::size_t)this->get_graph().get_number_of_vertices();
     auto stream = this->get_single_context()->stream();
-    frontier::frontier_t<vertex_t, edge_t> unused;  // reuse its fill kernel through a thin wrapper
-    (void)unused;
     hipLaunchKernelGGL((frontier::detail::fill_kernel<vertex_t>), dim3(frontier::detail::grid_for(n)), dim3(256), 0,
                        stream, result.distances, std::numeric_limits<vertex_t>::max(), n);
     const vertex_t zero = 0;

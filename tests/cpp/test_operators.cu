@@ -44,6 +44,38 @@ struct mark_t {
   __host__ __device__ void operator()(vertex_t const& v) const { out[v] = v * 3; }
 };
 
+// launch_box (cuda/launch_box.hxx:194-360 of the reference): generic kernels + a grid-wide barrier kernel
+struct add_index_t {
+  int* out;
+  __device__ void operator()(int const& tid, int const&) const { out[tid] += tid; }
+};
+__global__ void box_fill_kernel(int* out, int n, int value) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = value;
+}
+// two phases separated by a hand-rolled grid barrier: only completes if the whole grid is resident,
+// which is what launch_cooperative guarantees; the spin is bounded so a mistake fails instead of hanging
+__global__ void box_coop_kernel(int* data, int n, unsigned* arrive, int* timed_out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) data[i] = i;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(arrive, 1u);
+    long long spins = 0;
+    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > 20000000ll) { *timed_out = 1; break; }
+    }
+    __threadfence();
+  }
+  __syncthreads();
+  // phase 2 reads what OTHER workgroups wrote in phase 1
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int j = n - 1 - i;
+    const int other = __hip_atomic_load(&data[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (other != j) *timed_out = 2;
+  }
+}
+
 // Operators are asynchronous on the context's (non-blocking) stream -- unlike upstream,
 // which synchronises after every operator (thread_mapped.hxx:94) -- so host reads of a
 // frontier in the middle of a loop must synchronise the context first.
@@ -243,6 +275,41 @@ int main() {
     context->get_context(0)->synchronize();
     h = marks;
     check("parallel_for.element_skips_invalid", h[4] == 12 && h[10] == 30 && h[0] == -5);
+  }
+  // ---- launch_box: blocked / strided / launch / cooperative / occupancy -----------------------
+  {
+    using namespace gcuda::launch_box;
+    auto& sc = *context->get_context(0);
+    const int n = 100000;
+    thrust::device_vector<int> buf(n, 1);
+    launch_box_t<launch_params_dynamic_grid_t<fallback, dim3_t<128>, 4>> blocked;
+    blocked.launch_blocked(sc, add_index_t{buf.data().get()}, (std::size_t)n);
+    launch_box_t<launch_params_dynamic_grid_t<fallback, dim3_t<256>>> strided;
+    strided.launch_strided(sc, add_index_t{buf.data().get()}, (std::size_t)n);
+    sc.synchronize();
+    thrust::host_vector<int> h = buf;
+    bool ok = true;
+    for (int i = 0; i < n; ++i) ok = ok && h[i] == 1 + 2 * i;
+    check("launch_box.blocked_and_strided", ok);
+    launch_box_t<launch_params_t<fallback, dim3_t<64>, dim3_t<40>>> fixed;  // static grid of 40 workgroups
+    fixed.launch(sc, box_fill_kernel, buf.data().get(), n, 7);
+    sc.synchronize();
+    h = buf;
+    check("launch_box.launch_static_grid", fixed.grid_dimensions.x == 40 && h[0] == 7 && h[n - 1] == 7);
+    using coop_t = launch_box_t<launch_params_dynamic_grid_t<fallback, dim3_t<256>>>;
+    coop_t coop;
+    thrust::device_vector<unsigned> arrive(1, 0u);
+    thrust::device_vector<int> flag(1, 0);
+    int* dptr = buf.data().get();
+    unsigned* aptr = arrive.data().get();
+    int* fptr = flag.data().get();
+    int nn = n;
+    coop.launch_cooperative(sc, box_coop_kernel, (std::size_t)(1 << 22), dptr, nn, aptr, fptr);  // grid clamped to residency
+    sc.synchronize();
+    thrust::host_vector<int> hf = flag;
+    check("launch_box.cooperative_grid_barrier", hf[0] == 0 && coop.grid_dimensions.x > 1);
+    const float occ = occupancy<coop_t>(box_coop_kernel);
+    check("launch_box.occupancy", occ > 0.0f && occ <= 1.0f);
   }
   // ---- graph view accessors (graph/csr.hxx of the reference) -------------------------
   {
