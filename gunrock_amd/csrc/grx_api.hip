@@ -1,5 +1,6 @@
 // grx_api.hip -- context, graph view, scratch arena and statistics of the C ABI.
 #include "grx_engine.hpp"
+#include "grx_bin.hpp"
 
 #include <mutex>
 
@@ -163,6 +164,21 @@ grx_status_t grx_context_create(int32_t device, void* stream, grx_context_t* out
   // work on this context's (non-blocking) stream -- it once zeroed a running search
   GRX_HIP(hipMemsetAsync(c->d_ctrl, 0, sizeof(ctrl_t), c->stream));
   GRX_HIP(hipStreamSynchronize(c->stream));
+  {
+    // which XCDs does this device (or partition) have?  Every workgroup of a wide launch reports the
+    // hardware XCC id of its CU; kernels that give an XCD exclusive ownership of data (grx_bin.hpp)
+    // map the ids to dense indices through this mask.
+    unsigned* d_mask = reinterpret_cast<unsigned*>(c->d_ctrl);
+    hipLaunchKernelGGL(xcc_census_kernel, dim3(c->num_cus * 16), dim3(64), 0, c->stream, d_mask);
+    unsigned h_mask = 0;
+    GRX_HIP(hipMemcpyAsync(&h_mask, d_mask, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    GRX_HIP(hipStreamSynchronize(c->stream));
+    GRX_HIP(hipMemsetAsync(c->d_ctrl, 0, sizeof(ctrl_t), c->stream));
+    GRX_HIP(hipStreamSynchronize(c->stream));
+    if (h_mask == 0) h_mask = 1u;
+    c->xcc_mask = h_mask;
+    c->n_xcd = __builtin_popcount(h_mask);
+  }
   GRX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ctrl), sizeof(ctrl_t), hipHostMallocDefault));
   memset(c->h_ctrl, 0, sizeof(ctrl_t));
   void* mb = nullptr;
@@ -238,6 +254,7 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->bins) (void)hipFree(g->bins);
   if (g->bin_off) (void)hipFree(g->bin_off);
   if (g->bin_fill) (void)hipFree(g->bin_fill);
+  if (g->bin_tab8) (void)hipFree(g->bin_tab8);
   if (g->pr_blocks) (void)hipFree(g->pr_blocks);
   if (g->pr_piece) (void)hipFree(g->pr_piece);
   if (g->pr_long) (void)hipFree(g->pr_long);

@@ -31,7 +31,9 @@
 
 #include <climits>
 #include <cstddef>
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace grx {
 
@@ -218,7 +220,9 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
     in.level = h.level + 1;
     in.nt = h.nt(in.level & 1);
     in.bin_min = bn.min_edges;  // > 0: fat levels run binned (mode 2), see grx_bin.hpp
+    in.bin_max_degree = bn.max_degree;
     in.bin_fill = bn.fill;
+    in.bin_queue = bn.queue;
     in.bin_nb = bn.nb;
     in.bin_pad = BIN_PAD;
     plan_body<PLAN_BLOCK>(a, c, 0, s_wave, &s_red[0], in);
@@ -304,48 +308,101 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_claim_kernel(pipe_args a, bin_a
   ctrl_t* c = a.ctrl;
   const level_head h = load_level_head(c);
   if (h.done || h.mode != 2) return;
-  pol.ctrl = c;
-  pol.set_level(h.level);
-  bin_claim_block(a, bn, c, pol, sm, h.level & 1);
+  (void)pol;
+  bin_claim_block(a, bn, c, h.level + 1, sm, h.level & 1);
 }
 
 }  // namespace grx
 
 using namespace grx;
 
-// Per-graph static part of the binned levels (cached in the graph handle): bin width, capacities
-// (= in-edges of each bin's vertex range), the E-entry bin array and the fill counters.
+// Per-graph static part of the binned levels (cached in the graph handle): the bins -- runs of
+// granules with about equal numbers of in-edges -- their capacities, the XCD that claims each
+// bin (longest-processing-time assignment by capacity), the E-entry bin array and the counters.
 static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   if (g->bin_state != 0) return GRX_SUCCESS;
   g->bin_state = 2;  // unusable until proven otherwise
-  if (g->V <= 0 || g->E <= 0) return GRX_SUCCESS;
-  int shift = 5;
-  while (shift < 31 && (((long long)g->V + (1ll << shift) - 1) >> shift) > BIN_MAX) ++shift;
-  if (shift > BIN_SHIFT_MAX) return GRX_SUCCESS;  // a bin's bitmap slice would not fit the claim kernel's LDS
-  const int nb = (int)(((long long)g->V + (1ll << shift) - 1) >> shift);
+  if (g->V <= 0 || g->E <= 0 || ctx->n_xcd < 1) return GRX_SUCCESS;
+  int gshift = BIN_GSHIFT_MIN;
+  while (gshift < 31 && (((long long)g->V + (1ll << gshift) - 1) >> gshift) > BIN_GRAN_MAX) ++gshift;
+  if (gshift > BIN_SHIFT_MAX) return GRX_SUCCESS;  // a bin's bitmap slice would not fit the claim kernel's LDS
+  const int n_gran = (int)(((long long)g->V + (1ll << gshift) - 1) >> gshift);
+  const int max_width = 1 << (BIN_SHIFT_MAX - gshift);  // granules per bin
+  if ((n_gran + max_width - 1) / max_width > BIN_MAX) return GRX_SUCCESS;
   hipStream_t s = ctx->stream;
   int32_t* d_cnt = nullptr;
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt), BIN_MAX * sizeof(int32_t)));
-  GRX_HIP(hipMemsetAsync(d_cnt, 0, BIN_MAX * sizeof(int32_t), s));
-  hipLaunchKernelGGL(bin_count_kernel, dim3(ctx->num_cus * 8), dim3(BIN_MAX), 0, s, g->ci, (int64_t)g->E, shift, d_cnt);
-  int32_t h_cnt[BIN_MAX];
-  GRX_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt), BIN_GRAN_MAX * sizeof(int32_t)));
+  GRX_HIP(hipMemsetAsync(d_cnt, 0, BIN_GRAN_MAX * sizeof(int32_t), s));
+  hipLaunchKernelGGL(bin_count_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, g->ci, (int64_t)g->E, gshift, n_gran, d_cnt);
+  std::vector<int32_t> cnt(BIN_GRAN_MAX);
+  GRX_HIP(hipMemcpyAsync(cnt.data(), d_cnt, BIN_GRAN_MAX * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   GRX_HIP(hipStreamSynchronize(s));
   (void)hipFree(d_cnt);
-  int32_t h_off[BIN_MAX + 1];
-  long long acc = 0;
-  for (int b = 0; b <= BIN_MAX; ++b) {
-    h_off[b] = (int32_t)acc;
-    if (b < BIN_MAX) acc += h_cnt[b];
+  long long total = 0;
+  for (int i = 0; i < n_gran; ++i) total += cnt[(size_t)i];
+  if (total != (long long)g->E) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: a column index lies outside [0, V)");
+  // cut the granule sequence into <= BIN_MAX bins of about `target` in-edges each, no wider than max_width
+  std::vector<int> first;  // first granule of each bin
+  long long target = (total + 223) / 224;
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    first.clear();
+    long long acc = 0;
+    int width = 0;
+    for (int i = 0; i < n_gran; ++i) {
+      if (width == 0) first.push_back(i);
+      acc += cnt[(size_t)i];
+      ++width;
+      if (acc >= target || width == max_width) { acc = 0; width = 0; }
+    }
+    if ((int)first.size() <= BIN_MAX) break;
+    target += target / 4 + 1;
   }
-  if (acc != (long long)g->E) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: a column index lies outside [0, V)");
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_off), (BIN_MAX + 1) * sizeof(int32_t)));
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_fill), (size_t)BIN_MAX * BIN_PAD * sizeof(int32_t)));
+  const int nb = (int)first.size();
+  if (nb < 1 || nb > BIN_MAX) return GRX_SUCCESS;
+  first.push_back(n_gran);
+  std::vector<unsigned char> g2b((size_t)BIN_GRAN_MAX, 0), owner((size_t)BIN_MAX, 0);
+  std::vector<int32_t> off((size_t)BIN_MAX + 1, 0), v0((size_t)BIN_MAX + 1, 0);
+  std::vector<long long> cap((size_t)nb, 0);
+  for (int b = 0; b < nb; ++b) {
+    for (int i = first[(size_t)b]; i < first[(size_t)b + 1]; ++i) {
+      g2b[(size_t)i] = (unsigned char)b;
+      cap[(size_t)b] += cnt[(size_t)i];
+    }
+    v0[(size_t)b] = (int32_t)((long long)first[(size_t)b] << gshift);
+  }
+  {
+    long long acc = 0;
+    for (int b = 0; b <= BIN_MAX; ++b) {
+      off[(size_t)b] = (int32_t)acc;
+      if (b < nb) acc += cap[(size_t)b];
+      if (b >= nb) v0[(size_t)b] = (int32_t)((long long)n_gran << gshift);  // bitmap words exist up to the padded end
+    }
+  }
+  // owner: heaviest bin first, each to the least loaded XCD
+  std::vector<int> order((size_t)nb);
+  for (int b = 0; b < nb; ++b) order[(size_t)b] = b;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cap[(size_t)x] > cap[(size_t)y]; });
+  std::vector<long long> load((size_t)ctx->n_xcd, 0);
+  for (int b : order) {
+    int best = 0;
+    for (int x = 1; x < ctx->n_xcd; ++x)
+      if (load[(size_t)x] < load[(size_t)best]) best = x;
+    owner[(size_t)b] = (unsigned char)best;
+    load[(size_t)best] += cap[(size_t)b] + 1;
+  }
+  const size_t tab_bytes = (size_t)BIN_GRAN_MAX + (size_t)BIN_MAX;  // g2b, owner
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_tab8), tab_bytes));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_off), 2 * ((size_t)BIN_MAX + 1) * sizeof(int32_t)));  // off, v0
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_fill), ((size_t)BIN_MAX + 16) * BIN_PAD * sizeof(int32_t)));  // fill, queue
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bins), (size_t)g->E * sizeof(int32_t)));
-  GRX_HIP(hipMemcpyAsync(g->bin_off, h_off, sizeof(h_off), hipMemcpyHostToDevice, s));
-  GRX_HIP(hipMemsetAsync(g->bin_fill, 0, (size_t)BIN_MAX * BIN_PAD * sizeof(int32_t), s));
+  GRX_HIP(hipMemcpyAsync(g->bin_tab8, g2b.data(), (size_t)BIN_GRAN_MAX, hipMemcpyHostToDevice, s));
+  GRX_HIP(hipMemcpyAsync(g->bin_tab8 + BIN_GRAN_MAX, owner.data(), (size_t)BIN_MAX, hipMemcpyHostToDevice, s));
+  GRX_HIP(hipMemcpyAsync(g->bin_off, off.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  GRX_HIP(hipMemcpyAsync(g->bin_off + BIN_MAX + 1, v0.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  GRX_HIP(hipMemsetAsync(g->bin_fill, 0, ((size_t)BIN_MAX + 16) * BIN_PAD * sizeof(int32_t), s));
   GRX_HIP(hipStreamSynchronize(s));
-  g->bin_shift = shift;
+  g->bin_shift = gshift;
+  g->bin_ngran = n_gran;
   g->bin_nb = nb;
   g->bin_state = 1;
   return GRX_SUCCESS;
@@ -392,6 +449,14 @@ static int level_grid(grx_context_t ctx, grx_graph_t g, level_build* lb) {
   const int full = advance_grid_for(ctx, g);
   const int resident = ctx->num_cus * use;
   return full < resident ? full : resident;
+}
+
+// tuning aid: copy `n` 64-bit words of the context's debug scratch (GRX_BIN_DEBUG) to the host
+extern "C" grx_status_t grx_debug_read(grx_context_t ctx, long long* out, int64_t n) {
+  if (!ctx || !out || !ctx->far[1].ptr || (size_t)n * sizeof(long long) > ctx->far[1].bytes)
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_debug_read: nothing recorded");
+  GRX_HIP(hipMemcpy(out, ctx->far[1].ptr, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
+  return GRX_SUCCESS;
 }
 
 extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
@@ -514,16 +579,40 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     for (int i = 0; i < 3; ++i) lp.bm_f[i] = visited;  // every discovery sets its bit in `visited` itself
     lp.bm_words = (int)bm_words;
     lp.fwd_bitmap = 1;
-    lp.pre_bm = env_int("GRX_TD_PRE", 1) != 0 ? visited : nullptr;
+    // the read-only pre-filter of the label probe measured SLOWER (LJ stand-in, 31 M-edge level 525 -> 802 us:
+    // a second dependent round trip per edge costs more than the label sectors it saves): off by default
+    lp.pre_bm = env_int("GRX_TD_PRE", 0) != 0 ? visited : nullptr;
   }
   bin_args bn{};
   int grid_scatter = 0, grid_claim = 0;
   if (use_bins) {
     bn.bins = g->bins;
     bn.off = g->bin_off;
+    bn.v0 = g->bin_off + BIN_MAX + 1;
     bn.fill = g->bin_fill;
-    bn.shift = g->bin_shift;
+    bn.queue = g->bin_fill + (size_t)BIN_MAX * BIN_PAD;
+    bn.g2b = g->bin_tab8;
+    bn.owner = g->bin_tab8 + BIN_GRAN_MAX;
+    bn.gshift = g->bin_shift;
+    bn.n_gran = g->bin_ngran;
     bn.nb = g->bin_nb;
+    bn.xcc_mask = ctx->xcc_mask;
+    bn.n_xcd = ctx->n_xcd;
+    // A binned level pays one scattered L2 access per id that is new to its 8192-entry slice.  When a few
+    // thousand hubs are expanded into a mostly unvisited graph (the level right after the source's) nearly every
+    // entry is such an id and the claim-per-edge advance is as fast or faster (kron stand-in, 148 M-edge level:
+    // 1.31 ms vs 1.52 ms binned); once the frontier is wide most ids are already visited and are dropped in LDS
+    // (LJ stand-in 36 M-edge level: 0.56 -> 0.30 ms; kron 33 M-edge level: 0.34 -> 0.24 ms).  The frontier's
+    // mean out-degree separates the two cases on both graphs.
+    bn.max_degree = env_int("GRX_BIN_MAX_DEGREE", 512);
+    bn.debug_level = env_int("GRX_BIN_DEBUG", 0);
+    if (bn.debug_level != 0) {
+      // per-workgroup records of the LAST binned level: scatter at [0, 4096), claim at [4096 + grid, ...); read
+      // back with grx_debug_read
+      GRX_HIP(ctx->far[1].reserve((size_t)8 * 16384 * sizeof(long long)));
+      bn.debug = ctx->far[1].as<long long>();
+      GRX_HIP(hipMemsetAsync(bn.debug, 0, (size_t)8 * 16384 * sizeof(long long), s));
+    }
     bn.min_edges = (long long)env_int("GRX_BIN_MIN_EDGES", 1 << 20);
     if (bn.min_edges < 1) bn.min_edges = 1;
     bn.visited = visited;

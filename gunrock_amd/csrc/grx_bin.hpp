@@ -12,18 +12,19 @@
 // Here a fat level runs in two kernels whose global traffic is all coalesced streams:
 //   1. SCATTER (bin_scatter_block, inside the level kernel): the frontier is expanded exactly as
 //      in advance_block (tiles, 2048-edge chunks, lanes on consecutive edges), but a neighbour id
-//      is not probed -- it is appended to the BIN of its vertex range (bin = id >> shift, <= 256
-//      bins).  A workgroup sorts 4 chunks (8192 ids) by bin in LDS (histogram + rank with LDS
-//      atomics, block scan) and writes each bin's run with ONE reservation atomic per bin and
-//      batch; runs leave LDS as contiguous segments.  Bin capacities are STATIC: the number of
-//      in-edges of the bin's vertex range (each edge is traversed at most once per level), so the
-//      bins are one E-entry array that can never overflow and needs no size pass.
+//      is not probed -- it is appended to the BIN of its vertex range (<= 256 bins).  A workgroup
+//      sorts 4 chunks (8192 ids) by bin in LDS (histogram + rank with LDS atomics, block scan) and
+//      writes each bin's run with ONE reservation atomic per bin and batch; runs leave LDS as
+//      contiguous segments.  Bins are runs of GRANULES (>= 1024 vertices = one 128-byte line of the
+//      visited bitmap), cut once per graph so that every bin receives about the same number of
+//      in-edges (hub regions get narrow bins, sparse regions wide ones); their capacities are
+//      STATIC -- the in-edges of the vertex range, each edge is traversed at most once per level --
+//      so the bins are one E-entry array that can never overflow and needs no size pass.
 //   2. CLAIM (bin_claim_block, its own launch): a workgroup takes a slice of <= 8192 entries of
-//      ONE bin, copies that bin's slice of the visited bitmap into LDS (<= 16 KB), and tests /
-//      sets the bit of every entry THERE.  Only ids new to the workgroup go on to the
-//      reference's atomicMin on the label (bfs.hxx:117-119) -- about one per discovered vertex
-//      instead of one probe per edge -- and the winners are compacted into frontier tiles exactly
-//      as advance_block does.
+//      ONE bin, copies that bin's slice of the visited bitmap into LDS (<= 16 KB), filters its
+//      entries there, and claims the survivors with an XCD-local (L2) atomic on the global bitmap:
+//      every bin is claimed from ONE XCD only.  Winners get their label and are compacted into
+//      frontier tiles exactly as advance_block does.
 // The head kernel chooses per level (degree sum of the frontier >= bin_args::min_edges); all other
 // levels of the run go through advance_block, whose discoveries keep the same visited bitmap
 // current (bfs_policy::on_accept), so the formats never need converting.
@@ -37,96 +38,157 @@ constexpr int BIN_MAX = ADV_BLOCK;   // bins: one thread of a workgroup per bin
 constexpr int BIN_BATCH = 4;         // chunks sorted together (one reservation atomic per bin and batch:
                                      // a single word sustains only ~90 atomics/us)
 constexpr int BIN_SLICE = 8192;      // entries per claim work item
-constexpr int BIN_PAD = 32;          // ints between two fill counters (each in its own 128-byte line)
+constexpr int BIN_PAD = 32;          // ints between two counters (each in its own 128-byte line)
 constexpr int BIN_SHIFT_MAX = 17;    // widest vertex range per bin: 131072 vertices = 16 KB of bitmap in LDS
+constexpr int BIN_GRAN_MAX = 4096;   // granules (>= 1024 vertices each: one 128-byte line of the bitmap) per graph
+constexpr int BIN_GSHIFT_MIN = 10;
 
 struct bin_args {
-  int32_t* bins;          // E entries; bin b owns [off[b], off[b + 1])
-  const int32_t* off;     // nb + 1 static offsets
-  int32_t* fill;          // entries in bin b this level at fill[b * BIN_PAD] (zeroed by the head kernel)
-  int32_t shift;          // bin of vertex n = n >> shift
-  int32_t nb;             // bins in use (<= BIN_MAX)
-  long long min_edges;    // a level with at least this many out-edges is binned (0: never)
-  unsigned* visited;      // V-bit visited bitmap of the run
+  int32_t* bins;              // E entries; bin b owns [off[b], off[b + 1])
+  const int32_t* off;         // nb + 1 static offsets (capacity = in-edges of the bin's vertex range)
+  int32_t* fill;              // entries in bin b this level at fill[b * BIN_PAD] (zeroed by the head kernel)
+  int32_t* queue;             // claim work queue head of XCD x at queue[x * BIN_PAD] (zeroed by the head kernel)
+  const unsigned char* g2b;   // granule -> bin (bins are runs of granules: capacity-balanced, variable width)
+  const int32_t* v0;          // nb + 1: first vertex of each bin
+  const unsigned char* owner; // bin -> dense index of the XCD that claims its vertices
+  int32_t gshift;             // granule of vertex n = n >> gshift
+  int32_t n_gran;
+  int32_t nb;                 // bins in use (<= BIN_MAX)
+  uint32_t xcc_mask;          // hardware XCC ids present on this device (census at context creation)
+  int32_t n_xcd;
+  long long min_edges;        // a level with at least this many out-edges is binned (0: never) ...
+  unsigned* visited;          // V-bit visited bitmap of the run
   int32_t visited_words;
   int32_t* dist;
+  long long* debug;           // tuning aid (GRX_BIN_DEBUG=<level>): 8 words per workgroup and phase for that level, else null
+  int32_t debug_level;
+  int32_t max_degree;         // ... and whose frontier averages at most this many out-edges per vertex
 };
 
 struct bin_scatter_smem {
-  int seg[TILE + 1];
-  int start[TILE];
+  int seg[BIN_BATCH][TILE + 1];
+  int start[BIN_BATCH][TILE];
   int wave[ADV_BLOCK / 64 + 1];
   int hist[BIN_MAX];
   int off[BIN_MAX];
   int delta[BIN_MAX];
+  unsigned g2b[BIN_GRAN_MAX / 4];
   int sorted[BIN_BATCH * CHUNK];
 };
 
+__device__ __forceinline__ int bin_of(const unsigned* s_g2b, int n, int gshift) {
+  const unsigned g = (unsigned)n >> gshift;
+  return (int)((s_g2b[g >> 2] >> ((g & 3u) * 8u)) & 0xffu);
+}
+
 // Phase 1.  Chunks blockIdx.x, + gridDim.x, ... of the frontier with parity p, BIN_BATCH at a time.
+// The global loads of a batch travel together, one dependent round trip per stage for all its chunks
+// (chunk descriptors -> frontier slots -> row offsets -> column indices): the first version walked
+// the chunks one after the other and was bound by those four round trips per chunk.
 __device__ __forceinline__ void bin_scatter_block(const pipe_args& a, const bin_args& bn, bin_scatter_smem& sm, int p,
                                                   int total_chunks, const int* chunk_tile) {
   static_assert(BIN_MAX == ADV_BLOCK, "one thread per bin");
   const int tid = threadIdx.x;
   const int32_t* in = a.frontier[p];
   const int stride = (int)gridDim.x;
-  const int shift = bn.shift;
-  for (int u0 = (int)blockIdx.x; u0 < total_chunks; u0 += stride * BIN_BATCH) {
+  const int gshift = bn.gshift;
+  for (int w = tid; w < (bn.n_gran + 3) / 4; w += ADV_BLOCK) sm.g2b[w] = reinterpret_cast<const unsigned*>(bn.g2b)[w];
+  const bool dbg = bn.debug && a.ctrl->level == bn.debug_level;
+  const long long dbg_t0 = dbg ? (long long)wall_clock64() : 0ll;
+  int dbg_batches = 0;
+  // SOFTWARE PIPELINE of the front of a batch.  Chunk descriptors -> frontier slots -> row offsets are three
+  // DEPENDENT round trips; issued in one place they serialise (first version: ~27 us per batch, of which the
+  // sort itself is a few).  Here iteration i issues the row-offset loads of batch i + 1, the frontier-slot loads
+  // of batch i + 2 and the descriptor loads of batch i + 3 -- every one from values that arrived an iteration
+  // ago -- together with its own column-index loads: one round trip per batch for all four.
+  const int first = (int)blockIdx.x;
+  auto S1 = [&](int t, int2 (&tl)[BIN_BATCH]) {
+#pragma unroll
+    for (int j = 0; j < BIN_BATCH; ++j) {
+      const long long unit = (long long)first + ((long long)t * BIN_BATCH + j) * stride;  // uniform over the workgroup
+      tl[j] = reinterpret_cast<const int2*>(chunk_tile)[unit < total_chunks ? unit : 0];
+      if (unit >= total_chunks) tl[j].y = -1;  // not a chunk of this level: contributes no atoms (its tile is a real one)
+    }
+  };
+  auto S2 = [&](const int2 (&tl)[BIN_BATCH], int (&v)[BIN_BATCH]) {
+#pragma unroll
+    for (int j = 0; j < BIN_BATCH; ++j) v[j] = in[(size_t)tl[j].x * TILE + tid];
+  };
+  auto S3 = [&](const int (&v)[BIN_BATCH], int (&rs)[BIN_BATCH], int (&re)[BIN_BATCH]) {
+#pragma unroll
+    for (int j = 0; j < BIN_BATCH; ++j) {
+      const int vv = v[j] >= 0 ? v[j] : 0;  // unconditional loads from a clamped index (vertex 0 exists)
+      rs[j] = a.ro[vv];
+      re[j] = a.ro[vv + 1];
+    }
+  };
+  int2 tl0[BIN_BATCH], tl1[BIN_BATCH], tl2[BIN_BATCH], tl3[BIN_BATCH];
+  int v0[BIN_BATCH], v1[BIN_BATCH], v2[BIN_BATCH];
+  int rs0[BIN_BATCH], re0[BIN_BATCH], rs1[BIN_BATCH], re1[BIN_BATCH];
+  S1(0, tl0); S1(1, tl1); S1(2, tl2);
+  S2(tl0, v0); S2(tl1, v1);
+  S3(v0, rs0, re0);
+  for (int t = 0; (long long)first + (long long)t * BIN_BATCH * stride < total_chunks; ++t) {
+    ++dbg_batches;
     sm.hist[tid] = 0;
+    int2 tl_c[BIN_BATCH];
+    int rs_c[BIN_BATCH], dg_c[BIN_BATCH];
+#pragma unroll
+    for (int j = 0; j < BIN_BATCH; ++j) {
+      tl_c[j] = tl0[j];
+      rs_c[j] = rs0[j];
+      dg_c[j] = (v0[j] >= 0 && tl0[j].y >= 0) ? re0[j] - rs0[j] : 0;
+    }
+    S3(v1, rs1, re1);
+    S2(tl2, v2);
+    S1(t + 3, tl3);
+    __syncthreads();
+    int tot[BIN_BATCH];
+#pragma unroll
+    for (int j = 0; j < BIN_BATCH; ++j) {
+      const int ex = dev::block_exclusive_sum<ADV_BLOCK>(dg_c[j], sm.wave, &tot[j]);
+      sm.seg[j][tid] = ex;
+      sm.start[j][tid] = rs_c[j];
+      if (tid == 0) sm.seg[j][TILE] = tot[j];
+    }
     __syncthreads();
     int n_k[BIN_BATCH][ADV_ITEMS], r_k[BIN_BATCH][ADV_ITEMS];
 #pragma unroll
     for (int j = 0; j < BIN_BATCH; ++j) {
+      const int a0 = tl_c[j].y * CHUNK;
+      const int a_end = tl_c[j].y >= 0 ? min(tot[j], a0 + CHUNK) : 0;
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) {
-        n_k[j][k] = 0;
-        r_k[j][k] = -1;
-      }
-      const int unit = u0 + j * stride;
-      if (unit < total_chunks) {  // uniform over the workgroup
-        const int2 tl = reinterpret_cast<const int2*>(chunk_tile)[unit];
-        const int v = in[(size_t)tl.x * TILE + tid];
-        int rs = 0, deg = 0;
-        if (v >= 0) {
-          rs = a.ro[v];
-          deg = a.ro[v + 1] - rs;
+        const int atom = a0 + k * ADV_BLOCK + tid;
+        int e = -1;
+        if (tl_c[j].y >= 0 && atom < a_end) {
+          int lo = 0;
+#pragma unroll
+          for (int step = TILE / 2; step >= 1; step >>= 1)
+            if (sm.seg[j][lo + step] <= atom) lo += step;
+          e = sm.start[j][lo] + (atom - sm.seg[j][lo]);
         }
-        int tot;
-        const int ex = dev::block_exclusive_sum<ADV_BLOCK>(deg, sm.wave, &tot);
-        sm.seg[tid] = ex;
-        sm.start[tid] = rs;
-        if (tid == 0) sm.seg[TILE] = tot;
-        __syncthreads();
-        const int a0 = tl.y * CHUNK;
-        const int a_end = min(tot, a0 + CHUNK);
-        int e_k[ADV_ITEMS];
-#pragma unroll
-        for (int k = 0; k < ADV_ITEMS; ++k) {
-          const int atom = a0 + k * ADV_BLOCK + tid;
-          e_k[k] = -1;
-          if (atom < a_end) {
-            int lo = 0;
-#pragma unroll
-            for (int step = TILE / 2; step >= 1; step >>= 1)
-              if (sm.seg[lo + step] <= atom) lo += step;
-            e_k[k] = sm.start[lo] + (atom - sm.seg[lo]);
-          }
-        }
-        // all column-index loads of the chunk in flight together (lanes past the end read edge 0)
-#pragma unroll
-        for (int k = 0; k < ADV_ITEMS; ++k) n_k[j][k] = a.ci[e_k[k] >= 0 ? e_k[k] : 0];
-#pragma unroll
-        for (int k = 0; k < ADV_ITEMS; ++k)
-          if (e_k[k] >= 0) r_k[j][k] = atomicAdd(&sm.hist[n_k[j][k] >> shift], 1);
-        __syncthreads();  // seg / start are rewritten by the next chunk
+        r_k[j][k] = e;  // >= 0: a real edge
+        n_k[j][k] = a.ci[e >= 0 ? e : 0];  // lanes past the end read edge 0
       }
     }
+    // bin + rank inside the bin, packed as (bin << 16 | rank): rank < 8192
+#pragma unroll
+    for (int j = 0; j < BIN_BATCH; ++j)
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k)
+        if (r_k[j][k] >= 0) {
+          const int b = bin_of(sm.g2b, n_k[j][k], gshift);
+          r_k[j][k] = (b << 16) | atomicAdd(&sm.hist[b], 1);
+        }
+    __syncthreads();
     // one reservation per non-empty bin, issued ahead of the scan so that its round trip overlaps
     const int cnt = sm.hist[tid];
     int gbase = 0;
     if (cnt > 0) gbase = atomicAdd(&bn.fill[tid * BIN_PAD], cnt);
     const int boff = tid < bn.nb ? bn.off[tid] : 0;
-    int tot;
-    const int ex = dev::block_exclusive_sum<ADV_BLOCK>(cnt, sm.wave, &tot);
+    int btot;
+    const int ex = dev::block_exclusive_sum<ADV_BLOCK>(cnt, sm.wave, &btot);
     sm.off[tid] = ex;
     sm.delta[tid] = boff + gbase - ex;  // global slot of sorted position i of this bin: delta + i
     __syncthreads();
@@ -134,13 +196,26 @@ __device__ __forceinline__ void bin_scatter_block(const pipe_args& a, const bin_
     for (int j = 0; j < BIN_BATCH; ++j)
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k)
-        if (r_k[j][k] >= 0) sm.sorted[sm.off[n_k[j][k] >> shift] + r_k[j][k]] = n_k[j][k];
+        if (r_k[j][k] >= 0) sm.sorted[sm.off[r_k[j][k] >> 16] + (r_k[j][k] & 0xffff)] = n_k[j][k];
     __syncthreads();
-    for (int i = tid; i < tot; i += ADV_BLOCK) {
+    for (int i = tid; i < btot; i += ADV_BLOCK) {
       const int n = sm.sorted[i];
-      bn.bins[(size_t)(sm.delta[n >> shift] + i)] = n;
+      bn.bins[(size_t)(sm.delta[bin_of(sm.g2b, n, gshift)] + i)] = n;
+    }
+#pragma unroll
+    for (int j = 0; j < BIN_BATCH; ++j) {
+      tl0[j] = tl1[j]; tl1[j] = tl2[j]; tl2[j] = tl3[j];
+      v0[j] = v1[j]; v1[j] = v2[j];
+      rs0[j] = rs1[j]; re0[j] = re1[j];
     }
     __syncthreads();
+  }
+  if (dbg && tid == 0) {
+    long long* d = bn.debug + 8 * (size_t)blockIdx.x;
+    d[0] = (long long)((unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u);
+    d[1] = dbg_batches;
+    d[2] = dbg_t0;
+    d[3] = (long long)wall_clock64();
   }
 }
 
@@ -152,49 +227,93 @@ struct bin_claim_smem {
   int wave[ADV_BLOCK / 64 + 1];
   int cnt;
   int res[3];
+  int item;
   emit_smem emit;
 };
 
-// Phase 2.  Discoveries are emitted as tiles of parity p ^ 1; pol.on_accept keeps the global visited
-// bitmap current; pol.next_depth is the depth being assigned.
-__device__ __forceinline__ void bin_claim_block(const pipe_args& a, const bin_args& bn, ctrl_t* c, bfs_policy& pol,
+// hardware XCC id of this wave's CU -> dense index 0 .. n_xcd - 1 (s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4))
+__device__ __forceinline__ int xcd_index(uint32_t xcc_mask, int n_xcd) {
+  const unsigned id = (unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u;
+  const int dense = __popc(xcc_mask & ((1u << id) - 1u));
+  return ((xcc_mask >> id) & 1u) ? dense : (int)(id % (unsigned)n_xcd);
+}
+
+// Phase 2.  A bin's vertices are claimed ONLY by workgroups running on the XCD that owns the bin
+// (bin_args::owner, against the hardware XCC id -- so this holds under any dispatch order), which makes
+// the claim an L2-LOCAL atomic: a workgroup-scope atomicOr on the global visited bitmap executes in the
+// owning XCD's L2, where every other claimant of the same word runs too, and returns the exact old
+// word.  No fabric atomic per candidate (an agent-scope atomic is a memory-side operation at ~20 G/s
+// for the whole device: the first version spent 416 us of a 31 M-edge level on ~9 M of them), and no
+// duplicates across the slices of a bin.  Bins own whole 128-byte lines of the bitmap (granules of
+// >= 1024 vertices), so no line is ever touched from two XCDs within the launch; the words written
+// through L2 reach memory at the end of the kernel like any other store.
+// Work: the slices (<= BIN_SLICE entries) of the bins an XCD owns form that XCD's queue; workgroups pop it
+// with one atomic per slice.  A slice first filters its entries against an LDS copy of the bin's bitmap
+// (read past the L1: `sc1`), then claims the survivors in L2; winners store their label plainly and are
+// compacted into frontier tiles of parity p ^ 1 exactly as advance_block does.
+__device__ __forceinline__ void bin_claim_block(const pipe_args& a, const bin_args& bn, ctrl_t* c, int depth,
                                                 bin_claim_smem& sm, int p) {
   const int tid = threadIdx.x;
   const int lane = dev::lane_id();
+  const int x = xcd_index(bn.xcc_mask, bn.n_xcd);
+  const bool dbg = bn.debug && c->level == bn.debug_level;
+  const long long dbg_t0 = dbg ? (long long)wall_clock64() : 0ll;
+  long long dbg_items = 0, dbg_entries = 0, dbg_words = 0;
   if (tid == 0) { sm.cnt = 0; sm.res[0] = 0; sm.res[1] = 0; }
-  // work items: bin b contributes ceil(fill[b] / BIN_SLICE) slices
+  // this XCD's work items: bin b (owned by x) contributes ceil(fill[b] / BIN_SLICE) slices
   int fill = 0;
-  if (tid < bn.nb) fill = bn.fill[tid * BIN_PAD];
+  if (tid < bn.nb && (int)bn.owner[tid] == x) fill = bn.fill[tid * BIN_PAD];
   int tot_items;
   const int ex = dev::block_exclusive_sum<ADV_BLOCK>((fill + BIN_SLICE - 1) / BIN_SLICE, sm.wave, &tot_items);
   sm.pre[tid] = ex;
   sm.fillv[tid] = fill;
-  if (tid == 0) sm.pre[BIN_MAX] = tot_items;
+  if (tid == 0) {
+    sm.pre[BIN_MAX] = tot_items;
+    sm.item = tot_items > 0 ? atomicAdd(&bn.queue[x * BIN_PAD], 1) : 0;
+  }
   __syncthreads();
-  const int depth = pol.next_depth;
-  const int words = 1 << (bn.shift - 5);
-  for (int item = (int)blockIdx.x; item < tot_items; item += (int)gridDim.x) {
-    int b = 0;  // largest b with pre[b] <= item: the bin the item belongs to (empty bins are skipped over)
+  for (;;) {
+    const int item = sm.item;
+    if (item >= tot_items) break;
+    __syncthreads();
+    int next_item = 0;
+    if (tid == 0) next_item = atomicAdd(&bn.queue[x * BIN_PAD], 1);  // its round trip overlaps this slice
+    int b = 0;  // largest b with pre[b] <= item: the bin the item belongs to (bins without items are skipped over)
 #pragma unroll
     for (int step = BIN_MAX / 2; step >= 1; step >>= 1)
       if (sm.pre[b + step] <= item) b += step;
     const int e0 = (item - sm.pre[b]) * BIN_SLICE;
     const int n_e = min(sm.fillv[b], e0 + BIN_SLICE) - e0;
     const int32_t* src = bn.bins + (size_t)bn.off[b] + e0;
-    const int vbase = b << bn.shift;
+    const int vbase = bn.v0[b];
+    const int words = (bn.v0[b + 1] - vbase) >> 5;
+    ++dbg_items;
+    dbg_entries += n_e;
+    dbg_words += words;
     // this bin's slice of the visited bitmap -> LDS (words past the end of the bitmap: all visited)
     for (int w = tid; w < words; w += ADV_BLOCK) {
       const int gw = (vbase >> 5) + w;
-      sm.bm[w] = gw < bn.visited_words ? bn.visited[gw] : ~0u;
+      sm.bm[w] = gw < bn.visited_words
+                     ? __hip_atomic_load(&bn.visited[gw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                     : ~0u;
     }
     __syncthreads();
+    int n_next[ADV_ITEMS];  // the entries of a round are loaded one round ahead
+#pragma unroll
+    for (int k = 0; k < ADV_ITEMS; ++k) {
+      const int i = k * ADV_BLOCK + tid;
+      n_next[k] = src[i < n_e ? i : 0];  // n_e > 0: entry 0 exists
+    }
     for (int r0 = 0; r0 < n_e; r0 += CHUNK) {
-      int n_k[ADV_ITEMS], old_k[ADV_ITEMS];
+      int n_k[ADV_ITEMS];
+      unsigned old_k[ADV_ITEMS];
       bool cand_k[ADV_ITEMS];
 #pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) n_k[k] = n_next[k];
+#pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) {
-        const int i = r0 + k * ADV_BLOCK + tid;
-        n_k[k] = src[i < n_e ? i : 0];  // n_e > 0: entry 0 exists
+        const int i = r0 + CHUNK + k * ADV_BLOCK + tid;
+        n_next[k] = src[i < n_e ? i : 0];
       }
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) {
@@ -208,15 +327,25 @@ __device__ __forceinline__ void bin_claim_block(const pipe_args& a, const bin_ar
           if (!(sm.bm[local >> 5] & bit)) cand_k[k] = (atomicOr(&sm.bm[local >> 5], bit) & bit) == 0u;
         }
       }
-      // the reference's claim for the ids new to this workgroup, all issued before any result is used
+      // ids new to this slice.  The other slices of the bin run at the same time on other CUs of this XCD and
+      // most of them find the same vertices: re-read the global word past the L1 (one more L2 round trip for
+      // the round, unconditional loads) and keep only what is STILL unclaimed -- an L2 reads an order of
+      // magnitude more words than it can serve atomics (measured: ~15 M candidate atomics for 2.0 M discoveries
+      // on the 31 M-edge level without this, 22 us per round instead of 6)
+      // (Measured and dropped: re-reading the global word right before the claim, to skip ids another slice of the
+      // bin has claimed meanwhile -- sc1, nt and plain loads alike made the 31 M-edge level 2-3x SLOWER: the phase
+      // is bound by the number of scattered L2 accesses per round, and a load costs what the atomic costs.)
+      // claim in the owning XCD's L2, all issued before any result is used
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) {
-        old_k[k] = 0;
-        if (cand_k[k]) old_k[k] = atomicMin(&bn.dist[n_k[k]], depth);
+        old_k[k] = ~0u;
+        if (cand_k[k])
+          old_k[k] = __hip_atomic_fetch_or(&bn.visited[n_k[k] >> 5], 1u << (n_k[k] & 31), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
       }
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) {
-        const bool keep = cand_k[k] && depth < old_k[k];
+        const bool keep = cand_k[k] && ((old_k[k] >> (n_k[k] & 31)) & 1u) == 0u;
         const unsigned long long m = dev::ballot(keep);
         if (m) {
           int base = 0;
@@ -224,7 +353,7 @@ __device__ __forceinline__ void bin_claim_block(const pipe_args& a, const bin_ar
           base = __shfl(base, 0, 64);
           if (keep) {
             sm.out[base + dev::mask_rank(m)] = n_k[k];
-            pol.on_accept(n_k[k]);
+            bn.dist[n_k[k]] = depth;  // exactly one winner per vertex (bfs.hxx:117-119 assigns the same depth)
           }
         }
       }
@@ -238,27 +367,47 @@ __device__ __forceinline__ void bin_claim_block(const pipe_args& a, const bin_ar
       if (tid == 0) sm.cnt = cnt;
       __syncthreads();
     }
+    if (tid == 0) sm.item = next_item;
+    __syncthreads();
   }
   const int rem = sm.cnt;
   if (rem > 0) emit_tile(a, c, p ^ 1, sm.out, 0, rem, sm.wave, sm.res);
   __syncthreads();
   release_tiles(a, sm.res);
+  if (dbg && tid == 0) {
+    long long* d = bn.debug + 8 * (4096 + (size_t)blockIdx.x);
+    d[0] = (long long)((unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u);
+    d[1] = dbg_items;
+    d[2] = dbg_t0;
+    d[3] = (long long)wall_clock64();
+    d[4] = dbg_entries;
+    d[5] = dbg_words;
+    d[6] = tot_items;
+    d[7] = x;
+  }
 }
 
-// Per-graph static part: how many in-edges fall into each bin's vertex range (= its capacity).
-// One pass over the column indices, once per graph.  <<<grid, 256>>>
-__global__ void bin_count_kernel(const int32_t* __restrict__ ci, int64_t E, int shift, int32_t* cnt) {
-  __shared__ int s_hist[BIN_MAX];
-  s_hist[threadIdx.x] = 0;
+// Per-graph static part: in-edges per GRANULE (the unit bins are cut from).  One pass over the column
+// indices, once per graph.  <<<grid, 256>>>
+static __global__ void bin_count_kernel(const int32_t* __restrict__ ci, int64_t E, int gshift, int n_gran, int32_t* cnt) {
+  __shared__ int s_hist[BIN_GRAN_MAX];
+  for (int i = threadIdx.x; i < BIN_GRAN_MAX; i += blockDim.x) s_hist[i] = 0;
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride) {
-    const unsigned b = (unsigned)ci[e] >> shift;  // an id outside [0, V) is left uncounted: the host sees the shortfall
-    if (b < (unsigned)BIN_MAX) atomicAdd(&s_hist[b], 1);
+    const unsigned g = (unsigned)ci[e] >> gshift;  // an id outside [0, V) is left uncounted: the host sees the shortfall
+    if (g < (unsigned)n_gran) atomicAdd(&s_hist[g], 1);
   }
   __syncthreads();
-  const int v = s_hist[threadIdx.x];
-  if (v) atomicAdd(&cnt[threadIdx.x], v);
+  for (int i = threadIdx.x; i < n_gran; i += blockDim.x) {
+    const int v = s_hist[i];
+    if (v) atomicAdd(&cnt[i], v);
+  }
+}
+
+// Which hardware XCC ids exist on this device: every workgroup ORs its id into *mask.  <<<many, 64>>>
+static __global__ void xcc_census_kernel(unsigned* mask) {
+  if (threadIdx.x == 0) atomicOr(mask, 1u << ((unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u));
 }
 
 }  // namespace grx

@@ -116,6 +116,8 @@ struct grx_context {
   bool own_stream = false;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   int32_t num_cus = 256;
+  uint32_t xcc_mask = 1u;  // hardware XCC ids seen by a census at context creation
+  int32_t n_xcd = 1;
 
   grx::ctrl_t* d_ctrl = nullptr;       // device control block
   grx::ctrl_t* h_ctrl = nullptr;       // pinned host mirror (written by memcpy)
@@ -160,8 +162,9 @@ struct grx_graph {
   // binned top-down levels (grx_bin.hpp), built lazily; owned
   int32_t* bins = nullptr;      // E entries
   int32_t* bin_off = nullptr;   // static bin offsets (in-edges per vertex range)
-  int32_t* bin_fill = nullptr;  // per-level fill counters
-  int32_t bin_shift = 0, bin_nb = 0;
+  int32_t* bin_fill = nullptr;  // per-level fill counters + per-XCD claim queue heads
+  unsigned char* bin_tab8 = nullptr;  // granule -> bin, bin -> owning XCD
+  int32_t bin_shift = 0, bin_ngran = 0, bin_nb = 0;
   int32_t bin_state = 0;        // 0: not built, 1: usable, 2: not applicable to this graph
   double weight_sum = -1.0;  // sum of edge weights (lazy; near-far SSSP bucket width)
   bool uniform_weights = false;

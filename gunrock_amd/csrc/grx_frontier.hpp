@@ -136,7 +136,9 @@ struct plan_in {
   // binned top-down levels (grx_bin.hpp; external_control == 0 only): a level whose frontier has at
   // least bin_min out-edges runs as mode 2; the head zeroes the nb fill counters (bin_pad ints apart)
   long long bin_min = 0;
+  int bin_max_degree = 0;        // ... and at most this many out-edges per frontier vertex on average (0: no limit)
   int32_t* bin_fill = nullptr;
+  int32_t* bin_queue = nullptr;  // per-XCD claim queue heads (16 slots, bin_pad apart), zeroed with the fill counters
   int bin_nb = 0, bin_pad = 0;
 };
 
@@ -159,7 +161,10 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
     }
     return;
   }
-  if (in.bin_min > 0 && tid < in.bin_nb) in.bin_fill[tid * in.bin_pad] = 0;
+  if (in.bin_min > 0) {
+    if (tid < in.bin_nb) in.bin_fill[tid * in.bin_pad] = 0;
+    if (tid < 16) in.bin_queue[tid * in.bin_pad] = 0;
+  }
   long long esum = 0, vsum = 0;  // traversed edges / frontier vertices of the level (two 64-bit sums)
   int mine = 0, carry;
   const int R = external_control == 1 ? in.R : 0;
@@ -244,7 +249,8 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
       c->vertices_visited += nitems;
       c->n_items[p] = nitems;
       c->q_edges[p] = edges;
-      if (in.bin_min > 0) c->mode = edges >= in.bin_min ? 2 : 0;
+      if (in.bin_min > 0)
+        c->mode = (edges >= in.bin_min && (in.bin_max_degree <= 0 || edges <= (long long)in.bin_max_degree * nitems)) ? 2 : 0;
       if (!external_control) {
         c->level = level;
         c->n_tiles[p ^ 1] = 0;

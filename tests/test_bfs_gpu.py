@@ -201,9 +201,10 @@ def test_binned_forward_levels(gr, gpu_ctx, monkeypatch, golden):
         assert g.n_edges >= 4 * g.n_vertices  # dense enough for the forward bitmap path
         for src in sources:
             want, _, ev = O.bfs_queue(g, src)
-            for env in ({"GRX_BIN_MIN_EDGES": "1"}, {}, {"GRX_BIN_MIN_EDGES": "1", "GRX_TD_PRE": "0"},
-                        {"GRX_TD_BIN": "0"}, {"GRX_TD_BITMAP": "0"}):
-                for k in ("GRX_BIN_MIN_EDGES", "GRX_TD_PRE", "GRX_TD_BIN", "GRX_TD_BITMAP"):
+            for env in ({"GRX_BIN_MIN_EDGES": "1", "GRX_BIN_MAX_DEGREE": "0"}, {},
+                        {"GRX_BIN_MIN_EDGES": "1", "GRX_BIN_MAX_DEGREE": "0", "GRX_TD_PRE": "1"},
+                        {"GRX_BIN_MIN_EDGES": "1000"}, {"GRX_TD_BIN": "0"}, {"GRX_TD_BITMAP": "0"}):
+                for k in ("GRX_BIN_MIN_EDGES", "GRX_BIN_MAX_DEGREE", "GRX_TD_PRE", "GRX_TD_BIN", "GRX_TD_BITMAP"):
                     monkeypatch.delenv(k, raising=False)
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
@@ -212,7 +213,7 @@ def test_binned_forward_levels(gr, gpu_ctx, monkeypatch, golden):
                                     gr.options_t(advance_direction=gr.forward, engine_flags=flags))
                     assert np.array_equal(d, want), (g.n_vertices, src, env, flags)
                     assert st["edges_visited"] == ev and st["vertices_visited"] == int((want != INF).sum())
-                    if flags and env.get("GRX_BIN_MIN_EDGES") == "1" and "GRX_TD_BIN" not in env:
+                    if flags and env.get("GRX_BIN_MAX_DEGREE") == "0" and "GRX_TD_BIN" not in env:
                         prof = gr.level_profile(gpu_ctx)
                         assert all(l["bottom_up"] == 2 for l in prof if l["edges"] > 0), "a level did not run binned"
 

@@ -60,8 +60,10 @@ def sweep(budget_s, seed=1234, log=print, max_vertices=600_000):
                 force_bins = si % 2 == 0
                 if force_bins:
                     os.environ["GRX_BIN_MIN_EDGES"] = "1"
+                    os.environ["GRX_BIN_MAX_DEGREE"] = "0"
                 else:
                     os.environ.pop("GRX_BIN_MIN_EDGES", None)
+                    os.environ.pop("GRX_BIN_MAX_DEGREE", None)
                 for direction in (gr.forward, gr.optimized):
                     flags = gr.FLAG_ASYNC_RETURN if rng.integers(0, 2) else 0
                     o = gr.options_t(advance_direction=direction, engine_flags=flags)
@@ -86,6 +88,7 @@ def sweep(budget_s, seed=1234, log=print, max_vertices=600_000):
             log("%-8s V %7d E %9d weighted %d  %s" % (kind, V, nnz, weighted, "ok" if not bad else "BAD x%d" % bad))
             del G
     finally:
+        os.environ.pop("GRX_BIN_MAX_DEGREE", None)
         if saved_env is None:
             os.environ.pop("GRX_BIN_MIN_EDGES", None)
         else:

@@ -23,7 +23,7 @@ ctx = gr.multi_context_t(0)
 G = gr.build_graph(props, csr, ctx)
 V = G.get_number_of_vertices()
 d = torch.empty(V, dtype=torch.int32, device="cuda")
-KNOBS = ("GRX_TD_BITMAP", "GRX_TD_PRE", "GRX_TD_BIN", "GRX_BIN_MIN_EDGES", "GRX_LEVEL_MINW", "GRX_BU_BATCH", "GRX_DO_ALPHA", "GRX_DO_BETA", "GRX_DO_BACK_DIV", "GRX_LEVEL_WG_PER_CU", "GRX_PACE_DEPTH")
+KNOBS = ("GRX_BIN_MAX_DEGREE", "GRX_TD_BITMAP", "GRX_TD_PRE", "GRX_TD_BIN", "GRX_BIN_MIN_EDGES", "GRX_LEVEL_MINW", "GRX_BU_BATCH", "GRX_DO_ALPHA", "GRX_DO_BETA", "GRX_DO_BACK_DIV", "GRX_LEVEL_WG_PER_CU", "GRX_PACE_DEPTH")
 ref = None
 
 
@@ -96,3 +96,7 @@ if "bin" in groups:
     for m in (1 << 17, 1 << 18, 1 << 22):
         run("TD bins min_edges %d" % m, gr.forward, env={"GRX_BIN_MIN_EDGES": m})
     run("DO default (reference point)", gr.optimized)
+if "bin2" in groups:
+    run("TD round-1 body (no bitmap)", gr.forward, env={"GRX_TD_BITMAP": 0})
+    run("TD bins, default rule", gr.forward)
+    run("TD bins, every fat level", gr.forward, env={"GRX_BIN_MAX_DEGREE": 0})

@@ -1,0 +1,49 @@
+"""Per-workgroup timeline of the binned kernels of one BFS level (tuning aid):
+    GRX_BIN_DEBUG=<level> python tools/bin_debug.py [lj|kron] """
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gunrock_amd as gr  # noqa: E402
+from gunrock_amd import _capi  # noqa: E402
+from bench import WORKLOADS  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "lj"
+wl = WORKLOADS[name]
+props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], wl["c"], seed=42)
+src = int(np.argmax(np.diff(csr.row_offsets)))
+ctx = gr.multi_context_t(0)
+G = gr.build_graph(props, csr, ctx)
+d = torch.empty(G.get_number_of_vertices(), dtype=torch.int32, device="cuda")
+o = gr.options_t(advance_direction=gr.forward)
+for _ in range(3):
+    gr.bfs(G, src, d, None, ctx, o)
+ctx.synchronize()
+L = _capi.lib()
+L.grx_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+buf = np.zeros(8 * 16384, dtype=np.int64)
+_capi.check(L.grx_debug_read(ctx._h, buf.ctypes.data, buf.size))
+rec = buf.reshape(-1, 8)
+for phase, lo in (("scatter", 0), ("claim", 4096)):
+    r = rec[lo:lo + 4096]
+    r = r[r[:, 3] != 0]
+    if len(r) == 0:
+        print(phase, "no records")
+        continue
+    t0 = r[:, 2].min()
+    tick_us = 0.01  # wall_clock64: 100 MHz
+    print("%s: %d workgroups, span %.1f us" % (phase, len(r), (r[:, 3].max() - t0) * tick_us))
+    for x in sorted(set(r[:, 0].tolist())):
+        q = r[r[:, 0] == x]
+        dur = (q[:, 3] - q[:, 2]) * tick_us
+        extra = ""
+        if phase == "claim":
+            extra = " entries %d bitmap words %d queue items %d dense %s" % (q[:, 4].sum(), q[:, 5].sum(), q[0, 6], set(q[:, 7].tolist()))
+        print("  xcc %d: %4d wgs, work units %6d, start %.1f..%.1f end %.1f..%.1f us, busy mean %.1f max %.1f%s"
+              % (x, len(q), q[:, 1].sum(), (q[:, 2].min() - t0) * tick_us, (q[:, 2].max() - t0) * tick_us,
+                 (q[:, 3].min() - t0) * tick_us, (q[:, 3].max() - t0) * tick_us, dur.mean(), dur.max(), extra))
