@@ -1,6 +1,7 @@
 // grx_api.hip -- context, graph view, scratch arena and statistics of the C ABI.
 #include "grx_engine.hpp"
 #include "grx_bin.hpp"
+#include "grx_mid.hpp"
 
 #include <mutex>
 
@@ -110,6 +111,8 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   a->tile_count = ctx->tile_count.as<int32_t>();
   a->chunk_tile = ctx->chunk_tile.as<int32_t>();
   a->bu_part = nullptr;
+  GRX_HIP(ctx->mid_aux.reserve((size_t)2 * MID_AUX_CAP * 2 * sizeof(int32_t)));
+  a->mid_aux = ctx->mid_aux.ptr;
   return GRX_SUCCESS;
 }
 
@@ -215,6 +218,7 @@ grx_status_t grx_context_destroy(grx_context_t ctx) {
   ctx->labels.release();
   for (auto& b : ctx->fbuf) b.release();
   ctx->misc.release();
+  ctx->mid_aux.release();
   if (ctx->d_ctrl) (void)hipFree(ctx->d_ctrl);
   if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
   if (ctx->h_mailbox) (void)hipHostFree((void*)ctx->h_mailbox);

@@ -28,6 +28,7 @@
 #include "grx_engine.hpp"
 #include "grx_bfs_kernels.hpp"
 #include "grx_bin.hpp"
+#include "grx_mid.hpp"
 
 #include <climits>
 #include <cstddef>
@@ -221,6 +222,8 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
     in.nt = h.nt(in.level & 1);
     in.bin_min = bn.min_edges;  // > 0: fat levels run binned (mode 2), see grx_bin.hpp
     in.bin_max_degree = bn.max_degree;
+    in.mid_v = bn.mid_v;
+    in.mid_e = bn.mid_e;
     in.bin_fill = bn.fill;
     in.bin_queue = bn.queue;
     in.bin_nb = bn.nb;
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
   if (h.done) return;
   const int level = h.level;
   const int mode_now = h.mode;
+
   if (d.enabled) {
     uint4* z = reinterpret_cast<uint4*>(pick3(d.fbits, (level + 2) % 3));
     const uint4* fc = reinterpret_cast<const uint4*>(pick3(d.fbits, level % 3));
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
 // binned).  Separate from bfs_level_kernel so that the 38 KB of LDS the scatter phase sorts in do
 // not cost the direction-optimising path its resident workgroups.
 __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_bin_kernel(pipe_args a, bin_args bn, bfs_policy pol) {
-  using td_smem = advance_smem<bfs_policy>;
+  using td_smem = mid_smem<bfs_policy>;
   constexpr size_t LDS_BYTES = sizeof(td_smem) > sizeof(bin_scatter_smem) ? sizeof(td_smem) : sizeof(bin_scatter_smem);
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
   ctrl_t* c = a.ctrl;
@@ -295,10 +299,13 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_bin_kernel(pipe_args a, b
   if (h.done) return;
   if (h.mode == 2) {
     bin_scatter_block(a, bn, *reinterpret_cast<bin_scatter_smem*>(lds_raw), h.level & 1, h.total_chunks, a.chunk_tile);
+  } else if (h.mode == 3) {
+    pol.ctrl = c;
+    mid_levels_body(a, c, pol, *reinterpret_cast<td_smem*>(lds_raw), h, bn.xcc_mask);
   } else {
     pol.ctrl = c;
     pol.set_level(h.level);
-    advance_block<bfs_policy, false>(a, c, pol, *reinterpret_cast<td_smem*>(lds_raw), h.level & 1, blockIdx.x,
+    advance_block<bfs_policy, false>(a, c, pol, reinterpret_cast<td_smem*>(lds_raw)->adv, h.level & 1, blockIdx.x,
                                      gridDim.x, h.total_chunks, a.chunk_tile);
   }
 }
@@ -584,6 +591,14 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     lp.pre_bm = env_int("GRX_TD_PRE", 0) != 0 ? visited : nullptr;
   }
   bin_args bn{};
+  bn.xcc_mask = ctx->xcc_mask;
+  bn.n_xcd = ctx->n_xcd;
+  d.xcc_mask = ctx->xcc_mask;
+  // forward-only runs: frontiers of a few thousand vertices run many levels per launch (grx_mid.hpp); GRX_MID=0: off
+  if (!dopt && variant == 0 && env_int("GRX_MID", 1) != 0) {
+    bn.mid_v = env_int("GRX_MID_V", MID_ENTER_V);
+    bn.mid_e = env_int("GRX_MID_E", MID_ENTER_E);
+  }
   int grid_scatter = 0, grid_claim = 0;
   if (use_bins) {
     bn.bins = g->bins;
@@ -618,10 +633,14 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.visited = visited;
     bn.visited_words = (int32_t)bm_words;
     bn.dist = d_dist;
-    static const int per_cu_scatter = resident_per_cu(bfs_level_bin_kernel);
     static const int per_cu_claim = resident_per_cu(bfs_claim_kernel);
-    grid_scatter = ctx->num_cus * per_cu_scatter;
     grid_claim = ctx->num_cus * per_cu_claim;
+  }
+  if (!dopt && variant == 0) {
+    static const int per_cu_scatter = resident_per_cu(bfs_level_bin_kernel);
+    const int resident = ctx->num_cus * per_cu_scatter;
+    const int full = advance_grid_for(ctx, g);  // one workgroup per CU on road-like graphs
+    grid_scatter = full < resident ? full : resident;
   }
   hipError_t launch_err = hipSuccess;
   bool returned_fast = false;
@@ -634,10 +653,11 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       // head (tiny levels + decide + plan) -> level
       hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, lp, profile ? 0 : 1, seq, bn);
       if (profile) (void)hipEventRecord(pe[1], stream);
-      if (use_bins) {
-        // level = claim-per-edge advance or SCATTER phase; the CLAIM phase is a no-op unless the head binned the level
+      if (!dopt) {
+        // forward-only run.  level = claim-per-edge advance, many mid-size levels (grx_mid.hpp), or the SCATTER phase of
+        // a binned level; the CLAIM phase is launched only when levels can be binned (a no-op unless the head did)
         hipLaunchKernelGGL(bfs_level_bin_kernel, dim3(grid_scatter), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
-        hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_claim), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
+        if (use_bins) hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_claim), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
       } else {
         hipLaunchKernelGGL(lbuild->fn, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
       }
@@ -693,6 +713,10 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
      &returned_fast);
   if (st != GRX_SUCCESS) return st;
   if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));
+  if (ctx->h_mailbox[10] != 0 || (!returned_fast && ctx->h_ctrl->mid_err != 0)) {
+    ctx->h_mailbox[10] = 0;
+    return fail(GRX_ERROR_HIP, "grx_bfs: a device-side barrier timed out (grx_mid.hpp)");
+  }
 
   float ms = 0;
   if (returned_fast) {

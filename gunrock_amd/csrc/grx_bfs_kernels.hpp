@@ -51,6 +51,9 @@ struct bfs_policy_t {
   // forward-only runs with a visited bitmap (grx_bin.hpp): bm_f[0..2] all alias bm_visited, so
   // every discovery sets its bit there directly and nothing is ever cleared or folded
   int fwd_bitmap;
+  // set by mid_levels_body (grx_mid.hpp): every workgroup of the launch sits on ONE XCD and nobody else touches
+  // the labels, so the claim may execute in that XCD's L2 (workgroup scope) instead of at the memory side
+  int l2_local;
   // read-only bitmap pre-filter of the label probe (null: off).  The bitmap is 32 x denser than
   // the labels (V / 8 bytes: L2-resident), and a neighbour it already shows as visited -- most
   // of them on the fat levels -- costs no label sector at all; it may lag behind (it is a hint,
@@ -128,7 +131,12 @@ struct bfs_policy_t {
       return (__hip_atomic_load(&visited[n >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << (n & 31))) == 0u;
     return (visited[n >> 5] & (1u << (n & 31))) == 0u;
   }
+  // what precheck computes, without the probe (mid_levels_body)
+  __device__ __forceinline__ bool prepare(src_state, int, int, int&) const { return true; }
   __device__ __forceinline__ int claim(int n, int) const {
+    if constexpr (VARIANT == 0) {
+      if (l2_local) return __hip_atomic_fetch_min(&dist[n], next_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     if constexpr (VARIANT == 0 || VARIANT == 7) return atomicMin(&dist[n], next_depth);
     if constexpr (VARIANT == 3) atomicAdd(&ctrl->spare[0], 1);
     return (int)atomicOr(&visited[n >> 5], 1u << (n & 31));
@@ -162,6 +170,7 @@ struct dobfs_args {
   // visited / fbits are indexed by LOCAL chunk, labels / offsets / frontier probes by GLOBAL id
   int32_t ch_lo;               // 0 on a single GPU
   const unsigned* fin_global;  // whole-graph frontier bitmap to probe; null: fbits[level & 1]
+  uint32_t xcc_mask;           // hardware XCC ids of this device (grx_mid.hpp)
 };
 
 // Bottom-up level.  A wave owns 64 consecutive vertices (one "chunk") and works on

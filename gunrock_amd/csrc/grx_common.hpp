@@ -96,6 +96,13 @@ struct ctrl_t {
   int64_t bu_probes;        // bottom-up accounting: in-edges read (cumulative)
   int64_t g_edges_visited;  // partitioned BFS: out-edges of all expanded vertices, whole graph
   int64_t t_start;          // wall_clock64() at the seed of the search (init kernel)
+  // many mid-size levels in one launch (grx_mid.hpp)
+  int32_t mid_bar;          // arrivals at the barrier since the head kernel chose mode 3
+  int32_t mid_cnt[3];       // entries in the flat queue of level L at [L % 3]
+  int32_t mid_err;          // a barrier timed out (the host reports an error)
+  uint32_t mid_reg;         // registrations of workgroups on the home XCD (bit 31: window closed)
+  int32_t mid_G;            // number of workgroups taking part (published by the leader)
+  int32_t pad3[1];
 };
 
 struct level_rec {
@@ -139,6 +146,7 @@ struct grx_context {
   grx::dbuf labels;        // int32 per vertex (SSSP stamps etc.)
   grx::dbuf fbuf[4];       // float per vertex (PR plast, iweights, x, ...)
   grx::dbuf misc;          // reductions etc.
+  grx::dbuf mid_aux;       // grx_mid.hpp: row start / degree carried with the flat queue entries
 
   grx_run_stats_t stats{};
   std::vector<grx::level_rec> levels;

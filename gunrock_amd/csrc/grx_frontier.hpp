@@ -52,6 +52,7 @@ struct pipe_args {
   int32_t* tile_count;    // valid vertices per tile
   int32_t* chunk_tile;    // per chunk: int2 {owning tile, chunk index inside the tile}
   const long long* bu_part;  // direction-optimising BFS: 4 words per bottom-up workgroup (word 0 >> 40 = its tiles)
+  void* mid_aux;             // grx_mid.hpp: {row start, degree} of the first entries of the flat queues, per parity
 };
 
 // The search is over: final counters and the elapsed device time go to the host-pinned mailbox
@@ -137,6 +138,9 @@ struct plan_in {
   // least bin_min out-edges runs as mode 2; the head zeroes the nb fill counters (bin_pad ints apart)
   long long bin_min = 0;
   int bin_max_degree = 0;        // ... and at most this many out-edges per frontier vertex on average (0: no limit)
+  // many mid-size levels in one launch (grx_mid.hpp; external_control == 0 only): a level with at most mid_v
+  // frontier vertices and mid_e out-edges runs as mode 3 (0: off)
+  int mid_v = 0, mid_e = 0;
   int32_t* bin_fill = nullptr;
   int32_t* bin_queue = nullptr;  // per-XCD claim queue heads (16 slots, bin_pad apart), zeroed with the fill counters
   int bin_nb = 0, bin_pad = 0;
@@ -249,8 +253,23 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
       c->vertices_visited += nitems;
       c->n_items[p] = nitems;
       c->q_edges[p] = edges;
-      if (in.bin_min > 0)
-        c->mode = (edges >= in.bin_min && (in.bin_max_degree <= 0 || edges <= (long long)in.bin_max_degree * nitems)) ? 2 : 0;
+      if (in.bin_min > 0 || in.mid_v > 0) {
+        int mode = 0;
+        if (in.bin_min > 0 && edges >= in.bin_min &&
+            (in.bin_max_degree <= 0 || edges <= (long long)in.bin_max_degree * nitems))
+          mode = 2;
+        else if (in.mid_v > 0 && nitems > 0 && nitems <= in.mid_v && edges <= (long long)in.mid_e)
+          mode = 3;
+        c->mode = mode;
+        if (mode == 3) {
+          c->mid_bar = 0;
+          c->mid_reg = 0u;
+          c->mid_G = 0;
+          c->mid_cnt[0] = 0;
+          c->mid_cnt[1] = 0;
+          c->mid_cnt[2] = 0;
+        }
+      }
       if (!external_control) {
         c->level = level;
         c->n_tiles[p ^ 1] = 0;

@@ -1,0 +1,380 @@
+// grx_mid.hpp -- MANY MID-SIZE LEVELS IN ONE LAUNCH: a few workgroups keep expanding the frontier
+// level after level, separated by a device-side barrier, instead of one head + level launch pair per
+// level.
+//
+// What it replaces in the reference: the host loop of enactor_t::enact() (framework/enactor.hxx:274-277)
+// with its >= 2 blocking synchronisations per level, for the levels of a high-diameter search.
+//
+// Why.  On a road network a BFS / SSSP level has a few thousand vertices and ~10 k edges, and there are
+// thousands of them.  Round 1 ran such a level as a head kernel (one workgroup: bookkeeping + chunk map)
+// plus a level kernel: two launches, ~13 us per level, nearly all of it launch overhead and dependent
+// round trips (the LDS-resident tiny-level body covers only frontiers of <= 4096 edges: one CU retires
+// about one scattered transaction every two clocks).  Here MID_WGS workgroups of the level kernel stay
+// resident and run level after level themselves:
+//   * the frontier is a FLAT queue in the same two parity buffers the tile queue uses; workgroup w
+//     takes slots w * 256, (w + MID_WGS) * 256, ...: a block of 256 vertices is staged, its degrees
+//     scanned in LDS, and the lanes walk consecutive edges exactly as advance_block does (same policy
+//     interface, same phased loads / atomics), so hubs are shared by the 256 lanes of the workgroup;
+//   * accepted neighbours are compacted in LDS and appended to the next queue with one reservation atomic
+//     per 256 (or per level and workgroup);
+//   * a level ends at a counter barrier among the resident workgroups (every thread drains its stores, one
+//     arrival atomic per workgroup, one lane polls).
+//   * ALL OF THEM RUN ON ONE XCD.  The first version let any 32 workgroups stay and talked through agent-scope
+//     (memory-side) atomics and sc1 stores: a level cost 11.5 us on the road stand-in -- ten dependent round
+//     trips of ~1 us each across the fabric -- against 13 us for the launch pair.  Here only workgroups whose
+//     CU reports the HOME XCC id (HW_REG_XCC_ID) register -- a short registration window fixes their number,
+//     so nothing depends on how the grid was dispatched -- and everything they share lives in that XCD's L2:
+//     plain stores (the L1 writes through), loads that bypass the L1 (sc1: L2-served), and WORKGROUP-scope
+//     atomics, which execute in the L2 -- for the barrier, the queue counters and the label claims of the
+//     policy alike.  That is coherent because nobody else touches these words during the launch (the rest
+//     of the grid leaves at once), and it reaches memory at the end of the kernel like any other store.
+// The head kernel chooses (frontier <= MID_ENTER_V vertices and <= MID_ENTER_E out-edges -> ctrl.mode 3);
+// the body leaves when the search ends (it publishes `done` like every other kernel) or when the
+// frontier outgrows MID_EXIT_V, handing the queue back as tiles with their metadata.  Every spin is
+// bounded: a barrier that does not complete raises ctrl.mid_err instead of hanging the device.
+#pragma once
+
+#include "grx_frontier.hpp"
+
+namespace grx {
+
+constexpr int MID_WGS = 32;          // workgroups that stay (the rest of the grid leaves at once)
+constexpr int MID_ENTER_V = 8192;    // a level enters with at most this many frontier vertices ...
+constexpr int MID_ENTER_E = 65536;   // ... and out-edges
+constexpr int MID_EXIT_V = 32768;    // a frontier beyond this goes back to the regular kernels
+constexpr int MID_SPIN_LIMIT = 1 << 22;
+constexpr int MID_AUX_CAP = MID_EXIT_V + TILE;  // queue entries that carry their row start / degree along
+
+template <class Policy>
+struct mid_smem {
+  advance_smem<Policy> adv;
+  int out_rs[TILE + CHUNK];   // row start / degree of the staged output vertices (parallel to adv.out)
+  int out_deg[TILE + CHUNK];
+  int base;
+  int n_next;
+  int ok;
+  int rank;
+};
+
+// optional policy hook: `prepare(src_state, nbr, edge, cand&)` -- what precheck computes WITHOUT the read-only
+// probe of the neighbour's label.  Inside one XCD the claim itself is an L2 operation, cheaper than the extra
+// dependent round trip of a probe that mostly misses to HBM.
+template <class Policy, class = void>
+struct policy_has_prepare : std::false_type {};
+template <class Policy>
+struct policy_has_prepare<Policy, std::void_t<decltype(&Policy::prepare)>> : std::true_type {};
+
+// policies whose claims can be told to execute in the local L2 (see above)
+template <class Policy, class = void>
+struct policy_has_l2_local : std::false_type {};
+template <class Policy>
+struct policy_has_l2_local<Policy, std::void_t<decltype(std::declval<Policy&>().l2_local)>> : std::true_type {};
+
+// Barrier among the n_wg resident workgroups.  epoch: barriers passed so far in this launch (uniform).
+// Returns false if it timed out.
+template <class Policy>
+__device__ __forceinline__ bool mid_barrier(ctrl_t* c, int n_wg, int& epoch, mid_smem<Policy>& sm) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores have been acknowledged
+  __syncthreads();
+  ++epoch;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(&c->mid_bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // in the home L2
+    const int want = n_wg * epoch;
+    int spins = 0, ok = 1;
+    while (__hip_atomic_load(&c->mid_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > MID_SPIN_LIMIT) { ok = 0; break; }
+    }
+    sm.ok = ok;
+  }
+  __syncthreads();
+  return sm.ok != 0;
+}
+
+// Append sm.adv.out[lo .. lo + k) to the next queue (count word *cnt_out).  Block-wide.
+template <class Policy>
+__device__ __forceinline__ void mid_flush(int32_t* qout, int2* aux_out, int* cnt_out, mid_smem<Policy>& sm, int lo, int k) {
+  if (threadIdx.x == 0) sm.base = __hip_atomic_fetch_add(cnt_out, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __syncthreads();
+  const int base = sm.base;
+  for (int i = threadIdx.x; i < k; i += ADV_BLOCK) {
+    qout[base + i] = sm.adv.out[lo + i];  // through the L1 into the home L2
+    if (base + i < MID_AUX_CAP) aux_out[base + i] = make_int2(sm.out_rs[lo + i], sm.out_deg[lo + i]);
+  }
+  __syncthreads();
+}
+
+// Runs in the level kernel when ctrl.mode == 3.  h: the control block as the kernel read it (level = the level
+// to expand, its frontier is the tile queue of that parity).
+template <class Policy>
+__device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, Policy& pol, mid_smem<Policy>& sm,
+                                                const level_head& h, uint32_t xcc_mask) {
+  static_assert(!policy_has_side<Policy>::value, "policies with a side pile run their levels on advance_block");
+  const int tid = threadIdx.x;
+  const int lane = dev::lane_id();
+  // ---- who takes part: the workgroups on the home XCD that register before the leader closes the window
+  const unsigned my_xcc = (unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u;
+  if (my_xcc != (unsigned)__builtin_ctz(xcc_mask ? xcc_mask : 1u)) return;
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(&c->mid_reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    sm.rank = (old >> 31) ? -1 : (int)(old & 0xffffu);
+  }
+  __syncthreads();
+  const int w = sm.rank;
+  if (w < 0) return;  // the window had closed
+  if (tid == 0) {
+    int g = 0;
+    if (w == 0) {
+      // leader: wait (a few us at most) for the expected number of registrations, then close
+      const int expect = min(MID_WGS, max(1, (int)gridDim.x / max(1, __popc(xcc_mask))));
+      for (int i = 0; i < 64; ++i) {
+        if ((int)(__hip_atomic_load(&c->mid_reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu) >= expect) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      const unsigned old = __hip_atomic_fetch_or(&c->mid_reg, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      g = min((int)(old & 0xffffu), MID_WGS);
+      __hip_atomic_store(&c->mid_G, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      int spins = 0;
+      while ((g = __hip_atomic_load(&c->mid_G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > MID_SPIN_LIMIT) { g = -1; break; }
+      }
+    }
+    sm.n_next = g;
+  }
+  __syncthreads();
+  const int G = sm.n_next;
+  __syncthreads();
+  if (G < 0) {
+    if (tid == 0) { c->mid_err = 1; c->done = 1; a.mailbox[10] = 1; __threadfence_system(); a.mailbox[0] = 1; }
+    return;
+  }
+  if (w >= G) return;
+  if constexpr (policy_has_l2_local<Policy>::value) pol.l2_local = 1;
+  advance_smem<Policy>& ad = sm.adv;
+  int level = h.level;
+  int epoch = 0;
+  bool first = true;                       // the entering frontier is a tile queue (slots may be -1)
+  int n_in = ((level & 1) ? h.nt1 : h.nt0) * TILE;       // slots to look at
+  long long my_edges = 0, my_vertices = 0; // levels AFTER the entering one (the head accounted for that one)
+  for (;;) {
+    const int p = level & 1;
+    const int32_t* qin = a.frontier[p];
+    int32_t* qout = a.frontier[p ^ 1];
+    const int2* aux_in = reinterpret_cast<const int2*>(a.mid_aux) + (size_t)p * MID_AUX_CAP;
+    int2* aux_out = reinterpret_cast<int2*>(a.mid_aux) + (size_t)(p ^ 1) * MID_AUX_CAP;
+    int* cnt_out = &c->mid_cnt[(level + 1) % 3];
+    // the counter the level after next appends to (last read one level ago)
+    if (w == 0 && tid == 0) __hip_atomic_store(&c->mid_cnt[(level + 2) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    pol.set_level(level);
+    if (tid == 0) ad.cnt = 0;
+    __syncthreads();
+    for (int base = w * TILE; base < n_in; base += G * TILE) {
+      int v = -1;
+      if (first) {
+        // tile queue: tiles are front-packed, only the first tile_count slots of a tile were ever written
+        // (reserved-but-unused tiles have count 0 and hold garbage)
+        if (tid < a.tile_count[base / TILE]) v = qin[base + tid];
+      } else if (base + tid < n_in) {
+        v = __hip_atomic_load(&qin[base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      int rs = 0, deg = 0;
+      typename Policy::src_state st{};
+      if (v >= 0) {
+        if (!first && base + tid < MID_AUX_CAP) {
+          // the producer of this entry fetched its row start / degree while it waited at the barrier anyway
+          const long long rd = __hip_atomic_load(reinterpret_cast<const long long*>(&aux_in[base + tid]), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+          rs = (int)(rd & 0xffffffffll);
+          deg = (int)(rd >> 32);
+        } else {
+          rs = a.ro[v];
+          deg = a.ro[v + 1] - rs;
+        }
+        st = pol.load_source(v);
+      }
+      int tot;
+      const int ex = dev::block_exclusive_sum<ADV_BLOCK>(deg, ad.wave, &tot);
+      ad.seg[tid] = ex;
+      ad.start[tid] = rs;
+      ad.src[tid] = v;
+      ad.state[tid] = st;
+      if (tid == 0) ad.seg[TILE] = tot;
+      const int n_valid = __syncthreads_count(v >= 0);
+      if (!first) {
+        my_edges += tot;
+        my_vertices += n_valid;
+      }
+      for (int a0 = 0; a0 < tot; a0 += CHUNK) {
+        const int a_end = min(tot, a0 + CHUNK);
+        int e_k[ADV_ITEMS], slot_k[ADV_ITEMS], n_k[ADV_ITEMS], cand_k[ADV_ITEMS];
+#pragma unroll
+        for (int k = 0; k < ADV_ITEMS; ++k) {
+          const int atom = a0 + k * ADV_BLOCK + tid;
+          int lo = 0;
+          if (atom < a_end) {
+#pragma unroll
+            for (int step = TILE / 2; step >= 1; step >>= 1)
+              if (ad.seg[lo + step] <= atom) lo += step;
+            e_k[k] = ad.start[lo] + (atom - ad.seg[lo]);
+          } else {
+            e_k[k] = -1;
+          }
+          slot_k[k] = lo;
+        }
+#pragma unroll
+        for (int k = 0; k < ADV_ITEMS; ++k) n_k[k] = a.ci[e_k[k] >= 0 ? e_k[k] : 0];
+        bool pre_k[ADV_ITEMS];
+#pragma unroll
+        for (int k = 0; k < ADV_ITEMS; ++k) {
+          const bool ok = e_k[k] >= 0;
+          cand_k[k] = 0;
+          bool pass;
+          if constexpr (policy_has_prepare<Policy>::value)
+            pass = pol.prepare(ad.state[slot_k[k]], n_k[k], ok ? e_k[k] : 0, cand_k[k]);
+          else
+            pass = pol.precheck(ad.state[slot_k[k]], n_k[k], ok ? e_k[k] : 0, cand_k[k]);
+          pre_k[k] = pass & ok;
+        }
+        int r1_k[ADV_ITEMS], r2_k[ADV_ITEMS];
+#pragma unroll
+        for (int k = 0; k < ADV_ITEMS; ++k) {
+          r1_k[k] = 0;
+          r2_k[k] = 0;
+          if (pre_k[k]) r1_k[k] = pol.claim(n_k[k], cand_k[k]);
+        }
+        if constexpr (policy_two_claims<Policy>::value) {
+#pragma unroll
+          for (int k = 0; k < ADV_ITEMS; ++k) {
+            const bool need = pre_k[k] & pol.need2(r1_k[k], cand_k[k]);
+            if (need) r2_k[k] = pol.claim2(n_k[k]);
+          }
+        }
+        bool keep_k[ADV_ITEMS];
+        int nrs_k[ADV_ITEMS], nre_k[ADV_ITEMS];
+#pragma unroll
+        for (int k = 0; k < ADV_ITEMS; ++k) {
+          int code = 0;
+          if (pre_k[k]) code = pol.code(r1_k[k], r2_k[k], n_k[k], cand_k[k]);
+          keep_k[k] = code == 1;
+        }
+        // row offsets of the accepted vertices, for the level that expands them: unconditional loads from a
+        // clamped index (the others read row 0), all in flight together
+#pragma unroll
+        for (int k = 0; k < ADV_ITEMS; ++k) {
+          const int x = keep_k[k] ? n_k[k] : 0;
+          nrs_k[k] = a.ro[x];
+          nre_k[k] = a.ro[x + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < ADV_ITEMS; ++k) {
+          const bool keep = keep_k[k];
+          const unsigned long long m = dev::ballot(keep);
+          if (m) {
+            int at = 0;
+            if (lane == 0) at = atomicAdd(&ad.cnt, __popcll(m));
+            at = __shfl(at, 0, 64);
+            if (keep) {
+              const int pos = at + dev::mask_rank(m);
+              ad.out[pos] = n_k[k];
+              sm.out_rs[pos] = nrs_k[k];
+              sm.out_deg[pos] = nre_k[k] - nrs_k[k];
+              if constexpr (policy_has_accept<Policy>::value) pol.on_accept(n_k[k]);
+            }
+          }
+        }
+        __syncthreads();
+        int cnt = ad.cnt;
+        if (cnt >= TILE) {  // the last k * TILE entries leave, the first cnt % TILE stay
+          const int k = cnt / TILE;
+          mid_flush(qout, aux_out, cnt_out, sm, cnt - k * TILE, k * TILE);
+          cnt -= k * TILE;
+        }
+        if (tid == 0) ad.cnt = cnt;
+        __syncthreads();
+      }
+      __syncthreads();  // seg / start / src are rewritten by the next block of slots
+    }
+    {
+      const int rem = ad.cnt;
+      if (rem > 0) mid_flush(qout, aux_out, cnt_out, sm, 0, rem);
+    }
+    if (!mid_barrier(c, G, epoch, sm)) {
+      if (tid == 0) {
+        c->mid_err = 1;
+        c->done = 1;
+        a.mailbox[10] = 1;
+        __threadfence_system();
+        a.mailbox[0] = 1;
+      }
+      return;
+    }
+    if (tid == 0) sm.n_next = __hip_atomic_load(cnt_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    n_in = sm.n_next;
+    first = false;
+    ++level;
+    __syncthreads();
+    if (n_in == 0 || n_in > MID_EXIT_V) break;
+  }
+  // ---- leaving: this workgroup's share of the counters, then either the end of the search or a hand-back
+  if (tid == 0 && (my_edges | my_vertices)) {
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&c->edges_visited), (unsigned long long)my_edges,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&c->vertices_visited), (unsigned long long)my_vertices,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  if (n_in == 0) {
+    // every workgroup's counters must have landed before the leader publishes them
+    if (!mid_barrier(c, G, epoch, sm)) {
+      if (tid == 0) { c->mid_err = 1; c->done = 1; a.mailbox[10] = 1; __threadfence_system(); a.mailbox[0] = 1; }
+      return;
+    }
+    if (w == 0 && tid == 0) {
+      c->done = 1;
+      c->level = level;
+      // the counters were updated in the home L2: read them past the L1
+      c->mode = 0;
+      long long* mb64 = reinterpret_cast<long long*>(a.mailbox + 4);
+      mb64[0] = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&c->edges_visited), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+      mb64[1] = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&c->vertices_visited), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+      mb64[2] = (long long)wall_clock64() - c->t_start;
+      a.mailbox[1] = level;
+      __threadfence_system();
+      a.mailbox[0] = 1;
+    }
+    return;
+  }
+  // ---- hand the flat queue of `level` (n_in entries, dense) back as tiles with their metadata
+  {
+    const int p = level & 1;
+    int32_t* q = a.frontier[p];
+    const int tiles = (n_in + TILE - 1) / TILE;
+    for (int t = w; t < tiles; t += G) {
+      const int slot = t * TILE + tid;
+      int v = -1;
+      if (slot < n_in) v = __hip_atomic_load(&q[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else q[slot] = -1;
+      int deg = 0;
+      if (v >= 0) deg = a.ro[v + 1] - a.ro[v];
+      int tot;
+      (void)dev::block_exclusive_sum<ADV_BLOCK>(deg, ad.wave, &tot);
+      if (tid == 0) {
+        a.tile_sums[t] = tot;
+        a.tile_chunks[t] = (tot + CHUNK - 1) / CHUNK;
+        a.tile_count[t] = min(TILE, n_in - t * TILE);
+      }
+    }
+    if (w == 0 && tid == 0) {
+      c->n_tiles[p] = tiles;
+      c->n_tiles[p ^ 1] = 0;
+      c->level = level - 1;  // the next head plans `level`
+      c->mode = 0;
+    }
+  }
+}
+
+}  // namespace grx

@@ -24,6 +24,7 @@
 //    the distances are identical.  Unit-weight graphs and engine_flags bit 4 use the plain
 //    schedule.
 #include "grx_engine.hpp"
+#include "grx_mid.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -37,6 +38,10 @@ struct sssp_policy {
   int32_t* stamp;
   const float* w;
   int level;
+  int l2_local;  // set by mid_levels_body: the launch sits on one XCD, atomics may execute in its L2
+  // all weights equal: every tentative distance of a level is the same number, so exactly ONE relaxation per vertex
+  // ever finds `nd < old` (the first; its label is final) -- the output needs no per-level stamp to be duplicate-free
+  int uniform;
 
   __device__ __forceinline__ void begin(ctrl_t* c) { level = c->level; }
   __device__ __forceinline__ void set_level(int l) { level = l; }
@@ -54,20 +59,32 @@ struct sssp_policy {
     cand = __float_as_int(nd);
     return nd < dist[n];
   }
+  // what precheck computes, without the probe (mid_levels_body)
+  __device__ __forceinline__ bool prepare(src_state d_src, int, int e, int& cand) const {
+    cand = __float_as_int(d_src + edge_weight(e));
+    return true;
+  }
   __device__ __forceinline__ int claim(int n, int cand) const {
+    // tentative distances are >= 0: the integer order of the bit patterns is the float order
+    if (l2_local)
+      return __hip_atomic_fetch_min(reinterpret_cast<int*>(&dist[n]), cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __float_as_int(dev::atomic_min_f32(&dist[n], __int_as_float(cand)));
   }
-  __device__ __forceinline__ bool need2(int raw1, int cand) const { return __int_as_float(cand) < __int_as_float(raw1); }
+  __device__ __forceinline__ bool improved(int raw1, int cand) const { return __int_as_float(cand) < __int_as_float(raw1); }
+  __device__ __forceinline__ bool need2(int raw1, int cand) const { return !uniform && improved(raw1, cand); }
   // once per level: the iteration stamp de-duplicates the output exactly
-  __device__ __forceinline__ int claim2(int n) const { return atomicExch(&stamp[n], level); }
+  __device__ __forceinline__ int claim2(int n) const {
+    if (l2_local) return __hip_atomic_exchange(&stamp[n], level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return atomicExch(&stamp[n], level);
+  }
   __device__ __forceinline__ int code(int raw1, int raw2, int, int cand) const {
-    return (need2(raw1, cand) && raw2 != level) ? 1 : 0;
+    return (improved(raw1, cand) && (uniform || raw2 != level)) ? 1 : 0;
   }
   __device__ __forceinline__ int visit(src_state d_src, int n, int e) const {
     const int cand = __float_as_int(d_src + edge_weight(e));
     const int r1 = claim(n, cand);
-    if (!need2(r1, cand)) return 0;
-    return code(r1, claim2(n), n, cand);
+    if (!improved(r1, cand)) return 0;
+    return code(r1, uniform ? 0 : claim2(n), n, cand);
   }
 };
 
@@ -386,7 +403,8 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, s
 
 // Head of a plain (label-correcting) level, ONE launch of one workgroup: as many tiny levels
 // as there are (tiny_levels_body), then the bookkeeping + chunk map of the next regular level.
-__global__ __launch_bounds__(PLAN_BLOCK) void sssp_head_kernel(pipe_args a, sssp_policy pol, long long n_edges) {
+__global__ __launch_bounds__(PLAN_BLOCK) void sssp_head_kernel(pipe_args a, sssp_policy pol, long long n_edges,
+                                                               int mid_v, int mid_e) {
   __shared__ tiny_smem<sssp_policy> tsm;
   __shared__ unsigned long long s_esum[2];
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
@@ -404,7 +422,23 @@ __global__ __launch_bounds__(PLAN_BLOCK) void sssp_head_kernel(pipe_args a, sssp
   in.mode = 0;
   in.R = 0;
   in.T = 0;
+  in.mid_v = mid_v;  // frontiers of a few thousand vertices: many levels per launch (grx_mid.hpp)
+  in.mid_e = mid_e;
   plan_body<PLAN_BLOCK>(a, a.ctrl, 0, s_wave, s_esum, in);
+}
+
+// One plain (label-correcting) level, or -- ctrl.mode 3 -- many mid-size levels in this one launch.
+__global__ __launch_bounds__(ADV_BLOCK) void sssp_level_kernel(pipe_args a, sssp_policy pol, uint32_t xcc_mask) {
+  __shared__ mid_smem<sssp_policy> sm;
+  ctrl_t* c = a.ctrl;
+  const level_head h = load_level_head(c);
+  if (h.done) return;
+  if (h.mode == 3) {
+    mid_levels_body(a, c, pol, sm, h, xcc_mask);
+    return;
+  }
+  pol.begin(c);
+  advance_block<sssp_policy, false>(a, c, pol, sm.adv, h.level & 1, blockIdx.x, gridDim.x, h.total_chunks, a.chunk_tile);
 }
 
 // out[0] = sum of weights; bits[0] / bits[1] = min / max weight as ordered uints (w >= 0)
@@ -487,6 +521,10 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
   hipLaunchKernelGGL(sssp_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, src, delta);
 
   const int grid = advance_grid_for(ctx, g);
+  const char* mid_env = getenv("GRX_MID");
+  // (the L2-local claim of the mid-level body orders tentative distances by their bit patterns: non-negative only)
+  const bool mid_on = !(mid_env && *mid_env == '0') && (!w_eff || g->weight_min > 0.0f);
+  const int mid_v = mid_on ? MID_ENTER_V : 0, mid_e = mid_on ? MID_ENTER_E : 0;
   ctx->levels.clear();
   hipError_t launch_err = hipSuccess;
   // GRX_FLAG_PROFILE: one record per iteration -- head / level kernel times from events on this
@@ -530,16 +568,20 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
             [&] { hipLaunchKernelGGL(sssp_nf_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, nf, pol); });
     }, after);
   } else {
-    sssp_policy pol{d_dist, stamp, w_eff, 0};
+    sssp_policy pol{d_dist, stamp, w_eff, 0, 0, (!g->w || g->uniform_weights) ? 1 : 0};
     st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
       group(stream,
-            [&] { hipLaunchKernelGGL(sssp_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, pol, (long long)g->E); },
-            [&] { hipLaunchKernelGGL((advance_kernel<sssp_policy>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol); });
+            [&] { hipLaunchKernelGGL(sssp_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, pol, (long long)g->E, mid_v, mid_e); },
+            [&] { hipLaunchKernelGGL(sssp_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol, ctx->xcc_mask); });
     }, after);
   }
   if (profile) for (auto& e : pe) (void)hipEventDestroy(e);
   if (st != GRX_SUCCESS) return st;
   if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));
+  if (ctx->h_ctrl->mid_err != 0 || ctx->h_mailbox[10] != 0) {
+    ctx->h_mailbox[10] = 0;
+    return fail(GRX_ERROR_HIP, "grx_sssp: a device-side barrier timed out (grx_mid.hpp)");
+  }
 
   GRX_HIP(hipEventRecord(ctx->ev_end, s));
   GRX_HIP(hipEventSynchronize(ctx->ev_end));
