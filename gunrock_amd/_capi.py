@@ -24,6 +24,7 @@ FLAG_UNFUSED = 0x1
 FLAG_PROFILE = 0x2
 FLAG_SYNC_EACH_LEVEL = 0x4
 FLAG_ASYNC_RETURN = 0x8
+FLAG_LB_STRICT = 0x1000
 
 
 class grx_options_t(C.Structure):
@@ -115,6 +116,7 @@ def lib():
         "grx_bfs_dist_slice_bits": (i32, [i32, i32]),
         "grx_bfs_dist_create": (i32, [vp, vp, vp, i32, i32, C.c_longlong, i32, vp, vp, vp, vp, P(vp)]),
         "grx_bfs_dist_begin": (i32, [vp, i32, i32, vp]),
+        "grx_bfs_dist_begin_local": (i32, [vp, i32, i32, vp]),
         "grx_bfs_dist_pre": (i32, [vp, i32]),
         "grx_bfs_dist_post": (i32, [vp]),
         "grx_bfs_dist_poll": (i32, [vp, P(i32), P(i32)]),

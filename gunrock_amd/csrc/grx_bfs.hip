@@ -491,7 +491,10 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   // the claim-per-edge advance and carries the binned fat levels (grx_bin.hpp).
   // Tuning knobs: GRX_TD_BITMAP=0 (no bitmap at all), GRX_TD_PRE=0 (no pre-filter), GRX_TD_BIN=0 (no
   // binned levels), GRX_BIN_MIN_EDGES (out-edges of a frontier from which a level is binned).
-  const bool fwd_bm = !dopt && variant == 0 && (long long)g->E >= 4ll * g->V && env_int("GRX_TD_BITMAP", 1) != 0;
+  // GRX_FLAG_LB_STRICT + merge_path: every level on the chunked merge-path advance, nothing else
+  const bool strict_mp = ((opt.engine_flags & GRX_FLAG_LB_STRICT) != 0 || env_int("GRX_LB_STRICT", 0) != 0) &&
+                         (opt.advance_load_balance == GRX_LB_MERGE_PATH || opt.advance_load_balance == GRX_LB_MERGE_PATH_V2);
+  const bool fwd_bm = !dopt && !strict_mp && variant == 0 && (long long)g->E >= 4ll * g->V && env_int("GRX_TD_BITMAP", 1) != 0;
   bool use_bins = fwd_bm && env_int("GRX_TD_BIN", 1) != 0;
   if (use_bins) {
     st = graph_build_bins(ctx, g);
@@ -595,7 +598,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   bn.n_xcd = ctx->n_xcd;
   d.xcc_mask = ctx->xcc_mask;
   // forward-only runs: frontiers of a few thousand vertices run many levels per launch (grx_mid.hpp); GRX_MID=0: off
-  if (!dopt && variant == 0 && env_int("GRX_MID", 1) != 0) {
+  if (!dopt && !strict_mp && variant == 0 && env_int("GRX_MID", 1) != 0) {
     bn.mid_v = env_int("GRX_MID_V", MID_ENTER_V);
     bn.mid_e = env_int("GRX_MID_E", MID_ENTER_E);
   }
@@ -651,7 +654,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (profile) (void)hipEventRecord(pe[0], stream);
     if (variant == 0) {
       // head (tiny levels + decide + plan) -> level
-      hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, lp, profile ? 0 : 1, seq, bn);
+      hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, lp, (profile || strict_mp) ? 0 : 1, seq, bn);
       if (profile) (void)hipEventRecord(pe[1], stream);
       if (!dopt) {
         // forward-only run.  level = claim-per-edge advance, many mid-size levels (grx_mid.hpp), or the SCATTER phase of

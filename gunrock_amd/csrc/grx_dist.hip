@@ -422,6 +422,14 @@ grx_status_t grx_bfs_dist_create(grx_context_t ctx, grx_graph_t out_rows, grx_gr
 // problem.reset() + frontier seed.  The caller all-reduces stats_local into stats_global
 // before the first grx_bfs_dist_pre.  advance_direction: GRX_DIR_FORWARD keeps every level
 // top-down; GRX_DIR_OPTIMIZED enables the bottom-up step (needs in-rows or symmetry).
+// Sharded labels: d_local holds ONLY the owned slice (S = grx_bfs_dist_slice_bits entries, vertex v at
+// d_local[v - rank * S]).  Every kernel of the partitioned enactor dereferences labels of owned vertices only,
+// so they all work on the base pointer d_local - lo.
+grx_status_t grx_bfs_dist_begin_local(grx_bfs_dist_t h, int32_t source, int32_t advance_direction, int32_t* d_local) {
+  if (!h || !d_local) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_begin_local: null argument");
+  return grx_bfs_dist_begin(h, source, advance_direction, d_local - h->x.lo);
+}
+
 grx_status_t grx_bfs_dist_begin(grx_bfs_dist_t h, int32_t source, int32_t advance_direction, int32_t* d_dist) {
   if (!h || !d_dist) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_begin: null argument");
   if (source < 0 || source >= h->g->V) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_begin: source out of range");

@@ -404,13 +404,13 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, s
 // Head of a plain (label-correcting) level, ONE launch of one workgroup: as many tiny levels
 // as there are (tiny_levels_body), then the bookkeeping + chunk map of the next regular level.
 __global__ __launch_bounds__(PLAN_BLOCK) void sssp_head_kernel(pipe_args a, sssp_policy pol, long long n_edges,
-                                                               int mid_v, int mid_e) {
+                                                               int mid_v, int mid_e, int allow_tiny) {
   __shared__ tiny_smem<sssp_policy> tsm;
   __shared__ unsigned long long s_esum[2];
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
   static_assert(TINY_THREADS == PLAN_BLOCK, "head kernel runs both bodies");
   const ctrl_head h0 = load_ctrl_head(a.ctrl);
-  const int t = tiny_levels_body(a, pol, 0, n_edges, tsm, h0);
+  const int t = allow_tiny ? tiny_levels_body(a, pol, 0, n_edges, tsm, h0) : 0;
   if (t == 1) return;
   const ctrl_head h = t == 2 ? load_ctrl_head(a.ctrl) : h0;
   if (threadIdx.x < 2) s_esum[threadIdx.x] = 0ull;
@@ -523,7 +523,10 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
   const int grid = advance_grid_for(ctx, g);
   const char* mid_env = getenv("GRX_MID");
   // (the L2-local claim of the mid-level body orders tentative distances by their bit patterns: non-negative only)
-  const bool mid_on = !(mid_env && *mid_env == '0') && (!w_eff || g->weight_min > 0.0f);
+  const char* strict_env = getenv("GRX_LB_STRICT");
+  const bool strict_mp = ((opt.engine_flags & GRX_FLAG_LB_STRICT) != 0 || (strict_env && *strict_env == '1')) &&
+                         (opt.advance_load_balance == GRX_LB_MERGE_PATH || opt.advance_load_balance == GRX_LB_MERGE_PATH_V2);
+  const bool mid_on = !strict_mp && !(mid_env && *mid_env == '0') && (!w_eff || g->weight_min > 0.0f);
   const int mid_v = mid_on ? MID_ENTER_V : 0, mid_e = mid_on ? MID_ENTER_E : 0;
   ctx->levels.clear();
   hipError_t launch_err = hipSuccess;
@@ -571,7 +574,7 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     sssp_policy pol{d_dist, stamp, w_eff, 0, 0, (!g->w || g->uniform_weights) ? 1 : 0};
     st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
       group(stream,
-            [&] { hipLaunchKernelGGL(sssp_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, pol, (long long)g->E, mid_v, mid_e); },
+            [&] { hipLaunchKernelGGL(sssp_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, pol, (long long)g->E, mid_v, mid_e, strict_mp ? 0 : 1); },
             [&] { hipLaunchKernelGGL(sssp_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol, ctx->xcc_mask); });
     }, after);
   }

@@ -101,8 +101,18 @@ class GrxEngine:
             C.c_void_p(self.stats_local.data_ptr()), C.c_void_p(self.stats_global.data_ptr()), C.byref(self._h)))
 
     def new_labels(self):
-        """Label buffer for bfs(): int32[V] on the engine's device; only the owned slice is written."""
-        return self.torch.empty(self.V, dtype=self.torch.int32, device=self.device)
+        """SHARDED label buffer for bfs(): int32[S] on the engine's device, the owned slice only -- vertex v of
+        this rank at index v - rank * S (bfs() also accepts a full int32[V] tensor and then writes its owned
+        range)."""
+        return self.torch.empty(self.S, dtype=self.torch.int32, device=self.device)
+
+    @property
+    def lo(self):
+        return min(self.rank * self.S, self.V)
+
+    @property
+    def hi(self):
+        return min((self.rank + 1) * self.S, self.V)
 
     def transport_description(self):
         return ("level groups (kernels + both collectives) enqueued through torch.distributed and replayed as one "
@@ -114,8 +124,15 @@ class GrxEngine:
 
     def begin(self, source, distances, optimized=True):
         from . import forward, optimized as OPT
-        _capi.check(_capi.lib().grx_bfs_dist_begin(self._h, int(source), int(OPT if optimized else forward),
-                                                   C.c_void_p(distances.data_ptr())))
+        L = _capi.lib()
+        n = int(distances.numel())
+        if n >= self.V:
+            fn = L.grx_bfs_dist_begin        # full-size labels, owned range written in place
+        elif n >= self.hi - self.lo:
+            fn = L.grx_bfs_dist_begin_local  # sharded labels (new_labels())
+        else:
+            raise ValueError("distances must hold V labels or at least the owned slice")
+        _capi.check(fn(self._h, int(source), int(OPT if optimized else forward), C.c_void_p(distances.data_ptr())))
 
     def pre(self, part=0):
         _capi.check(_capi.lib().grx_bfs_dist_pre(self._h, int(part)))
@@ -221,8 +238,9 @@ def _group_graph(engine, dist, key):
 
 
 def bfs(engine, dist, source, distances, optimized=True, first_batch=4):
-    """Partitioned BFS driven by this rank.  `distances`: full-size int32 tensor on the
-    engine's device; on return its owned slice holds the depths.  `dist`: the
+    """Partitioned BFS driven by this rank.  `distances`: int32 tensor on the engine's device, either
+    SHARDED (engine.new_labels(): the owned slice only, vertex v at v - engine.lo) or full-size (V entries,
+    the owned range is written); on return it holds the depths of the owned vertices.  `dist`: the
     torch.distributed module (or None for a single rank).  Returns run stats (edges /
     vertices are this rank's share; search_depth is global)."""
     torch = engine.torch

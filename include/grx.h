@@ -92,6 +92,14 @@ typedef struct grx_options {
                                   reference pipeline does (frontier with -1 holes between them) */
 #define GRX_FLAG_PROFILE 0x2   /* record per-iteration operator timings (adds events + syncs) */
 #define GRX_FLAG_SYNC_EACH_LEVEL 0x4 /* host reads the frontier size after every level */
+#define GRX_FLAG_LB_STRICT 0x1000    /* advance_load_balance is an ORDER, not a hint.  By default the engine picks the
+                                        body of every level on the device from the frontier's statistics (vertices, out-edges,
+                                        mean degree, share of the graph already visited): LDS-resident tiny levels, many
+                                        mid-size levels per launch (block-mapped staging), the chunked merge-path advance,
+                                        binned scatter + claim, bottom-up; grx_level_profile_t::body reports the choice.
+                                        With this flag and MERGE_PATH every level runs the chunked merge-path advance (the
+                                        reference pipeline of BASELINE configs[1] as written); with BLOCK_MAPPED the
+                                        block-staged bodies are preferred wherever the frontier fits them */
 #define GRX_FLAG_ASYNC_RETURN 0x8    /* grx_bfs may return as soon as the device has PUBLISHED the end
                                         of the search (results final) instead of after its stream drained;
                                         see grx_bfs.  Off by default: the reference's run() returns after a
@@ -211,7 +219,10 @@ typedef struct grx_level_profile {
   int64_t edges;          /* their out-degree sum (the level's traversed edges) */
   float advance_ms;       /* advance (top-down) or bottom-up kernel time */
   float other_ms;         /* planning / direction / conversion kernels */
-  int32_t bottom_up;      /* 1 if the level ran bottom-up (direction-optimising BFS) */
+  int32_t bottom_up;      /* body the device chose for the level: 0 chunked merge-path advance, 1 bottom-up
+                             (direction-optimising BFS), 2 binned scatter + claim (grx_bin.hpp; near-far SSSP: a
+                             bucket pull), 3 many mid-size levels in one launch (grx_mid.hpp: the record then covers
+                             all of them) */
   int32_t reserved;
   int64_t bu_open;        /* bottom-up: unvisited vertices examined */
   int64_t bu_probes;      /* bottom-up: in-edges read */
@@ -249,6 +260,10 @@ grx_status_t grx_bfs_dist_create(grx_context_t ctx, grx_graph_t out_rows, grx_gr
  * d_distances: device int32[V]; only the owned range is written (and authoritative). */
 grx_status_t grx_bfs_dist_begin(grx_bfs_dist_t h, int32_t source, int32_t advance_direction,
                                 int32_t* d_distances);
+/* the same with SHARDED labels: d_local holds only the owned slice, S = grx_bfs_dist_slice_bits(V, n_ranks)
+ * entries; vertex v of this rank is at d_local[v - my_rank * S] */
+grx_status_t grx_bfs_dist_begin_local(grx_bfs_dist_t h, int32_t source, int32_t advance_direction,
+                                      int32_t* d_local);
 grx_status_t grx_bfs_dist_pre(grx_bfs_dist_t h, int32_t part);
 grx_status_t grx_bfs_dist_post(grx_bfs_dist_t h);
 /* synchronises the stream; *done != 0 once the global frontier ran empty */

@@ -35,6 +35,24 @@ def _unpack(words):
     return np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little").astype(bool)
 
 
+class _Shifted:
+    """numpy view of a sharded label array addressed by GLOBAL vertex id (owned ids only)."""
+
+    def __init__(self, arr, lo):
+        self.a, self.lo = arr, lo
+
+    def _k(self, k):
+        if isinstance(k, slice):
+            return slice(k.start - self.lo, k.stop - self.lo)
+        return k - self.lo
+
+    def __getitem__(self, k):
+        return self.a[self._k(k)]
+
+    def __setitem__(self, k, v):
+        self.a[self._k(k)] = v
+
+
 class FakeEngine:
     """Host stand-in for GrxEngine with the same contract (tests only): numpy versions of
     the head / prep / advance / apply / bottom-up / stats kernels of csrc/grx_dist.hip."""
@@ -64,8 +82,15 @@ class FakeEngine:
         n = self.P * self.slice_words
         return self.send[part * n:(part + 1) * n], self.recv[part * n:(part + 1) * n]
 
+    def new_labels(self):
+        return self.torch.empty(self.S, dtype=self.torch.int32)
+
     def begin(self, source, distances, optimized=True):
-        self.dist = distances.numpy()
+        arr = distances.numpy()
+        if len(arr) < self.V:  # sharded labels, addressed by global id (owned entries only are touched)
+            self.dist = _Shifted(arr, self.lo)
+        else:
+            self.dist = arr
         self.dist[self.lo:self.hi] = INF
         self.sent = np.zeros(self.P * self.S, bool)
         self.level, self.done, self.mode, self.optimized = -1, False, 0, optimized
@@ -195,15 +220,14 @@ def _worker(rank, world, port, use_gpu, out_dir):
             if use_gpu:
                 eng = D.GrxEngine(props, mine, rank, world, "cuda:0", e_global,
                                   in_rows=mine_in if kind == "rmat" else None, overlap=overlap)
-                d = torch.empty(V, dtype=torch.int32, device="cuda:0")
             else:
                 eng = FakeEngine((mine.row_offsets, mine.column_indices), (mine_in.row_offsets, mine_in.column_indices),
                                  rank, world, e_global, overlap=overlap)
-                d = torch.empty(V, dtype=torch.int32)
+            d = eng.new_labels()  # sharded: the owned slice only
             for s, optimized in ((src, True), (src, False), (0, True), (V - 1, True)):
                 st = D.bfs(eng, dist, s, d, optimized=optimized)
                 key = "%s_%d_%d_%d" % (kind, s, int(optimized), int(overlap))
-                results[key] = (d.cpu().numpy()[lo:hi].copy(), lo, hi, st["edges_visited"], st["search_depth"],
+                results[key] = (d.cpu().numpy()[:hi - lo].copy(), lo, hi, st["edges_visited"], st["search_depth"],
                                 list(getattr(eng, "modes", [])))
             del eng
     np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([results], dtype=object), allow_pickle=True)
