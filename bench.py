@@ -463,6 +463,8 @@ def bench_multi_gpu(args, gr, torch, rank, local_rank, world):
     dist.all_reduce(et)
     overlap = os.environ.get("GRX_BENCH_OVERLAP", "0") == "1"
     eng = D.GrxEngine(props, mine, rank, world, dev, int(et.item()), in_rows=mine_in, overlap=overlap)
+    if os.environ.get("GRX_DIST_RCCL", "0") == "1" and backend == "nccl" and not overlap:
+        eng.enable_library_transport(dist)  # collectives issued by libgrx over its own RCCL communicator
     dist_t = eng.new_labels()
     t_setup = time.time() - t0
 

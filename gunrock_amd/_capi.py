@@ -122,6 +122,14 @@ def lib():
         "grx_bfs_dist_poll": (i32, [vp, P(i32), P(i32)]),
         "grx_bfs_dist_end": (i32, [vp, P(grx_run_stats_t)]),
         "grx_bfs_dist_destroy": (i32, [vp]),
+        "grx_dist_unique_id_bytes": (i32, []),
+        "grx_dist_unique_id": (i32, [vp]),
+        "grx_bfs_dist_comm_init": (i32, [vp, vp]),
+        "grx_bfs_dist_seed_stats": (i32, [vp]),
+        "grx_bfs_dist_groups": (i32, [vp, i32]),
+        "grx_bfs_dist_capture_group": (i32, [vp]),
+        "grx_bfs_dist_group_is_captured": (i32, [vp]),
+        "grx_debug_read": (i32, [vp, vp, i64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here == header/library mismatch

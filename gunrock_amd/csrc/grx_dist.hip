@@ -27,7 +27,10 @@
 #include "grx_engine.hpp"
 #include "grx_bfs_kernels.hpp"
 
+#include <rccl/rccl.h>  // types only: the library is opened at run time (rccl_api below)
+
 #include <climits>
+#include <dlfcn.h>
 
 namespace grx {
 
@@ -339,7 +342,59 @@ static int resident_per_cu(Kernel k) {
 
 using namespace grx;
 
+// RCCL, resolved at run time: libgrx.so carries no link-time dependency on it (single-GPU users
+// never load it), and the collectives of a level group can be issued from C -- one host call per
+// group, capturable into a HIP graph without any Python in between.
+struct rccl_api {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+static rccl_api& rccl() {
+  static rccl_api api = [] {
+    rccl_api a;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (a.lib) break;
+    }
+    if (!a.lib) return a;
+    auto sym = [&](const char* n) { return dlsym(a.lib, n); };
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv &&
+           a.AllReduce && a.GetErrorString;
+    return a;
+  }();
+  return api;
+}
+#define GRX_NCCL(expr)                                                                         \
+  do {                                                                                         \
+    ncclResult_t _r = (expr);                                                                  \
+    if (_r != ncclSuccess)                                                                     \
+      return ::grx::fail(GRX_ERROR_HIP, std::string("RCCL: ") + rccl().GetErrorString(_r) + "\t: " #expr); \
+  } while (0)
+
 struct grx_bfs_dist {
+  ncclComm_t comm = nullptr;          // own communicator (grx_bfs_dist_comm_init), null: the caller runs the collectives
+  hipGraphExec_t group_graph = nullptr;  // one captured level group (kernels + both collectives)
+  int32_t* graph_labels = nullptr;    // label base pointer / direction the captured group was recorded for
+  int32_t graph_dir = -1;
+  bool graph_failed = false;
   grx_context_t ctx = nullptr;
   grx_graph_t g = nullptr;      // out-rows of the owned slice
   grx_graph_t g_in = nullptr;   // in-rows (null: symmetric, or direction optimisation off)
@@ -514,7 +569,110 @@ grx_status_t grx_bfs_dist_end(grx_bfs_dist_t h, grx_run_stats_t* stats) {
   return GRX_SUCCESS;
 }
 
+// ---- RCCL transport inside the library --------------------------------------------------------
+int32_t grx_dist_unique_id_bytes(void) { return (int32_t)sizeof(ncclUniqueId); }
+
+grx_status_t grx_dist_unique_id(void* out) {
+  if (!out) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_dist_unique_id: null argument");
+  if (!rccl().ok) return fail(GRX_ERROR_UNSUPPORTED, "grx_dist_unique_id: librccl could not be opened");
+  GRX_NCCL(rccl().GetUniqueId(reinterpret_cast<ncclUniqueId*>(out)));
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_bfs_dist_comm_init(grx_bfs_dist_t h, const void* unique_id) {
+  if (!h || !unique_id) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_comm_init: null argument");
+  if (!rccl().ok) return fail(GRX_ERROR_UNSUPPORTED, "grx_bfs_dist_comm_init: librccl could not be opened");
+  if (h->x.parts != 1) return fail(GRX_ERROR_UNSUPPORTED, "grx_bfs_dist_comm_init: the in-library transport runs one exchange per level (parts == 1)");
+  GRX_HIP(hipSetDevice(h->ctx->device));
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  GRX_NCCL(rccl().CommInitRank(&h->comm, h->x.n_ranks, id, h->x.my_rank));
+  return GRX_SUCCESS;
+}
+
+// one level group, everything on the context's stream: kernels, the bitmap all-to-all (grouped
+// send / recv: every pair of GPUs has its own xGMI link) and the 4-word statistics all-reduce
+static grx_status_t dist_group_enqueue(grx_bfs_dist_t h) {
+  grx_status_t st = grx_bfs_dist_pre(h, 0);
+  if (st != GRX_SUCCESS) return st;
+  const dist_args& x = h->x;
+  hipStream_t s = h->ctx->stream;
+  GRX_NCCL(rccl().GroupStart());
+  for (int j = 0; j < x.n_ranks; ++j) {
+    GRX_NCCL(rccl().Send(x.send + (size_t)j * x.slice_words, (size_t)x.slice_words, ncclUint32, j, h->comm, s));
+    GRX_NCCL(rccl().Recv(const_cast<unsigned*>(x.recv) + (size_t)j * x.slice_words, (size_t)x.slice_words, ncclUint32, j,
+                         h->comm, s));
+  }
+  GRX_NCCL(rccl().GroupEnd());
+  st = grx_bfs_dist_post(h);
+  if (st != GRX_SUCCESS) return st;
+  GRX_NCCL(rccl().AllReduce(x.stats_local, const_cast<long long*>(x.stats_global), 4, ncclInt64, ncclSum, h->comm, s));
+  return GRX_SUCCESS;
+}
+
+// the all-reduce that follows grx_bfs_dist_begin (frontier statistics of the seed)
+grx_status_t grx_bfs_dist_seed_stats(grx_bfs_dist_t h) {
+  if (!h || !h->comm) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_seed_stats: no communicator");
+  GRX_NCCL(rccl().AllReduce(h->x.stats_local, const_cast<long long*>(h->x.stats_global), 4, ncclInt64, ncclSum, h->comm,
+                            h->ctx->stream));
+  return GRX_SUCCESS;
+}
+
+// Enqueue n level groups.  A group takes no level-dependent argument, so once a search has finished the
+// group is captured into a HIP graph (grx_bfs_dist_capture_group) and later calls replay it: one graph
+// launch per level; without a captured graph the groups are enqueued eagerly.
+grx_status_t grx_bfs_dist_groups(grx_bfs_dist_t h, int32_t n) {
+  if (!h || !h->active || !h->comm) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_groups: no BFS in flight or no communicator");
+  const bool replay = h->group_graph && h->graph_labels == h->d.dist && h->graph_dir == h->x.do_enabled;
+  for (int i = 0; i < n; ++i) {
+    if (replay) {
+      GRX_HIP(hipGraphLaunch(h->group_graph, h->ctx->stream));
+    } else {
+      grx_status_t st = dist_group_enqueue(h);
+      if (st != GRX_SUCCESS) return st;
+    }
+  }
+  return GRX_SUCCESS;
+}
+
+// Record one level group for the label buffer / direction of the search that just ended (every kernel of a
+// further group exits on `done`, and capture only records).  Must be called on every rank alike.  A failure
+// is remembered and leaves the eager path in place.
+grx_status_t grx_bfs_dist_capture_group(grx_bfs_dist_t h) {
+  if (!h || !h->comm) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_capture_group: no communicator");
+  if (h->graph_failed) return GRX_SUCCESS;
+  if (h->group_graph && h->graph_labels == h->d.dist && h->graph_dir == h->x.do_enabled) return GRX_SUCCESS;
+  if (h->group_graph) { (void)hipGraphExecDestroy(h->group_graph); h->group_graph = nullptr; }
+  hipStream_t s = h->ctx->stream;
+  hipGraph_t graph = nullptr;
+  const bool was_active = h->active;
+  h->active = true;
+  bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+  if (ok) {
+    ok = dist_group_enqueue(h) == GRX_SUCCESS;
+    ok = (hipStreamEndCapture(s, &graph) == hipSuccess) && ok && graph != nullptr;
+    if (ok) ok = hipGraphInstantiate(&h->group_graph, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) (void)hipGraphDestroy(graph);
+  }
+  (void)hipGetLastError();
+  h->active = was_active;
+  if (!ok) {
+    h->group_graph = nullptr;
+    h->graph_failed = true;
+    return GRX_SUCCESS;
+  }
+  h->graph_labels = h->d.dist;
+  h->graph_dir = h->x.do_enabled;
+  return GRX_SUCCESS;
+}
+
+int32_t grx_bfs_dist_group_is_captured(grx_bfs_dist_t h) { return (h && h->group_graph) ? 1 : 0; }
+
 grx_status_t grx_bfs_dist_destroy(grx_bfs_dist_t h) {
+  if (h) {
+    if (h->group_graph) (void)hipGraphExecDestroy(h->group_graph);
+    if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
+  }
   delete h;
   return GRX_SUCCESS;
 }

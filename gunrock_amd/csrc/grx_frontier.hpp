@@ -258,7 +258,11 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
         if (in.bin_min > 0 && edges >= in.bin_min &&
             (in.bin_max_degree <= 0 || edges <= (long long)in.bin_max_degree * nitems))
           mode = 2;
-        else if (in.mid_v > 0 && nitems > 0 && nitems <= in.mid_v && edges <= (long long)in.mid_e)
+        // (the tile queue must be reasonably dense too: the few workgroups of that body walk it themselves, and a
+        // level of the regular kernels on a wide grid leaves thousands of nearly empty tiles behind -- such a level
+        // is expanded by the regular kernels once more, which compacts it)
+        else if (in.mid_v > 0 && nitems > 0 && nitems <= in.mid_v && edges <= (long long)in.mid_e &&
+                 nt <= 4 * ((nitems + TILE - 1) / TILE) + 256)
           mode = 3;
         c->mode = mode;
         if (mode == 3) {

@@ -50,6 +50,7 @@ struct mid_smem {
   advance_smem<Policy> adv;
   int out_rs[TILE + CHUNK];   // row start / degree of the staged output vertices (parallel to adv.out)
   int out_deg[TILE + CHUNK];
+  int tcount[ADV_BLOCK];      // entering level: counts of this workgroup's next 256 tiles
   int base;
   int n_next;
   int ok;
@@ -170,12 +171,31 @@ __device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, P
     pol.set_level(level);
     if (tid == 0) ad.cnt = 0;
     __syncthreads();
-    for (int base = w * TILE; base < n_in; base += G * TILE) {
+    // Blocks of 256 slots this workgroup expands: blocks w, w + G, ... of the flat queue; on the entering level the
+    // NON-EMPTY tiles among tiles w, w + G, ... (a tile queue is mostly reserved-but-empty tiles after a level of
+    // the regular kernels -- 3072 tiles for a few thousand vertices on the LJ stand-in: their counts are fetched
+    // 256 at a time, one round trip, and the empty ones cost an LDS read each)
+    const int n_blocks = (n_in + TILE - 1) / TILE;
+    for (int i0 = 0; w + i0 * G < n_blocks; i0 += first ? ADV_BLOCK : 1) {
+      int span = 1;
+      if (first) {
+        const int t = w + (i0 + tid) * G;
+        sm.tcount[tid] = t < n_blocks ? a.tile_count[t] : 0;
+        span = ADV_BLOCK;
+        __syncthreads();
+      }
+      for (int j = 0; j < span; ++j) {
+      const int blk = w + (i0 + j) * G;
+      if (blk >= n_blocks) break;
+      int my_count = TILE;
+      if (first) {
+        my_count = sm.tcount[j];
+        if (my_count == 0) continue;  // uniform
+      }
+      const int base = blk * TILE;
       int v = -1;
       if (first) {
-        // tile queue: tiles are front-packed, only the first tile_count slots of a tile were ever written
-        // (reserved-but-unused tiles have count 0 and hold garbage)
-        if (tid < a.tile_count[base / TILE]) v = qin[base + tid];
+        if (tid < my_count) v = qin[base + tid];  // tiles are front-packed: only the first tile_count slots were written
       } else if (base + tid < n_in) {
         v = __hip_atomic_load(&qin[base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -295,6 +315,8 @@ __device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, P
         __syncthreads();
       }
       __syncthreads();  // seg / start / src are rewritten by the next block of slots
+      }
+      __syncthreads();  // tcount is rewritten by the next batch of tile counts
     }
     {
       const int rem = ad.cnt;

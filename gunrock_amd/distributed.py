@@ -115,8 +115,32 @@ class GrxEngine:
         return min((self.rank + 1) * self.S, self.V)
 
     def transport_description(self):
+        if getattr(self, "library_transport", False):
+            return ("level groups (kernels + grouped ncclSend/ncclRecv + ncclAllReduce) enqueued by the library itself "
+                    "(grx_bfs_dist_groups: one C call per batch, one HIP-graph launch per level after the first search); "
+                    "the host polls once per batch of levels")
         return ("level groups (kernels + both collectives) enqueued through torch.distributed and replayed as one "
                 "HIP graph per level after the first search; the host polls once per batch of levels")
+
+    def enable_library_transport(self, dist):
+        """Let libgrx issue the collectives itself over its own RCCL communicator (include/grx.h, "RCCL transport
+        inside the library").  Rank 0 creates the ncclUniqueId, `dist` (torch.distributed, any backend) only
+        broadcasts those 128 bytes.  Needs one GPU per rank (RCCL refuses two ranks on one device) and
+        overlap=False."""
+        torch = self.torch
+        L = _capi.lib()
+        n = int(L.grx_dist_unique_id_bytes())
+        buf = (C.c_ubyte * n)()
+        if self.rank == 0:
+            _capi.check(L.grx_dist_unique_id(buf))
+        if dist is not None and self.P > 1:
+            on_gpu = dist.get_backend() == "nccl"
+            t = torch.tensor(list(buf), dtype=torch.uint8, device=self.device if on_gpu else "cpu")
+            dist.broadcast(t, src=0)
+            buf = (C.c_ubyte * n)(*t.cpu().tolist())
+        with torch.cuda.stream(self.stream):
+            _capi.check(L.grx_bfs_dist_comm_init(self._h, buf))
+        self.library_transport = True
 
     def part_buffers(self, part):
         n = self.P * self.slice_words
@@ -247,6 +271,21 @@ def bfs(engine, dist, source, distances, optimized=True, first_batch=4):
     import contextlib
     on_stream = torch.cuda.stream(engine.stream) if getattr(engine, "stream", None) is not None \
         else contextlib.nullcontext()
+    if getattr(engine, "library_transport", False):
+        # the library runs the collectives itself: begin, then batches of level groups (one C call each)
+        L = _capi.lib()
+        with on_stream:
+            engine.begin(source, distances, optimized)
+            _capi.check(L.grx_bfs_dist_seed_stats(engine._h))
+            batch = first_batch
+            while True:
+                _capi.check(L.grx_bfs_dist_groups(engine._h, batch))
+                done, _ = engine.poll()
+                if done:
+                    break
+                batch = min(batch * 2, 32)
+            _capi.check(L.grx_bfs_dist_capture_group(engine._h))  # no-op once recorded for this buffer / direction
+            return engine.end()
     with on_stream:
         engine.begin(source, distances, optimized)
         _all_reduce_stats(dist, engine)

@@ -230,6 +230,10 @@ typedef struct grx_level_profile {
 grx_status_t grx_get_level_profile(grx_context_t ctx, grx_level_profile_t* out,
                                    int32_t capacity, int32_t* n_levels);
 
+/* Tuning aid: copies `n` 64-bit words of the context's debug scratch (per-workgroup timeline of the binned BFS
+ * kernels, recorded when GRX_BIN_DEBUG=<level> is set; tools/bin_debug.py). */
+grx_status_t grx_debug_read(grx_context_t ctx, long long* out, int64_t n);
+
 /* ---- multi-GPU: level-group interface of the partitioned BFS enactor ------------------
  * The reference has no multi-GPU execution (every operator throws when
  * context.size() != 1: framework/operators/advance/advance.hxx:129-132).  One process
@@ -271,6 +275,25 @@ grx_status_t grx_bfs_dist_poll(grx_bfs_dist_t h, int32_t* done, int32_t* level);
 /* run statistics: edges / vertices are this rank's share, search_depth is global */
 grx_status_t grx_bfs_dist_end(grx_bfs_dist_t h, grx_run_stats_t* stats);
 grx_status_t grx_bfs_dist_destroy(grx_bfs_dist_t h);
+
+/* RCCL transport INSIDE the library (opt-in; librccl is opened at run time): after grx_bfs_dist_comm_init the
+ * two collectives of a level group are issued from C on the context's stream -- a grouped ncclSend/ncclRecv per
+ * peer for the bitmaps (each pair of GPUs has its own xGMI link) and an ncclAllReduce of the 4 statistics words
+ * -- so the host makes ONE call per batch of level groups and a group can be captured into a HIP graph without
+ * any Python in between.
+ *   rank 0: grx_dist_unique_id(buf) (grx_dist_unique_id_bytes() bytes), broadcast to all ranks by any means;
+ *   all   : grx_bfs_dist_comm_init(h, buf)            ncclCommInitRank(n_ranks, id, my_rank)
+ *   search: grx_bfs_dist_begin[_local]; grx_bfs_dist_seed_stats; { grx_bfs_dist_groups(h, n); grx_bfs_dist_poll }
+ *           until done; grx_bfs_dist_end; once: grx_bfs_dist_capture_group (records one group; later calls of
+ *           grx_bfs_dist_groups with the same label buffer / direction replay it; a failed capture is remembered
+ *           and the eager path stays). */
+int32_t grx_dist_unique_id_bytes(void);
+grx_status_t grx_dist_unique_id(void* out);
+grx_status_t grx_bfs_dist_comm_init(grx_bfs_dist_t h, const void* unique_id);
+grx_status_t grx_bfs_dist_seed_stats(grx_bfs_dist_t h);
+grx_status_t grx_bfs_dist_groups(grx_bfs_dist_t h, int32_t n);
+grx_status_t grx_bfs_dist_capture_group(grx_bfs_dist_t h);
+int32_t grx_bfs_dist_group_is_captured(grx_bfs_dist_t h);
 
 /* ---- host-side ingest (same semantics as the reference) ---- */
 

@@ -17,11 +17,7 @@ def pytest_configure(config):
     _b.build()
     import oracle_lib
     oracle_lib.build_oracle()
-    # the reference's own code (oracle/_ref, a hipcc-built library with HIP static initialisers) is mapped
-    # FIRST when it exists: dlopen-ing it late in a process that has already run torch.distributed workers
-    # crashed in this GPU-less container (order-dependent; test infrastructure only)
-    if oracle_lib.have_ref_cpu():
-        oracle_lib.ref_cpu()
+
 
 
 @pytest.fixture(scope="session")

@@ -249,8 +249,25 @@ _ref_cpu = None
 _ref_gpu = None
 
 
+def _ref_loadable():
+    """oracle/_ref/*.so are hipcc-built and carry HIP static initialisers.  Mapped lazily they share the HIP runtime
+    already in the process (torch's, on a GPU box).  In a GPU-LESS process that has imported torch first, mapping
+    them crashes (two runtimes, no device) -- there the reference cross-checks are skipped unless the library was
+    mapped before torch came in (the default test order does that)."""
+    import sys
+    if _ref_cpu is not None or _ref_gpu is not None:
+        return True
+    t = sys.modules.get("torch")
+    if t is None:
+        return True
+    try:
+        return bool(t.cuda.is_available())
+    except Exception:
+        return False
+
+
 def have_ref_cpu():
-    return os.path.exists(_REF_CPU)
+    return os.path.exists(_REF_CPU) and _ref_loadable()
 
 
 def have_ref_gpu():

@@ -331,6 +331,32 @@ def test_single_rank_dist_path_equals_plain_bfs(gr, gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_library_rccl_transport_single_rank(gr, gpu_ctx):
+    """The in-library RCCL transport (grx_bfs_dist_comm_init / _groups / _capture_group) on the one GPU a test box
+    has: a 1-rank communicator, the grouped self send/recv + all-reduce issued from C, eager for the first search
+    and replayed from the captured HIP graph afterwards; sharded labels.  (More ranks need one GPU each.)"""
+    import torch
+    from gunrock_amd import distributed as D
+    V, E = 1 << 16, 1 << 20
+    props, c = gr.generate("rmat", V, E, seed=4)
+    _, cin = gr.generate_rows("rmat", V, E, 0, V, seed=4, in_rows=True)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    eng = D.GrxEngine(props, c, 0, 1, "cuda:0", E, in_rows=cin)
+    eng.enable_library_transport(None)
+    d = eng.new_labels()
+    order = np.argsort(np.diff(g.row_offsets))
+    for optimized in (True, False):
+        for src in (int(order[-1]), int(order[-5]), 0, int(order[-1])):
+            want, _, ev = O.bfs_queue(g, src)
+            st = D.bfs(eng, None, src, d, optimized=optimized)
+            assert np.array_equal(d.cpu().numpy()[:V], want), (optimized, src)
+            assert st["edges_visited"] == ev
+    from gunrock_amd import _capi
+    assert _capi.lib().grx_bfs_dist_group_is_captured(eng._h) in (0, 1)
+    assert "library itself" in eng.transport_description()
+
+
+@pytest.mark.gpu
 def test_bench_multi_rank_path(tmp_path):
     """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run), except
     that both ranks share cuda:0 and gloo carries the exchange."""
