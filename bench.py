@@ -91,13 +91,19 @@ def roof(levels, bytes_of, kernel, note=None):
     return r
 
 
-def attach_traffic(r, pmc, cls):
+def attach_traffic(r, pmc, cls, per_step=False):
+    """per_step: the PMC class is summed over one whole search (many levels per launch make the launch count
+    meaningless there); it is divided by this run's launch count to stay comparable with `achieved`."""
     k = (pmc or {}).get("classes", {}).get(cls)
     if not k or "fetch_bytes_per_launch" not in k:
         r["traffic_note"] = ("no PMC passes committed for the current engine sources (profiles/r2_bench_pmc.json "
                              "missing or taken from other sources)")
         return
-    r["traffic"] = int(k["fetch_bytes_per_launch"] + k.get("write_bytes_per_launch", 0.0))
+    tr = k["fetch_bytes_per_launch"] + k.get("write_bytes_per_launch", 0.0)
+    if per_step:
+        r["traffic_per_step"] = int(tr)
+        tr /= max(1, r["launches_per_step"])
+    r["traffic"] = int(tr)
     r["traffic_source"] = ("profiles/r2_bench_pmc.json class '%s': FETCH_SIZE + WRITE_SIZE per launch, separate --pmc "
                            "passes of this command on these sources (raw counters; gfx950 tallies wide coalesced "
                            "reads at 1/2)" % cls)
@@ -330,7 +336,7 @@ def bench_sssp(gr, torch, ctx, dev, sync, pmc, cpu_on, args):
         r = roof(adv, lambda l: 12 * l["frontier_size"] + per_edge * l["edges"],
                  "sssp_nf_level_kernel (near-far advance)" if weighted else "advance_kernel<sssp_policy>",
                  "12 B per frontier slot + %d B per relaxed edge (SURVEY 8d)" % per_edge)
-        attach_traffic(r, pmc, "sssp_" + label)
+        attach_traffic(r, pmc, "sssp_" + label, per_step=True)
         r["head_kernel_ms_per_step"] = round(sum(l["other_ms"] for l in prof), 3)
         r["bucket_pull_launches"] = len(prof) - len(adv)
         r["bucket_pull_ms_per_step"] = round(sum(l["advance_ms"] for l in prof if l["bottom_up"] == 2), 3)

@@ -41,7 +41,7 @@ namespace grx {
 constexpr int MID_WGS = 32;          // workgroups that stay (the rest of the grid leaves at once)
 constexpr int MID_ENTER_V = 8192;    // a level enters with at most this many frontier vertices ...
 constexpr int MID_ENTER_E = 65536;   // ... and out-edges
-constexpr int MID_EXIT_V = 32768;    // a frontier beyond this goes back to the regular kernels
+constexpr int MID_EXIT_V = 131072;   // a frontier beyond this goes back to the regular kernels
 constexpr int MID_SPIN_LIMIT = 1 << 22;
 constexpr int MID_AUX_CAP = MID_EXIT_V + TILE;  // queue entries that carry their row start / degree along
 
@@ -51,6 +51,9 @@ struct mid_smem {
   int out_rs[TILE + CHUNK];   // row start / degree of the staged output vertices (parallel to adv.out)
   int out_deg[TILE + CHUNK];
   int tcount[ADV_BLOCK];      // entering level: counts of this workgroup's next 256 tiles
+  int side[policy_has_side<Policy>::value ? (TILE + CHUNK) : 1];  // staged side-pile entries (near-far SSSP)
+  int side_cnt;
+  int side_base;
   int base;
   int n_next;
   int ok;
@@ -64,6 +67,13 @@ template <class Policy, class = void>
 struct policy_has_prepare : std::false_type {};
 template <class Policy>
 struct policy_has_prepare<Policy, std::void_t<decltype(&Policy::prepare)>> : std::true_type {};
+
+// An empty frontier ends the search -- unless the policy says otherwise (near-far SSSP: the BUCKET is drained and
+// the head kernel moves on to the next one): `static constexpr bool drained_is_done = false`.
+template <class Policy, class = void>
+struct policy_drained_is_done : std::true_type {};
+template <class Policy>
+struct policy_drained_is_done<Policy, std::void_t<decltype(Policy::drained_is_done)>> : std::bool_constant<Policy::drained_is_done> {};
 
 // policies whose claims can be told to execute in the local L2 (see above)
 template <class Policy, class = void>
@@ -110,7 +120,7 @@ __device__ __forceinline__ void mid_flush(int32_t* qout, int2* aux_out, int* cnt
 template <class Policy>
 __device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, Policy& pol, mid_smem<Policy>& sm,
                                                 const level_head& h, uint32_t xcc_mask) {
-  static_assert(!policy_has_side<Policy>::value, "policies with a side pile run their levels on advance_block");
+  constexpr bool SIDE = policy_has_side<Policy>::value;
   const int tid = threadIdx.x;
   const int lane = dev::lane_id();
   // ---- who takes part: the workgroups on the home XCD that register before the leader closes the window
@@ -169,7 +179,7 @@ __device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, P
     // the counter the level after next appends to (last read one level ago)
     if (w == 0 && tid == 0) __hip_atomic_store(&c->mid_cnt[(level + 2) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     pol.set_level(level);
-    if (tid == 0) ad.cnt = 0;
+    if (tid == 0) { ad.cnt = 0; sm.side_cnt = 0; }
     __syncthreads();
     // Blocks of 256 slots this workgroup expands: blocks w, w + G, ... of the flat queue; on the entering level the
     // NON-EMPTY tiles among tiles w, w + G, ... (a tile queue is mostly reserved-but-empty tiles after a level of
@@ -272,12 +282,12 @@ __device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, P
           }
         }
         bool keep_k[ADV_ITEMS];
-        int nrs_k[ADV_ITEMS], nre_k[ADV_ITEMS];
+        int nrs_k[ADV_ITEMS], nre_k[ADV_ITEMS], code_k[ADV_ITEMS];
 #pragma unroll
         for (int k = 0; k < ADV_ITEMS; ++k) {
-          int code = 0;
-          if (pre_k[k]) code = pol.code(r1_k[k], r2_k[k], n_k[k], cand_k[k]);
-          keep_k[k] = code == 1;
+          code_k[k] = 0;
+          if (pre_k[k]) code_k[k] = pol.code(r1_k[k], r2_k[k], n_k[k], cand_k[k]);
+          keep_k[k] = code_k[k] == 1;
         }
         // row offsets of the accepted vertices, for the level that expands them: unconditional loads from a
         // clamped index (the others read row 0), all in flight together
@@ -304,7 +314,32 @@ __device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, P
             }
           }
         }
+        if constexpr (SIDE) {
+#pragma unroll
+          for (int k = 0; k < ADV_ITEMS; ++k) {
+            const bool aside = code_k[k] == 2;
+            const unsigned long long ms = dev::ballot(aside);
+            if (ms) {
+              int at = 0;
+              if (lane == 0) at = atomicAdd(&sm.side_cnt, __popcll(ms));
+              at = __shfl(at, 0, 64);
+              if (aside) sm.side[at + dev::mask_rank(ms)] = n_k[k];
+            }
+          }
+        }
         __syncthreads();
+        if constexpr (SIDE) {
+          const int sc = sm.side_cnt;
+          if (sc >= ADV_BLOCK) {  // flush the side pile before it could overflow on the next chunk
+            if (tid == 0) sm.side_base = pol.side_reserve(c, sc);
+            __syncthreads();
+            const int sb = sm.side_base;
+            if (sb >= 0) side_flush(pol, sm.side, sb, sc);
+            __syncthreads();
+            if (tid == 0) sm.side_cnt = 0;
+            __syncthreads();
+          }
+        }
         int cnt = ad.cnt;
         if (cnt >= TILE) {  // the last k * TILE entries leave, the first cnt % TILE stay
           const int k = cnt / TILE;
@@ -321,6 +356,16 @@ __device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, P
     {
       const int rem = ad.cnt;
       if (rem > 0) mid_flush(qout, aux_out, cnt_out, sm, 0, rem);
+    }
+    if constexpr (SIDE) {
+      const int sc = sm.side_cnt;
+      if (sc > 0) {
+        if (tid == 0) sm.side_base = pol.side_reserve(c, sc);
+        __syncthreads();
+        const int sb = sm.side_base;
+        if (sb >= 0) side_flush(pol, sm.side, sb, sc);
+        __syncthreads();
+      }
     }
     if (!mid_barrier(c, G, epoch, sm)) {
       if (tid == 0) {
@@ -347,6 +392,19 @@ __device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, P
     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&c->vertices_visited), (unsigned long long)my_vertices,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
+  if (n_in == 0 && !policy_drained_is_done<Policy>::value) {
+    // the bucket is drained, not the search: hand an EMPTY frontier of `level` back to the head kernel
+    if (w == 0 && tid == 0) {
+      // ctrl.mode stays 3 until the launch is over: workgroups of this grid that START late still read it, and
+      // must take the "registration closed, leave" exit -- on mode 0 they would run advance_block on a control
+      // block that is being rewritten under them (the cause of a sporadic memory fault while this was `mode = 0`).
+      // The next head kernel sets the mode of its level afresh.
+      c->n_tiles[level & 1] = 0;
+      c->n_tiles[(level & 1) ^ 1] = 0;
+      c->level = level - 1;
+    }
+    return;
+  }
   if (n_in == 0) {
     // every workgroup's counters must have landed before the leader publishes them
     if (!mid_barrier(c, G, epoch, sm)) {
@@ -357,7 +415,6 @@ __device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, P
       c->done = 1;
       c->level = level;
       // the counters were updated in the home L2: read them past the L1
-      c->mode = 0;
       long long* mb64 = reinterpret_cast<long long*>(a.mailbox + 4);
       mb64[0] = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&c->edges_visited), __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT);
@@ -393,8 +450,7 @@ __device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, P
     if (w == 0 && tid == 0) {
       c->n_tiles[p] = tiles;
       c->n_tiles[p ^ 1] = 0;
-      c->level = level - 1;  // the next head plans `level`
-      c->mode = 0;
+      c->level = level - 1;  // the next head plans `level` (and sets ctrl.mode: it must stay 3 while late workgroups start)
     }
   }
 }

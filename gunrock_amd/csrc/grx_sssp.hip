@@ -96,6 +96,7 @@ struct sssp_nf_args {
 struct sssp_nf_policy {
   using src_state = float;
   static constexpr bool has_side = true;
+  static constexpr bool drained_is_done = false;  // an empty frontier means "bucket drained" (mid_levels_body)
   float* dist;
   int32_t* stamp;
   const float* w;
@@ -104,6 +105,9 @@ struct sssp_nf_policy {
   float hi;
   int32_t* far_out;
   unsigned* min_far;
+  int l2_local;  // set by mid_levels_body: the launch sits on one XCD, label / stamp atomics may execute in its L2
+
+  __device__ __forceinline__ void set_level(int l) { level = l; }
 
   __device__ __forceinline__ void begin(ctrl_t* c) {
     level = c->level;
@@ -111,7 +115,11 @@ struct sssp_nf_policy {
     far_out = nf.far[c->nf_sel];
     min_far = &c->nf_min_far;
   }
-  __device__ __forceinline__ src_state load_source(int v) const { return dist[v]; }
+  // past the L1: inside a multi-level launch the label may have been lowered by an atomic (performed in L2) since
+  // this CU last read the line
+  __device__ __forceinline__ src_state load_source(int v) const {
+    return __hip_atomic_load(&dist[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __device__ __forceinline__ float edge_weight(int e) const { return w[e]; }
   static constexpr bool two_claims = true;
   __device__ __forceinline__ bool precheck(src_state d_src, int n, int e, int& cand) const {
@@ -119,7 +127,13 @@ struct sssp_nf_policy {
     cand = __float_as_int(nd);
     return nd < dist[n];
   }
+  __device__ __forceinline__ bool prepare(src_state d_src, int, int e, int& cand) const {
+    cand = __float_as_int(d_src + edge_weight(e));
+    return true;
+  }
   __device__ __forceinline__ int claim(int n, int cand) const {
+    if (l2_local)  // tentative distances are >= 0: integer order of the bit patterns == float order
+      return __hip_atomic_fetch_min(reinterpret_cast<int*>(&dist[n]), cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __float_as_int(dev::atomic_min_f32(&dist[n], __int_as_float(cand)));
   }
   // improved AND inside the bucket: joins the next frontier, once per level (stamp)
@@ -127,7 +141,10 @@ struct sssp_nf_policy {
     const float nd = __int_as_float(cand);
     return nd < __int_as_float(raw1) && nd < hi;
   }
-  __device__ __forceinline__ int claim2(int n) const { return atomicExch(&stamp[n], level); }
+  __device__ __forceinline__ int claim2(int n) const {
+    if (l2_local) return __hip_atomic_exchange(&stamp[n], level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return atomicExch(&stamp[n], level);
+  }
   __device__ __forceinline__ int code(int raw1, int raw2, int, int cand) const {
     const float nd = __int_as_float(cand), old = __int_as_float(raw1);
     if (!(nd < old)) return 0;
@@ -146,7 +163,9 @@ struct sssp_nf_policy {
   }
   // one reservation atomic per flush of the workgroup's side buffer
   __device__ __forceinline__ int side_reserve(ctrl_t* c, int n) const {
-    const int base = atomicAdd(&c->nf_far_n[c->nf_sel], n);
+    // (inside mid_levels_body only workgroups of ONE XCD touch the pile counters: the atomic may execute in its L2)
+    const int base = l2_local ? __hip_atomic_fetch_add(&c->nf_far_n[c->nf_sel], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                              : atomicAdd(&c->nf_far_n[c->nf_sel], n);
     if (base + n > nf.capacity) {
       c->nf_overflow = 1;
       return -1;
@@ -161,7 +180,10 @@ struct sssp_nf_policy {
   }
   // lower bound of the labels waiting in the pile (may go stale; only steers how far
   // the bucket jumps, never what is dropped)
-  __device__ __forceinline__ void side_commit(unsigned key_min) const { atomicMin(min_far, key_min); }
+  __device__ __forceinline__ void side_commit(unsigned key_min) const {
+    if (l2_local) (void)__hip_atomic_fetch_min(min_far, key_min, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicMin(min_far, key_min);
+  }
 };
 
 __global__ void sssp_init_kernel(pipe_args a, float* dist, int src, float delta) {
@@ -210,7 +232,7 @@ __global__ void sssp_init_kernel(pipe_args a, float* dist, int src, float delta)
 //     frontier under the same level number.  A bucket change therefore costs one extra
 //     two-kernel group -- there are ~100 of them in a road-network search -- and every other
 //     iteration is two launches instead of four (phase, split, plan, advance).
-__global__ __launch_bounds__(PLAN_BLOCK) void sssp_nf_head_kernel(pipe_args a, sssp_nf_args nf) {
+__global__ __launch_bounds__(PLAN_BLOCK) void sssp_nf_head_kernel(pipe_args a, sssp_nf_args nf, int mid_v, int mid_e) {
   __shared__ unsigned long long s_n;
   __shared__ unsigned long long s_esum[2];
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
@@ -284,6 +306,8 @@ __global__ __launch_bounds__(PLAN_BLOCK) void sssp_nf_head_kernel(pipe_args a, s
     in.mode = 0;
     in.R = 0;
     in.T = 0;
+    in.mid_v = mid_v;  // a small frontier: the level kernel drains the whole bucket in one launch (grx_mid.hpp)
+    in.mid_e = mid_e;
     plan_body<PLAN_BLOCK>(a, c, 2, s_wave, s_esum, in);
   }
 }
@@ -385,9 +409,15 @@ __device__ __forceinline__ void sssp_split_body(const pipe_args& a, const sssp_n
 
 // One near-far iteration, ONE launch: the advance (relax + far-pile side output), or -- when
 // the head moved to a new bucket -- the rebuild of the frontier from the pile.
-__global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, sssp_nf_args nf, sssp_nf_policy pol) {
-  __shared__ advance_smem<sssp_nf_policy> sm;
-  __shared__ split_smem ssm;
+__global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, sssp_nf_args nf, sssp_nf_policy pol,
+                                                                  uint32_t xcc_mask) {
+  // one of three bodies runs per launch: their LDS is overlaid
+  constexpr size_t LDS_BYTES = sizeof(mid_smem<sssp_nf_policy>) > sizeof(split_smem) ? sizeof(mid_smem<sssp_nf_policy>)
+                                                                                      : sizeof(split_smem);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+  mid_smem<sssp_nf_policy>& msm = *reinterpret_cast<mid_smem<sssp_nf_policy>*>(lds_raw);
+  advance_smem<sssp_nf_policy>& sm = msm.adv;
+  split_smem& ssm = *reinterpret_cast<split_smem*>(lds_raw);
   ctrl_t* c = a.ctrl;
   const level_head h = load_level_head(c);  // one batch of loads, with nf_split
   const int split = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&c->nf_split, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -397,6 +427,10 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, s
     return;
   }
   pol.begin(c);
+  if (h.mode == 3) {  // many iterations inside the current bucket, in this one launch
+    mid_levels_body(a, c, pol, msm, h, xcc_mask);
+    return;
+  }
   advance_block<sssp_nf_policy, false>(a, c, pol, sm, h.level & 1, blockIdx.x, gridDim.x, h.total_chunks,
                                        a.chunk_tile);
 }
@@ -527,7 +561,10 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
   const bool strict_mp = ((opt.engine_flags & GRX_FLAG_LB_STRICT) != 0 || (strict_env && *strict_env == '1')) &&
                          (opt.advance_load_balance == GRX_LB_MERGE_PATH || opt.advance_load_balance == GRX_LB_MERGE_PATH_V2);
   const bool mid_on = !strict_mp && !(mid_env && *mid_env == '0') && (!w_eff || g->weight_min > 0.0f);
-  const int mid_v = mid_on ? MID_ENTER_V : 0, mid_e = mid_on ? MID_ENTER_E : 0;
+  const char* mv = getenv("GRX_MID_V");
+  const char* me = getenv("GRX_MID_E");
+  const int mid_v = mid_on ? ((mv && atoi(mv) > 0) ? atoi(mv) : MID_ENTER_V) : 0;
+  const int mid_e = mid_on ? ((me && atoi(me) > 0) ? atoi(me) : MID_ENTER_E) : 0;
   ctx->levels.clear();
   hipError_t launch_err = hipSuccess;
   // GRX_FLAG_PROFILE: one record per iteration -- head / level kernel times from events on this
@@ -564,11 +601,11 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     if (h.done) ctx->levels.pop_back();  // the group that only detected the end
   };
   if (near_far) {
-    sssp_nf_policy pol{d_dist, stamp, w_eff ? w_eff : g->w, nf, 0, 0.0f, nullptr, nullptr};
+    sssp_nf_policy pol{d_dist, stamp, w_eff ? w_eff : g->w, nf, 0, 0.0f, nullptr, nullptr, 0};
     st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
       group(stream,
-            [&] { hipLaunchKernelGGL(sssp_nf_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, nf); },
-            [&] { hipLaunchKernelGGL(sssp_nf_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, nf, pol); });
+            [&] { hipLaunchKernelGGL(sssp_nf_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, nf, mid_v, mid_e); },
+            [&] { hipLaunchKernelGGL(sssp_nf_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, nf, pol, ctx->xcc_mask); });
     }, after);
   } else {
     sssp_policy pol{d_dist, stamp, w_eff, 0, 0, (!g->w || g->uniform_weights) ? 1 : 0};

@@ -146,3 +146,29 @@ def test_full_size_road_standin_unit_weights(gr, gpu_ctx):
     assert np.array_equal(d[reached], depths[reached].astype(np.float32))
     assert np.all(d[~reached] == FMAX)
     assert st["edges_visited"] == ev  # level-synchronous: every reached vertex relaxed exactly once
+
+
+def test_regression_late_workgroups_of_a_multi_level_launch(gr, gpu_ctx):
+    """The many-levels-per-launch body (grx_mid.hpp) rewrites the control block while workgroups of the same grid
+    may still be STARTING; they must find ctrl.mode == 3 and leave.  (With `mode = 0` written at the hand-back a
+    late workgroup ran the per-level advance on the half-rewritten control block: a sporadic memory fault, first
+    seen on a near-far search from an isolated source right after another near-far search.)"""
+    import torch
+    rng = np.random.default_rng(5)
+    for _ in range(2):
+        V = int(rng.integers(200, 30000))
+        E = int(rng.integers(V, 10 * V))
+    _, c = gr.generate("rmat", V, E, seed=501)
+    w = (rng.random(E, dtype=np.float32) * np.float32(9.7) + np.float32(0.01)).astype(np.float32)
+    g = O.Csr(c.row_offsets, c.column_indices, w)
+    deg = np.diff(g.row_offsets)
+    hub, lone = int(np.argmax(deg)), int(np.nonzero(deg == 0)[0][0])
+    csr = gr.csr_t.from_arrays(g.row_offsets, g.column_indices, w)
+    G = gr.build_graph(gr.graph_properties_t(True, True, False), csr, gpu_ctx)
+    d = torch.empty(V, dtype=torch.float32, device="cuda:0")
+    want = {s: O.sssp(g, s)[0] for s in (hub, lone)}
+    nf, plain = gr.options_t(engine_flags=0x20), gr.options_t(engine_flags=0x10)
+    for rep in range(8):
+        for s, o in ((hub, nf), (lone, nf), (hub, plain), (lone, nf), (hub, None), (lone, plain)):
+            gr.sssp(G, s, d, None, gpu_ctx, o)
+            assert np.array_equal(d.cpu().numpy(), want[s]), (rep, s)

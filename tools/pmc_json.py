@@ -1,88 +1,159 @@
-"""Per-launch rocprofv3 numbers of the BFS level kernel, split by what the launch did.
+"""rocprofv3 numbers of the engine's dominant kernels, per launch / per search, for bench.py's `traffic` fields.
 
-    python tools/pmc_json.py <prof dir of tools/profile.sh> [bottom-up level positions, default 1,2,3] > profiles/rNN_bench_pmc.json
+    python tools/pmc_json.py <prof dir> [<prof dir> ...] > profiles/rNN_bench_pmc.json
 
-The single per-level kernel (bfs_level_kernel) runs a level top-down or bottom-up as the head
-kernel decided, so its dispatches are classified by POSITION inside a search: a search starts at
-a bfs_init_kernel dispatch; searches whose reset was a bfs_reset_kernel (labels + bitmaps) are
-direction-optimising runs, whose level dispatches at the given 0-based positions ran bottom-up
-(bench.py's `all_levels` shows the same flags); searches without them are top-down-only runs,
-whose positions 1 and 2 are the two fat top-down levels of the LJ stand-in.
+Each <prof dir> is the output of tools/profile.sh for ONE command (kt/ = --kernel-trace --stats pass, pmc*/ = one
+--pmc group per pass).  Dispatches are grouped into SEARCHES (a search starts at a *_init_kernel dispatch) and the
+kernels of interest are classified by name and by their position inside the search:
 
-Every counter group comes from its own rocprofv3 pass (--kernel-trace --pmc <group>); durations
-come from the --kernel-trace --stats pass.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 a wide
-coalesced read is tallied at half its bytes and a random 4-byte gather at one 64-B sector
-(MI355X_MICROARCH.md, HBM section; tools/calibrate_fetch.py on this box) -- the values here
-are the raw counters x 1024, uncorrected."""
+  bottom_up            bfs_level_kernel launches 1..3 of a direction-optimising search (after a bfs_reset_kernel);
+                       per LAUNCH
+  topdown_fat          launches 1 and 2 of a forward search, bfs_level_bin_kernel (+ the bfs_claim_kernel of the same
+                       level when the level ran binned): per LEVEL (= what bench.py's forward profile calls a launch)
+  sssp_unit_weights    all sssp_level_kernel launches of a search; per SEARCH (with many levels per launch the
+  sssp_weighted_1_1000 all sssp_nf_level_kernel launches           launch count is not a unit of work)
+  pr_pull              pr_pull_xcd_kernel / pr_pull_kernel + pr_long* + pr_combine_kernel launches that did work
+                       (launches queued past convergence exit at once and are dropped: < 10 % of the largest value);
+                       per ITERATION
+
+Only the LAST search of a kind in a process is used (warm caches, layouts built).  Every counter group comes from
+its own rocprofv3 pass; durations come from the kernel-trace pass.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 a
+wide coalesced read is tallied at half its bytes and a random 4-byte gather at one 64-B sector
+(MI355X_MICROARCH.md, HBM section; tools/calibrate_fetch.py) -- values here are the raw counters x 1024.
+`source_sha` = hash of gunrock_amd/csrc at the time of profiling: bench.py attaches these numbers only while the
+sources still hash to it."""
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
 
-out = sys.argv[1]
-bu_pos = set(int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,2,3").split(","))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def classify(rows):
-    """rows: (dispatch id, kernel name) in launch order -> {dispatch id: class}"""
-    cls, cur = {}, None
-    searches = []
-    reset_seen = False
+def source_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gunrock_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def searches_of(rows):
+    """rows: [(id, kernel name)] in launch order -> list of searches {kind, do, kernels: [(id, name)]}"""
+    out, cur, reset_seen = [], None, False
     for did, name in rows:
         if "bfs_reset_kernel" in name:
             reset_seen = True
-        elif "bfs_init_kernel" in name:
-            cur = {"convert": reset_seen, "levels": []}
-            searches.append(cur)
+        kind = None
+        if "bfs_init_kernel" in name:
+            kind = "bfs"
+        elif "sssp_init_kernel" in name:
+            kind = "sssp"
+        elif "pr_init_kernel" in name:
+            kind = "pr"
+        if kind:
+            cur = {"kind": kind, "do": reset_seen, "kernels": []}
+            out.append(cur)
             reset_seen = False
-        elif cur is not None and "bfs_level_kernel" in name:
-            cur["levels"].append(did)
-    for s in searches:
-        for pos, did in enumerate(s["levels"]):
-            if s["convert"]:
-                cls[did] = "bottom_up" if pos in bu_pos else ("do_topdown_first" if pos == 0 else "do_other")
-            else:
-                cls[did] = "topdown_fat" if pos in (1, 2) else "td_other"
-    return cls, searches
+        elif cur is not None:
+            cur["kernels"].append((did, name))
+    return out
 
 
-result = {"source": "tools/profile.sh passes in " + os.path.basename(out.rstrip("/")),
-          "units": "bytes = FETCH_SIZE / WRITE_SIZE x 1024, raw (gfx950 tallies wide coalesced reads at 1/2, "
-                   "random 4-byte gathers at one 64-B sector each); durations from the kernel-trace pass",
-          "bottom_up_positions": sorted(bu_pos), "classes": {}}
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
+def classify(rows):
+    """-> {dispatch id: (class, unit index)}: values of one unit are summed, units are averaged"""
+    cls = {}
+    ss = searches_of(rows)
+    last = {}
+    for s in ss:
+        key = (s["kind"], s["do"], any("sssp_nf_level" in n for _, n in s["kernels"]))
+        last[key] = s
+    for (kind, do, nf), s in last.items():
+        if kind == "bfs" and do:
+            lv = [d for d, n in s["kernels"] if "bfs_level_kernel" in n]
+            for pos, d in enumerate(lv):
+                if pos in (1, 2, 3):
+                    cls[d] = ("bottom_up", pos)
+        elif kind == "bfs":
+            lv = [d for d, n in s["kernels"] if "bfs_level_bin_kernel" in n]
+            cl = [d for d, n in s["kernels"] if "bfs_claim_kernel" in n]
+            for pos in (1, 2):
+                if pos < len(lv):
+                    cls[lv[pos]] = ("topdown_fat", pos)
+                if pos < len(cl):
+                    cls[cl[pos]] = ("topdown_fat", pos)
+        elif kind == "sssp":
+            name = "sssp_weighted_1_1000" if nf else "sssp_unit_weights"
+            for d, n in s["kernels"]:
+                if "sssp_nf_level_kernel" in n or "sssp_level_kernel" in n or "advance_kernel" in n:
+                    cls[d] = (name, 0)
+        elif kind == "pr":
+            it = -1
+            for d, n in s["kernels"]:
+                if "pr_prepare_kernel" in n:
+                    it += 1
+                if any(k in n for k in ("pr_pull", "pr_long", "pr_combine")):
+                    cls[d] = ("pr_pull", it)
+    return cls
 
-kt = glob.glob(os.path.join(out, "kt", "**", "p_kernel_trace.csv"), recursive=True)
-if kt:
-    rows = sorted(csv.DictReader(open(kt[0])), key=lambda r: int(r["Start_Timestamp"]))
-    ids = [(i, r["Kernel_Name"]) for i, r in enumerate(rows)]
-    cls, searches = classify(ids)
-    for i, r in enumerate(rows):
-        if i in cls:
-            acc[cls[i]]["duration_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    result["searches_direction_optimising"] = sum(1 for s in searches if s["convert"])
-    result["searches_topdown_only"] = sum(1 for s in searches if not s["convert"])
 
-for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "p_counter_collection.csv"), recursive=True)):
-    per = collections.OrderedDict()
-    for r in csv.DictReader(open(f)):
-        per.setdefault(int(r["Dispatch_Id"]), [r["Kernel_Name"], {}])[1][r["Counter_Name"]] = float(r["Counter_Value"])
-    order = sorted(per)
-    cls, _ = classify([(d, per[d][0]) for d in order])
-    for d in order:
-        if d in cls:
-            for c, v in per[d][1].items():
-                acc[cls[d]][c].append(v)
+result = {"source_sha": source_sha(),
+          "units": "bytes = FETCH_SIZE / WRITE_SIZE x 1024, raw (gfx950 tallies wide coalesced reads at 1/2, random 4-byte "
+                   "gathers at one 64-B sector each); durations from the kernel-trace pass; `per_launch` = per unit of the "
+                   "class (see tools/pmc_json.py: launch, level, search or iteration)",
+          "sources": [], "classes": {}}
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))  # class -> counter -> unit -> sum
 
-for k, counters in acc.items():
-    o = {"launches_seen": len(counters.get("duration_us", []))}
-    for c, vals in counters.items():
-        o[c + "_per_launch"] = sum(vals) / max(1, len(vals))
+for out in sys.argv[1:]:
+    result["sources"].append(os.path.basename(out.rstrip("/")))
+    kt = glob.glob(os.path.join(out, "kt", "**", "p_kernel_trace.csv"), recursive=True)
+    if kt:
+        rows = sorted(csv.DictReader(open(kt[0])), key=lambda r: int(r["Start_Timestamp"]))
+        cls = classify([(i, r["Kernel_Name"]) for i, r in enumerate(rows)])
+        for i, r in enumerate(rows):
+            if i in cls:
+                c, u = cls[i]
+                acc[c]["duration_us"][u] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                acc[c]["dispatches"][u] += 1
+    for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "p_counter_collection.csv"), recursive=True)):
+        per = collections.OrderedDict()
+        for r in csv.DictReader(open(f)):
+            per.setdefault(int(r["Dispatch_Id"]), [r["Kernel_Name"], {}])[1][r["Counter_Name"]] = float(r["Counter_Value"])
+        order = sorted(per)
+        cls = classify([(d, per[d][0]) for d in order])
+        for d in order:
+            if d in cls:
+                c, u = cls[d]
+                for name, v in per[d][1].items():
+                    acc[c][name][u] += v
+
+for c, counters in acc.items():
+    o = {}
+    units = counters.get("duration_us", {})
+    keep = set(units)
+    if c == "pr_pull" and units:  # iterations queued past convergence did nothing
+        top = max(units.values())
+        keep = {u for u, v in units.items() if v >= 0.1 * top}
+    o["units_seen"] = len(keep)
+    for name, per_unit in counters.items():
+        vals = [v for u, v in per_unit.items() if u in keep] if name in ("duration_us", "dispatches") else None
+        if vals is None:
+            # a counter pass may see the same units (positions are stable run to run)
+            vals = [v for u, v in per_unit.items() if u in keep or not keep]
+            if c == "pr_pull" and vals:
+                top = max(vals)
+                vals = [v for v in vals if v >= 0.1 * top]
+        if vals:
+            o[name + "_per_launch"] = sum(vals) / len(vals)
     if "FETCH_SIZE_per_launch" in o:
         o["fetch_bytes_per_launch"] = o["FETCH_SIZE_per_launch"] * 1024.0
     if "WRITE_SIZE_per_launch" in o:
         o["write_bytes_per_launch"] = o["WRITE_SIZE_per_launch"] * 1024.0
-    result["classes"][k] = o
+    if "duration_us_per_launch" in o:
+        o["duration_us_per_launch"] = o["duration_us_per_launch"]
+    result["classes"][c] = o
 print(json.dumps(result, indent=1))

@@ -1,5 +1,6 @@
 """Tiny workload driver for profiling: run one algorithm a few times on a bench workload.
-    python tools/run_algo.py bfs|sssp|pr lj|kron|road|small [runs] [engine_flags] [lb] [direction: forward|optimized]"""
+    python tools/run_algo.py bfs|sssp|ssspu|pr lj|kron|road|small [runs] [engine_flags] [lb] [direction: forward|optimized]
+sssp: weights U{1..1000} (drawn here for pattern graphs); ssspu: the graph's own weights (1.0 for pattern files)"""
 import os
 import sys
 
@@ -16,7 +17,9 @@ runs = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 lb = getattr(gr, sys.argv[5]) if len(sys.argv) > 5 else gr.merge_path
 props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], wl["c"], seed=42)
-if algo == "sssp" and not props.weighted:
+if algo == "sssp" and sys.argv[2] == "road":
+    props, csr = gr.generate("road", wl["V"], 0, wl["a"], 0.0, 1.0, seed=42)  # the weighted road variant of bench.py
+elif algo == "sssp" and not props.weighted:
     rng = np.random.default_rng(1)
     csr.nonzero_values = rng.integers(1, 1001, csr.number_of_nonzeros).astype(np.float32)
     csr._device = None
@@ -34,7 +37,7 @@ for _ in range(runs):
     if algo == "bfs":
         d = torch.empty(V, dtype=torch.int32, device="cuda")
         times.append(gr.bfs(G, src, d, None, ctx, o))
-    elif algo == "sssp":
+    elif algo in ("sssp", "ssspu"):
         d = torch.empty(V, dtype=torch.float32, device="cuda")
         times.append(gr.sssp(G, src, d, None, ctx, o))
     else:
