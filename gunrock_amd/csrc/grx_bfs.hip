@@ -702,16 +702,15 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     }
     prof_open = h.bu_open;
     prof_probe = h.bu_probes;
-    if (h.done) {
-      ctx->levels.pop_back();  // the level that only detected the empty frontier
-      return;
-    }
     level_rec& r = ctx->levels.back();
     r.frontier_size = h.vertices_visited - prof_v;
     r.edges = h.edges_visited - prof_e;
     r.bottom_up = h.mode;
     prof_v = h.vertices_visited;
     prof_e = h.edges_visited;
+    // the group that only detected the empty frontier carries no work; a group that ran the last levels itself
+    // (many levels per launch, grx_mid.hpp) and found the end is a record like any other
+    if (h.done && r.frontier_size == 0 && r.edges == 0) ctx->levels.pop_back();
   }, /*first_batch=*/dense ? 8 : 4, /*pace_depth=*/pace, /*fast_return=*/pace > 0 && ((opt.engine_flags & GRX_FLAG_ASYNC_RETURN) != 0 || env_int("GRX_FAST_RETURN", 0) != 0),
      &returned_fast);
   if (st != GRX_SUCCESS) return st;

@@ -598,7 +598,9 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     r.bottom_up = near_far ? 2 * h.nf_split : 0;  // 2: this iteration only pulled a bucket out of the far pile
     prof_v = h.vertices_visited;
     prof_e = h.edges_visited;
-    if (h.done) ctx->levels.pop_back();  // the group that only detected the end
+    // the group that only detected the end carries no work; one that ran the last iterations itself (many per
+    // launch, grx_mid.hpp) and found the end is a record like any other
+    if (h.done && r.frontier_size == 0 && r.edges == 0) ctx->levels.pop_back();
   };
   if (near_far) {
     sssp_nf_policy pol{d_dist, stamp, w_eff ? w_eff : g->w, nf, 0, 0.0f, nullptr, nullptr, 0};
