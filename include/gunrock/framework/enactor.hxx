@@ -12,6 +12,8 @@
 // records the iteration count / runtime in benchmark::current().
 #pragma once
 
+#include <gunrock/util/trace.hxx>
+
 #include <memory>
 #include <vector>
 
@@ -95,8 +97,12 @@ struct enactor_t {
     auto stream = single_context->stream();
     timer.reset();
     timer.begin(stream);
+    GUNROCK_TRACE_RANGE("enact");
     prepare_frontier(get_input_frontier(), *context);
     while (!is_converged(*context)) {
+#ifdef GUNROCK_ROCTX
+      GUNROCK_TRACE_RANGE(std::string("iteration ") + std::to_string(iteration));
+#endif
       loop(*context);
       ++iteration;
     }

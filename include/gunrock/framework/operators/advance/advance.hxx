@@ -23,6 +23,7 @@
 #include <gunrock/framework/operators/advance/thread_mapped.hxx>
 #include <gunrock/framework/operators/advance/warp_mapped.hxx>
 #include <gunrock/framework/operators/configs.hxx>
+#include <gunrock/util/trace.hxx>
 
 namespace gunrock {
 namespace operators {
@@ -35,6 +36,7 @@ template <load_balance_t lb = load_balance_t::merge_path,
           typename frontier_t, typename work_tiles_t>
 void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, work_tiles_t& segments,
              gcuda::multi_context_t& context) {
+  GUNROCK_TRACE_RANGE("advance");
   using type_t = typename frontier_t::type_t;
   using edge_t = typename graph_t::edge_type;
   error::throw_if_exception(context.size() != 1, "`context.size() != 1` not supported");

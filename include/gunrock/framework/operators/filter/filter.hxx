@@ -17,6 +17,8 @@
 //                        (filter/bypass.hxx:31-69).
 #pragma once
 
+#include <gunrock/util/trace.hxx>
+
 #include <gunrock/cuda/context.hxx>
 #include <gunrock/error.hxx>
 #include <gunrock/framework/operators/configs.hxx>
@@ -172,6 +174,7 @@ std::size_t stable_compact(operator_t op, const type_t* in, std::size_t n, type_
 
 template <filter_algorithm_t alg_type, typename graph_t, typename operator_t, typename frontier_t>
 void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, gcuda::multi_context_t& context) {
+  GUNROCK_TRACE_RANGE("filter");
   using type_t = typename frontier_t::type_t;
   error::throw_if_exception(context.size() != 1, "`context.size() != 1` not supported");
   auto& ctx = *context.get_context(0);

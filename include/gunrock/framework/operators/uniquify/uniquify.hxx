@@ -10,6 +10,8 @@
 // active after the swap.  Invalid (-1) slots are dropped as well.
 #pragma once
 
+#include <gunrock/util/trace.hxx>
+
 #include <gunrock/cuda/context.hxx>
 #include <gunrock/error.hxx>
 #include <gunrock/framework/operators/configs.hxx>
