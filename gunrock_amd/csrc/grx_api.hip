@@ -111,8 +111,17 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   a->tile_count = ctx->tile_count.as<int32_t>();
   a->chunk_tile = ctx->chunk_tile.as<int32_t>();
   a->bu_part = nullptr;
-  GRX_HIP(ctx->mid_aux.reserve((size_t)2 * MID_AUX_CAP * 2 * sizeof(int32_t)));
+  // grx_mid.hpp: [first version: 2 x MID_AUX_CAP int2][second version: 2 x MID_AUX2_CAP int4][flag words]
+  const size_t aux1 = (size_t)2 * MID_AUX_CAP * 2 * sizeof(int32_t);
+  const size_t aux2 = (size_t)2 * MID_AUX2_CAP * 4 * sizeof(int32_t);
+  GRX_HIP(ctx->mid_aux.reserve(aux1 + aux2 + MID_FLAG_WORDS * sizeof(unsigned long long)));
   a->mid_aux = ctx->mid_aux.ptr;
+  a->mid_aux2 = static_cast<char*>(ctx->mid_aux.ptr) + aux1;
+  a->mid_flags = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->mid_aux.ptr) + aux1 + aux2);
+  // the second version lays MID_WGS private regions + an overflow area of up to V entries over a parity buffer
+  const char* mv = getenv("GRX_MID_VERSION");
+  a->mid_version = (mv && *mv == '1') ? 1 : 2;
+  if ((size_t)MID_OVF_BASE + V + TILE > max_tiles * TILE || (size_t)MID_WGS * MID_SEG_TILES + V / TILE + 2 > max_tiles) a->mid_version = 1;
   return GRX_SUCCESS;
 }
 

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_bin_kernel(pipe_args a, b
     bin_scatter_block(a, bn, *reinterpret_cast<bin_scatter_smem*>(lds_raw), h.level & 1, h.total_chunks, a.chunk_tile);
   } else if (h.mode == 3) {
     pol.ctrl = c;
-    mid_levels_body(a, c, pol, *reinterpret_cast<td_smem*>(lds_raw), h, bn.xcc_mask);
+    mid_levels_run(a, c, pol, *reinterpret_cast<td_smem*>(lds_raw), h, bn.xcc_mask);
   } else {
     pol.ctrl = c;
     pol.set_level(h.level);
@@ -317,6 +317,15 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_claim_kernel(pipe_args a, bin_a
   if (h.done || h.mode != 2) return;
   (void)pol;
   bin_claim_block(a, bn, c, h.level + 1, sm, h.level & 1);
+}
+
+// The claim phase as a sweep (grx_bin.hpp, third version): one workgroup of 1024 threads per bin (or part of a fat bin).
+__global__ __launch_bounds__(SWEEP_BLOCK) void bfs_sweep_kernel(pipe_args a, bin_args bn) {
+  __shared__ bin_sweep_smem sm;
+  ctrl_t* c = a.ctrl;
+  const level_head h = load_level_head(c);
+  if (h.done || h.mode != 2) return;
+  bin_sweep_block(a, bn, c, h.level + 1, sm, h.level & 1);
 }
 
 }  // namespace grx
@@ -401,7 +410,7 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_tab8), tab_bytes));
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_off), 2 * ((size_t)BIN_MAX + 1) * sizeof(int32_t)));  // off, v0
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_fill), ((size_t)BIN_MAX + 16) * BIN_PAD * sizeof(int32_t)));  // fill, queue
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bins), (size_t)g->E * sizeof(int32_t)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bins), ((size_t)g->E + 16) * sizeof(int32_t)));  // + the tail of a 16-byte load
   GRX_HIP(hipMemcpyAsync(g->bin_tab8, g2b.data(), (size_t)BIN_GRAN_MAX, hipMemcpyHostToDevice, s));
   GRX_HIP(hipMemcpyAsync(g->bin_tab8 + BIN_GRAN_MAX, owner.data(), (size_t)BIN_MAX, hipMemcpyHostToDevice, s));
   GRX_HIP(hipMemcpyAsync(g->bin_off, off.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -603,6 +612,8 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.mid_e = env_int("GRX_MID_E", MID_ENTER_E);
   }
   int grid_scatter = 0, grid_claim = 0;
+  // claim phase of a binned level: 3 = sweep (one workgroup per bin, vertex-ordered output), 2 = slices claimed in the owning XCD's L2
+  const int claim_version = env_int("GRX_BIN_CLAIM", 3);
   if (use_bins) {
     bn.bins = g->bins;
     bn.off = g->bin_off;
@@ -660,7 +671,10 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         // forward-only run.  level = claim-per-edge advance, many mid-size levels (grx_mid.hpp), or the SCATTER phase of
         // a binned level; the CLAIM phase is launched only when levels can be binned (a no-op unless the head did)
         hipLaunchKernelGGL(bfs_level_bin_kernel, dim3(grid_scatter), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
-        if (use_bins) hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_claim), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
+        if (use_bins && claim_version == 2)
+          hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_claim), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
+        else if (use_bins)
+          hipLaunchKernelGGL(bfs_sweep_kernel, dim3(ctx->num_cus * 2), dim3(SWEEP_BLOCK), 0, stream, a, bn);
       } else {
         hipLaunchKernelGGL(lbuild->fn, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
       }

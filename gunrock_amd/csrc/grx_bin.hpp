@@ -388,6 +388,247 @@ __device__ __forceinline__ void bin_claim_block(const pipe_args& a, const bin_ar
   }
 }
 
+// Phase 2, third version (default): SWEEP claim.  What the slice-wise claim above still pays per candidate that is
+// new to its slice -- an L2 atomic on the global bitmap, a scattered label store, two scattered row-offset loads
+// for the tile it is emitted into -- this version pays per DISCOVERED VERTEX, and in vertex order:
+//   A. a workgroup of 1024 threads owns one work item = one bin (a bin with more than SWEEP_PART candidates is cut
+//      into parts claimed by several workgroups).  It copies the bin's slice of the visited bitmap into LDS and
+//      streams the candidates through it: 16-byte loads two rounds ahead, a plain LDS read and -- only when the
+//      bit is still clear -- a fire-and-forget LDS atomicOr.  No result is consumed: nothing in the loop waits
+//      for anything but the candidate stream itself.
+//   B. the LDS words are compared with the global ones; a word with new bits is merged with ONE atomicOr whose
+//      return value tells which of the bits this workgroup was first to set (parts of a fat bin race here, and
+//      only here: <= 4096 atomics per item, ~150 k per level on the LJ stand-in against millions before).
+//   C. the new-bit masks are expanded 256 words at a time into a list of vertex ids IN ASCENDING ORDER: labels are
+//      stored to neighbouring addresses, row offsets of a tile are neighbouring loads, and the NEXT level's
+//      scatter walks rows that are adjacent in the CSR arrays.
+// Tiles are reserved exactly (one atomic per emission of up to 33 tiles); a workgroup carries its partial tile
+// from item to item and emits at most one short tile at the end.
+constexpr int SWEEP_BLOCK = 1024;
+constexpr int SWEEP_PART = 1 << 17;
+constexpr int SWEEP_SEG_WORDS = 256;
+constexpr int SWEEP_LIST = SWEEP_SEG_WORDS * 32 + TILE;
+constexpr int SWEEP_PASSES = (SWEEP_LIST + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+constexpr int SWEEP_U = 2;  // 16-byte loads per thread and round
+
+struct bin_sweep_smem {
+  unsigned bm[1 << (BIN_SHIFT_MAX - 5)];
+  int list[SWEEP_LIST];
+  int pre[BIN_MAX + 1];
+  int fillv[BIN_MAX];
+  int wave[SWEEP_BLOCK / 64 + 1];
+  int sum[SWEEP_LIST / TILE + 1][4];
+  int tile_base;
+};
+
+// emit list[0 .. k * TILE) as k full tiles of parity q.  Block-wide call.
+__device__ __forceinline__ void sweep_emit_full(const pipe_args& a, ctrl_t* c, int q, bin_sweep_smem& sm, int k) {
+  const int tid = threadIdx.x;
+  const int lane = dev::lane_id();
+  const int wid = tid >> 6;
+  if (tid == 0) sm.tile_base = atomicAdd(&c->n_tiles[q], k);  // travels together with the degree loads
+  int x[SWEEP_PASSES], deg[SWEEP_PASSES];
+#pragma unroll
+  for (int j = 0; j < SWEEP_PASSES; ++j) {
+    const int idx = j * SWEEP_BLOCK + tid;
+    x[j] = sm.list[idx < k * TILE ? idx : 0];
+  }
+#pragma unroll
+  for (int j = 0; j < SWEEP_PASSES; ++j) deg[j] = a.ro[x[j] + 1] - a.ro[x[j]];  // unconditional: a valid vertex
+#pragma unroll
+  for (int j = 0; j < SWEEP_PASSES; ++j) {
+    const int idx = j * SWEEP_BLOCK + tid;
+    if (idx - lane < k * TILE) {  // wave-uniform: tiles are multiples of the wave size
+      const int t = dev::wave_sum(deg[j]);
+      if (lane == 0) sm.sum[idx >> 8][wid & 3] = t;
+    }
+  }
+  __syncthreads();
+  const int base = sm.tile_base;
+#pragma unroll
+  for (int j = 0; j < SWEEP_PASSES; ++j) {
+    const int idx = j * SWEEP_BLOCK + tid;
+    if (idx < k * TILE) {
+      const int tix = base + (idx >> 8);
+      a.frontier[q][(size_t)tix * TILE + (idx & (TILE - 1))] = x[j];
+      if ((idx & (TILE - 1)) == 0) {
+        const int tot = sm.sum[idx >> 8][0] + sm.sum[idx >> 8][1] + sm.sum[idx >> 8][2] + sm.sum[idx >> 8][3];
+        a.tile_sums[tix] = tot;
+        a.tile_chunks[tix] = (tot + CHUNK - 1) / CHUNK;
+        a.tile_count[tix] = TILE;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_args& bn, ctrl_t* c, int depth,
+                                                bin_sweep_smem& sm, int p) {
+  static_assert(TILE == 256 && SWEEP_BLOCK == 4 * SWEEP_SEG_WORDS, "a thread expands one byte of a bitmap word");
+  const int tid = threadIdx.x;
+  const int lane = dev::lane_id();
+  const int wid = tid >> 6;
+  const int q = p ^ 1;
+  const bool dbg = bn.debug && c->level == bn.debug_level;
+  const long long dbg_t0 = dbg ? (long long)wall_clock64() : 0ll;
+  long long dbg_items = 0, dbg_entries = 0, dbg_words = 0, dbg_tA = 0, dbg_tB = 0;
+  int fill = 0;
+  if (tid < bn.nb) fill = bn.fill[tid * BIN_PAD];
+  int tot_items;
+  const int ex0 = dev::block_exclusive_sum<SWEEP_BLOCK>((fill + SWEEP_PART - 1) / SWEEP_PART, sm.wave, &tot_items);
+  if (tid < BIN_MAX) {
+    sm.pre[tid] = ex0;
+    sm.fillv[tid] = fill;
+  }
+  if (tid == 0) sm.pre[BIN_MAX] = tot_items;
+  __syncthreads();
+  int n_list = 0;  // uniform: entries waiting in sm.list (labels already stored)
+  const int4* src4 = reinterpret_cast<const int4*>(bn.bins);
+  for (int item = (int)blockIdx.x; item < tot_items; item += (int)gridDim.x) {
+    int b = 0;  // largest b with pre[b] <= item (bins without items are skipped over)
+#pragma unroll
+    for (int step = BIN_MAX / 2; step >= 1; step >>= 1)
+      if (sm.pre[b + step] <= item) b += step;
+    const int e0 = (item - sm.pre[b]) * SWEEP_PART;
+    const int n_e = min(sm.fillv[b], e0 + SWEEP_PART) - e0;
+    const int lo = bn.off[b] + e0, hi = lo + n_e;
+    const int vbase = bn.v0[b];
+    const int words = (bn.v0[b + 1] - vbase) >> 5;
+    const int gw0 = vbase >> 5;
+    ++dbg_items;
+    dbg_entries += n_e;
+    dbg_words += words;
+    // first candidates on their way while the bitmap slice is copied
+    const int i4_first = lo >> 2, i4_last = (hi - 1) >> 2;
+    int4 nx[SWEEP_U], nx2[SWEEP_U];
+    auto LOAD = [&](int r, int4(&v)[SWEEP_U]) {
+#pragma unroll
+      for (int u = 0; u < SWEEP_U; ++u) {
+        const int idx = i4_first + (r * SWEEP_U + u) * SWEEP_BLOCK + tid;
+        v[u] = src4[idx < i4_last ? idx : i4_last];
+      }
+    };
+    LOAD(0, nx);
+    LOAD(1, nx2);
+    for (int w = tid; w < words; w += SWEEP_BLOCK) sm.bm[w] = (gw0 + w) < bn.visited_words ? bn.visited[gw0 + w] : ~0u;
+    __syncthreads();
+    // A. candidates -> LDS bitmap
+    const int rounds = (i4_last - i4_first + SWEEP_U * SWEEP_BLOCK) / (SWEEP_U * SWEEP_BLOCK);
+    for (int r = 0; r < rounds; ++r) {
+      int4 cur[SWEEP_U];
+#pragma unroll
+      for (int u = 0; u < SWEEP_U; ++u) { cur[u] = nx[u]; nx[u] = nx2[u]; }
+      LOAD(r + 2, nx2);
+#pragma unroll
+      for (int u = 0; u < SWEEP_U; ++u) {
+        const int idx = i4_first + (r * SWEEP_U + u) * SWEEP_BLOCK + tid;
+        const int g0 = idx << 2;
+        const int n4[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gi = g0 + j;
+          if (idx <= i4_last && gi >= lo && gi < hi) {
+            const int local = n4[j] - vbase;
+            const unsigned bit = 1u << (local & 31);
+            // plain read first: a visited hub is hit by many lanes at once, and a read broadcasts where an
+            // atomic on one word serialises
+            if (!(sm.bm[local >> 5] & bit)) atomicOr(&sm.bm[local >> 5], bit);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (dbg) dbg_tA += (long long)wall_clock64();
+    // B. words with bits the global bitmap lacks: one atomic each; what it returns decides between the parts of a bin
+    for (int w0 = 0; w0 < words; w0 += 4 * SWEEP_BLOCK) {
+      unsigned cand[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = w0 + j * SWEEP_BLOCK + tid;
+        cand[j] = 0u;
+        if (w < words && gw0 + w < bn.visited_words) cand[j] = sm.bm[w] & ~bn.visited[gw0 + w];
+      }
+      unsigned old[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = w0 + j * SWEEP_BLOCK + tid;
+        old[j] = 0u;
+        if (cand[j]) old[j] = atomicOr(&bn.visited[gw0 + w], cand[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = w0 + j * SWEEP_BLOCK + tid;
+        if (w < words) sm.bm[w] = cand[j] & ~old[j];
+      }
+    }
+    __syncthreads();
+    if (dbg) dbg_tB += (long long)wall_clock64();
+    // C. new bits -> ascending vertex ids -> labels, tiles
+    for (int s0 = 0; s0 < words; s0 += SWEEP_SEG_WORDS) {
+      const int w = s0 + (tid >> 2);
+      unsigned byte = w < words ? (sm.bm[w] >> ((tid & 3) * 8)) & 0xffu : 0u;
+      int tot;
+      const int ex = dev::block_exclusive_sum<SWEEP_BLOCK>(__popc(byte), sm.wave, &tot);
+      if (tot == 0) continue;
+      int pos = n_list + ex;
+      const int v_first = vbase + (w << 5) + (tid & 3) * 8;
+      while (byte) {
+        const int v = v_first + __ffs(byte) - 1;
+        byte &= byte - 1u;
+        sm.list[pos++] = v;
+        bn.dist[v] = depth;  // exactly one winner per vertex (bfs.hxx:117-119 assigns the same depth)
+      }
+      n_list += tot;
+      __syncthreads();
+      if (n_list >= TILE) {
+        const int k = n_list / TILE;
+        sweep_emit_full(a, c, q, sm, k);
+        const int rem = n_list - k * TILE;
+        int keep = 0;
+        if (tid < rem) keep = sm.list[k * TILE + tid];
+        __syncthreads();
+        if (tid < rem) sm.list[tid] = keep;
+        n_list = rem;
+        __syncthreads();
+      }
+    }
+  }
+  if (n_list > 0) {  // the one short tile of this workgroup
+    if (tid == 0) sm.tile_base = atomicAdd(&c->n_tiles[q], 1);
+    int x = -1, deg = 0;
+    if (tid < n_list) {
+      x = sm.list[tid];
+      deg = a.ro[x + 1] - a.ro[x];
+    }
+    if (tid < TILE) {
+      const int t = dev::wave_sum(deg);
+      if (lane == 0) sm.sum[0][wid] = t;
+    }
+    __syncthreads();
+    if (tid < TILE) {
+      const int tix = sm.tile_base;
+      a.frontier[q][(size_t)tix * TILE + tid] = x;
+      if (tid == 0) {
+        const int tot = sm.sum[0][0] + sm.sum[0][1] + sm.sum[0][2] + sm.sum[0][3];
+        a.tile_sums[tix] = tot;
+        a.tile_chunks[tix] = (tot + CHUNK - 1) / CHUNK;
+        a.tile_count[tix] = n_list;
+      }
+    }
+  }
+  if (dbg && tid == 0) {
+    long long* d = bn.debug + 8 * (4096 + (size_t)blockIdx.x);
+    d[0] = (long long)((unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u);
+    d[1] = dbg_items;
+    d[2] = dbg_t0;
+    d[3] = (long long)wall_clock64();
+    d[4] = dbg_entries;
+    d[5] = dbg_words;
+    d[6] = dbg_tA;
+    d[7] = dbg_tB;
+  }
+}
+
 // Per-graph static part: in-edges per GRANULE (the unit bins are cut from).  One pass over the column
 // indices, once per graph.  <<<grid, 256>>>
 static __global__ void bin_count_kernel(const int32_t* __restrict__ ci, int64_t E, int gshift, int n_gran, int32_t* cnt) {

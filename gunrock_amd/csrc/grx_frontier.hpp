@@ -38,6 +38,7 @@ constexpr int ADV_ITEMS = 8;         // atoms per thread per chunk
 constexpr int CHUNK = ADV_BLOCK * ADV_ITEMS;  // 2048 atoms
 constexpr int PLAN_BLOCK = 1024;
 constexpr int TILE_RESERVE = 4;      // tile indices a workgroup reserves per global atomic
+constexpr int MID_FLAG_WORDS = 64;   // grx_mid.hpp: 2 x MID_WGS barrier words
 
 struct pipe_args {
   const int32_t* ro;
@@ -53,6 +54,9 @@ struct pipe_args {
   int32_t* chunk_tile;    // per chunk: int2 {owning tile, chunk index inside the tile}
   const long long* bu_part;  // direction-optimising BFS: 4 words per bottom-up workgroup (word 0 >> 40 = its tiles)
   void* mid_aux;             // grx_mid.hpp: {row start, degree} of the first entries of the flat queues, per parity
+  void* mid_aux2;            // grx_mid.hpp, second version: int4 {row start, degree, state, -} per entry of the private regions, per parity
+  unsigned long long* mid_flags;  // second version: 2 x MID_WGS barrier / count words (zeroed by the head kernel that chooses mode 3)
+  int32_t mid_version;       // 1 | 2
 };
 
 // The search is over: final counters and the elapsed device time go to the host-pinned mailbox
@@ -272,6 +276,8 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
           c->mid_cnt[0] = 0;
           c->mid_cnt[1] = 0;
           c->mid_cnt[2] = 0;
+          if (a.mid_flags)
+            for (int i = 0; i < MID_FLAG_WORDS; ++i) a.mid_flags[i] = 0ull;
         }
       }
       if (!external_control) {

@@ -44,6 +44,13 @@ constexpr int MID_ENTER_E = 65536;   // ... and out-edges
 constexpr int MID_EXIT_V = 131072;   // a frontier beyond this goes back to the regular kernels
 constexpr int MID_SPIN_LIMIT = 1 << 22;
 constexpr int MID_AUX_CAP = MID_EXIT_V + TILE;  // queue entries that carry their row start / degree along
+// second version (mid_levels_body2): every workgroup appends to a PRIVATE region of the next queue -- no reservation
+// atomic -- and the barrier carries the counts; what does not fit goes to a shared overflow area behind the regions
+static_assert(MID_FLAG_WORDS == 2 * MID_WGS, "two sets of flag words");
+constexpr int MID_SEG = 16384;
+constexpr int MID_SEG_TILES = MID_SEG / TILE;
+constexpr int MID_OVF_BASE = MID_WGS * MID_SEG;
+constexpr int MID_AUX2_CAP = MID_OVF_BASE;      // int4 {row start, degree, state, -} per entry of the private regions
 
 template <class Policy>
 struct mid_smem {
@@ -52,13 +59,24 @@ struct mid_smem {
   int out_deg[TILE + CHUNK];
   int tcount[ADV_BLOCK];      // entering level: counts of this workgroup's next 256 tiles
   int side[policy_has_side<Policy>::value ? (TILE + CHUNK) : 1];  // staged side-pile entries (near-far SSSP)
+  int out_st[TILE + CHUNK];   // second version: state of the staged output vertices (policies that carry it along)
+  int seg_pre[MID_WGS + 1];   // second version: entries of the private regions before region i
   int side_cnt;
   int side_base;
   int base;
   int n_next;
+  int n_ovf;
   int ok;
   int rank;
 };
+
+// optional policy hooks of the second version: `bool carry_state() const` -- the state a vertex is expanded from is
+// known when it is claimed (`src_state state_of(int cand)`), so it travels with the queue entry instead of being
+// loaded again (one dependent round trip less per level)
+template <class Policy, class = void>
+struct policy_carries_state : std::false_type {};
+template <class Policy>
+struct policy_carries_state<Policy, std::void_t<decltype(&Policy::carry_state)>> : std::true_type {};
 
 // optional policy hook: `prepare(src_state, nbr, edge, cand&)` -- what precheck computes WITHOUT the read-only
 // probe of the neighbour's label.  Inside one XCD the claim itself is an L2 operation, cheaper than the extra
@@ -453,6 +471,435 @@ __device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, P
       c->level = level - 1;  // the next head plans `level` (and sets ctrl.mode: it must stay 3 while late workgroups start)
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// SECOND VERSION.  Same role, same entry / exit conditions, three dependent round trips fewer per level:
+//   * no reservation atomic: workgroup w appends to its PRIVATE region [w * MID_SEG, (w + 1) * MID_SEG) of the next
+//     queue (what does not fit -- never on the graphs this body is for -- goes to a shared overflow area behind the
+//     regions, reserved with an atomic as before);
+//   * the barrier IS the count exchange: a workgroup publishes {epoch, entries it appended} in ONE 64-bit store to
+//     its flag word, wave 0 of every workgroup polls the <= 32 flag words (one load instruction) until all carry the
+//     epoch, and the counts it has just read give the layout of the next level's input -- no arrival atomic, no
+//     counter to read afterwards.  Two sets of flag words (epoch parity): a fast workgroup can only be one barrier
+//     ahead of a slow one;
+//   * the row offsets of the accepted vertices are loaded for ALL neighbours of the chunk, in the shadow of the claim
+//     atomics, instead of after them; policies whose labels are final when claimed (BFS, SSSP with equal weights)
+//     pass the label along with the entry, so the next level does not load it.
+// Entry g of the level's input is found through the 32 region counts (5-step search in LDS).
+template <class Policy>
+__device__ __forceinline__ bool mid_exchange(const pipe_args& a, int G, int w, int& epoch, unsigned word,
+                                             const int* ovf_cnt, mid_smem<Policy>& sm) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores have been acknowledged (they sit in the home L2)
+  __syncthreads();
+  ++epoch;
+  unsigned long long* fl = a.mid_flags + (size_t)(epoch & 1) * MID_WGS;
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&fl[w], ((unsigned long long)(unsigned)epoch << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (threadIdx.x < 64) {
+    const int lane = dev::lane_id();
+    unsigned long long v = 0ull;
+    int spins = 0, ok = 1;
+    for (;;) {
+      if (lane < G) v = __hip_atomic_load(&fl[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past the L1
+      const bool late = lane < G && (unsigned)(v >> 32) != (unsigned)epoch;
+      if (dev::ballot(late) == 0ull) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > MID_SPIN_LIMIT) { ok = 0; break; }
+    }
+    const int cnt = lane < G ? (int)(v & 0x7fffffffull) : 0;
+    const bool ovf = lane < G && ((v >> 31) & 1ull) != 0ull;
+    const int inc = dev::wave_inclusive_sum(cnt);
+    if (lane <= MID_WGS) sm.seg_pre[lane] = inc - cnt;  // lanes >= G: the total
+    const bool any_ovf = dev::ballot(ovf) != 0ull;
+    if (lane == 0) {
+      sm.ok = ok;
+      sm.n_ovf = any_ovf ? __hip_atomic_load(ovf_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    }
+  }
+  __syncthreads();
+  return sm.ok != 0;
+}
+
+template <class Policy>
+__device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid_smem<Policy>& sm,
+                                                 const level_head& h, uint32_t xcc_mask) {
+  constexpr bool SIDE = policy_has_side<Policy>::value;
+  constexpr bool CARRY = policy_carries_state<Policy>::value;
+  const int tid = threadIdx.x;
+  const int lane = dev::lane_id();
+  // ---- who takes part: as in the first version
+  const unsigned my_xcc = (unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u;
+  if (my_xcc != (unsigned)__builtin_ctz(xcc_mask ? xcc_mask : 1u)) return;
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(&c->mid_reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    sm.rank = (old >> 31) ? -1 : (int)(old & 0xffffu);
+  }
+  __syncthreads();
+  const int w = sm.rank;
+  if (w < 0) return;
+  if (tid == 0) {
+    int g = 0;
+    if (w == 0) {
+      const int expect = min(MID_WGS, max(1, (int)gridDim.x / max(1, __popc(xcc_mask))));
+      for (int i = 0; i < 64; ++i) {
+        if ((int)(__hip_atomic_load(&c->mid_reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu) >= expect) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      const unsigned old = __hip_atomic_fetch_or(&c->mid_reg, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      g = min((int)(old & 0xffffu), MID_WGS);
+      __hip_atomic_store(&c->mid_G, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      int spins = 0;
+      while ((g = __hip_atomic_load(&c->mid_G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > MID_SPIN_LIMIT) { g = -1; break; }
+      }
+    }
+    sm.n_next = g;
+  }
+  __syncthreads();
+  const int G = sm.n_next;
+  __syncthreads();
+  auto fail_out = [&]() {
+    if (tid == 0) { c->mid_err = 1; c->done = 1; a.mailbox[10] = 1; __threadfence_system(); a.mailbox[0] = 1; }
+  };
+  if (G < 0) { fail_out(); return; }
+  if (w >= G) return;
+  if constexpr (policy_has_l2_local<Policy>::value) pol.l2_local = 1;
+  advance_smem<Policy>& ad = sm.adv;
+  int level = h.level;
+  int epoch = 0;
+  bool first = true;                                   // the entering frontier is a tile queue (slots may be -1)
+  int n_in = ((level & 1) ? h.nt1 : h.nt0) * TILE;     // slots to look at
+  int n_priv = 0;                                      // of which in the private regions (levels after the first)
+  int my_pub = 0;                                      // entries of MY region in the current input queue
+  long long my_edges = 0, my_vertices = 0;
+  for (;;) {
+    const int p = level & 1;
+    const int32_t* qin = a.frontier[p];
+    int32_t* qout = a.frontier[p ^ 1];
+    const int4* aux_in = reinterpret_cast<const int4*>(a.mid_aux2) + (size_t)p * MID_AUX2_CAP;
+    int4* aux_out = reinterpret_cast<int4*>(a.mid_aux2) + (size_t)(p ^ 1) * MID_AUX2_CAP;
+    int* ovf_cnt = &c->mid_cnt[(level + 1) % 3];
+    if (w == 0 && tid == 0) __hip_atomic_store(&c->mid_cnt[(level + 2) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    pol.set_level(level);
+    if (tid == 0) { ad.cnt = 0; sm.side_cnt = 0; }
+    __syncthreads();
+    int my_out = 0;     // entries appended to my region this level (uniform)
+    unsigned my_ovf = 0u;
+    // append sm.adv.out[lo .. lo + k) (+ their row start / degree / state) to the next queue.  Block-wide.
+    auto flush = [&](int lo, int k) {
+      int base;
+      if (my_out + k <= MID_SEG) {
+        base = w * MID_SEG + my_out;
+        my_out += k;
+      } else {
+        if (tid == 0) sm.base = __hip_atomic_fetch_add(ovf_cnt, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        base = MID_OVF_BASE + sm.base;
+        my_ovf = 0x80000000u;
+      }
+      for (int i = tid; i < k; i += ADV_BLOCK) {
+        qout[base + i] = ad.out[lo + i];
+        if (base + i < MID_AUX2_CAP) aux_out[base + i] = make_int4(sm.out_rs[lo + i], sm.out_deg[lo + i], sm.out_st[lo + i], 0);
+      }
+      __syncthreads();
+    };
+    const int n_blocks = (n_in + TILE - 1) / TILE;
+    for (int i0 = 0; w + i0 * G < n_blocks; i0 += first ? ADV_BLOCK : 1) {
+      int span = 1;
+      if (first) {
+        const int t = w + (i0 + tid) * G;
+        sm.tcount[tid] = t < n_blocks ? a.tile_count[t] : 0;
+        span = ADV_BLOCK;
+        __syncthreads();
+      }
+      for (int j = 0; j < span; ++j) {
+        const int blk = w + (i0 + j) * G;
+        if (blk >= n_blocks) break;
+        if (first && sm.tcount[j] == 0) continue;  // uniform
+        int v = -1, rs = 0, deg = 0;
+        typename Policy::src_state st{};
+        if (first) {
+          if (tid < sm.tcount[j]) v = qin[blk * TILE + tid];  // tiles are front-packed
+          if (v >= 0) {
+            rs = a.ro[v];
+            deg = a.ro[v + 1] - rs;
+            st = pol.load_source(v);
+          }
+        } else {
+          const int g = blk * TILE + tid;
+          if (g < n_in) {
+            int addr;
+            if (g < n_priv) {
+              int s = 0;
+#pragma unroll
+              for (int step = MID_WGS / 2; step >= 1; step >>= 1)
+                if (sm.seg_pre[s + step] <= g) s += step;
+              addr = s * MID_SEG + (g - sm.seg_pre[s]);
+            } else {
+              addr = MID_OVF_BASE + (g - n_priv);
+            }
+            v = __hip_atomic_load(&qin[addr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (addr < MID_AUX2_CAP) {
+              // 16 bytes written by the producer before its flag: two 8-byte loads past the L1
+              const long long lo8 = __hip_atomic_load(reinterpret_cast<const long long*>(&aux_in[addr]), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+              rs = (int)(lo8 & 0xffffffffll);
+              deg = (int)(lo8 >> 32);
+              bool have = false;
+              if constexpr (CARRY) {
+                if (pol.carry_state()) {
+                  const int sb = __hip_atomic_load(reinterpret_cast<const int*>(&aux_in[addr]) + 2, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                  st = pol.state_from_bits(sb);
+                  have = true;
+                }
+              }
+              if (!have) st = pol.load_source(v);
+            } else {
+              rs = a.ro[v];
+              deg = a.ro[v + 1] - rs;
+              st = pol.load_source(v);
+            }
+          }
+        }
+        int tot;
+        const int ex = dev::block_exclusive_sum<ADV_BLOCK>(deg, ad.wave, &tot);
+        ad.seg[tid] = ex;
+        ad.start[tid] = rs;
+        ad.src[tid] = v;
+        ad.state[tid] = st;
+        if (tid == 0) ad.seg[TILE] = tot;
+        const int n_valid = __syncthreads_count(v >= 0);
+        if (!first) {
+          my_edges += tot;
+          my_vertices += n_valid;
+        }
+        for (int a0 = 0; a0 < tot; a0 += CHUNK) {
+          const int a_end = min(tot, a0 + CHUNK);
+          int e_k[ADV_ITEMS], slot_k[ADV_ITEMS], n_k[ADV_ITEMS], cand_k[ADV_ITEMS];
+#pragma unroll
+          for (int k = 0; k < ADV_ITEMS; ++k) {
+            const int atom = a0 + k * ADV_BLOCK + tid;
+            int lo = 0;
+            if (atom < a_end) {
+#pragma unroll
+              for (int step = TILE / 2; step >= 1; step >>= 1)
+                if (ad.seg[lo + step] <= atom) lo += step;
+              e_k[k] = ad.start[lo] + (atom - ad.seg[lo]);
+            } else {
+              e_k[k] = -1;
+            }
+            slot_k[k] = lo;
+          }
+#pragma unroll
+          for (int k = 0; k < ADV_ITEMS; ++k) n_k[k] = a.ci[e_k[k] >= 0 ? e_k[k] : 0];
+          bool pre_k[ADV_ITEMS];
+#pragma unroll
+          for (int k = 0; k < ADV_ITEMS; ++k) {
+            const bool ok = e_k[k] >= 0;
+            cand_k[k] = 0;
+            bool pass;
+            if constexpr (policy_has_prepare<Policy>::value)
+              pass = pol.prepare(ad.state[slot_k[k]], n_k[k], ok ? e_k[k] : 0, cand_k[k]);
+            else
+              pass = pol.precheck(ad.state[slot_k[k]], n_k[k], ok ? e_k[k] : 0, cand_k[k]);
+            pre_k[k] = pass & ok;
+          }
+          int r1_k[ADV_ITEMS], r2_k[ADV_ITEMS];
+#pragma unroll
+          for (int k = 0; k < ADV_ITEMS; ++k) {
+            r1_k[k] = 0;
+            r2_k[k] = 0;
+            if (pre_k[k]) r1_k[k] = pol.claim(n_k[k], cand_k[k]);
+          }
+          // row offsets of every neighbour (n_k is a valid vertex even where there is no edge), issued behind the
+          // claims: they are on their way while the claims are, and only the accepted ones are used
+          int nrs_k[ADV_ITEMS], nre_k[ADV_ITEMS];
+#pragma unroll
+          for (int k = 0; k < ADV_ITEMS; ++k) {
+            nrs_k[k] = a.ro[n_k[k]];
+            nre_k[k] = a.ro[n_k[k] + 1];
+          }
+          if constexpr (policy_two_claims<Policy>::value) {
+#pragma unroll
+            for (int k = 0; k < ADV_ITEMS; ++k) {
+              const bool need = pre_k[k] & pol.need2(r1_k[k], cand_k[k]);
+              if (need) r2_k[k] = pol.claim2(n_k[k]);
+            }
+          }
+          int code_k[ADV_ITEMS];
+#pragma unroll
+          for (int k = 0; k < ADV_ITEMS; ++k) {
+            code_k[k] = 0;
+            if (pre_k[k]) code_k[k] = pol.code(r1_k[k], r2_k[k], n_k[k], cand_k[k]);
+          }
+#pragma unroll
+          for (int k = 0; k < ADV_ITEMS; ++k) {
+            const bool keep = code_k[k] == 1;
+            const unsigned long long m = dev::ballot(keep);
+            if (m) {
+              int at = 0;
+              if (lane == 0) at = atomicAdd(&ad.cnt, __popcll(m));
+              at = __shfl(at, 0, 64);
+              if (keep) {
+                const int pos = at + dev::mask_rank(m);
+                ad.out[pos] = n_k[k];
+                sm.out_rs[pos] = nrs_k[k];
+                sm.out_deg[pos] = nre_k[k] - nrs_k[k];
+                if constexpr (CARRY) sm.out_st[pos] = cand_k[k];
+                if constexpr (policy_has_accept<Policy>::value) pol.on_accept(n_k[k]);
+              }
+            }
+          }
+          if constexpr (SIDE) {
+#pragma unroll
+            for (int k = 0; k < ADV_ITEMS; ++k) {
+              const bool aside = code_k[k] == 2;
+              const unsigned long long ms = dev::ballot(aside);
+              if (ms) {
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&sm.side_cnt, __popcll(ms));
+                at = __shfl(at, 0, 64);
+                if (aside) sm.side[at + dev::mask_rank(ms)] = n_k[k];
+              }
+            }
+          }
+          __syncthreads();
+          if constexpr (SIDE) {
+            const int sc = sm.side_cnt;
+            if (sc >= ADV_BLOCK) {
+              if (tid == 0) sm.side_base = pol.side_reserve(c, sc);
+              __syncthreads();
+              const int sb = sm.side_base;
+              if (sb >= 0) side_flush(pol, sm.side, sb, sc);
+              __syncthreads();
+              if (tid == 0) sm.side_cnt = 0;
+              __syncthreads();
+            }
+          }
+          int cnt = ad.cnt;
+          if (cnt >= TILE) {  // the last k * TILE entries leave, the first cnt % TILE stay
+            const int k = cnt / TILE;
+            flush(cnt - k * TILE, k * TILE);
+            cnt -= k * TILE;
+          }
+          if (tid == 0) ad.cnt = cnt;
+          __syncthreads();
+        }
+        __syncthreads();  // seg / start / src are rewritten by the next block of slots
+      }
+      __syncthreads();  // tcount is rewritten by the next batch of tile counts
+    }
+    {
+      const int rem = ad.cnt;
+      if (rem > 0) flush(0, rem);
+    }
+    if constexpr (SIDE) {
+      const int sc = sm.side_cnt;
+      if (sc > 0) {
+        if (tid == 0) sm.side_base = pol.side_reserve(c, sc);
+        __syncthreads();
+        const int sb = sm.side_base;
+        if (sb >= 0) side_flush(pol, sm.side, sb, sc);
+        __syncthreads();
+      }
+    }
+    if (!mid_exchange(a, G, w, epoch, (unsigned)my_out | my_ovf, ovf_cnt, sm)) { fail_out(); return; }
+    n_priv = sm.seg_pre[MID_WGS];
+    n_in = n_priv + sm.n_ovf;
+    my_pub = my_out;
+    first = false;
+    ++level;
+    __syncthreads();
+    if (n_in == 0 || n_in > MID_EXIT_V) break;
+  }
+  // ---- leaving
+  if (tid == 0 && (my_edges | my_vertices)) {
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&c->edges_visited), (unsigned long long)my_edges,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&c->vertices_visited), (unsigned long long)my_vertices,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  if (n_in == 0 && !policy_drained_is_done<Policy>::value) {
+    // the bucket is drained, not the search (ctrl.mode stays 3: see the first version)
+    if (w == 0 && tid == 0) {
+      c->n_tiles[level & 1] = 0;
+      c->n_tiles[(level & 1) ^ 1] = 0;
+      c->level = level - 1;
+    }
+    return;
+  }
+  if (n_in == 0) {
+    // every workgroup's counters must have landed before the leader publishes them
+    if (!mid_exchange(a, G, w, epoch, 0u, &c->mid_cnt[0], sm)) { fail_out(); return; }
+    if (w == 0 && tid == 0) {
+      c->done = 1;
+      c->level = level;
+      long long* mb64 = reinterpret_cast<long long*>(a.mailbox + 4);
+      mb64[0] = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&c->edges_visited), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+      mb64[1] = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&c->vertices_visited), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+      mb64[2] = (long long)wall_clock64() - c->t_start;
+      a.mailbox[1] = level;
+      __threadfence_system();
+      a.mailbox[0] = 1;
+    }
+    return;
+  }
+  // ---- hand the queue of `level` back as tiles: the regions ARE tiles already (MID_SEG_TILES per region, the unused
+  // ones empty), the overflow area follows them; only the metadata and the padding of the last tile are missing
+  {
+    const int p = level & 1;
+    int32_t* q = a.frontier[p];
+    const int n_ovf = n_in - n_priv;
+    auto one_tile = [&](int t, int n_t) {  // n_t > 0 valid entries at the front of tile t.  Block-wide.
+      const int slot = t * TILE + tid;
+      int v = -1;
+      if (tid < n_t) v = __hip_atomic_load(&q[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else q[slot] = -1;
+      int deg = 0;
+      if (v >= 0) deg = a.ro[v + 1] - a.ro[v];
+      int tot;
+      (void)dev::block_exclusive_sum<ADV_BLOCK>(deg, ad.wave, &tot);
+      if (tid == 0) {
+        a.tile_sums[t] = tot;
+        a.tile_chunks[t] = (tot + CHUNK - 1) / CHUNK;
+        a.tile_count[t] = n_t;
+      }
+    };
+    const int my_tiles = (my_pub + TILE - 1) / TILE;
+    for (int j = 0; j < my_tiles; ++j) one_tile(w * MID_SEG_TILES + j, min(TILE, my_pub - j * TILE));
+    // empty tiles: the rest of my region, and the regions nobody owns
+    for (int r = w; r < MID_WGS; r += G) {
+      const int j0 = r == w ? my_tiles : 0;
+      if (tid >= j0 && tid < MID_SEG_TILES) {
+        const int t = r * MID_SEG_TILES + tid;
+        a.tile_sums[t] = 0;
+        a.tile_chunks[t] = 0;
+        a.tile_count[t] = 0;
+      }
+    }
+    const int ovf_tiles = (n_ovf + TILE - 1) / TILE;
+    for (int i = w; i < ovf_tiles; i += G) one_tile(MID_WGS * MID_SEG_TILES + i, min(TILE, n_ovf - i * TILE));
+    if (w == 0 && tid == 0) {
+      c->n_tiles[p] = MID_WGS * MID_SEG_TILES + ovf_tiles;
+      c->n_tiles[p ^ 1] = 0;
+      c->level = level - 1;  // the next head plans `level`
+    }
+  }
+}
+
+// the body the host asked for (pipe_args::mid_version; the first version stays selectable for A/B runs: GRX_MID_VERSION=1)
+template <class Policy>
+__device__ __forceinline__ void mid_levels_run(const pipe_args& a, ctrl_t* c, Policy& pol, mid_smem<Policy>& sm,
+                                               const level_head& h, uint32_t xcc_mask) {
+  if (a.mid_version == 2) mid_levels_body2(a, c, pol, sm, h, xcc_mask);
+  else mid_levels_body(a, c, pol, sm, h, xcc_mask);
 }
 
 }  // namespace grx

@@ -50,6 +50,9 @@ struct sssp_policy {
   __device__ __forceinline__ src_state load_source(int v) const {
     return __hip_atomic_load(&dist[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // equal weights: the label a vertex is claimed with is final, so it travels with the queue entry (grx_mid.hpp)
+  __device__ __forceinline__ bool carry_state() const { return uniform != 0; }
+  __device__ __forceinline__ src_state state_from_bits(int b) const { return __int_as_float(b); }
   __device__ __forceinline__ float edge_weight(int e) const { return w ? w[e] : 1.0f; }
   static constexpr bool two_claims = true;
   __device__ __forceinline__ bool precheck(src_state d_src, int n, int e, int& cand) const {
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, s
   }
   pol.begin(c);
   if (h.mode == 3) {  // many iterations inside the current bucket, in this one launch
-    mid_levels_body(a, c, pol, msm, h, xcc_mask);
+    mid_levels_run(a, c, pol, msm, h, xcc_mask);
     return;
   }
   advance_block<sssp_nf_policy, false>(a, c, pol, sm, h.level & 1, blockIdx.x, gridDim.x, h.total_chunks,
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_level_kernel(pipe_args a, sssp
   const level_head h = load_level_head(c);
   if (h.done) return;
   if (h.mode == 3) {
-    mid_levels_body(a, c, pol, sm, h, xcc_mask);
+    mid_levels_run(a, c, pol, sm, h, xcc_mask);
     return;
   }
   pol.begin(c);

@@ -1,5 +1,5 @@
 """A/B runs of the BFS engine's tuning knobs in ONE process (one graph build):
-    python tools/ab_bfs.py [lj|kron] [group ...]      groups: do td knobs bin
+    python tools/ab_bfs.py [lj|kron] [group ...]      groups: do td knobs bin bin2 claim
 Every configuration is checked against the first one's depths.  Prints one line per
 configuration: wall ms per BFS (reset + enact, median), enact ms (events), per-level profile."""
 import os
@@ -23,7 +23,7 @@ ctx = gr.multi_context_t(0)
 G = gr.build_graph(props, csr, ctx)
 V = G.get_number_of_vertices()
 d = torch.empty(V, dtype=torch.int32, device="cuda")
-KNOBS = ("GRX_BIN_MAX_DEGREE", "GRX_TD_BITMAP", "GRX_TD_PRE", "GRX_TD_BIN", "GRX_BIN_MIN_EDGES", "GRX_LEVEL_MINW", "GRX_BU_BATCH", "GRX_DO_ALPHA", "GRX_DO_BETA", "GRX_DO_BACK_DIV", "GRX_LEVEL_WG_PER_CU", "GRX_PACE_DEPTH")
+KNOBS = ("GRX_BIN_CLAIM", "GRX_MID_VERSION", "GRX_BIN_MAX_DEGREE", "GRX_TD_BITMAP", "GRX_TD_PRE", "GRX_TD_BIN", "GRX_BIN_MIN_EDGES", "GRX_LEVEL_MINW", "GRX_BU_BATCH", "GRX_DO_ALPHA", "GRX_DO_BETA", "GRX_DO_BACK_DIV", "GRX_LEVEL_WG_PER_CU", "GRX_PACE_DEPTH")
 ref = None
 
 
@@ -100,3 +100,9 @@ if "bin2" in groups:
     run("TD round-1 body (no bitmap)", gr.forward, env={"GRX_TD_BITMAP": 0})
     run("TD bins, default rule", gr.forward)
     run("TD bins, every fat level", gr.forward, env={"GRX_BIN_MAX_DEGREE": 0})
+if "claim" in groups:
+    # claim phase of the binned levels: slices claimed in the owning XCD's L2 (round-2 first version) vs the sweep
+    run("TD bins, slice claim (v2)", gr.forward, env={"GRX_BIN_CLAIM": 2})
+    run("TD bins, sweep claim (v3)", gr.forward, env={"GRX_BIN_CLAIM": 3})
+    run("TD bins, sweep, every fat level", gr.forward, env={"GRX_BIN_CLAIM": 3, "GRX_BIN_MAX_DEGREE": 0})
+    run("TD bins, sweep, mid v1", gr.forward, env={"GRX_BIN_CLAIM": 3, "GRX_MID_VERSION": 1})

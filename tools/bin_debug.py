@@ -42,8 +42,16 @@ for phase, lo in (("scatter", 0), ("claim", 4096)):
         q = r[r[:, 0] == x]
         dur = (q[:, 3] - q[:, 2]) * tick_us
         extra = ""
-        if phase == "claim":
+        if phase == "claim" and os.environ.get("GRX_BIN_CLAIM", "3") == "2":
             extra = " entries %d bitmap words %d queue items %d dense %s" % (q[:, 4].sum(), q[:, 5].sum(), q[0, 6], set(q[:, 7].tolist()))
+        elif phase == "claim":
+            # sweep claim: [6] = clock after the candidate pass, [7] = after the word claims (single-item workgroups)
+            one = q[q[:, 1] == 1]
+            if len(one):
+                extra = " entries %d (max %d) words %d | 1-item wgs: stream %.1f claim %.1f expand %.1f us (means), slowest %.1f us with %d entries / %d words" % (
+                    q[:, 4].sum(), q[:, 4].max(), q[:, 5].sum(), ((one[:, 6] - one[:, 2]) * tick_us).mean(),
+                    ((one[:, 7] - one[:, 6]) * tick_us).mean(), ((one[:, 3] - one[:, 7]) * tick_us).mean(),
+                    ((one[:, 3] - one[:, 2]) * tick_us).max(), one[np.argmax(one[:, 3] - one[:, 2]), 4], one[np.argmax(one[:, 3] - one[:, 2]), 5])
         print("  xcc %d: %4d wgs, work units %6d, start %.1f..%.1f end %.1f..%.1f us, busy mean %.1f max %.1f%s"
               % (x, len(q), q[:, 1].sum(), (q[:, 2].min() - t0) * tick_us, (q[:, 2].max() - t0) * tick_us,
                  (q[:, 3].min() - t0) * tick_us, (q[:, 3].max() - t0) * tick_us, dur.mean(), dur.max(), extra))
