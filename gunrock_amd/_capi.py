@@ -130,6 +130,7 @@ def lib():
         "grx_bfs_dist_capture_group": (i32, [vp]),
         "grx_bfs_dist_group_is_captured": (i32, [vp]),
         "grx_debug_read": (i32, [vp, vp, i64]),
+        "grx_debug_ctrl": (i32, [vp, vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here == header/library mismatch

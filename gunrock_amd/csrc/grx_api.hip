@@ -121,6 +121,8 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   // the second version lays MID_WGS private regions + an overflow area of up to V entries over a parity buffer
   const char* mv = getenv("GRX_MID_VERSION");
   a->mid_version = (mv && *mv == '1') ? 1 : 2;
+  const char* md = getenv("GRX_MID_DEBUG");
+  if (md && *md == '1') a->mid_version |= 0x100;  // per-phase clock sums in ctrl.spare (grx_debug_ctrl)
   if ((size_t)MID_OVF_BASE + V + TILE > max_tiles * TILE || (size_t)MID_WGS * MID_SEG_TILES + V / TILE + 2 > max_tiles) a->mid_version = 1;
   return GRX_SUCCESS;
 }

@@ -467,6 +467,17 @@ static int level_grid(grx_context_t ctx, grx_graph_t g, level_build* lb) {
   return full < resident ? full : resident;
 }
 
+// tuning aid: the control block's spare counters as they are on the device now (GRX_MID_DEBUG=1: per-phase clock sums
+// of the multi-level body, grx_mid.hpp)
+extern "C" grx_status_t grx_debug_ctrl(grx_context_t ctx, int32_t* out, int32_t n) {
+  if (!ctx || !out || n < 1 || n > 5) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_debug_ctrl: 1..5 counters");
+  GRX_HIP(hipStreamSynchronize(ctx->stream));
+  ctrl_t h;
+  GRX_HIP(hipMemcpy(&h, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) out[i] = h.spare[i];
+  return GRX_SUCCESS;
+}
+
 // tuning aid: copy `n` 64-bit words of the context's debug scratch (GRX_BIN_DEBUG) to the host
 extern "C" grx_status_t grx_debug_read(grx_context_t ctx, long long* out, int64_t n) {
   if (!ctx || !out || !ctx->far[1].ptr || (size_t)n * sizeof(long long) > ctx->far[1].bytes)
@@ -627,13 +638,12 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.nb = g->bin_nb;
     bn.xcc_mask = ctx->xcc_mask;
     bn.n_xcd = ctx->n_xcd;
-    // A binned level pays one scattered L2 access per id that is new to its 8192-entry slice.  When a few
-    // thousand hubs are expanded into a mostly unvisited graph (the level right after the source's) nearly every
-    // entry is such an id and the claim-per-edge advance is as fast or faster (kron stand-in, 148 M-edge level:
-    // 1.31 ms vs 1.52 ms binned); once the frontier is wide most ids are already visited and are dropped in LDS
-    // (LJ stand-in 36 M-edge level: 0.56 -> 0.30 ms; kron 33 M-edge level: 0.34 -> 0.24 ms).  The frontier's
-    // mean out-degree separates the two cases on both graphs.
-    bn.max_degree = env_int("GRX_BIN_MAX_DEGREE", 512);
+    // The slice-wise claim (GRX_BIN_CLAIM=2) pays one scattered L2 access per id that is new to its 8192-entry
+    // slice: when a few thousand hubs are expanded into a mostly unvisited graph nearly every entry is such an id and
+    // the claim-per-edge advance was as fast or faster (kron stand-in, 148 M-edge level: 1.31 ms vs 1.52 ms binned),
+    // hence a limit on the frontier's mean out-degree for that version.  The sweep claim pays per DISCOVERED VERTEX
+    // and wins on that level too (1.45 -> 0.80 ms): no limit.
+    bn.max_degree = env_int("GRX_BIN_MAX_DEGREE", claim_version == 2 ? 512 : 0);
     bn.debug_level = env_int("GRX_BIN_DEBUG", 0);
     if (bn.debug_level != 0) {
       // per-workgroup records of the LAST binned level: scatter at [0, 4096), claim at [4096 + grid, ...); read

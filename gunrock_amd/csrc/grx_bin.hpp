@@ -67,15 +67,19 @@ struct bin_args {
 };
 
 struct bin_scatter_smem {
-  int seg[BIN_BATCH][TILE + 1];
-  int start[BIN_BATCH][TILE];
+  int dlt[BIN_BATCH][TILE];        // per staged slot: row start - exclusive degree prefix (edge = atom + dlt[owner])
+  int wtot[BIN_BATCH][ADV_BLOCK / 64];
+  int wmax[BIN_BATCH][ADV_BLOCK / 64];
   int wave[ADV_BLOCK / 64 + 1];
   int hist[BIN_MAX];
   int off[BIN_MAX];
   int delta[BIN_MAX];
   unsigned g2b[BIN_GRAN_MAX / 4];
+  // the sorted ids of a batch; before that, its first 8 KB hold the OWNER MAP of the batch: one byte per atom
+  // (edge slot) of the four chunks = the staged slot the atom belongs to
   int sorted[BIN_BATCH * CHUNK];
 };
+static_assert(TILE <= 256, "owner map entries are bytes");
 
 __device__ __forceinline__ int bin_of(const unsigned* s_g2b, int n, int gshift) {
   const unsigned g = (unsigned)n >> gshift;
@@ -97,6 +101,14 @@ __device__ __forceinline__ void bin_scatter_block(const pipe_args& a, const bin_
   const bool dbg = bn.debug && a.ctrl->level == bn.debug_level;
   const long long dbg_t0 = dbg ? (long long)wall_clock64() : 0ll;
   int dbg_batches = 0;
+  long long dbg_ph[7] = {0, 0, 0, 0, 0, 0, 0}, dbg_t = dbg_t0;  // front wait | (4: degree scans, 5: owner search, 6: column indices arrive) histogram | reserve + scan + sort | copy-out
+  auto dbg_mark = [&](int i) {
+    if (dbg) {
+      const long long now = (long long)wall_clock64();
+      dbg_ph[i] += now - dbg_t;
+      dbg_t = now;
+    }
+  };
   // SOFTWARE PIPELINE of the front of a batch.  Chunk descriptors -> frontier slots -> row offsets are three
   // DEPENDENT round trips; issued in one place they serialise (first version: ~27 us per batch, of which the
   // sort itself is a few).  Here iteration i issues the row-offset loads of batch i + 1, the frontier-slot loads
@@ -144,34 +156,116 @@ __device__ __forceinline__ void bin_scatter_block(const pipe_args& a, const bin_
     S2(tl2, v2);
     S1(t + 3, tl3);
     __syncthreads();
-    int tot[BIN_BATCH];
+    dbg_mark(0);
+    // --- owner of every atom (edge slot) of the four chunks.  The first version searched the degree prefix per
+    // atom (8 dependent LDS probes each: 12 of the 26 us a batch took on the LJ stand-in's fat level).  Here the
+    // slots mark where their rows begin in a byte map of the chunk and a running maximum fills the gaps: one
+    // 8-byte read-modify-write per thread and chunk, then one byte + one word per atom.
+    int tot[BIN_BATCH], ex_c[BIN_BATCH];
+    const int lane = dev::lane_id();
+    const int wid = tid >> 6;
+    {
+      int inc[BIN_BATCH];
+#pragma unroll
+      for (int j = 0; j < BIN_BATCH; ++j) inc[j] = dev::wave_inclusive_sum(dg_c[j]);
+      if (lane == 63) {
+#pragma unroll
+        for (int j = 0; j < BIN_BATCH; ++j) sm.wtot[j][wid] = inc[j];
+      }
+      unsigned char* own0 = reinterpret_cast<unsigned char*>(sm.sorted);
+#pragma unroll
+      for (int j = 0; j < BIN_BATCH; ++j) reinterpret_cast<uint2*>(own0 + j * CHUNK)[tid] = make_uint2(0u, 0u);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < BIN_BATCH; ++j) {
+        int base = 0, t_all = 0;
+#pragma unroll
+        for (int i = 0; i < ADV_BLOCK / 64; ++i) {
+          const int x = sm.wtot[j][i];
+          if (i < wid) base += x;
+          t_all += x;
+        }
+        tot[j] = t_all;
+        ex_c[j] = base + inc[j] - dg_c[j];
+        sm.dlt[j][tid] = rs_c[j] - ex_c[j];
+      }
+    }
+    unsigned char* own = reinterpret_cast<unsigned char*>(sm.sorted);
 #pragma unroll
     for (int j = 0; j < BIN_BATCH; ++j) {
-      const int ex = dev::block_exclusive_sum<ADV_BLOCK>(dg_c[j], sm.wave, &tot[j]);
-      sm.seg[j][tid] = ex;
-      sm.start[j][tid] = rs_c[j];
-      if (tid == 0) sm.seg[j][TILE] = tot[j];
+      if (tl_c[j].y >= 0 && dg_c[j] > 0) {
+        const int pos = ex_c[j] - tl_c[j].y * CHUNK;  // where this slot's row begins inside the chunk's window
+        if (pos > 0) {
+          if (pos < CHUNK) own[j * CHUNK + pos] = (unsigned char)tid;
+        } else if (pos + dg_c[j] > 0) {
+          own[j * CHUNK] = (unsigned char)tid;  // the one row that is under way where the window begins
+        }
+      }
     }
     __syncthreads();
+    dbg_mark(4);
+    {
+      unsigned m_k[BIN_BATCH][8];
+      int excl[BIN_BATCH];
+#pragma unroll
+      for (int j = 0; j < BIN_BATCH; ++j) {
+        const uint2 w8 = reinterpret_cast<const uint2*>(own + j * CHUNK)[tid];
+        unsigned run = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned b = ((i < 4 ? w8.x : w8.y) >> ((i & 3) * 8)) & 0xffu;
+          run = b > run ? b : run;
+          m_k[j][i] = run;
+        }
+        int inc = (int)run;  // inclusive running maximum across the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int y = __shfl_up(inc, o, 64);
+          if (lane >= o) inc = y > inc ? y : inc;
+        }
+        const int up = __shfl_up(inc, 1, 64);
+        excl[j] = lane == 0 ? 0 : up;
+        if (lane == 63) sm.wmax[j][wid] = inc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < BIN_BATCH; ++j) {
+        unsigned carry = (unsigned)excl[j];
+#pragma unroll
+        for (int i = 0; i < ADV_BLOCK / 64; ++i) {
+          const unsigned x = (unsigned)sm.wmax[j][i];
+          if (i < wid && x > carry) carry = x;
+        }
+        uint2 r8 = make_uint2(0u, 0u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned v = m_k[j][i] > carry ? m_k[j][i] : carry;
+          if (i < 4) r8.x |= v << (i * 8);
+          else r8.y |= v << ((i - 4) * 8);
+        }
+        reinterpret_cast<uint2*>(own + j * CHUNK)[tid] = r8;
+      }
+      __syncthreads();
+    }
     int n_k[BIN_BATCH][ADV_ITEMS], r_k[BIN_BATCH][ADV_ITEMS];
 #pragma unroll
     for (int j = 0; j < BIN_BATCH; ++j) {
       const int a0 = tl_c[j].y * CHUNK;
-      const int a_end = tl_c[j].y >= 0 ? min(tot[j], a0 + CHUNK) : 0;
+      const int n_at = tl_c[j].y >= 0 ? min(tot[j] - a0, CHUNK) : 0;  // atoms of this chunk
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) {
-        const int atom = a0 + k * ADV_BLOCK + tid;
+        const int al = k * ADV_BLOCK + tid;
         int e = -1;
-        if (tl_c[j].y >= 0 && atom < a_end) {
-          int lo = 0;
-#pragma unroll
-          for (int step = TILE / 2; step >= 1; step >>= 1)
-            if (sm.seg[j][lo + step] <= atom) lo += step;
-          e = sm.start[j][lo] + (atom - sm.seg[j][lo]);
-        }
+        if (al < n_at) e = a0 + al + sm.dlt[j][own[j * CHUNK + al]];
         r_k[j][k] = e;  // >= 0: a real edge
         n_k[j][k] = a.ci[e >= 0 ? e : 0];  // lanes past the end read edge 0
       }
+    }
+    if (dbg) {  // (debug runs only: split the phase at the points where the LDS searches / the loads have completed)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      dbg_mark(5);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      dbg_mark(6);
     }
     // bin + rank inside the bin, packed as (bin << 16 | rank): rank < 8192
 #pragma unroll
@@ -183,6 +277,7 @@ __device__ __forceinline__ void bin_scatter_block(const pipe_args& a, const bin_
           r_k[j][k] = (b << 16) | atomicAdd(&sm.hist[b], 1);
         }
     __syncthreads();
+    dbg_mark(1);
     // one reservation per non-empty bin, issued ahead of the scan so that its round trip overlaps
     const int cnt = sm.hist[tid];
     int gbase = 0;
@@ -199,6 +294,7 @@ __device__ __forceinline__ void bin_scatter_block(const pipe_args& a, const bin_
       for (int k = 0; k < ADV_ITEMS; ++k)
         if (r_k[j][k] >= 0) sm.sorted[sm.off[r_k[j][k] >> 16] + (r_k[j][k] & 0xffff)] = n_k[j][k];
     __syncthreads();
+    dbg_mark(2);
     for (int i = tid; i < btot; i += ADV_BLOCK) {
       const int n = sm.sorted[i];
       bn.bins[(size_t)(sm.delta[bin_of(sm.g2b, n, gshift)] + i)] = n;
@@ -210,6 +306,7 @@ __device__ __forceinline__ void bin_scatter_block(const pipe_args& a, const bin_
       rs0[j] = rs1[j]; re0[j] = re1[j];
     }
     __syncthreads();
+    dbg_mark(3);
   }
   if (dbg && tid == 0) {
     long long* d = bn.debug + 8 * (size_t)blockIdx.x;
@@ -217,6 +314,10 @@ __device__ __forceinline__ void bin_scatter_block(const pipe_args& a, const bin_
     d[1] = dbg_batches;
     d[2] = dbg_t0;
     d[3] = (long long)wall_clock64();
+    d[4] = dbg_ph[0];
+    d[5] = dbg_ph[1] | (dbg_ph[4] << 40) | (dbg_ph[5] << 20);  // histogram | degree scans | owner search (ticks < 2^20)
+    d[6] = dbg_ph[2] | (dbg_ph[6] << 40);                         // reserve + scan + sort | column indices arrive
+    d[7] = dbg_ph[3];
   }
 }
 
@@ -405,7 +506,7 @@ __device__ __forceinline__ void bin_claim_block(const pipe_args& a, const bin_ar
 // Tiles are reserved exactly (one atomic per emission of up to 33 tiles); a workgroup carries its partial tile
 // from item to item and emits at most one short tile at the end.
 constexpr int SWEEP_BLOCK = 1024;
-constexpr int SWEEP_PART = 1 << 17;
+constexpr int SWEEP_PART_MIN = 1 << 15;  // a bin with more candidates than total / 160 (at least this many) is claimed in parts
 constexpr int SWEEP_SEG_WORDS = 256;
 constexpr int SWEEP_LIST = SWEEP_SEG_WORDS * 32 + TILE;
 constexpr int SWEEP_PASSES = (SWEEP_LIST + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
@@ -474,6 +575,11 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
   long long dbg_items = 0, dbg_entries = 0, dbg_words = 0, dbg_tA = 0, dbg_tB = 0;
   int fill = 0;
   if (tid < bn.nb) fill = bn.fill[tid * BIN_PAD];
+  // part size: about as many work items as there are CUs (one workgroup of this size is resident per CU), none much
+  // heavier than the average -- bins have about equal CAPACITIES, but what a level sends them differs
+  int tot_fill;
+  (void)dev::block_exclusive_sum<SWEEP_BLOCK>(fill, sm.wave, &tot_fill);
+  const int SWEEP_PART = max(SWEEP_PART_MIN, ((tot_fill / 160) + 3) & ~3);
   int tot_items;
   const int ex0 = dev::block_exclusive_sum<SWEEP_BLOCK>((fill + SWEEP_PART - 1) / SWEEP_PART, sm.wave, &tot_items);
   if (tid < BIN_MAX) {
@@ -563,13 +669,26 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
     }
     __syncthreads();
     if (dbg) dbg_tB += (long long)wall_clock64();
-    // C. new bits -> ascending vertex ids -> labels, tiles
+    // C. new bits -> ascending vertex ids -> labels, tiles.  The list is emitted when the next 256 words might not fit
+    // and at the end of the item: one reservation and one round of row-offset loads for up to 33 tiles.
+    auto emit_list = [&]() {
+      const int k = n_list / TILE;
+      sweep_emit_full(a, c, q, sm, k);
+      const int rem = n_list - k * TILE;
+      int keep = 0;
+      if (tid < rem) keep = sm.list[k * TILE + tid];
+      __syncthreads();
+      if (tid < rem) sm.list[tid] = keep;
+      n_list = rem;
+      __syncthreads();
+    };
     for (int s0 = 0; s0 < words; s0 += SWEEP_SEG_WORDS) {
       const int w = s0 + (tid >> 2);
       unsigned byte = w < words ? (sm.bm[w] >> ((tid & 3) * 8)) & 0xffu : 0u;
       int tot;
       const int ex = dev::block_exclusive_sum<SWEEP_BLOCK>(__popc(byte), sm.wave, &tot);
       if (tot == 0) continue;
+      if (n_list + tot > SWEEP_LIST) emit_list();  // n_list >= TILE here: tot <= SWEEP_LIST - TILE
       int pos = n_list + ex;
       const int v_first = vbase + (w << 5) + (tid & 3) * 8;
       while (byte) {
@@ -580,18 +699,8 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
       }
       n_list += tot;
       __syncthreads();
-      if (n_list >= TILE) {
-        const int k = n_list / TILE;
-        sweep_emit_full(a, c, q, sm, k);
-        const int rem = n_list - k * TILE;
-        int keep = 0;
-        if (tid < rem) keep = sm.list[k * TILE + tid];
-        __syncthreads();
-        if (tid < rem) sm.list[tid] = keep;
-        n_list = rem;
-        __syncthreads();
-      }
     }
+    if (n_list >= TILE) emit_list();
   }
   if (n_list > 0) {  // the one short tile of this workgroup
     if (tid == 0) sm.tile_base = atomicAdd(&c->n_tiles[q], 1);

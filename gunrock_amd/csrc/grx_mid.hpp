@@ -576,6 +576,18 @@ __device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, 
   int n_priv = 0;                                      // of which in the private regions (levels after the first)
   int my_pub = 0;                                      // entries of MY region in the current input queue
   long long my_edges = 0, my_vertices = 0;
+  // tuning aid (GRX_MID_DEBUG=1): wall-clock ticks the leader spends per phase, summed over the levels of the launch ->
+  // ctrl.spare[0..3] {input staged | column indices + claims + compaction | flush | exchange}, spare[4] += levels
+  const bool dbg = (a.mid_version & 0x100) != 0 && w == 0 && tid == 0;
+  long long dbg_ph[4] = {0, 0, 0, 0}, dbg_t = dbg ? (long long)wall_clock64() : 0ll;
+  int dbg_levels = 0;
+  auto dbg_mark = [&](int i) {
+    if (dbg) {
+      const long long now = (long long)wall_clock64();
+      dbg_ph[i] += now - dbg_t;
+      dbg_t = now;
+    }
+  };
   for (;;) {
     const int p = level & 1;
     const int32_t* qin = a.frontier[p];
@@ -674,6 +686,7 @@ __device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, 
         ad.state[tid] = st;
         if (tid == 0) ad.seg[TILE] = tot;
         const int n_valid = __syncthreads_count(v >= 0);
+        dbg_mark(0);
         if (!first) {
           my_edges += tot;
           my_vertices += n_valid;
@@ -781,6 +794,7 @@ __device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, 
               __syncthreads();
             }
           }
+          dbg_mark(1);
           int cnt = ad.cnt;
           if (cnt >= TILE) {  // the last k * TILE entries leave, the first cnt % TILE stay
             const int k = cnt / TILE;
@@ -808,7 +822,10 @@ __device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, 
         __syncthreads();
       }
     }
+    dbg_mark(2);
     if (!mid_exchange(a, G, w, epoch, (unsigned)my_out | my_ovf, ovf_cnt, sm)) { fail_out(); return; }
+    dbg_mark(3);
+    ++dbg_levels;
     n_priv = sm.seg_pre[MID_WGS];
     n_in = n_priv + sm.n_ovf;
     my_pub = my_out;
@@ -818,6 +835,10 @@ __device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, 
     if (n_in == 0 || n_in > MID_EXIT_V) break;
   }
   // ---- leaving
+  if (dbg) {
+    for (int i = 0; i < 4; ++i) atomicAdd(&c->spare[i], (int)dbg_ph[i]);
+    atomicAdd(&c->spare[4], dbg_levels);
+  }
   if (tid == 0 && (my_edges | my_vertices)) {
     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&c->edges_visited), (unsigned long long)my_edges,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -898,7 +919,7 @@ __device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, 
 template <class Policy>
 __device__ __forceinline__ void mid_levels_run(const pipe_args& a, ctrl_t* c, Policy& pol, mid_smem<Policy>& sm,
                                                const level_head& h, uint32_t xcc_mask) {
-  if (a.mid_version == 2) mid_levels_body2(a, c, pol, sm, h, xcc_mask);
+  if ((a.mid_version & 0xff) == 2) mid_levels_body2(a, c, pol, sm, h, xcc_mask);
   else mid_levels_body(a, c, pol, sm, h, xcc_mask);
 }
 

@@ -233,6 +233,9 @@ grx_status_t grx_get_level_profile(grx_context_t ctx, grx_level_profile_t* out,
 /* Tuning aid: copies `n` 64-bit words of the context's debug scratch (per-workgroup timeline of the binned BFS
  * kernels, recorded when GRX_BIN_DEBUG=<level> is set; tools/bin_debug.py). */
 grx_status_t grx_debug_read(grx_context_t ctx, long long* out, int64_t n);
+/* Tuning aid: the first n (<= 5) spare counters of the device control block (GRX_MID_DEBUG=1: wall-clock ticks the
+ * leader of a multi-level launch spent per phase, and the levels it ran; tools/ab_mid.py). */
+grx_status_t grx_debug_ctrl(grx_context_t ctx, int32_t* out, int32_t n);
 
 /* ---- multi-GPU: level-group interface of the partitioned BFS enactor ------------------
  * The reference has no multi-GPU execution (every operator throws when

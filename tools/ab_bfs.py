@@ -62,8 +62,8 @@ def run(label, direction, variant=0, env=None, reps=15, profile=True):
             t = sum(l["advance_ms"] for l in prof)
             if best is None or t < best[0]:
                 best = (t, prof)
-        lv = " ".join("%d/%d:%s%.0f" % (l["frontier_size"], l["edges"], {0: "T", 1: "B", 2: "N"}.get(l.get("bottom_up"), "?"),
-                                        l["advance_ms"] * 1e3) for l in best[1])
+        lv = " ".join("%d/%d:%s%.0f+h%.0f" % (l["frontier_size"], l["edges"], {0: "T", 1: "B", 2: "N", 3: "M"}.get(l.get("bottom_up"), "?"),
+                                              l["advance_ms"] * 1e3, l["other_ms"] * 1e3) for l in best[1])
     walls.sort()
     enacts.sort()
     print("%-34s wall med %.3f min %.3f | enact med %.3f min %.3f | GTEPS %.1f | same %s | groups %s | %s"

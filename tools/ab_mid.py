@@ -16,6 +16,17 @@ runs = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 wl = WORKLOADS["road"]
 src = (4894 // 2) * 4894 + 4894 // 2
 ctx = gr.multi_context_t(0)
+import ctypes as C  # noqa: E402
+from gunrock_amd import _capi  # noqa: E402
+
+
+def spare():
+    out = (C.c_int32 * 5)()
+    _capi.check(_capi.lib().grx_debug_ctrl(ctx._h, out, 5))
+    return np.array(list(out), dtype=np.int64)
+
+
+DEBUG = os.environ.get("GRX_MID_DEBUG") == "1"
 for algo in ("bfs", "ssspu", "sssp"):
     if algo == "sssp":
         props, csr = gr.generate("road", wl["V"], 0, wl["a"], 0.0, 1.0, seed=42)
@@ -34,7 +45,15 @@ for algo in ("bfs", "ssspu", "sssp"):
         d = torch.empty(V, dtype=torch.int32 if algo == "bfs" else torch.float32, device="cuda")
         times = []
         for _ in range(runs):
+            s0 = spare() if DEBUG else None
             times.append(gr.bfs(G, src, d, None, ctx, o) if algo == "bfs" else gr.sssp(G, src, d, None, ctx, o))
+            if DEBUG and label == "mid v2":
+                ds = spare() - s0
+                if algo == "bfs":
+                    ds[0] += s0[0]  # the BFS seed kernel zeroes spare[0]
+                lv = max(1, int(ds[4]))
+                print("   phases, us per level over %d levels in multi-level launches: staged %.2f | ci+claims+compaction %.2f | flush %.2f | exchange %.2f"
+                      % (lv, ds[0] * 0.01 / lv, ds[1] * 0.01 / lv, ds[2] * 0.01 / lv, ds[3] * 0.01 / lv), flush=True)
         st = gr.run_stats(ctx)
         h = d.cpu().numpy()
         if ref is None:

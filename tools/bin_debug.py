@@ -42,6 +42,12 @@ for phase, lo in (("scatter", 0), ("claim", 4096)):
         q = r[r[:, 0] == x]
         dur = (q[:, 3] - q[:, 2]) * tick_us
         extra = ""
+        if phase == "scatter":
+            nb = max(1, q[:, 1].sum())
+            m20 = (1 << 20) - 1
+            parts = (q[:, 4], q[:, 5] >> 40, (q[:, 5] >> 20) & m20, q[:, 6] >> 40, q[:, 5] & m20, q[:, 6] & ((1 << 40) - 1), q[:, 7])
+            extra = " | per batch us: front %.2f scans %.2f search %.2f ci-arrive %.2f hist %.2f reserve+scan+sort %.2f copy-out %.2f" % tuple(
+                x.sum() * tick_us / nb for x in parts)
         if phase == "claim" and os.environ.get("GRX_BIN_CLAIM", "3") == "2":
             extra = " entries %d bitmap words %d queue items %d dense %s" % (q[:, 4].sum(), q[:, 5].sum(), q[0, 6], set(q[:, 7].tolist()))
         elif phase == "claim":
