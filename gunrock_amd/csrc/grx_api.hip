@@ -121,6 +121,10 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   // the second version lays MID_WGS private regions + an overflow area of up to V entries over a parity buffer
   const char* mv = getenv("GRX_MID_VERSION");
   a->mid_version = (mv && *mv == '1') ? 1 : 2;
+  a->mid_seg_cap = MID_SEG;
+  a->mid_exit_v = MID_EXIT_V;
+  if (const char* e = getenv("GRX_MID_SEG_CAP")) { const int x = atoi(e); if (x >= 0 && x <= MID_SEG) a->mid_seg_cap = x; }    // test knobs
+  if (const char* e = getenv("GRX_MID_EXIT_V")) { const int x = atoi(e); if (x >= 1 && x <= MID_EXIT_V) a->mid_exit_v = x; }
   const char* md = getenv("GRX_MID_DEBUG");
   if (md && *md == '1') a->mid_version |= 0x100;  // per-phase clock sums in ctrl.spare (grx_debug_ctrl)
   if ((size_t)MID_OVF_BASE + V + TILE > max_tiles * TILE || (size_t)MID_WGS * MID_SEG_TILES + V / TILE + 2 > max_tiles) a->mid_version = 1;

@@ -83,6 +83,8 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
     c->n_tiles[1] = 0;
     c->n_items[1] = 0;
     c->total_chunks = 0;
+    c->map_chunks = 0;
+    c->map_level = -2;
     c->edges_visited = 0;
     c->vertices_visited = 0;
     c->spare[0] = 0;

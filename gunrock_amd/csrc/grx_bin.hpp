@@ -115,11 +115,17 @@ __device__ __forceinline__ void bin_scatter_block(const pipe_args& a, const bin_
   // of batch i + 2 and the descriptor loads of batch i + 3 -- every one from values that arrived an iteration
   // ago -- together with its own column-index loads: one round trip per batch for all four.
   const int first = (int)blockIdx.x;
+  // The chunk descriptors are the same for the whole workgroup; as SCALAR loads they would be counted in lgkmcnt,
+  // and the barrier a few instructions later (s_waitcnt lgkmcnt(0)) would wait out their full latency in every
+  // batch (measured: 2.6 us of a 26 us batch).  An index the compiler cannot prove uniform keeps them vector loads.
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  const int boff = tid < bn.nb ? bn.off[tid] : 0;  // static offset of bin `tid`
   auto S1 = [&](int t, int2 (&tl)[BIN_BATCH]) {
 #pragma unroll
     for (int j = 0; j < BIN_BATCH; ++j) {
       const long long unit = (long long)first + ((long long)t * BIN_BATCH + j) * stride;  // uniform over the workgroup
-      tl[j] = reinterpret_cast<const int2*>(chunk_tile)[unit < total_chunks ? unit : 0];
+      tl[j] = reinterpret_cast<const int2*>(chunk_tile)[(unit < total_chunks ? unit : 0) + vzero];
       if (unit >= total_chunks) tl[j].y = -1;  // not a chunk of this level: contributes no atoms (its tile is a real one)
     }
   };
@@ -282,17 +288,17 @@ __device__ __forceinline__ void bin_scatter_block(const pipe_args& a, const bin_
     const int cnt = sm.hist[tid];
     int gbase = 0;
     if (cnt > 0) gbase = atomicAdd(&bn.fill[tid * BIN_PAD], cnt);
-    const int boff = tid < bn.nb ? bn.off[tid] : 0;
     int btot;
     const int ex = dev::block_exclusive_sum<ADV_BLOCK>(cnt, sm.wave, &btot);
     sm.off[tid] = ex;
-    sm.delta[tid] = boff + gbase - ex;  // global slot of sorted position i of this bin: delta + i
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < BIN_BATCH; ++j)
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k)
         if (r_k[j][k] >= 0) sm.sorted[sm.off[r_k[j][k] >> 16] + (r_k[j][k] & 0xffff)] = n_k[j][k];
+    sm.delta[tid] = boff + gbase - ex;  // global slot of sorted position i of this bin: delta + i (the reservation's
+                                        // round trip was covered by the sort)
     __syncthreads();
     dbg_mark(2);
     for (int i = tid; i < btot; i += ADV_BLOCK) {
@@ -518,30 +524,63 @@ struct bin_sweep_smem {
   int pre[BIN_MAX + 1];
   int fillv[BIN_MAX];
   int wave[SWEEP_BLOCK / 64 + 1];
-  int sum[SWEEP_LIST / TILE + 1][4];
+  int sum[64][4];       // per tile of an emission (<= 34) and wave of the tile: degree sums
+  int ttot[64];         // per tile: degree sum
+  int cpre[64];         // per tile: chunks of the tiles before it
   int tile_base;
+  int chunk_base;
+  int n_chunks;
 };
+static_assert(SWEEP_LIST / TILE + 1 <= 64, "one lane per tile of an emission");
 
-// emit list[0 .. k * TILE) as k full tiles of parity q.  Block-wide call.
-__device__ __forceinline__ void sweep_emit_full(const pipe_args& a, ctrl_t* c, int q, bin_sweep_smem& sm, int k) {
+// Emit list[0 .. n) as ceil(n / TILE) tiles of parity q (only the last one may be short) AND everything the next
+// head kernel would otherwise have to derive from them: their entries of the chunk map (space reserved with one
+// atomic on ctrl.map_chunks) and their share of the next frontier's vertex / out-edge counts.  Block-wide call.
+__device__ __forceinline__ void sweep_emit(const pipe_args& a, ctrl_t* c, int q, bin_sweep_smem& sm, int n) {
   const int tid = threadIdx.x;
   const int lane = dev::lane_id();
   const int wid = tid >> 6;
+  const int k = (n + TILE - 1) / TILE;
   if (tid == 0) sm.tile_base = atomicAdd(&c->n_tiles[q], k);  // travels together with the degree loads
   int x[SWEEP_PASSES], deg[SWEEP_PASSES];
 #pragma unroll
   for (int j = 0; j < SWEEP_PASSES; ++j) {
     const int idx = j * SWEEP_BLOCK + tid;
-    x[j] = sm.list[idx < k * TILE ? idx : 0];
+    x[j] = idx < n ? sm.list[idx] : -1;
   }
 #pragma unroll
-  for (int j = 0; j < SWEEP_PASSES; ++j) deg[j] = a.ro[x[j] + 1] - a.ro[x[j]];  // unconditional: a valid vertex
+  for (int j = 0; j < SWEEP_PASSES; ++j) {
+    const int xx = x[j] >= 0 ? x[j] : 0;  // unconditional loads from a clamped index
+    deg[j] = a.ro[xx + 1] - a.ro[xx];
+  }
 #pragma unroll
   for (int j = 0; j < SWEEP_PASSES; ++j) {
     const int idx = j * SWEEP_BLOCK + tid;
     if (idx - lane < k * TILE) {  // wave-uniform: tiles are multiples of the wave size
-      const int t = dev::wave_sum(deg[j]);
+      const int t = dev::wave_sum(x[j] >= 0 ? deg[j] : 0);
       if (lane == 0) sm.sum[idx >> 8][wid & 3] = t;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {  // k <= 34 tiles: one lane each
+    int tot = 0, ch = 0;
+    if (lane < k) {
+      tot = sm.sum[lane][0] + sm.sum[lane][1] + sm.sum[lane][2] + sm.sum[lane][3];
+      ch = (tot + CHUNK - 1) / CHUNK;
+    }
+    const int inc = dev::wave_inclusive_sum(ch);
+    long long es = (long long)tot;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) es += __shfl_xor(es, o, 64);
+    sm.ttot[lane] = tot;
+    sm.cpre[lane] = inc - ch;
+    if (lane == 63) {
+      sm.n_chunks = inc;
+      sm.chunk_base = inc > 0 ? atomicAdd(&c->map_chunks, inc) : 0;
+    }
+    if (lane == 0) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(&c->q_edges[q]), (unsigned long long)es);
+      atomicAdd(&c->n_items[q], n);
     }
   }
   __syncthreads();
@@ -553,11 +592,22 @@ __device__ __forceinline__ void sweep_emit_full(const pipe_args& a, ctrl_t* c, i
       const int tix = base + (idx >> 8);
       a.frontier[q][(size_t)tix * TILE + (idx & (TILE - 1))] = x[j];
       if ((idx & (TILE - 1)) == 0) {
-        const int tot = sm.sum[idx >> 8][0] + sm.sum[idx >> 8][1] + sm.sum[idx >> 8][2] + sm.sum[idx >> 8][3];
+        const int tot = sm.ttot[idx >> 8];
         a.tile_sums[tix] = tot;
         a.tile_chunks[tix] = (tot + CHUNK - 1) / CHUNK;
-        a.tile_count[tix] = TILE;
+        a.tile_count[tix] = min(TILE, n - (idx >> 8) * TILE);
       }
+    }
+  }
+  {
+    int2* map = reinterpret_cast<int2*>(a.chunk_tile) + sm.chunk_base;
+    const int nc = sm.n_chunks;
+    for (int ci = tid; ci < nc; ci += SWEEP_BLOCK) {
+      int t = 0;  // largest t with cpre[t] <= ci (tiles without chunks are skipped over): 64 entries, 6 steps
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1)
+        if (t + step < k && sm.cpre[t + step] <= ci) t += step;
+      map[ci] = make_int2(base + t, ci - sm.cpre[t]);
     }
   }
   __syncthreads();
@@ -570,6 +620,7 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
   const int lane = dev::lane_id();
   const int wid = tid >> 6;
   const int q = p ^ 1;
+  if (blockIdx.x == 0 && tid == 0) c->map_level = depth;  // the chunk map and the counters of level `depth` come from this kernel
   const bool dbg = bn.debug && c->level == bn.debug_level;
   const long long dbg_t0 = dbg ? (long long)wall_clock64() : 0ll;
   long long dbg_items = 0, dbg_entries = 0, dbg_words = 0, dbg_tA = 0, dbg_tB = 0;
@@ -673,7 +724,7 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
     // and at the end of the item: one reservation and one round of row-offset loads for up to 33 tiles.
     auto emit_list = [&]() {
       const int k = n_list / TILE;
-      sweep_emit_full(a, c, q, sm, k);
+      sweep_emit(a, c, q, sm, k * TILE);
       const int rem = n_list - k * TILE;
       int keep = 0;
       if (tid < rem) keep = sm.list[k * TILE + tid];
@@ -702,29 +753,7 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
     }
     if (n_list >= TILE) emit_list();
   }
-  if (n_list > 0) {  // the one short tile of this workgroup
-    if (tid == 0) sm.tile_base = atomicAdd(&c->n_tiles[q], 1);
-    int x = -1, deg = 0;
-    if (tid < n_list) {
-      x = sm.list[tid];
-      deg = a.ro[x + 1] - a.ro[x];
-    }
-    if (tid < TILE) {
-      const int t = dev::wave_sum(deg);
-      if (lane == 0) sm.sum[0][wid] = t;
-    }
-    __syncthreads();
-    if (tid < TILE) {
-      const int tix = sm.tile_base;
-      a.frontier[q][(size_t)tix * TILE + tid] = x;
-      if (tid == 0) {
-        const int tot = sm.sum[0][0] + sm.sum[0][1] + sm.sum[0][2] + sm.sum[0][3];
-        a.tile_sums[tix] = tot;
-        a.tile_chunks[tix] = (tot + CHUNK - 1) / CHUNK;
-        a.tile_count[tix] = n_list;
-      }
-    }
-  }
+  if (n_list > 0) sweep_emit(a, c, q, sm, n_list);  // the one short tile of this workgroup
   if (dbg && tid == 0) {
     long long* d = bn.debug + 8 * (4096 + (size_t)blockIdx.x);
     d[0] = (long long)((unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u);

@@ -65,10 +65,10 @@ struct ctrl_t {
   int32_t n_tiles[2];     // frontier tiles (256 slots each) per parity buffer
   int32_t n_items[2];     // valid frontier entries per parity buffer
   int32_t total_chunks;   // advance work items of the current level
-  int32_t pad0;
+  int32_t map_chunks;     // chunk map entries written by the producers of the NEXT frontier (sweep claim, grx_bin.hpp)
   int64_t edges_visited;
   int64_t vertices_visited;
-  int32_t n_hub;          // spare counters for load-balance variants
+  int32_t map_level;      // level whose chunk map / counters (map_chunks, n_items, q_edges) the producers wrote; else the head builds them
   int32_t spare[5];
   // PageRank scalars
   float pr_dsum;

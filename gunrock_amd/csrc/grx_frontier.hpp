@@ -57,6 +57,8 @@ struct pipe_args {
   void* mid_aux2;            // grx_mid.hpp, second version: int4 {row start, degree, state, -} per entry of the private regions, per parity
   unsigned long long* mid_flags;  // second version: 2 x MID_WGS barrier / count words (zeroed by the head kernel that chooses mode 3)
   int32_t mid_version;       // 1 | 2
+  int32_t mid_seg_cap;       // second version: entries of a private region in use (<= MID_SEG; tests shrink it to reach the overflow path)
+  int32_t mid_exit_v;        // second version: a frontier beyond this many vertices goes back to the regular kernels (<= MID_EXIT_V)
 };
 
 // The search is over: final counters and the elapsed device time go to the host-pinned mailbox
@@ -201,6 +203,15 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
         pre += ch;
       }
     }
+  } else if (!external_control && in.bin_min > 0 && c->map_level == level) {
+    // The producers of this frontier (sweep claim of a binned level, grx_bin.hpp) wrote the chunk map and summed the
+    // counters themselves: nothing to walk.  (Planning 8 k tiles / 18 k chunks here took 33 us on the LJ stand-in,
+    // 72 k chunks 63 us on the kron stand-in.)
+    carry = c->map_chunks;
+    if (tid == 0) {
+      esum = c->q_edges[p];
+      vsum = c->n_items[p];
+    }
   } else {
   // Thread t owns the contiguous tiles [t * K, (t + 1) * K), K = ceil(nt / BLOCK): all its loads
   // are independent (issued G at a time), ONE block scan serves the whole level, and a second
@@ -269,6 +280,11 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
                  nt <= 4 * ((nitems + TILE - 1) / TILE) + 256)
           mode = 3;
         c->mode = mode;
+        if (mode == 2) {  // the sweep claim of this level accumulates the next level's counters and chunk map
+          c->map_chunks = 0;
+          c->n_items[p ^ 1] = 0;
+          c->q_edges[p ^ 1] = 0;
+        }
         if (mode == 3) {
           c->mid_bar = 0;
           c->mid_reg = 0u;

@@ -604,7 +604,7 @@ __device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, 
     // append sm.adv.out[lo .. lo + k) (+ their row start / degree / state) to the next queue.  Block-wide.
     auto flush = [&](int lo, int k) {
       int base;
-      if (my_out + k <= MID_SEG) {
+      if (my_out + k <= a.mid_seg_cap) {
         base = w * MID_SEG + my_out;
         my_out += k;
       } else {
@@ -832,7 +832,7 @@ __device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, 
     first = false;
     ++level;
     __syncthreads();
-    if (n_in == 0 || n_in > MID_EXIT_V) break;
+    if (n_in == 0 || n_in > a.mid_exit_v) break;
   }
   // ---- leaving
   if (dbg) {
