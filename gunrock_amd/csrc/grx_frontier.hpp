@@ -239,11 +239,27 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
   }
   int pre = dev::block_exclusive_sum<BLOCK>(mine, s_wave, &carry);
   {
-    // chunk -> {tile, chunk index inside the tile}: ONE 8-byte load per chunk in the level kernel
+    // chunk -> {tile, chunk index inside the tile}: ONE 8-byte load per chunk in the level kernel.
+    // The entries of a tile are written by the 64 lanes of its owner's WAVE together: a tile of hubs has
+    // hundreds to thousands of chunks (the frontier right behind a hub source), and one lane storing them one
+    // after the other made this kernel 30-60 us on the levels where it matters.
     int2* map = reinterpret_cast<int2*>(a.chunk_tile);
-    for (int i = t0; i < t1; ++i) {
-      const int ch = a.tile_chunks[i];
-      for (int j = 0; j < ch; ++j) map[pre + j] = make_int2(i, j);
+    const int lane = dev::lane_id();
+    for (int k = 0; k < K; ++k) {  // K is uniform; lanes past t1 contribute empty tiles
+      const int i = t0 + k;
+      const int ch = i < t1 ? a.tile_chunks[i] : 0;
+      const int any_big = dev::ballot(ch > 4) != 0ull;
+      if (!any_big) {
+        for (int j = 0; j < ch; ++j) map[pre + j] = make_int2(i, j);
+      } else {
+        for (int l = 0; l < 64; ++l) {
+          const int c_l = __shfl(ch, l, 64);
+          if (c_l == 0) continue;  // uniform
+          const int i_l = __shfl(i, l, 64);
+          const int p_l = __shfl(pre, l, 64);
+          for (int j = lane; j < c_l; j += 64) map[p_l + j] = make_int2(i_l, j);
+        }
+      }
       pre += ch;
     }
   }

@@ -8,8 +8,8 @@ kernels of interest are classified by name and by their position inside the sear
 
   bottom_up            bfs_level_kernel launches 1..3 of a direction-optimising search (after a bfs_reset_kernel);
                        per LAUNCH
-  topdown_fat          launches 1 and 2 of a forward search, bfs_level_bin_kernel (+ the bfs_claim_kernel of the same
-                       level when the level ran binned): per LEVEL (= what bench.py's forward profile calls a launch)
+  topdown_fat          launches 1 and 2 of a forward search, bfs_level_bin_kernel (+ the bfs_sweep_kernel / bfs_claim_kernel of
+                       the same level when the level ran binned): per LEVEL (= what bench.py's forward profile calls a launch)
   sssp_unit_weights    all sssp_level_kernel launches of a search; per SEARCH (with many levels per launch the
   sssp_weighted_1_1000 all sssp_nf_level_kernel launches           launch count is not a unit of work)
   pr_pull              pr_pull_xcd_kernel / pr_pull_kernel + pr_long* + pr_combine_kernel launches that did work
@@ -80,7 +80,7 @@ def classify(rows):
                     cls[d] = ("bottom_up", pos)
         elif kind == "bfs":
             lv = [d for d, n in s["kernels"] if "bfs_level_bin_kernel" in n]
-            cl = [d for d, n in s["kernels"] if "bfs_claim_kernel" in n]
+            cl = [d for d, n in s["kernels"] if "bfs_claim_kernel" in n or "bfs_sweep_kernel" in n]
             for pos in (1, 2):
                 if pos < len(lv):
                     cls[lv[pos]] = ("topdown_fat", pos)
