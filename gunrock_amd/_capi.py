@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgrx.so")
+# GRX_LIB_PATH: another build of the same library (A/B runs of tools/, e.g. an older commit); default: the in-tree one
+LIB_PATH = os.environ.get("GRX_LIB_PATH") or os.path.join(_HERE, "libgrx.so")
 
 GRX_SUCCESS = 0
 
@@ -133,6 +134,8 @@ def lib():
         "grx_debug_ctrl": (i32, [vp, vp, i32]),
     }
     for name, (res, args) in sig.items():
+        if name.startswith("grx_debug_") and not hasattr(L, name):
+            continue  # tuning aids: an older build loaded through GRX_LIB_PATH may lack them
         fn = getattr(L, name)  # AttributeError here == header/library mismatch
         fn.restype = res
         fn.argtypes = args

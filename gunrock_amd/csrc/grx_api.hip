@@ -120,7 +120,7 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   a->mid_flags = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->mid_aux.ptr) + aux1 + aux2);
   // the second version lays MID_WGS private regions + an overflow area of up to V entries over a parity buffer
   const char* mv = getenv("GRX_MID_VERSION");
-  a->mid_version = (mv && *mv == '1') ? 1 : 2;
+  a->mid_version = (mv && *mv == '1') ? 1 : 2;  // honoured by builds that carry both bodies (grx_mid.hpp)
   a->mid_seg_cap = MID_SEG;
   a->mid_exit_v = MID_EXIT_V;
   if (const char* e = getenv("GRX_MID_SEG_CAP")) { const int x = atoi(e); if (x >= 0 && x <= MID_SEG) a->mid_seg_cap = x; }    // test knobs

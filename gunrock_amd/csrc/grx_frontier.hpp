@@ -737,7 +737,10 @@ struct policy_stateless<Policy, std::void_t<decltype(Policy::stateless)>> : std:
 template <class Policy>
 struct tiny_smem {
   static constexpr bool STATELESS = policy_stateless<Policy>::value;
-  static constexpr int CAP = 4096;   // frontier vertices resident in LDS
+  // frontier vertices resident in LDS.  3072, not 4096: the head kernels must stay BELOW 64 KB of LDS -- a kernel that
+  // asks for more pays 10-20 us on EVERY launch on this part (measured on sssp_nf_level_kernel: shortest launch 2.8 us
+  // with 51 KB, 13-25 us with 82 KB), and these kernels are launched once per level
+  static constexpr int CAP = 3072;
   static constexpr int ITEMS = 4;    // atoms per thread per pass: one pass covers TINY_EDGES
   static_assert(CAP + 1 >= TINY_MAX_TILES + 1, "seg[] doubles as the tile-offset scratch of the entry gather");
   int buf[2][CAP];
@@ -872,6 +875,9 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
   long long edges_done = 0, vertices_done = 0;
   const long long edges_before = h.edges_visited;
   constexpr int PER = CAP / TINY_THREADS;  // frontier slots per thread in the degree scan
+  static_assert(CAP % TINY_THREADS == 0, "whole slots per thread");
+  constexpr int SEARCH0 = CAP > 2048 ? 2048 : (CAP > 1024 ? 1024 : 512);  // first step of the owner search: largest power of two below CAP
+  static_assert(SEARCH0 < CAP && 2 * SEARCH0 >= CAP, "the steps must reach every slot");
   for (;;) {
     const int* cur = sm.buf[sel];
     int* nxt = sm.buf[sel ^ 1];
@@ -961,7 +967,7 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
         e_k[k] = -1;
         if (atom < m) {
 #pragma unroll
-          for (int step = CAP / 2; step >= 1; step >>= 1)
+          for (int step = SEARCH0; step >= 1; step >>= 1)
             if (lo + step < n && sm.seg[lo + step] <= atom) lo += step;
           e_k[k] = sm.start[lo] + (atom - sm.seg[lo]);
         }

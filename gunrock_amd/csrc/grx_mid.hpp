@@ -38,6 +38,13 @@
 
 namespace grx {
 
+// The bodies are large; GRX_MID_NOINLINE keeps them out of line (experiment: code layout of the launch-bound kernels)
+#ifdef GRX_MID_NOINLINE
+#define GRX_MID_FN __device__ __attribute__((noinline))
+#else
+#define GRX_MID_FN __device__ __forceinline__
+#endif
+
 constexpr int MID_WGS = 32;          // workgroups that stay (the rest of the grid leaves at once)
 constexpr int MID_ENTER_V = 8192;    // a level enters with at most this many frontier vertices ...
 constexpr int MID_ENTER_E = 65536;   // ... and out-edges
@@ -52,6 +59,14 @@ constexpr int MID_SEG_TILES = MID_SEG / TILE;
 constexpr int MID_OVF_BASE = MID_WGS * MID_SEG;
 constexpr int MID_AUX2_CAP = MID_OVF_BASE;      // int4 {row start, degree, state, -} per entry of the private regions
 
+// optional policy hooks of the second version: `bool carry_state() const` -- the state a vertex is expanded from is
+// known when it is claimed (`src_state state_of(int cand)`), so it travels with the queue entry instead of being
+// loaded again (one dependent round trip less per level)
+template <class Policy, class = void>
+struct policy_carries_state : std::false_type {};
+template <class Policy>
+struct policy_carries_state<Policy, std::void_t<decltype(&Policy::carry_state)>> : std::true_type {};
+
 template <class Policy>
 struct mid_smem {
   advance_smem<Policy> adv;
@@ -59,7 +74,7 @@ struct mid_smem {
   int out_deg[TILE + CHUNK];
   int tcount[ADV_BLOCK];      // entering level: counts of this workgroup's next 256 tiles
   int side[policy_has_side<Policy>::value ? (TILE + CHUNK) : 1];  // staged side-pile entries (near-far SSSP)
-  int out_st[TILE + CHUNK];   // second version: state of the staged output vertices (policies that carry it along)
+  int out_st[policy_carries_state<Policy>::value ? (TILE + CHUNK) : 1];  // state of the staged output vertices (policies that carry it along)
   int seg_pre[MID_WGS + 1];   // second version: entries of the private regions before region i
   int side_cnt;
   int side_base;
@@ -70,13 +85,7 @@ struct mid_smem {
   int rank;
 };
 
-// optional policy hooks of the second version: `bool carry_state() const` -- the state a vertex is expanded from is
-// known when it is claimed (`src_state state_of(int cand)`), so it travels with the queue entry instead of being
-// loaded again (one dependent round trip less per level)
-template <class Policy, class = void>
-struct policy_carries_state : std::false_type {};
-template <class Policy>
-struct policy_carries_state<Policy, std::void_t<decltype(&Policy::carry_state)>> : std::true_type {};
+
 
 // optional policy hook: `prepare(src_state, nbr, edge, cand&)` -- what precheck computes WITHOUT the read-only
 // probe of the neighbour's label.  Inside one XCD the claim itself is an L2 operation, cheaper than the extra
@@ -136,7 +145,7 @@ __device__ __forceinline__ void mid_flush(int32_t* qout, int2* aux_out, int* cnt
 // Runs in the level kernel when ctrl.mode == 3.  h: the control block as the kernel read it (level = the level
 // to expand, its frontier is the tile queue of that parity).
 template <class Policy>
-__device__ __forceinline__ void mid_levels_body(const pipe_args& a, ctrl_t* c, Policy& pol, mid_smem<Policy>& sm,
+GRX_MID_FN void mid_levels_body(const pipe_args& a, ctrl_t* c, Policy& pol, mid_smem<Policy>& sm,
                                                 const level_head& h, uint32_t xcc_mask) {
   constexpr bool SIDE = policy_has_side<Policy>::value;
   const int tid = threadIdx.x;
@@ -523,7 +532,7 @@ __device__ __forceinline__ bool mid_exchange(const pipe_args& a, int G, int w, i
 }
 
 template <class Policy>
-__device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid_smem<Policy>& sm,
+GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid_smem<Policy>& sm,
                                                  const level_head& h, uint32_t xcc_mask) {
   constexpr bool SIDE = policy_has_side<Policy>::value;
   constexpr bool CARRY = policy_carries_state<Policy>::value;
@@ -578,7 +587,11 @@ __device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, 
   long long my_edges = 0, my_vertices = 0;
   // tuning aid (GRX_MID_DEBUG=1): wall-clock ticks the leader spends per phase, summed over the levels of the launch ->
   // ctrl.spare[0..3] {input staged | column indices + claims + compaction | flush | exchange}, spare[4] += levels
+#ifdef GRX_MID_TIMERS
   const bool dbg = (a.mid_version & 0x100) != 0 && w == 0 && tid == 0;
+#else
+  constexpr bool dbg = false;
+#endif
   long long dbg_ph[4] = {0, 0, 0, 0}, dbg_t = dbg ? (long long)wall_clock64() : 0ll;
   int dbg_levels = 0;
   auto dbg_mark = [&](int i) {
@@ -615,7 +628,8 @@ __device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, 
       }
       for (int i = tid; i < k; i += ADV_BLOCK) {
         qout[base + i] = ad.out[lo + i];
-        if (base + i < MID_AUX2_CAP) aux_out[base + i] = make_int4(sm.out_rs[lo + i], sm.out_deg[lo + i], sm.out_st[lo + i], 0);
+        if (base + i < MID_AUX2_CAP)
+          aux_out[base + i] = make_int4(sm.out_rs[lo + i], sm.out_deg[lo + i], CARRY ? sm.out_st[CARRY ? lo + i : 0] : 0, 0);
       }
       __syncthreads();
     };
@@ -915,12 +929,22 @@ __device__ __forceinline__ void mid_levels_body2(const pipe_args& a, ctrl_t* c, 
   }
 }
 
-// the body the host asked for (pipe_args::mid_version; the first version stays selectable for A/B runs: GRX_MID_VERSION=1)
+// Which body a build carries.  ONE by default (the second version): the launch-bound searches turned out to be sensitive to
+// the sheer size of the level kernel's code -- with both bodies inlined (58 KB) a near-far iteration of the road stand-in
+// took 42.6 us against 31.5 us with one body (45 KB), although the extra code is never executed in that run
+// (tools/ab_mid.py, GRX_MID=0, libraries built from the same sources).  -DGRX_MID_BOTH builds both (then
+// GRX_MID_VERSION=1|2 selects at run time), -DGRX_MID_FIRST_VERSION the first one only.
 template <class Policy>
 __device__ __forceinline__ void mid_levels_run(const pipe_args& a, ctrl_t* c, Policy& pol, mid_smem<Policy>& sm,
                                                const level_head& h, uint32_t xcc_mask) {
+#if defined(GRX_MID_BOTH)
   if ((a.mid_version & 0xff) == 2) mid_levels_body2(a, c, pol, sm, h, xcc_mask);
   else mid_levels_body(a, c, pol, sm, h, xcc_mask);
+#elif defined(GRX_MID_FIRST_VERSION)
+  mid_levels_body(a, c, pol, sm, h, xcc_mask);
+#else
+  mid_levels_body2(a, c, pol, sm, h, xcc_mask);
+#endif
 }
 
 }  // namespace grx

@@ -115,7 +115,9 @@ struct sssp_nf_policy {
   __device__ __forceinline__ void begin(ctrl_t* c) {
     level = c->level;
     hi = c->nf_hi;
-    far_out = nf.far[c->nf_sel];
+    // (a select, not far[sel]: a dynamically indexed member forces the whole by-value policy into memory -- the compiler
+    // then keeps one copy per thread in LDS, 20 KB, which pushed this kernel past 64 KB of LDS: see sssp_nf_level_kernel)
+    far_out = c->nf_sel ? nf.far[1] : nf.far[0];
     min_far = &c->nf_min_far;
   }
   // past the L1: inside a multi-level launch the label may have been lowered by an atomic (performed in L2) since
@@ -331,8 +333,8 @@ __device__ __forceinline__ void sssp_split_body(const pipe_args& a, const sssp_n
   const int level = c->level;
   const int p = level & 1;
   const int in_sel = c->nf_sel ^ 1;
-  const int32_t* fin = nf.far[in_sel];
-  int32_t* fout = nf.far[in_sel ^ 1];
+  const int32_t* fin = in_sel ? nf.far[1] : nf.far[0];
+  int32_t* fout = in_sel ? nf.far[0] : nf.far[1];
   const int n = min(c->nf_far_n[in_sel], nf.capacity);
   const float lo = c->nf_lo, hi = c->nf_hi;
   const int tid = threadIdx.x;
@@ -412,6 +414,10 @@ __device__ __forceinline__ void sssp_split_body(const pipe_args& a, const sssp_n
 
 // One near-far iteration, ONE launch: the advance (relax + far-pile side output), or -- when
 // the head moved to a new bucket -- the rebuild of the frontier from the pile.
+// KEEP THE LDS OF THIS KERNEL BELOW 64 KB.  Measured (rocprofv3 kernel trace, road stand-in, one launch pair per
+// iteration): with 81,920 B of LDS per workgroup the SHORTEST launch of this kernel -- one that only finds `done` set --
+// took 13-25 us depending on the box, with 51,712 B it took 2.8 us; 7228 launches per search.  (The 30 KB came from
+// a staging array only some policies need and from a per-thread LDS copy of the by-value policy, see sssp_nf_policy::begin.)
 __global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, sssp_nf_args nf, sssp_nf_policy pol,
                                                                   uint32_t xcc_mask) {
   // one of three bodies runs per launch: their LDS is overlaid
@@ -430,12 +436,21 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, s
     return;
   }
   pol.begin(c);
+#ifdef GRX_ADVANCE_FIRST
+  if (h.mode != 3) {
+    advance_block<sssp_nf_policy, false>(a, c, pol, sm, h.level & 1, blockIdx.x, gridDim.x, h.total_chunks,
+                                         a.chunk_tile);
+    return;
+  }
+  mid_levels_run(a, c, pol, msm, h, xcc_mask);  // many iterations inside the current bucket, in this one launch
+#else
   if (h.mode == 3) {  // many iterations inside the current bucket, in this one launch
     mid_levels_run(a, c, pol, msm, h, xcc_mask);
     return;
   }
   advance_block<sssp_nf_policy, false>(a, c, pol, sm, h.level & 1, blockIdx.x, gridDim.x, h.total_chunks,
                                        a.chunk_tile);
+#endif
 }
 
 // Head of a plain (label-correcting) level, ONE launch of one workgroup: as many tiny levels

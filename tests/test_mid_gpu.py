@@ -1,7 +1,7 @@
 """The many-levels-per-launch body (gunrock_amd/csrc/grx_mid.hpp) on the paths a benchmark graph never takes:
 the shared overflow area behind the private output regions, the hand-back of a growing frontier to the regular
-kernels, the first version of the body.  Test knobs (read per run by the library): GRX_MID_SEG_CAP = entries of a
-private region in use, GRX_MID_EXIT_V = frontier size at which the body hands back, GRX_MID_VERSION.
+kernels, the launch-pair-per-level schedule.  Test knobs (read per run by the library): GRX_MID_SEG_CAP = entries of a
+private region in use, GRX_MID_EXIT_V = frontier size at which the body hands back, GRX_MID=0.
 BFS depths / SSSP distances must equal the oracle's bit for bit in every configuration
 (what the reference's --validate checks: examples/algorithms/bfs/bfs.cu:96-113, sssp/sssp.cu)."""
 import os
@@ -19,7 +19,6 @@ CONFIGS = (
     {"GRX_MID_SEG_CAP": "0"},                             # everything goes through the overflow area
     {"GRX_MID_EXIT_V": "3000"},                           # early hand-back (regions become tiles)
     {"GRX_MID_SEG_CAP": "256", "GRX_MID_EXIT_V": "9000"}, # hand-back with a non-empty overflow area
-    {"GRX_MID_VERSION": "1"},                             # first version of the body
     {"GRX_MID": "0"},                                     # one launch pair per level
 )
 

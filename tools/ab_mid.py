@@ -27,7 +27,8 @@ def spare():
 
 
 DEBUG = os.environ.get("GRX_MID_DEBUG") == "1"
-for algo in ("bfs", "ssspu", "sssp"):
+ALGOS = sys.argv[2].split(",") if len(sys.argv) > 2 else ["bfs", "ssspu", "sssp"]
+for algo in ALGOS:
     if algo == "sssp":
         props, csr = gr.generate("road", wl["V"], 0, wl["a"], 0.0, 1.0, seed=42)
     else:
