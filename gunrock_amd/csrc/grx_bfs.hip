@@ -66,7 +66,15 @@ __global__ void bfs_closed0_kernel(const int32_t* t_ro, int32_t V, unsigned* out
   }
 }
 
-__global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, int src, dobfs_args d) {
+// source_level: 1 = the launch that follows (bfs_source_kernel) expands the source itself when source_level_applies();
+// this kernel then leaves the control block as the head of level 0 would have (level = 0, its frontier accounted for)
+__device__ __forceinline__ bool source_level_applies(int deg, const dobfs_args& d) {
+  // small sources: the LDS-resident tiny levels of the first head kernel take them (and the levels behind them);
+  // a source with more out-edges than 1/alpha of the graph would be expanded bottom-up by the direction rule
+  return deg > TINY_EDGES && !(d.enabled && (long long)deg > d.n_edges / (long long)(d.alpha > 0 ? d.alpha : 1));
+}
+
+__global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, int src, dobfs_args d, int source_level) {
   const int tid = threadIdx.x;
   int32_t* f0 = a.frontier[0];
   f0[tid] = (tid == 0) ? src : -1;
@@ -98,6 +106,16 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
     c->bu_R = 0;
     c->bu_T = 0;
     c->t_start = (long long)wall_clock64();
+    if (source_level && source_level_applies(deg, d)) {
+      // what the head of level 0 leaves behind (plan_body / bfs_decide_body on a one-vertex frontier)
+      c->level = 0;
+      c->edges_visited = deg;
+      c->vertices_visited = 1;
+      c->n_tiles[0] = 0;
+      c->total_chunks = (deg + CHUNK - 1) / CHUNK;
+      a.mailbox[1] = 0;
+      a.mailbox[2] = 1;
+    }
     dist[src] = 0;
     if (d.enabled) {
       const unsigned bit = 1u << (src & 31);
@@ -110,6 +128,80 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
     a.mailbox[1] = 0;
     a.mailbox[2] = 0;
   }
+}
+
+// LEVEL 0 WITHOUT A LAUNCH PAIR.  Every search starts from one vertex; when that vertex is a hub (the benchmark sources
+// are: 125 k out-edges on the LJ stand-in) level 0 used to cost a head kernel (12 us: bookkeeping and a chunk map for ONE
+// tile) plus a level kernel (27 us: the general advance body, staging a 256-slot tile of which one slot is used).  Here
+// the seed kernel does the bookkeeping and this kernel expands the source's row directly: lanes on consecutive edges, the
+// policy's claim (no probe first: nothing but the source is visited), discoveries compacted into tiles exactly as
+// advance_block emits them.  The first level group then starts at level 1.  <<<ceil(deg / 2048) capped, 256>>>
+struct source_smem {
+  int out[TILE + CHUNK];
+  int wave[ADV_BLOCK / 64 + 1];
+  int cnt;
+  int res[3];
+  emit_smem emit;
+};
+__global__ __launch_bounds__(ADV_BLOCK) void bfs_source_kernel(pipe_args a, dobfs_args d, bfs_policy pol, int src) {
+  __shared__ source_smem sm;
+  const int tid = threadIdx.x;
+  const int lane = dev::lane_id();
+  const int rs = a.ro[src];
+  const int deg = a.ro[src + 1] - rs;
+  if (!source_level_applies(deg, d)) return;
+  ctrl_t* c = a.ctrl;
+  pol.ctrl = c;
+  pol.set_level(0);
+  if (d.enabled) {
+    // level 0's share of the bitmap upkeep of a direction-optimising run: the frontier bitmap level 1 writes into
+    uint4* z = reinterpret_cast<uint4*>(pick3(d.fbits, 2));
+    for (int i = blockIdx.x * ADV_BLOCK + tid; i < d.n_words / 4; i += gridDim.x * ADV_BLOCK) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (tid == 0) { sm.cnt = 0; sm.res[0] = 0; sm.res[1] = 0; }
+  __syncthreads();
+  for (int a0 = (int)blockIdx.x * CHUNK; a0 < deg; a0 += (int)gridDim.x * CHUNK) {
+    int n_k[ADV_ITEMS], r_k[ADV_ITEMS];
+    bool ok_k[ADV_ITEMS];
+#pragma unroll
+    for (int k = 0; k < ADV_ITEMS; ++k) {
+      const int i = a0 + k * ADV_BLOCK + tid;
+      ok_k[k] = i < deg;
+      n_k[k] = a.ci[rs + (ok_k[k] ? i : 0)];
+    }
+#pragma unroll
+    for (int k = 0; k < ADV_ITEMS; ++k) {
+      r_k[k] = 0;
+      if (ok_k[k]) r_k[k] = pol.claim(n_k[k], 0);
+    }
+#pragma unroll
+    for (int k = 0; k < ADV_ITEMS; ++k) {
+      const bool keep = ok_k[k] && pol.code(r_k[k], 0, n_k[k], 0) == 1;
+      const unsigned long long m = dev::ballot(keep);
+      if (m) {
+        int at = 0;
+        if (lane == 0) at = atomicAdd(&sm.cnt, __popcll(m));
+        at = __shfl(at, 0, 64);
+        if (keep) {
+          sm.out[at + dev::mask_rank(m)] = n_k[k];
+          pol.on_accept(n_k[k]);
+        }
+      }
+    }
+    __syncthreads();
+    int cnt = sm.cnt;
+    if (cnt >= TILE) {
+      const int k = cnt / TILE;
+      emit_full_tiles(a, c, 1, sm.out, cnt - k * TILE, k, sm.emit, sm.res);
+      cnt -= k * TILE;
+    }
+    if (tid == 0) sm.cnt = cnt;
+    __syncthreads();
+  }
+  const int rem = sm.cnt;
+  if (rem > 0) emit_tile(a, c, 1, sm.out, 0, rem, sm.wave, sm.res);
+  __syncthreads();
+  release_tiles(a, sm.res);
 }
 
 // Level bookkeeping + direction choice (one workgroup of PLAN_BLOCK threads).
@@ -592,7 +684,6 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   ctx->h_mailbox[0] = 0;
   ctx->h_mailbox[3] = -1;
   GRX_HIP(hipEventRecord(ctx->ev_begin, s));
-  hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, visited, src, d);
 
   const int grid = (variant == 0) ? level_grid(ctx, g, lbuild) : advance_grid_for(ctx, g);
   const bool profile = (opt.engine_flags & GRX_FLAG_PROFILE) != 0;
@@ -615,6 +706,12 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     // a second dependent round trip per edge costs more than the label sectors it saves): off by default
     lp.pre_bm = env_int("GRX_TD_PRE", 0) != 0 ? visited : nullptr;
   }
+  // seed; then level 0 itself when the source is a hub (bfs_source_kernel: a no-op otherwise).  Profiled and
+  // strict-merge-path runs keep one launch pair per level, level 0 included.
+  const int source_level = (variant == 0 && !profile && !strict_mp && env_int("GRX_SOURCE_LEVEL", 1) != 0) ? 1 : 0;
+  hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, visited, src, d, source_level);
+  if (source_level)
+    hipLaunchKernelGGL(bfs_source_kernel, dim3(ctx->num_cus), dim3(ADV_BLOCK), 0, s, a, d, lp, src);
   bin_args bn{};
   bn.xcc_mask = ctx->xcc_mask;
   bn.n_xcd = ctx->n_xcd;
@@ -670,7 +767,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   }
   hipError_t launch_err = hipSuccess;
   bool returned_fast = false;
-  const int pace = (dense && variant == 0) ? env_int("GRX_PACE_DEPTH", 2) : 0;
+  const int pace = (dense && variant == 0) ? env_int("GRX_PACE_DEPTH", 3) : 0;
   int64_t prof_v = 0, prof_e = 0, prof_open = 0, prof_probe = 0;
   int launches = 0;
   st = run_levels(ctx, opt, [&](hipStream_t stream, int seq) {

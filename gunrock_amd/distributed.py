@@ -261,6 +261,20 @@ def _group_graph(engine, dist, key):
         return None
 
 
+def _first_batch(engine, default):
+    """Groups enqueued before the first look at `done`.  Every rank must enqueue the SAME number of groups (a group
+    carries two collectives), so the schedule may only depend on values all ranks share: here the depth of the previous
+    search on this engine (global by construction).  A repeated or similar search then costs exactly its groups and one
+    poll -- the doubling schedule from 4 spent 12 groups and two polls on a 7-level search."""
+    last = getattr(engine, "_last_groups", 0)
+    return max(2, min(int(last), 64)) if last else default
+
+
+def _remember_groups(engine, stats):
+    engine._last_groups = int(stats["search_depth"]) + 1  # + the group whose head finds the frontier empty
+    return stats
+
+
 def bfs(engine, dist, source, distances, optimized=True, first_batch=4):
     """Partitioned BFS driven by this rank.  `distances`: int32 tensor on the engine's device, either
     SHARDED (engine.new_labels(): the owned slice only, vertex v at v - engine.lo) or full-size (V entries,
@@ -277,7 +291,7 @@ def bfs(engine, dist, source, distances, optimized=True, first_batch=4):
         with on_stream:
             engine.begin(source, distances, optimized)
             _capi.check(L.grx_bfs_dist_seed_stats(engine._h))
-            batch = first_batch
+            batch = _first_batch(engine, first_batch)
             while True:
                 _capi.check(L.grx_bfs_dist_groups(engine._h, batch))
                 done, _ = engine.poll()
@@ -285,14 +299,14 @@ def bfs(engine, dist, source, distances, optimized=True, first_batch=4):
                     break
                 batch = min(batch * 2, 32)
             _capi.check(L.grx_bfs_dist_capture_group(engine._h))  # no-op once recorded for this buffer / direction
-            return engine.end()
+            return _remember_groups(engine, engine.end())
     with on_stream:
         engine.begin(source, distances, optimized)
         _all_reduce_stats(dist, engine)
         key = (int(distances.data_ptr()), bool(optimized))
         cached = getattr(engine, "_graph", None)
         graph = cached[1] if (cached is not None and cached[0] == key) else None
-        batch = first_batch
+        batch = _first_batch(engine, first_batch)
         while True:
             for _ in range(batch):
                 if graph is not None:
@@ -307,4 +321,4 @@ def bfs(engine, dist, source, distances, optimized=True, first_batch=4):
             # the search is over (every kernel of a further group would exit on `done`): record the
             # group for the next search with the same label buffer and direction setting
             _group_graph(engine, dist, key)
-        return engine.end()
+        return _remember_groups(engine, engine.end())

@@ -164,7 +164,7 @@ int32_t grx_graph_number_of_edges(grx_graph_t graph);    /* graph_t::get_number_
  * Completion: on return d_distances is final and the context's stream has drained, like the
  * reference's run().  With GRX_FLAG_ASYNC_RETURN (opt-in; scale-free graphs, E >= 8 V) the call
  * returns as soon as the device publishes the end of the search in pinned host memory -- the
- * distances are final, but at most two no-op kernel groups may still be draining on the context's
+ * distances are final, but at most three no-op kernel groups may still be draining on the context's
  * stream (work enqueued on that stream afterwards is ordered behind them,
  * grx_context_synchronize waits for them). */
 grx_status_t grx_bfs(grx_context_t ctx,
