@@ -57,6 +57,12 @@ struct pr_args {
   int32_t n_xb_long;
   float* partial_y;      // NB * V partial sums, block-major
   const int32_t* x_perm; // XCD-blocked variant: position of vertex v's value in x[] (null: v)
+  // partitioned run (grx_pr_dist_*): this rank prepares / updates the rows [row_lo, row_hi) only; the dangling mass and
+  // the convergence norm are combined over the ranks' {dsum, err} pairs in `gathered` (null: single GPU)
+  int32_t row_lo, row_hi;
+  int32_t n_ranks;
+  unsigned* scal_out;        // this rank's pair, written by pr_dist_pack_kernel
+  const unsigned* gathered;  // n_ranks pairs after the all-gather
 };
 
 constexpr int XB = 8;  // source blocks == XCDs
@@ -97,8 +103,8 @@ __global__ void pr_iweights_kernel(pr_args a) {
 __global__ __launch_bounds__(PR_BLOCK) void pr_prepare_kernel(pr_args a) {
   __shared__ float s_w[PR_BLOCK / 64];
   if (a.ctrl->done) return;
-  const int64_t per = ((int64_t)a.V + gridDim.x - 1) / gridDim.x;
-  const int64_t lo = (int64_t)blockIdx.x * per, hi = min((int64_t)a.V, lo + per);
+  const int64_t per = ((int64_t)(a.row_hi - a.row_lo) + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)a.row_lo + (int64_t)blockIdx.x * per, hi = min((int64_t)a.row_hi, lo + per);
   float acc = 0.0f;
   for (int64_t v = lo + threadIdx.x; v < hi; v += PR_BLOCK) {
     const float pv = a.p[v], iwv = a.iw[v];
@@ -123,7 +129,11 @@ __global__ __launch_bounds__(PR_BLOCK) void pr_scalar_kernel(pr_args a, int iter
   ctrl_t* c = a.ctrl;
   if (c->done) return;
   if (iter > 0) {
-    const float err = __uint_as_float(a.err_bits[(iter - 1) & 1]);
+    float err = __uint_as_float(a.err_bits[(iter - 1) & 1]);
+    if (a.gathered) {  // the norm is the maximum over the ranks (every rank reads the same pairs: same decision)
+      err = 0.0f;
+      for (int r = 0; r < a.n_ranks; ++r) err = fmaxf(err, __uint_as_float(a.gathered[2 * r + 1]));
+    }
     if (err < a.tol) {
       if (threadIdx.x == 0) { c->done = 1; c->pr_iter = iter; c->pr_err = err; }
       return;
@@ -138,10 +148,32 @@ __global__ __launch_bounds__(PR_BLOCK) void pr_scalar_kernel(pr_args a, int iter
     float dsum = 0.0f;
 #pragma unroll
     for (int i = 0; i < PR_BLOCK / 64; ++i) dsum += s_w[i];
+    if (a.gathered) {  // partitioned run: the ranks' dangling sums, added in rank order on every rank
+      dsum = 0.0f;
+      for (int r = 0; r < a.n_ranks; ++r) dsum += __uint_as_float(a.gathered[2 * r]);
+    }
     *a.base = (1 - a.alpha + dsum) / a.V;   // (1 - alpha + dsum) / n_vertices, pr.hxx:134
     a.err_bits[iter & 1] = 0u;
     c->pr_dsum = dsum;
     c->pr_iter = iter + 1;
+  }
+}
+
+// Partitioned run, before the exchange of iteration `iter`: this rank's {dangling sum of its rows, norm of its rows in
+// the previous iteration} -- the pair every rank all-gathers.  Fixed summation order.  <<<1, PR_BLOCK>>>
+__global__ __launch_bounds__(PR_BLOCK) void pr_dist_pack_kernel(pr_args a, int iter) {
+  __shared__ float s_w[PR_BLOCK / 64];
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < a.n_partial; i += PR_BLOCK) acc += a.partial[i];
+  acc = dev::wave_sum_f(acc);
+  if (dev::lane_id() == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float dsum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PR_BLOCK / 64; ++i) dsum += s_w[i];
+    a.scal_out[0] = __float_as_uint(dsum);
+    a.scal_out[1] = iter > 0 ? a.err_bits[(iter - 1) & 1] : 0x7f7fffffu;
   }
 }
 
@@ -372,14 +404,18 @@ __global__ void pr_init_kernel(pr_args a) {
 // Static pull partition, built once per graph on the host from the transpose
 // offsets: consecutive short rows are packed up to PR_NNZ non-zeros (and
 // PR_MAXROWS rows); rows longer than PR_LONG become pieces of PR_NNZ.
-static grx_status_t build_pr_partition(grx_graph_t g) {
-  if (g->pr_blocks) return GRX_SUCCESS;
-  const int32_t V = g->V;
-  const std::vector<int32_t>& ro = g->h_t_ro;
+struct pr_partition {
+  void* blocks = nullptr;
+  int32_t* piece = nullptr;
+  int32_t* longrows = nullptr;
+  int32_t n_blocks = 0, n_pieces = 0, n_long = 0;
+};
+// rows [lo, hi) of the matrix whose (host) row offsets are `ro`
+static grx_status_t build_pr_partition_rows(const std::vector<int32_t>& ro, int32_t lo, int32_t hi, pr_partition* out) {
   std::vector<int4> blocks;
   std::vector<int32_t> piece, longrows;
   int32_t n_pieces = 0;
-  int32_t row0 = 0;
+  int32_t row0 = lo;
   auto flush = [&](int32_t row_end) {
     if (row_end > row0) {
       blocks.push_back(make_int4(row0, row_end - row0, ro[row0], ro[row_end]));
@@ -387,7 +423,7 @@ static grx_status_t build_pr_partition(grx_graph_t g) {
     }
     row0 = row_end;
   };
-  for (int32_t v = 0; v < V; ++v) {
+  for (int32_t v = lo; v < hi; ++v) {
     const int32_t deg = ro[v + 1] - ro[v];
     if (deg > PR_LONG) {
       flush(v);
@@ -405,19 +441,32 @@ static grx_status_t build_pr_partition(grx_graph_t g) {
     }
     if (ro[v + 1] - ro[row0] > PR_NNZ || v - row0 >= PR_MAXROWS) flush(v);
   }
-  flush(V);
-  g->n_pr_blocks = (int32_t)blocks.size();
-  g->n_pr_pieces = n_pieces;
-  g->n_pr_long = (int32_t)(longrows.size() / 3);
-  GRX_HIP(hipMalloc(&g->pr_blocks, std::max<size_t>(1, blocks.size()) * sizeof(int4)));
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->pr_piece), std::max<size_t>(1, piece.size()) * sizeof(int32_t)));
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->pr_long), std::max<size_t>(1, longrows.size()) * sizeof(int32_t)));
+  flush(hi);
+  out->n_blocks = (int32_t)blocks.size();
+  out->n_pieces = n_pieces;
+  out->n_long = (int32_t)(longrows.size() / 3);
+  GRX_HIP(hipMalloc(&out->blocks, std::max<size_t>(1, blocks.size()) * sizeof(int4)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&out->piece), std::max<size_t>(1, piece.size()) * sizeof(int32_t)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&out->longrows), std::max<size_t>(1, longrows.size()) * sizeof(int32_t)));
   if (!blocks.empty()) {
-    GRX_HIP(hipMemcpy(g->pr_blocks, blocks.data(), blocks.size() * sizeof(int4), hipMemcpyHostToDevice));
-    GRX_HIP(hipMemcpy(g->pr_piece, piece.data(), piece.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    GRX_HIP(hipMemcpy(out->blocks, blocks.data(), blocks.size() * sizeof(int4), hipMemcpyHostToDevice));
+    GRX_HIP(hipMemcpy(out->piece, piece.data(), piece.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   if (!longrows.empty())
-    GRX_HIP(hipMemcpy(g->pr_long, longrows.data(), longrows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    GRX_HIP(hipMemcpy(out->longrows, longrows.data(), longrows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  return GRX_SUCCESS;
+}
+static grx_status_t build_pr_partition(grx_graph_t g) {
+  if (g->pr_blocks) return GRX_SUCCESS;
+  pr_partition pt;
+  grx_status_t st = build_pr_partition_rows(g->h_t_ro, 0, g->V, &pt);
+  if (st != GRX_SUCCESS) return st;
+  g->pr_blocks = pt.blocks;
+  g->pr_piece = pt.piece;
+  g->pr_long = pt.longrows;
+  g->n_pr_blocks = pt.n_blocks;
+  g->n_pr_pieces = pt.n_pieces;
+  g->n_pr_long = pt.n_long;
   return GRX_SUCCESS;
 }
 
@@ -567,7 +616,7 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   if (xcd_blocked) GRX_HIP(ctx->far[0].reserve((size_t)XB * V * sizeof(float)));  // partial sums (scratch reuse)
   GRX_HIP(ctx->misc.reserve(64));
 
-  pr_args a;
+  pr_args a{};
   a.ro = g->ro; a.w = unit ? nullptr : g->w;
   a.t_ro = g->t_ro; a.t_ci = g->t_ci; a.t_w = unit ? nullptr : g->t_w;
   a.V = g->V; a.ctrl = ctx->d_ctrl;
@@ -590,6 +639,7 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   a.n_xb_long = g->n_xb_long;
   a.partial_y = xcd_blocked ? ctx->far[0].as<float>() : nullptr;
   a.x_perm = xcd_blocked ? g->xb_perm : nullptr;
+  a.row_lo = 0; a.row_hi = g->V; a.n_ranks = 1; a.scal_out = nullptr; a.gathered = nullptr;
 
   // problem.reset() (pr.hxx:65-93), outside the timed region as in the reference
   GRX_HIP(fill_f32(s, d_p, (float)(1.0 / (double)g->V), g->V));
@@ -657,3 +707,153 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   if (elapsed_ms) *elapsed_ms = ms;
   return GRX_SUCCESS;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Partitioned PageRank: rank r owns the vertices [lo, hi) -- their out-rows (for the inverse weight
+// sums) and their in-rows (what the pull gathers over), both as V-row CSRs with the other rows empty and global
+// column ids, i.e. what grx_host_csr_generate_rows / _in_rows produce.  One iteration on every rank:
+//   pre : x[v] = p[v] * iw[v] for the owned v, written into this rank's slice of the GLOBAL x buffer; the rank's
+//         {dangling sum, norm of the previous iteration} pair
+//   (caller) all-gather of the x slices (S floats per rank) and of the pairs (2 words per rank)
+//   post: convergence test + base term from the gathered pairs (identical on every rank), pull over the owned rows
+// p is SHARDED: d_p_local holds the owned slice only (vertex v at v - lo).  The reference has no multi-GPU PageRank
+// (every operator throws for context.size() != 1: advance/advance.hxx:129-132); the recurrence is pr.hxx:107-195.
+struct grx_pr_dist {
+  grx_context_t ctx = nullptr;
+  grx_graph_t g_out = nullptr, g_in = nullptr;
+  int32_t rank = 0, n_ranks = 1, lo = 0, hi = 0;
+  pr_partition part;
+  pr_args a{};
+  int32_t launched = 0;
+  bool active = false;
+};
+
+extern "C" {
+
+grx_status_t grx_pr_dist_create(grx_context_t ctx, grx_graph_t out_rows, grx_graph_t in_rows, int32_t n_ranks,
+                                int32_t my_rank, int32_t lo, int32_t hi, grx_pr_dist** out) {
+  if (!ctx || !out_rows || !in_rows || !out) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_pr_dist_create: null argument");
+  if (out_rows->V != in_rows->V || n_ranks < 1 || my_rank < 0 || my_rank >= n_ranks || lo < 0 || hi < lo || hi > out_rows->V)
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_pr_dist_create: inconsistent partition");
+  GRX_HIP(hipSetDevice(ctx->device));
+  auto* h = new grx_pr_dist();
+  h->ctx = ctx; h->g_out = out_rows; h->g_in = in_rows;
+  h->rank = my_rank; h->n_ranks = n_ranks; h->lo = lo; h->hi = hi;
+  std::vector<int32_t> ro((size_t)in_rows->V + 1);
+  GRX_HIP(hipMemcpy(ro.data(), in_rows->ro, ro.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  grx_status_t st = build_pr_partition_rows(ro, lo, hi, &h->part);
+  if (st != GRX_SUCCESS) { delete h; return st; }
+  *out = h;
+  return GRX_SUCCESS;
+}
+
+// d_p_local: hi - lo floats (the owned slice); d_x: the global x buffer (>= V floats, this rank writes [lo, hi));
+// d_pair_out: 2 words; d_pairs: 2 * n_ranks words (the all-gathered pairs)
+grx_status_t grx_pr_dist_begin(grx_pr_dist* h, float alpha, float tol, float* d_p_local, float* d_x,
+                               uint32_t* d_pair_out, const uint32_t* d_pairs) {
+  if (!h || !d_p_local || !d_x || !d_pair_out || !d_pairs) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_pr_dist_begin: null argument");
+  grx_context_t ctx = h->ctx;
+  GRX_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const bool unit = !h->g_in->w;  // (uniform 1.0 weights on ONE rank say nothing about the others: only "no values")
+  const size_t V = (size_t)h->g_out->V;
+  const int n_rows = h->hi - h->lo;
+  const int n_partial = std::max(1, std::min<int>(2048, (n_rows + PR_BLOCK - 1) / PR_BLOCK));
+  GRX_HIP(ctx->fbuf[1].reserve(V * sizeof(float)));  // iweights (owned rows are the ones that matter)
+  GRX_HIP(ctx->fbuf[2].reserve(((size_t)n_partial + 16) * sizeof(float)));
+  GRX_HIP(ctx->fbuf[3].reserve(((size_t)h->part.n_pieces + 16) * sizeof(float)));
+  GRX_HIP(ctx->misc.reserve(64));
+  pr_args a{};
+  a.ro = h->g_out->ro; a.w = unit ? nullptr : h->g_out->w;
+  a.t_ro = h->g_in->ro; a.t_ci = h->g_in->ci; a.t_w = unit ? nullptr : h->g_in->w;
+  a.V = (int32_t)V; a.ctrl = ctx->d_ctrl;
+  a.p = d_p_local - h->lo;  // indexed by global row: only [lo, hi) is touched
+  a.x = d_x;
+  a.iw = ctx->fbuf[1].as<float>();
+  a.partial = ctx->fbuf[2].as<float>();
+  a.piece_sum = ctx->fbuf[3].as<float>();
+  a.blocks = reinterpret_cast<const int4*>(h->part.blocks);
+  a.piece = h->part.piece;
+  a.longrows = h->part.longrows;
+  a.n_blocks = h->part.n_blocks; a.n_long = h->part.n_long; a.n_partial = n_partial;
+  a.alpha = alpha; a.tol = tol;
+  a.err_bits = ctx->misc.as<unsigned>();
+  a.base = reinterpret_cast<float*>(ctx->misc.as<unsigned>() + 4);
+  a.row_lo = h->lo; a.row_hi = h->hi; a.n_ranks = h->n_ranks;
+  a.scal_out = d_pair_out; a.gathered = d_pairs;
+  h->a = a;
+  if (n_rows > 0) GRX_HIP(fill_f32(s, d_p_local, (float)(1.0 / (double)V), n_rows));
+  hipLaunchKernelGGL(pr_iweights_kernel, dim3(1024), dim3(256), 0, s, a);
+  GRX_HIP(hipEventRecord(ctx->ev_begin, s));
+  hipLaunchKernelGGL(pr_init_kernel, dim3(1), dim3(64), 0, s, a);
+  h->launched = 0;
+  h->active = true;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_pr_dist_pre(grx_pr_dist* h) {
+  if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_pr_dist_pre: no run in progress");
+  hipStream_t s = h->ctx->stream;
+  hipLaunchKernelGGL(pr_prepare_kernel, dim3(h->a.n_partial), dim3(PR_BLOCK), 0, s, h->a);
+  hipLaunchKernelGGL(pr_dist_pack_kernel, dim3(1), dim3(PR_BLOCK), 0, s, h->a, h->launched);
+  GRX_HIP(hipGetLastError());
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_pr_dist_post(grx_pr_dist* h) {
+  if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_pr_dist_post: no run in progress");
+  hipStream_t s = h->ctx->stream;
+  hipLaunchKernelGGL(pr_scalar_kernel, dim3(1), dim3(PR_BLOCK), 0, s, h->a, h->launched);
+  const int pull_grid = std::max(1, std::min(std::max(1, h->part.n_blocks), h->ctx->num_cus * 8));
+  hipLaunchKernelGGL(pr_pull_kernel, dim3(pull_grid), dim3(PR_BLOCK), 0, s, h->a, h->launched);
+  if (h->part.n_long > 0)
+    hipLaunchKernelGGL(pr_long_kernel, dim3((h->part.n_long + 255) / 256), dim3(256), 0, s, h->a, h->launched);
+  ++h->launched;
+  GRX_HIP(hipGetLastError());
+  return GRX_SUCCESS;
+}
+
+// synchronises the stream; *done != 0 once the run has converged (the same iteration on every rank)
+grx_status_t grx_pr_dist_poll(grx_pr_dist* h, int32_t* done, int32_t* iterations) {
+  if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_pr_dist_poll: no run in progress");
+  grx_context_t ctx = h->ctx;
+  GRX_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost, ctx->stream));
+  GRX_HIP(hipStreamSynchronize(ctx->stream));
+  if (done) *done = ctx->h_ctrl->done;
+  if (iterations) *iterations = ctx->h_ctrl->pr_iter;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_pr_dist_end(grx_pr_dist* h, grx_run_stats_t* stats) {
+  if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_pr_dist_end: no run in progress");
+  grx_context_t ctx = h->ctx;
+  hipStream_t s = ctx->stream;
+  GRX_HIP(hipEventRecord(ctx->ev_end, s));
+  GRX_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost, s));
+  GRX_HIP(hipEventSynchronize(ctx->ev_end));
+  GRX_HIP(hipStreamSynchronize(s));
+  float ms = 0;
+  GRX_HIP(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+  const int iters = ctx->h_ctrl->pr_iter;
+  ctx->stats = grx_run_stats_t{};
+  ctx->stats.edges_visited = (int64_t)h->g_in->E * iters;  // this rank's share
+  ctx->stats.vertices_visited = (int64_t)(h->hi - h->lo) * iters;
+  ctx->stats.search_depth = iters;
+  ctx->stats.elapsed_ms = ms;
+  if (stats) *stats = ctx->stats;
+  h->active = false;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_pr_dist_destroy(grx_pr_dist* h) {
+  if (!h) return GRX_SUCCESS;
+  (void)hipSetDevice(h->ctx->device);
+  (void)hipStreamSynchronize(h->ctx->stream);
+  if (h->part.blocks) (void)hipFree(h->part.blocks);
+  if (h->part.piece) (void)hipFree(h->part.piece);
+  if (h->part.longrows) (void)hipFree(h->part.longrows);
+  delete h;
+  return GRX_SUCCESS;
+}
+
+}  // extern "C"

@@ -322,3 +322,115 @@ def bfs(engine, dist, source, distances, optimized=True, first_batch=4):
             # group for the next search with the same label buffer and direction setting
             _group_graph(engine, dist, key)
         return _remember_groups(engine, engine.end())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Partitioned PageRank (device side: grx_pr_dist_* in csrc/grx_pr.hip).
+#   rank r owns the vertices [r * S, min((r + 1) * S, V)) with their out-rows (inverse weight sums) and in-rows (the
+#   pull), p is sharded.  One iteration, per rank and stream-ordered:
+#     pre   x[v] = p[v] * iweights[v] for the owned v, into this rank's slice of the global x buffer (vertex v sits at
+#           x[v]: slices are S apart and S-aligned); the rank's {dangling sum, norm of the previous iteration}
+#     ag    all_gather of the x slices (S floats per rank) and of the pairs (2 words per rank)
+#     post  convergence test + base term from the gathered pairs, summed / maximised in rank order on every rank (so
+#           all ranks stop in the same iteration without talking to the host), then the pull over the owned rows
+#   The host enqueues iterations blindly in batches and polls `done` once per batch; iterations after `done` are no-ops.
+
+
+class GrxPrEngine:
+    """Device side of the partitioned PageRank: the C ABI grx_pr_dist_*."""
+
+    def __init__(self, properties, out_rows, in_rows, rank, n_ranks, device):
+        import torch
+        from . import build_graph, multi_context_t
+        self.torch = torch
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.ctx = multi_context_t(self.device.index or 0, stream=self.stream)
+        with torch.cuda.stream(self.stream):
+            self.g = build_graph(properties, out_rows, self.ctx, device=device)
+            self.g_in = build_graph(properties, in_rows, self.ctx, device=device)
+        self.rank, self.P = int(rank), int(n_ranks)
+        self.V = self.g.get_number_of_vertices()
+        self.S = slice_bits(self.V, self.P)
+        self.lo, self.hi = min(self.rank * self.S, self.V), min((self.rank + 1) * self.S, self.V)
+        with torch.cuda.stream(self.stream):
+            self.x = torch.zeros(self.P * self.S, dtype=torch.float32, device=device)
+            self.pair_out = torch.zeros(2, dtype=torch.int32, device=device)
+            self.pairs = torch.zeros(2 * self.P, dtype=torch.int32, device=device)
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().grx_pr_dist_create(self.ctx._h, self.g._h, self.g_in._h, self.P, self.rank,
+                                                   self.lo, self.hi, C.byref(self._h)))
+
+    def new_ranks(self):
+        """SHARDED result buffer: float32[S], vertex v of this rank at index v - rank * S"""
+        return self.torch.empty(self.S, dtype=self.torch.float32, device=self.device)
+
+    def begin(self, alpha, tol, p_local):
+        assert p_local.dtype == self.torch.float32 and p_local.numel() >= self.hi - self.lo
+        self._p = p_local
+        _capi.check(_capi.lib().grx_pr_dist_begin(
+            self._h, float(alpha), float(tol), C.c_void_p(p_local.data_ptr()), C.c_void_p(self.x.data_ptr()),
+            C.c_void_p(self.pair_out.data_ptr()), C.c_void_p(self.pairs.data_ptr())))
+
+    def pre(self):
+        _capi.check(_capi.lib().grx_pr_dist_pre(self._h))
+
+    def post(self):
+        _capi.check(_capi.lib().grx_pr_dist_post(self._h))
+
+    def poll(self):
+        done, it = C.c_int32(0), C.c_int32(0)
+        _capi.check(_capi.lib().grx_pr_dist_poll(self._h, C.byref(done), C.byref(it)))
+        return bool(done.value), it.value
+
+    def end(self):
+        s = _capi.grx_run_stats_t()
+        _capi.check(_capi.lib().grx_pr_dist_end(self._h, C.byref(s)))
+        return {"edges_visited": s.edges_visited, "vertices_visited": s.vertices_visited,
+                "iterations": s.search_depth, "elapsed_ms": s.elapsed_ms}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _capi.lib().grx_pr_dist_destroy(h)
+            self._h = None
+
+
+def _all_gather_slices(dist, buf, mine_off, n):
+    """every rank's [r * n, (r + 1) * n) of `buf` <- that rank's own slice (this rank's slice is already in place)"""
+    if dist is None or dist.get_world_size() == 1:
+        return
+    mine = buf[mine_off:mine_off + n]
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(buf, mine)  # in place: the input IS the rank's slice of the output
+    else:
+        outs = [buf[r * n:(r + 1) * n] for r in range(dist.get_world_size())]
+        dist.all_gather(outs, mine.clone())
+
+
+def pagerank(engine, dist, alpha=0.85, tol=1e-6, p_local=None, first_batch=4, max_iterations=1000):
+    """Partitioned PageRank driven by this rank.  `p_local`: float32 tensor on the engine's device holding the OWNED slice
+    (engine.new_ranks()); on return it holds the ranks of the owned vertices.  Returns (p_local, stats); stats["iterations"]
+    is global (every rank stops in the same iteration)."""
+    torch = engine.torch
+    import contextlib
+    on_stream = torch.cuda.stream(engine.stream) if getattr(engine, "stream", None) is not None \
+        else contextlib.nullcontext()
+    if p_local is None:
+        p_local = engine.new_ranks()
+    with on_stream:
+        engine.begin(alpha, tol, p_local)
+        launched, batch = 0, first_batch
+        while True:
+            for _ in range(batch):
+                engine.pre()
+                _all_gather_slices(dist, engine.x, engine.rank * engine.S, engine.S)
+                engine.pairs[2 * engine.rank:2 * engine.rank + 2].copy_(engine.pair_out)
+                _all_gather_slices(dist, engine.pairs, 2 * engine.rank, 2)
+                engine.post()
+                launched += 1
+            done, _ = engine.poll()
+            if done or launched >= max_iterations:
+                break
+            batch = min(batch * 2, 16)
+        return p_local, engine.end()

@@ -279,6 +279,28 @@ grx_status_t grx_bfs_dist_poll(grx_bfs_dist_t h, int32_t* done, int32_t* level);
 grx_status_t grx_bfs_dist_end(grx_bfs_dist_t h, grx_run_stats_t* stats);
 grx_status_t grx_bfs_dist_destroy(grx_bfs_dist_t h);
 
+/* ---- multi-GPU: partitioned PageRank -------------------------------------------------------
+ * Rank r owns the vertices [lo, hi): `out_rows` / `in_rows` are V-row CSRs holding the out-edges / in-edges of the
+ * owned vertices only (global column ids; grx_host_csr_generate_rows / _in_rows produce exactly these).  p is SHARDED
+ * (d_p_local: hi - lo floats).  One iteration = grx_pr_dist_pre (x = p * iweights for the owned rows into this rank's
+ * slice of the global x buffer; the rank's {dangling sum, norm} pair), the caller's two all-gathers (x slices, pairs:
+ * torch.distributed = RCCL in gunrock_amd/distributed.py), grx_pr_dist_post (convergence test and base term from
+ * the gathered pairs -- identical on every rank -- then the pull over the owned rows).  Iterations are enqueued blindly,
+ * several per grx_pr_dist_poll; iterations after `done` are no-ops.  The recurrence is the reference's
+ * (algorithms/pr.hxx:107-195); the reference itself has no multi-GPU execution. */
+typedef struct grx_pr_dist* grx_pr_dist_t;
+grx_status_t grx_pr_dist_create(grx_context_t ctx, grx_graph_t out_rows, grx_graph_t in_rows, int32_t n_ranks,
+                                int32_t my_rank, int32_t lo, int32_t hi, grx_pr_dist_t* out);
+/* d_x: the global x buffer (>= V floats; this rank writes [lo, hi)); d_pair_out: this rank's 2 words;
+ * d_pairs: 2 * n_ranks words, the all-gathered pairs */
+grx_status_t grx_pr_dist_begin(grx_pr_dist_t h, float alpha, float tol, float* d_p_local, float* d_x,
+                               uint32_t* d_pair_out, const uint32_t* d_pairs);
+grx_status_t grx_pr_dist_pre(grx_pr_dist_t h);
+grx_status_t grx_pr_dist_post(grx_pr_dist_t h);
+grx_status_t grx_pr_dist_poll(grx_pr_dist_t h, int32_t* done, int32_t* iterations);
+grx_status_t grx_pr_dist_end(grx_pr_dist_t h, grx_run_stats_t* stats);
+grx_status_t grx_pr_dist_destroy(grx_pr_dist_t h);
+
 /* RCCL transport INSIDE the library (opt-in; librccl is opened at run time): after grx_bfs_dist_comm_init the
  * two collectives of a level group are issued from C on the context's stream -- a grouped ncclSend/ncclRecv per
  * peer for the bitmaps (each pair of GPUs has its own xGMI link) and an ncclAllReduce of the 4 statistics words
