@@ -130,6 +130,13 @@ def lib():
         "grx_bfs_dist_groups": (i32, [vp, i32]),
         "grx_bfs_dist_capture_group": (i32, [vp]),
         "grx_bfs_dist_group_is_captured": (i32, [vp]),
+        "grx_sssp_dist_create": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+        "grx_sssp_dist_begin": (i32, [vp, i32, vp]),
+        "grx_sssp_dist_pre": (i32, [vp]),
+        "grx_sssp_dist_post": (i32, [vp]),
+        "grx_sssp_dist_poll": (i32, [vp, vp, vp]),
+        "grx_sssp_dist_end": (i32, [vp, vp]),
+        "grx_sssp_dist_destroy": (i32, [vp]),
         "grx_pr_dist_create": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
         "grx_pr_dist_begin": (i32, [vp, f32, f32, vp, vp, vp, vp]),
         "grx_pr_dist_pre": (i32, [vp]),

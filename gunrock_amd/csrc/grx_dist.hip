@@ -115,6 +115,8 @@ __global__ void dist_init_kernel(pipe_args a, dist_args x, int32_t* dist, int sr
     c->g_edges_visited = 0;
     c->frontier_bitmap = 0;
     c->convert = 0;
+    c->bu_R = 0;
+    c->bu_T = 0;
     c->bu_open = 0;
     c->bu_probes = 0;
     if (src >= 0) dist[src] = 0;

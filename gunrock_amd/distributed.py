@@ -434,3 +434,93 @@ def pagerank(engine, dist, alpha=0.85, tol=1e-6, p_local=None, first_batch=4, ma
                 break
             batch = min(batch * 2, 16)
         return p_local, engine.end()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Partitioned SSSP (device side: csrc/grx_dist_sssp.hip).  The level-group pattern of the BFS with a float
+# payload: per iteration every pair of ranks exchanges S floats -- the smallest tentative distance the sender found
+# for each of the receiver's vertices (FLT_MAX: none) -- and one all-reduce carries the size of the next frontier.
+
+
+class GrxSsspEngine:
+    """Device side of the partitioned SSSP: the C ABI grx_sssp_dist_*."""
+
+    def __init__(self, properties, out_rows, rank, n_ranks, device):
+        import torch
+        from . import build_graph, multi_context_t
+        self.torch = torch
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.ctx = multi_context_t(self.device.index or 0, stream=self.stream)
+        with torch.cuda.stream(self.stream):
+            self.g = build_graph(properties, out_rows, self.ctx, device=device)
+        self.rank, self.P = int(rank), int(n_ranks)
+        self.V = self.g.get_number_of_vertices()
+        self.S = slice_bits(self.V, self.P)
+        self.lo, self.hi = min(self.rank * self.S, self.V), min((self.rank + 1) * self.S, self.V)
+        with torch.cuda.stream(self.stream):
+            self.send = torch.zeros(self.P * self.S, dtype=torch.float32, device=device)
+            self.recv = torch.zeros(self.P * self.S, dtype=torch.float32, device=device)
+            self.stats_local = torch.zeros(4, dtype=torch.int64, device=device)
+            self.stats_global = torch.zeros(4, dtype=torch.int64, device=device)
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().grx_sssp_dist_create(
+            self.ctx._h, self.g._h, self.P, self.rank, C.c_void_p(self.send.data_ptr()), C.c_void_p(self.recv.data_ptr()),
+            C.c_void_p(self.stats_local.data_ptr()), C.c_void_p(self.stats_global.data_ptr()), C.byref(self._h)))
+
+    def new_labels(self):
+        """SHARDED distance buffer: float32[S], vertex v of this rank at index v - rank * S"""
+        return self.torch.empty(self.S, dtype=self.torch.float32, device=self.device)
+
+    def begin(self, source, distances):
+        assert distances.dtype == self.torch.float32 and distances.numel() >= self.hi - self.lo
+        self._d = distances
+        _capi.check(_capi.lib().grx_sssp_dist_begin(self._h, int(source), C.c_void_p(distances.data_ptr())))
+
+    def pre(self):
+        _capi.check(_capi.lib().grx_sssp_dist_pre(self._h))
+
+    def post(self):
+        _capi.check(_capi.lib().grx_sssp_dist_post(self._h))
+
+    def poll(self):
+        done, level = C.c_int32(0), C.c_int32(0)
+        _capi.check(_capi.lib().grx_sssp_dist_poll(self._h, C.byref(done), C.byref(level)))
+        return bool(done.value), level.value
+
+    def end(self):
+        s = _capi.grx_run_stats_t()
+        _capi.check(_capi.lib().grx_sssp_dist_end(self._h, C.byref(s)))
+        return {"edges_visited": s.edges_visited, "vertices_visited": s.vertices_visited,
+                "search_depth": s.search_depth, "elapsed_ms": s.elapsed_ms}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _capi.lib().grx_sssp_dist_destroy(h)
+            self._h = None
+
+
+def sssp(engine, dist, source, distances, first_batch=4):
+    """Partitioned SSSP driven by this rank.  `distances`: float32 tensor on the engine's device holding the OWNED slice
+    (engine.new_labels()); on return it holds the distances of the owned vertices (FLT_MAX: unreachable).  Returns run
+    stats (edges / vertices are this rank's share; search_depth = iterations, global)."""
+    torch = engine.torch
+    import contextlib
+    on_stream = torch.cuda.stream(engine.stream) if getattr(engine, "stream", None) is not None \
+        else contextlib.nullcontext()
+    with on_stream:
+        engine.begin(source, distances)
+        _all_reduce_stats(dist, engine)
+        batch = _first_batch(engine, first_batch)
+        while True:
+            for _ in range(batch):
+                engine.pre()
+                _all_to_all(dist, engine.send, engine.recv)
+                engine.post()
+                _all_reduce_stats(dist, engine)
+            done, _ = engine.poll()
+            if done:
+                break
+            batch = min(batch * 2, 32)
+        return _remember_groups(engine, engine.end())

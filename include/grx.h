@@ -301,6 +301,27 @@ grx_status_t grx_pr_dist_poll(grx_pr_dist_t h, int32_t* done, int32_t* iteration
 grx_status_t grx_pr_dist_end(grx_pr_dist_t h, grx_run_stats_t* stats);
 grx_status_t grx_pr_dist_destroy(grx_pr_dist_t h);
 
+/* ---- multi-GPU: partitioned SSSP ----------------------------------------------------------
+ * Rank r owns the vertex slice [r * S, min((r + 1) * S, V)), S = grx_bfs_dist_slice_bits(V, n_ranks), and its out-rows
+ * (a V-row CSR with the other rows empty, global column ids); labels are SHARDED (d_local: S floats).  One
+ * iteration group = grx_sssp_dist_pre (termination from the all-reduced frontier size, chunk map, advance: owned
+ * targets are relaxed on the label, remote ones min-reduced into d_send -- n_ranks slices of S floats, slice j for
+ * rank j), the caller's all_to_all_single of the slices (d_send -> d_recv) , grx_sssp_dist_post (the owner applies the
+ * minima it received and appends the improved vertices to its frontier; size of the next frontier into
+ * d_stats_local[0]), the caller's all-reduce of d_stats_local into d_stats_global.  Groups are enqueued blindly,
+ * several per grx_sssp_dist_poll; groups after `done` are no-ops.  Distances equal grx_sssp's bit for bit.  The
+ * recurrence is the reference's (algorithms/sssp.hxx:104-159); the reference has no multi-GPU execution. */
+typedef struct grx_sssp_dist* grx_sssp_dist_t;
+grx_status_t grx_sssp_dist_create(grx_context_t ctx, grx_graph_t out_rows, int32_t n_ranks, int32_t my_rank,
+                                  float* d_send, const float* d_recv, long long* d_stats_local,
+                                  const long long* d_stats_global, grx_sssp_dist_t* out);
+grx_status_t grx_sssp_dist_begin(grx_sssp_dist_t h, int32_t source, float* d_local);
+grx_status_t grx_sssp_dist_pre(grx_sssp_dist_t h);
+grx_status_t grx_sssp_dist_post(grx_sssp_dist_t h);
+grx_status_t grx_sssp_dist_poll(grx_sssp_dist_t h, int32_t* done, int32_t* iteration);
+grx_status_t grx_sssp_dist_end(grx_sssp_dist_t h, grx_run_stats_t* stats);
+grx_status_t grx_sssp_dist_destroy(grx_sssp_dist_t h);
+
 /* RCCL transport INSIDE the library (opt-in; librccl is opened at run time): after grx_bfs_dist_comm_init the
  * two collectives of a level group are issued from C on the context's stream -- a grouped ncclSend/ncclRecv per
  * peer for the bitmaps (each pair of GPUs has its own xGMI link) and an ncclAllReduce of the 4 statistics words
