@@ -123,14 +123,23 @@ def best_profile(run, profile_of, tries=3):
 
 
 def timed(run, sync, steps, warmup):
+    """warm-up steps, then EXACTLY `steps` steps between two synchronisations.  The collector is held off for the timed
+    region: a generation-2 pass over the graph generator's arrays takes tens of milliseconds, and a step takes 0.2."""
+    import gc
     for _ in range(warmup):
         run()
     sync()
-    t1 = time.perf_counter()
-    for _ in range(steps):
-        run()
-    sync()
-    return (time.perf_counter() - t1) * 1e3 / max(1, steps)
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        sync()
+        return (time.perf_counter() - t1) * 1e3 / max(1, steps)
+    finally:
+        if was:
+            gc.enable()
 
 
 def main():
