@@ -387,10 +387,14 @@ __global__ void pr_long_xcd_kernel(pr_args a) {
   a.partial_y[idx] = acc;  // idx = s * V + row
 }
 
+// The 8 partial sums of a row, in fixed order -> the new rank; and, in the same pass, what pr_prepare_kernel would do
+// for the NEXT iteration (x = p * iweights, this block's share of the dangling mass): one sweep over p and iw less per
+// iteration.  The block -> vertices map is fixed by the grid, so the partials (and dsum) stay reproducible.
 __global__ __launch_bounds__(256) void pr_combine_kernel(pr_args a, int iter) {
+  __shared__ float s_w[256 / 64];
   if (a.ctrl->done) return;
   const float base = *a.base;
-  float err = 0.0f;
+  float err = 0.0f, dang = 0.0f;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < a.V; v += (int64_t)gridDim.x * 256) {
     float acc = 0.0f;
 #pragma unroll
@@ -398,9 +402,16 @@ __global__ __launch_bounds__(256) void pr_combine_kernel(pr_args a, int iter) {
     const float np = base + acc;
     err = fmaxf(err, fabsf(np - a.p[v]));
     a.p[v] = np;
+    const float iwv = a.iw[v];
+    a.x[a.x_perm ? a.x_perm[v] : v] = np * iwv;
+    dang += (iwv == 0.0f) ? a.alpha * np : 0.0f;
   }
   err = dev::wave_max_f(err);
   if (dev::lane_id() == 0 && err > 0.0f) atomicMax(&a.err_bits[iter & 1], __float_as_uint(err));
+  dang = dev::wave_sum_f(dang);
+  if (dev::lane_id() == 0) s_w[threadIdx.x >> 6] = dang;
+  __syncthreads();
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
 // bucket in-edges by (source block, destination): counts, then fill with cursors
@@ -653,7 +664,9 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   }
 
   const size_t V = (size_t)g->V;
-  const int n_partial = std::min<int>(2048, (int)((V + PR_BLOCK - 1) / PR_BLOCK));
+  // dangling-mass partials: one per prepare block; the XCD-blocked path prepares inside pr_combine_kernel (its grid)
+  const int combine_grid = ctx->num_cus * 4;
+  const int n_partial = xcd_blocked ? combine_grid : std::min<int>(2048, (int)((V + PR_BLOCK - 1) / PR_BLOCK));
   GRX_HIP(ctx->fbuf[0].reserve(((V + XB - 1) / XB) * XB * sizeof(float)));  // x (permuted positions reach 8 * ceil(V / 8))
   GRX_HIP(ctx->fbuf[1].reserve(V * sizeof(float)));  // iweights
   GRX_HIP(ctx->fbuf[2].reserve(((size_t)n_partial + 16) * sizeof(float)));
@@ -705,14 +718,16 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   for (;;) {
     for (int i = 0; i < batch && launched < max_iter; ++i, ++launched) {
       if (profile) (void)hipEventRecord(pe[0], s);
-      hipLaunchKernelGGL(pr_prepare_kernel, dim3(n_partial), dim3(PR_BLOCK), 0, s, a);
+      // (XCD-blocked path: x and the dangling partials of this iteration were written by the previous iteration's
+      // combine kernel, or by the one prepare launch ahead of the loop)
+      if (!xcd_blocked || launched == 0) hipLaunchKernelGGL(pr_prepare_kernel, dim3(n_partial), dim3(PR_BLOCK), 0, s, a);
       hipLaunchKernelGGL(pr_scalar_kernel, dim3(1), dim3(PR_BLOCK), 0, s, a, launched);
       if (profile) (void)hipEventRecord(pe[1], s);
       if (xcd_blocked) {
         hipLaunchKernelGGL(pr_pull_xcd_kernel, dim3(ctx->num_cus * 8), dim3(PR_BLOCK), 0, s, a);
         if (g->n_xb_long > 0)
           hipLaunchKernelGGL(pr_long_xcd_kernel, dim3((g->n_xb_long + 255) / 256), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(pr_combine_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, a, launched);
+        hipLaunchKernelGGL(pr_combine_kernel, dim3(combine_grid), dim3(256), 0, s, a, launched);
       } else {
         hipLaunchKernelGGL(pr_pull_kernel, dim3(pull_grid), dim3(PR_BLOCK), 0, s, a, launched);
         if (g->n_pr_long > 0)
