@@ -94,7 +94,7 @@ def classify(rows):
         elif kind == "pr":
             it = -1
             for d, n in s["kernels"]:
-                if "pr_prepare_kernel" in n:
+                if "pr_scalar_kernel" in n:  # one per iteration (pr_prepare_kernel runs once on the XCD-blocked path)
                     it += 1
                 if any(k in n for k in ("pr_pull", "pr_long", "pr_combine")):
                     cls[d] = ("pr_pull", it)
