@@ -218,7 +218,7 @@ def main():
     def forward_roofline():
         prof = bfs_profile(gr.forward)
         r = roof(prof, td_bytes, "bfs level kernels, forward-only run: claim-per-edge advance (advance_block) on the "
-                 "thin levels, binned advance (scatter + claim kernels, grx_bin.hpp) on the fat ones",
+                 "thin levels, binned advance (scatter kernel + sweep claim kernel, grx_bin.hpp) on the fat ones",
                  "12 B per frontier slot + 12 B per traversed edge (SURVEY 8d)")
         attach_traffic(r, pmc, "topdown_fat")
         fat = sorted(prof, key=lambda l: -l["edges"])[:2]
