@@ -1,0 +1,51 @@
+"""Static guard for a measured launch-cost rule ("launch-cost findings"): on the MI355X a kernel whose
+workgroup asks for more than 64 KB of LDS paid 10-20 us on EVERY launch (sssp_nf_level_kernel: shortest launch 2.8 us
+at 51,712 B, 13-25 us at 81,920 B).  The kernels that are launched once or twice per BFS / SSSP level or PageRank
+iteration must therefore stay below 64 KB -- and must not spill to scratch.  Reads the metadata notes of the code
+objects inside the built libgrx.so (no GPU needed)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+PER_LEVEL = ("bfs_head_kernel", "bfs_level_kernel", "bfs_level_bin_kernel", "bfs_sweep_kernel", "bfs_source_kernel",
+             "sssp_head_kernel", "sssp_level_kernel", "sssp_nf_head_kernel", "sssp_nf_level_kernel",
+             "pr_pull_kernel", "pr_pull_xcd_kernel", "pr_combine_kernel", "pr_scalar_kernel",
+             "dist_head_kernel", "dist_prep_kernel", "dist_advance_kernel", "dist_post_kernel", "dist_stats_kernel",
+             "sdist_head_kernel", "sdist_advance_kernel", "sdist_post_kernel")
+
+
+def kernel_metadata(tmp_path):
+    from gunrock_amd import _capi
+    so = os.path.join(str(tmp_path), "libgrx.so")
+    shutil.copy(_capi.LIB_PATH, so)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", so], check=True, capture_output=True, cwd=str(tmp_path))
+    out = {}
+    for f in os.listdir(str(tmp_path)):
+        if "amdgcn" not in f:
+            continue
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(str(tmp_path), f)],
+                               check=True, capture_output=True, text=True).stdout
+        # one YAML map per kernel: .group_segment_fixed_size ... .name ... .private_segment_fixed_size (keys are sorted)
+        for m in re.finditer(r"\.group_segment_fixed_size:\s*(\d+).*?\.name:\s*(\S+).*?\.private_segment_fixed_size:\s*(\d+)",
+                             notes, re.S):
+            out[m.group(2)] = (int(m.group(1)), int(m.group(3)))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="no llvm-readelf")
+def test_per_level_kernels_stay_below_64k_lds_and_off_scratch(tmp_path):
+    meta = kernel_metadata(tmp_path)
+    assert meta, "no kernel metadata found in libgrx.so"
+    seen = set()
+    for mangled, (lds, scratch) in meta.items():
+        for k in PER_LEVEL:
+            if ("3grx%d%s" % (len(k), k)) in mangled:
+                seen.add(k)
+                assert lds < 65536, (k, lds)
+                assert scratch == 0, (k, scratch)
+    missing = [k for k in PER_LEVEL if k not in seen]
+    assert not missing, missing
