@@ -15,6 +15,6 @@ grep -v amdgpu.ids $G/final_ab_mid.log > $P/r2_ab_multilevel_bodies_road.txt
 { for a in bfs ssspu sssp; do echo "== $a, GRX_LB_STRICT=1 (chunked merge-path body on every level)"; grep -h "^algo" $G/final_road_${a}_strict1.log; done; } > $P/r2_ab_road_lb_strict.txt
 { echo "== level 1 (89 k vertices, 31 M edges)"; grep -v amdgpu.ids $G/final_bin_debug_l1.log; echo "== level 2 (2.0 M vertices, 36 M edges)"; grep -v amdgpu.ids $G/final_bin_debug_l2.log; } | cut -c1-400 > $P/r2_binned_levels_timeline_lj.txt
 grep -h '^{' $G/final_bench_all.log > $P/r2_all_configs.jsonl
-tail -5 $G/final_pytest_gpu.log | grep -v "^ROCm\|^Hostname\|^Librccl" > $P/r2_pytest_gpu.log
+cat $G/final_pytest_gpu.log | grep -E "passed|failed|rc " > $P/r2_pytest_gpu.log
 tail -3 $G/final_smoke.log | grep -v amdgpu.ids > $P/r2_smoke.log
 ls -la $P | grep r2_ | wc -l
