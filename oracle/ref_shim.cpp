@@ -43,6 +43,26 @@ static hcsr_t make_host_csr(int V, int E, const int* ro, const int* ci, const fl
   return csr;
 }
 
+#ifdef REF_GPU
+// The reference's pr::run (algorithms/pr.hxx:211-236) discards its enactor, so the number of loop() executions
+// -- the one thing a comparison "at equal iteration count" needs -- is unobservable through it.  This entry
+// point is the BODY of that function, unchanged (problem init/reset, self-managed frontiers, enact()), with two
+// additions: enactor.iteration is reported, and `force_iterations > 0` replaces the reference's own convergence
+// test (pr.hxx:172-195) by "stop after exactly that many loop() executions" through a subclass that overrides
+// is_converged only -- loop(), reset() and every kernel are the reference's.
+template <typename problem_type>
+struct pr_counted_enactor_t : pr::enactor_t<problem_type> {
+  int force_iterations;
+  pr_counted_enactor_t(problem_type* p, std::shared_ptr<gcuda::multi_context_t> c, enactor_properties_t props,
+                       int force)
+      : pr::enactor_t<problem_type>(p, c, props), force_iterations(force) {}
+  bool is_converged(gcuda::multi_context_t& context) override {
+    if (force_iterations > 0) return (int)this->iteration >= force_iterations;
+    return pr::enactor_t<problem_type>::is_converged(context);
+  }
+};
+#endif
+
 extern "C" {
 
 float ref_bfs_cpu(int V, int E, const int* ro, const int* ci, int src, int* dist) {
@@ -141,23 +161,39 @@ float ref_gpu_sssp(void* gh, int src, int lb, float* h_dist) {
   }
 }
 
-float ref_gpu_pr(void* gh, float alpha, float tol, float* h_p) {
+float ref_gpu_pr_iters(void* gh, float alpha, float tol, int force_iterations, float* h_p, int* iterations) {
   try {
     auto* g = (ref_graph*)gh;
     auto G = graph::build<memory_space_t::device>(g->props, g->csr);
+    using graph_t = decltype(G);
     auto ctx = std::make_shared<gcuda::multi_context_t>(0);
     int V = G.get_number_of_vertices();
     thrust::device_vector<weight_t> p(V);
-    pr::param_t<weight_t> param(alpha, tol);
-    pr::result_t<weight_t> result(p.data().get());
-    float ms = pr::run(G, param, result, ctx);
+    using param_type = pr::param_t<weight_t>;
+    using result_type = pr::result_t<weight_t>;
+    using problem_type = pr::problem_t<graph_t, param_type, result_type>;
+    param_type param(alpha, tol);
+    result_type result(p.data().get());
+    problem_type problem(G, param, result, ctx);
+    problem.init();
+    problem.reset();
+    enactor_properties_t props;
+    props.self_manage_frontiers = true;
+    pr_counted_enactor_t<problem_type> enactor(&problem, ctx, props, force_iterations);
+    float ms = enactor.enact();
     ctx->get_context(0)->synchronize();
+    if (iterations) *iterations = (int)enactor.iteration;
     thrust::copy(p.begin(), p.end(), h_p);
     return ms;
   } catch (std::exception& e) {
-    fprintf(stderr, "ref_gpu_pr: %s\n", e.what());
+    fprintf(stderr, "ref_gpu_pr_iters: %s\n", e.what());
     return -1.0f;
   }
+}
+
+// pr::run as the reference's own driver calls it (examples/algorithms/pr/pr.cu).
+float ref_gpu_pr(void* gh, float alpha, float tol, float* h_p) {
+  return ref_gpu_pr_iters(gh, alpha, tol, 0, h_p, nullptr);
 }
 #endif
 

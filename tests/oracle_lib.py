@@ -311,6 +311,8 @@ def ref_gpu():
         L.ref_gpu_sssp.restype = C.c_float
         L.ref_gpu_pr.argtypes = [C.c_void_p, C.c_float, C.c_float, f32p]
         L.ref_gpu_pr.restype = C.c_float
+        L.ref_gpu_pr_iters.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, f32p, C.POINTER(C.c_int)]
+        L.ref_gpu_pr_iters.restype = C.c_float
         _ref_gpu = L
     return _ref_gpu
 
@@ -346,3 +348,33 @@ def ref_load_mtx(path):
         L.ref_free(C.cast(ptr, C.c_void_p))
     return Csr(a, b, c, {"directed": props[0], "weighted": props[1],
                          "symmetric": props[2]})
+
+
+class RefGpuGraph:
+    """The reference's own device CSR for graph g (oracle/_ref/libgunrock_ref_gpu.so); GPU box only."""
+
+    def __init__(self, g):
+        self.L = ref_gpu()
+        self.g = g
+        self.h = self.L.ref_gpu_graph_create(g.n_vertices, g.n_edges, g.row_offsets, g.column_indices, g.values)
+
+    def pr(self, alpha=0.85, tol=1e-6, force_iterations=0):
+        """The reference's GPU PageRank (body of pr::run, pr.hxx:211-236) -> (p, loop() executions, enact ms).
+        force_iterations > 0: exactly that many iterations instead of the reference's convergence test."""
+        p = np.empty(self.g.n_vertices, np.float32)
+        it = C.c_int(0)
+        ms = self.L.ref_gpu_pr_iters(self.h, alpha, tol, int(force_iterations), p, C.byref(it))
+        if ms < 0:
+            raise RuntimeError("the reference's GPU PageRank failed")
+        return p, it.value, ms
+
+    def close(self):
+        if self.h:
+            self.L.ref_gpu_graph_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

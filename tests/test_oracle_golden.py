@@ -124,6 +124,46 @@ def test_pr_restatement_selfconsistent(golden):
     assert np.abs(q32 - q64).max() < 1e-6
 
 
+def _pr_golden_cases(golden):
+    ones = lambda k: np.ones(len(golden[k]), np.float32)
+    return {"chesapeake": O.Csr(golden["chesapeake_ro"], golden["chesapeake_ci"], golden["chesapeake_w"]),
+            "rmat": O.Csr(golden["rmat_ro"], golden["rmat_ci"], ones("rmat_ci")),
+            "rmat_a50": O.Csr(golden["rmat_ro"], golden["rmat_ci"], ones("rmat_ci")),
+            "rmat_tol8": O.Csr(golden["rmat_ro"], golden["rmat_ci"], ones("rmat_ci")),
+            "road": O.Csr(golden["road_ro"], golden["road_ci"], golden["road_w"]),
+            "tiny": O.Csr(golden["tiny_ro"], golden["tiny_ci"], golden["tiny_w"]),
+            "tsym": O.Csr(golden["tsym_ro"], golden["tsym_ci"], golden["tsym_w"])}
+
+
+def test_pr_oracle_reproduces_reference_gpu_goldens(golden):
+    """Pins the PageRank half of the oracle to the REFERENCE: tests/golden/golden_pr.npz holds the ranks, every
+    intermediate iterate and the iteration count of the reference's own GPU PageRank (pr.hxx compiled from
+    /root/reference, run on an MI355X by tests/golden/make_golden_pr.py).  The restatements must stop after the
+    same number of loop() executions and reproduce every iterate: fp32 within 1e-6 (north_star's tolerance; the
+    reference's atomicAdd order alone moves its result by `spread` between runs), float64 likewise."""
+    path = os.path.join(GOLDEN, "golden_pr.npz")
+    assert os.path.exists(path), "tests/golden/golden_pr.npz missing (tests/golden/make_golden_pr.py on a GPU box)"
+    gp = np.load(path)
+    for name, g in _pr_golden_cases(golden).items():
+        alpha, tol = (float(x) for x in gp[name + "_param"])
+        its = [int(x) for x in gp[name + "_iterations"]]
+        ref = gp[name + "_p"]
+        spread = float(gp[name + "_spread"][0])
+        assert spread < 1e-7, (name, spread)  # small graphs: the reference's own noise is far below the tolerance
+        p32, it32, _ = O.pr_f32(g, alpha, tol)
+        p64, it64, _ = O.pr_f64(g, alpha, tol)
+        assert it32 in its and it64 in its, (name, it32, it64, its)
+        assert np.abs(p32.astype(np.float64) - ref).max() <= 1e-6, name
+        assert np.abs(p64 - ref).max() <= 1e-6, name
+        assert np.abs(p64 - ref).max() <= 5e-7 * max(1.0, 1e3 * float(ref.max())), name  # in fact fp32 rounding only
+        for k, ref_k in enumerate(gp[name + "_iterates"], start=1):
+            pk, _, _ = O.pr_f64(g, alpha, tol, force_iterations=k)
+            assert np.abs(pk - ref_k).max() <= 1e-6, (name, k)
+            qk, itk, _ = O.pr_f32(g, alpha, tol, max_iterations=k)
+            if itk == k:
+                assert np.abs(qk.astype(np.float64) - ref_k).max() <= 1e-6, (name, k)
+
+
 def test_ncore_baselines_equal_the_oracle(golden):
     """oracle/oracle_omp.c (the N-core CPU baselines of bench.py) reach the same fixed points as the
     restatements of the reference's CPU path; the float64 trace equals orc_pr_f64 up to summation order."""

@@ -109,29 +109,83 @@ def _c4_graph(gr):
     return O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
 
 
+def _golden_pr_graphs(golden):
+    ones = lambda k: np.ones(len(golden[k]), np.float32)
+    return [("chesapeake", O.Csr(golden["chesapeake_ro"], golden["chesapeake_ci"], golden["chesapeake_w"]), 0.85, 1e-6),
+            ("rmat", O.Csr(golden["rmat_ro"], golden["rmat_ci"], ones("rmat_ci")), 0.85, 1e-6),
+            ("rmat_a50", O.Csr(golden["rmat_ro"], golden["rmat_ci"], ones("rmat_ci")), 0.5, 1e-6),
+            ("rmat_tol8", O.Csr(golden["rmat_ro"], golden["rmat_ci"], ones("rmat_ci")), 0.85, 1e-8),
+            ("road", O.Csr(golden["road_ro"], golden["road_ci"], golden["road_w"]), 0.85, 1e-6),
+            ("tiny", O.Csr(golden["tiny_ro"], golden["tiny_ci"], golden["tiny_w"]), 0.85, 1e-7),
+            ("tsym", O.Csr(golden["tsym_ro"], golden["tsym_ci"], golden["tsym_w"]), 0.85, 1e-6)]
+
+
+def test_reference_made_goldens(gr, gpu_ctx, golden):
+    """ours vs the committed output of the REFERENCE's GPU PageRank (tests/golden/golden_pr.npz, made by
+    tests/golden/make_golden_pr.py from oracle/_ref): same iteration count, every rank within 1e-6, and -- run
+    with max_iterations = k -- every intermediate iterate of the reference within 1e-6 as well."""
+    path = os.path.join(GOLDEN, "golden_pr.npz")
+    assert os.path.exists(path), "tests/golden/golden_pr.npz missing"
+    gp = np.load(path)
+    for name, g, alpha, tol in _golden_pr_graphs(golden):
+        p, it = run_pr(gr, gpu_ctx, g, alpha, tol)
+        assert it in [int(x) for x in gp[name + "_iterations"]], (name, it, gp[name + "_iterations"])
+        assert np.abs(p.astype(np.float64) - gp[name + "_p"]).max() <= ABS_TOL, name
+        for k, ref_k in enumerate(gp[name + "_iterates"], start=1):
+            pk, itk = run_pr(gr, gpu_ctx, g, alpha, tol, max_iterations=k)
+            assert itk == k, (name, k, itk)
+            assert np.abs(pk.astype(np.float64) - ref_k).max() <= ABS_TOL, (name, k)
+
+
+def test_reference_gpu_path_live_equal_iterations(gr, gpu_ctx, golden):
+    """The reference's GPU PageRank run LIVE beside ours (when oracle/_ref travels with the tree) on graphs small
+    enough that its atomicAdd-order noise is negligible: equal iteration count and |ours - reference| <= 1e-6."""
+    if not O.have_ref_gpu():
+        pytest.skip("oracle/_ref/libgunrock_ref_gpu.so not built (needs /root/reference at build time)")
+    _, c = gr.generate("rmat", 50_000, 800_000, seed=21)
+    graphs = _golden_pr_graphs(golden) + [("rmat50k", O.Csr(c.row_offsets, c.column_indices, c.nonzero_values), 0.85, 1e-6)]
+    for name, g, alpha, tol in graphs:
+        with O.RefGpuGraph(g) as R:
+            ref, k_ref, _ = R.pr(alpha, tol)
+        p, it = run_pr(gr, gpu_ctx, g, alpha, tol)
+        assert it == k_ref, (name, it, k_ref)
+        assert np.abs(p.astype(np.float64) - ref).max() <= ABS_TOL, name
+
+
 def test_kron_c4_full_size_and_reference_gpu_path(gr, gpu_ctx):
     """Pins PageRank at the headline size.
     (a) ours vs the float64 recurrence after the SAME number of iterations: |d| <= 1e-6, rel <= 1e-4, and the
         iteration count equals float64's (+-1).  One OpenMP float64 pass (orc_pr_f64_trace) gives every
         iterate's distance to our result and the float64 convergence iteration.
-    (b) when the reference compiled here travels with the tree (oracle/_ref/libgunrock_ref_gpu.so), its own GPU
-        PageRank runs on the same arrays; its iteration count is not observable, so it is compared with its
-        BEST-matching float64 iterate -- the most favourable reading.  Reported side by side (also written to
-        gpurun_out/pr_parity_c4.json): |ours - f64|, |ref - f64|, |ours - ref|."""
+    (b) when the reference compiled here travels with the tree (oracle/_ref/libgunrock_ref_gpu.so): its own GPU
+        PageRank on the same arrays, with its iteration count k_ref OBSERVED (ref_gpu_pr_iters = the body of
+        pr::run with enactor.iteration returned).  Ours is re-run with max_iterations = k_ref and compared with
+        the reference AT EQUAL ITERATION COUNT; the reference is also forced to OUR natural count and compared
+        there.  At this size the reference's fp32 atomicAdd accumulation (182 M atomics per iteration, hubs
+        receive > 1e5 of them in arrival order) has an error of its own against exact arithmetic -- measured
+        here as |ref_k - float64_k| and as the spread between two runs of the reference -- so the assertion is
+            |ours_k - ref_k| <= 1e-6 + |ref_k - float64_k|     with     |ours_k - float64_k| <= 1e-6 (in fact ~1e-10),
+        i.e. everything beyond north_star's 1e-6 must be the reference's own distance from exact arithmetic at
+        that iterate.  All numbers go to gpurun_out/pr_parity_c4.json (committed as profiles/r3_pr_parity_c4.json)."""
     import json
     g = _c4_graph(gr)
     assert g.n_edges > 180_000_000
     p, it = run_pr(gr, gpu_ctx, g, weighted=False)
     cmp = [p]
-    ref = None
-    if O.have_ref_gpu():
-        L = O.ref_gpu()
-        rh = L.ref_gpu_graph_create(g.n_vertices, g.n_edges, g.row_offsets, g.column_indices, g.values)
-        ref = np.empty(g.n_vertices, np.float32)
-        ms = L.ref_gpu_pr(rh, 0.85, 1e-6, ref)
-        L.ref_gpu_graph_destroy(rh)
-        assert ms >= 0, "the reference's own GPU PageRank failed"
-        cmp.append(ref)
+    out = {"workload": "C4' kron stand-in, 2^21 V / %d E" % g.n_edges, "ours_iterations": it}
+    have_ref = O.have_ref_gpu()
+    if have_ref:
+        with O.RefGpuGraph(g) as R:
+            ref, k_ref, ms_ref = R.pr(0.85, 1e-6)
+            ref2, k_ref2, _ = R.pr(0.85, 1e-6)
+            ref_at_ours, _, _ = R.pr(0.85, 1e-6, force_iterations=it) if it != k_ref else (ref, k_ref, 0.0)
+        # tol = 0: `err < tol` never holds, so exactly k_ref iterations run whatever our own convergence test says
+        p_k, it_k = run_pr(gr, gpu_ctx, g, tol=0.0, weighted=False, max_iterations=k_ref)
+        assert it_k == k_ref, (it_k, k_ref, it)
+        cmp += [ref, p_k, ref_at_ours]
+        out.update({"ref_gpu_iterations": k_ref, "ref_gpu_iterations_second_run": k_ref2,
+                    "ref_gpu_enact_ms": round(float(ms_ref), 3),
+                    "ref_gpu_run_to_run_max_abs": float(np.abs(ref.astype(np.float64) - ref2).max())})
     n_iter = max(it + 2, 24)
     delta, err, _ = O.pr_f64_trace(g, n_iter, cmp, pattern=True)
     it64 = O.pr_iterations_from_trace(delta)
@@ -142,18 +196,29 @@ def test_kron_c4_full_size_and_reference_gpu_path(gr, gpu_ctx):
     _, _, p64 = O.pr_f64_trace(g, it, [], pattern=True, want_final=True)
     rel = np.abs(p.astype(np.float64) - p64) / np.maximum(p64, 1e-30)
     assert rel.max() <= REL_TOL, rel.max()
-    out = {"workload": "C4' kron stand-in, 2^21 V / %d E" % g.n_edges, "ours_iterations": it,
-           "f64_iterations": it64, "ours_vs_f64_same_iterations_max_abs": e_ours,
-           "ours_vs_f64_max_rel": float(rel.max())}
-    if ref is not None:
-        k_ref = int(np.argmin(err[1])) + 1
-        e_ref = float(err[1][k_ref - 1])
-        out.update({"ref_gpu_best_matching_f64_iteration": k_ref, "ref_gpu_vs_f64_best_max_abs": e_ref,
-                    "ref_gpu_vs_f64_at_ours_iterations_max_abs": float(err[1][it - 1]),
-                    "ours_vs_ref_gpu_max_abs": float(np.abs(p.astype(np.float64) - ref).max())})
-        # ours must be inside the contract; and either closer to its float64 iterate than the reference's
-        # GPU path is to ANY float64 iterate, or both are inside the tolerance
-        assert e_ours <= e_ref or e_ref <= ABS_TOL, out
+    out.update({"f64_iterations": it64, "f64_delta_per_iteration": [float(x) for x in delta[:it + 2]],
+                "ours_vs_f64_same_iterations_max_abs": e_ours, "ours_vs_f64_max_rel": float(rel.max())})
+    if have_ref:
+        e_ref_k = float(err[1][k_ref - 1])            # reference vs exact arithmetic at ITS iteration count
+        e_ours_k = float(err[2][it_k - 1])            # ours stopped at the same count vs exact arithmetic
+        d_k = float(np.abs(p_k.astype(np.float64) - ref).max())
+        e_ref_at_ours = float(err[3][it - 1])
+        d_at_ours = float(np.abs(p.astype(np.float64) - ref_at_ours).max())
+        hub = int(np.argmax(np.abs(p_k.astype(np.float64) - ref)))
+        out.update({"equal_iterations_k": k_ref, "ours_k_vs_ref_k_max_abs": d_k,
+                    "ours_k_vs_f64_k_max_abs": e_ours_k, "ref_k_vs_f64_k_max_abs": e_ref_k,
+                    "ours_vs_ref_forced_to_ours_iterations_max_abs": d_at_ours,
+                    "ref_forced_vs_f64_max_abs": e_ref_at_ours,
+                    "worst_vertex": hub, "worst_vertex_in_degree_rank_value": float(ref[hub]),
+                    "ours_natural_vs_ref_natural_max_abs": float(np.abs(p.astype(np.float64) - ref).max())})
+        os.makedirs(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "pr_parity_c4.json"), "w") as f:
+            json.dump(out, f, indent=1)
+        print(json.dumps(out))
+        assert e_ours_k <= ABS_TOL, out
+        assert d_k <= ABS_TOL + e_ref_k, out            # equal iteration count: the excess is the reference's own error
+        assert d_at_ours <= ABS_TOL + e_ref_at_ours, out
+        return
     os.makedirs(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "pr_parity_c4.json"), "w") as f:
         json.dump(out, f, indent=1)
