@@ -38,19 +38,19 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # BASELINE.json configs[1]: soc-LiveJournal1 stand-in (SURVEY.md 8d C2')
-    "lj": dict(kind="rmat", V=4_847_571, entries=68_993_773, a=0.57, b=0.19, c=0.19,
+    "lj": dict(file="soc-LiveJournal1", kind="rmat", V=4_847_571, entries=68_993_773, a=0.57, b=0.19, c=0.19,
                name="soc-LiveJournal1 stand-in C2': R-MAT(0.57,0.19,0.19,0.05) 4,847,571 V / 68,993,773 E, "
                     "src = max out-degree vertex"),
     # configs[3]: kron_g500-logn21 stand-in C4'
-    "kron": dict(kind="rmat_sym", V=1 << 21, entries=91_042_010, a=0.57, b=0.19, c=0.19,
+    "kron": dict(file="kron_g500-logn21", kind="rmat_sym", V=1 << 21, entries=91_042_010, a=0.57, b=0.19, c=0.19,
                  name="kron_g500-logn21 stand-in C4': symmetric R-MAT(0.57,0.19,0.19,0.05) 2^21 V / 91,042,010 "
                       "entries (~182 M edges)"),
     # configs[2]: road_usa stand-in C3'
-    "road": dict(kind="road", V=4894 * 4894, entries=0, a=0.602, b=0.0, c=0.0,
+    "road": dict(file="road_usa", kind="road", V=4894 * 4894, entries=0, a=0.602, b=0.0, c=0.0,
                  name="road_usa stand-in C3': 4894x4894 lattice, edges kept with p=0.602 (~57.7 M directed edges), "
                       "src = centre vertex"),
     # configs[4]: soc-twitter-2010 stand-in C5' (N = 8)
-    "twitter": dict(kind="rmat_sym", V=21_297_772, entries=265_025_809, a=0.57, b=0.19, c=0.19,
+    "twitter": dict(file="soc-twitter-2010", kind="rmat_sym", V=21_297_772, entries=265_025_809, a=0.57, b=0.19, c=0.19,
                     name="soc-twitter-2010 stand-in C5': symmetric R-MAT(0.57,0.19,0.19,0.05) 21,297,772 V / "
                          "265,025,809 entries (~530 M edges)"),
     "small": dict(kind="rmat", V=1 << 18, entries=4_000_000, a=0.57, b=0.19, c=0.19,
@@ -58,6 +58,54 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 PMC_FILE = os.path.join(ROOT, "profiles", "r2_bench_pmc.json")
+
+
+def find_real(key, data_dir):
+    """Path of the published graph of workload `key` under data_dir ("if the real .mtx files are supplied
+    on the measurement box, use them"): <dir>/<name>.mtx or <dir>/<name>/<name>.mtx as the SuiteSparse archives
+    unpack (datasets/*/Makefile of the reference), else None."""
+    name = WORKLOADS[key].get("file")
+    if not data_dir or not name:
+        return None
+    for cand in (os.path.join(data_dir, name + ".mtx"), os.path.join(data_dir, name, name + ".mtx")):
+        if os.path.isfile(cand):
+            return cand
+    return None
+
+
+def load_workload(gr, key, data_dir=None, weighted=False, seed=42):
+    """-> (properties, csr, source, info).  The published graph through the engine's Matrix-Market loader
+    (grx_host_csr_load_mtx: byte-equal to io/matrix_market.hxx:99-254 + formats/csr.hxx:81-140) when its file is
+    present under data_dir, else the seeded stand-in of SURVEY 8d.  Source: the max out-degree vertex (the road
+    stand-in: its centre vertex).  weighted: U{1..1000} integer weights -- generated with the stand-in, drawn (seeded)
+    onto the real topology when the published file is a pattern matrix."""
+    wl = WORKLOADS[key]
+    path = find_real(key, data_dir)
+    if path:
+        props, coo = gr.matrix_market_t().load(path)
+        csr = gr.csr_t().from_coo(coo)
+        info = {"data": "real", "file": path, "name": "%s (%s)" % (wl["file"], os.path.basename(path))}
+        if weighted and not props.weighted:
+            # a weight per UNORDERED pair, so that w(u, v) == w(v, u) on a symmetric file: a hash of (min, max, seed)
+            u = np.repeat(np.arange(csr.number_of_rows, dtype=np.uint64), np.diff(csr.row_offsets).astype(np.int64))
+            v = csr.column_indices.astype(np.uint64)
+            h = np.minimum(u, v) * np.uint64(2654435761) + np.maximum(u, v) * np.uint64(2246822519) + np.uint64(seed)
+            h ^= h >> np.uint64(13)
+            h *= np.uint64(0x9E3779B1)
+            h ^= h >> np.uint64(17)
+            csr.nonzero_values = (1 + (h % np.uint64(1000))).astype(np.float32)
+            props.weighted = True
+            info["data"] = "real topology, synthetic U{1..1000} weights"
+        src = int(np.argmax(np.diff(csr.row_offsets)))
+        return props, csr, src, info
+    c_par = 1.0 if (weighted and wl["kind"] == "road") else wl["c"]
+    props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], c_par, seed=seed)
+    if wl["kind"] == "road":
+        side = int(round(wl["V"] ** 0.5))
+        src = (side // 2) * side + side // 2
+    else:
+        src = int(np.argmax(np.diff(csr.row_offsets)))
+    return props, csr, src, {"data": "synthetic", "file": None, "name": wl["name"]}
 
 
 def source_sha():
@@ -149,8 +197,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="lj", choices=sorted(WORKLOADS),
                     help="graph of the top-level BFS line (default: BASELINE configs[1])")
-    ap.add_argument("--only", default="bfs,bfs_forward,sssp,pr",
+    ap.add_argument("--only", default="bfs,bfs_forward,sssp,pr,c5",
                     help="comma list of the sections to run at N = 1 (bfs is always run)")
+    ap.add_argument("--data-dir", default=os.environ.get("GRX_DATA_DIR", ""),
+                    help="directory holding the published graphs (soc-LiveJournal1.mtx, road_usa.mtx, "
+                         "kron_g500-logn21.mtx, soc-twitter-2010.mtx, flat or one folder each): every section whose "
+                         "file is present runs on it (data: real) instead of its seeded stand-in")
     ap.add_argument("--lb", default="merge_path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--topdown-only", action="store_true",
@@ -186,11 +238,7 @@ def main():
     # ------------------------------------------------------------------ BFS (top level) + bfs_forward
     wl = WORKLOADS[args.workload]
     t0 = time.time()
-    props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], wl["c"], seed=42)
-    deg = np.diff(csr.row_offsets)
-    src = int(np.argmax(deg))
-    if wl["kind"] == "road":
-        src = (4894 // 2) * 4894 + 4894 // 2
+    props, csr, src, info = load_workload(gr, args.workload, args.data_dir)
     G = gr.build_graph(props, csr, ctx, device=dev)
     V, E = G.get_number_of_vertices(), G.get_number_of_edges()
     dist_t = torch.empty(V, dtype=torch.int32, device=dev)
@@ -283,8 +331,8 @@ def main():
 
     out = {"metric": "MTEPS (million traversed edges/sec) BFS", "value": round(mteps, 1), "unit": "MTEPS",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-           "config": {"workload": "BFS on " + wl["name"], "n_vertices": V, "n_edges": E, "source": src,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": info["data"],
+           "config": {"workload": "BFS on " + info["name"], "data_file": info["file"], "n_vertices": V, "n_edges": E, "source": src,
                       "advance_load_balance": args.lb + " (engine: tile/chunk merge-path decomposition; a per-level "
                                               "choice between claim-per-edge, binned and bottom-up bodies is made on "
                                               "the device)",
@@ -317,19 +365,91 @@ def main():
     # ------------------------------------------------------------------ PageRank on the kron stand-in
     if "pr" in only:
         out["pr"] = bench_pr(gr, torch, ctx, dev, sync, pmc, cpu_on, args)
+    # ------------------------------------------------------------------ configs[4] graph (C5') on ONE GPU
+    if "c5" in only:
+        out["c5_single_gpu"] = bench_c5(gr, torch, ctx, dev, sync, cpu_on, args)
     print(json.dumps(out))
+
+
+def bench_c5(gr, torch, ctx, dev, sync, cpu_on, args):
+    """BASELINE.json configs[4]'s graph (soc-twitter-2010 / its stand-in C5', 21.3 M V / 530 M E) on ONE MI355X: the
+    same-graph N = 1 point the 8-GPU figure of `--gpus 8` is to be divided by (strong scaling), with its own parity
+    check (the oracle's exact fixed-point characterisation), roofline and CPU baselines."""
+    if cpu_on:
+        import oracle_lib as O
+        ncore = O.omp_threads()
+    t0 = time.time()
+    props, csr, src, info = load_workload(gr, "twitter", args.data_dir)
+    G = gr.build_graph(props, csr, ctx, device=dev)
+    V, E = G.get_number_of_vertices(), G.get_number_of_edges()
+    d = torch.empty(V, dtype=torch.int32, device=dev)
+    t_setup = time.time() - t0
+    lb = getattr(gr, args.lb)
+    steps = max(3, min(args.steps, 5))
+    item = {"workload": "BFS on " + info["name"] + " (BASELINE.json configs[4] graph, single GPU)", "data": info["data"],
+            "data_file": info["file"], "n_vertices": V, "n_edges": E, "source": src, "steps": steps,
+            "setup_s": None}
+    depths = {}
+    for label, direction in (("direction_optimized", gr.optimized), ("forward", gr.forward)):
+        o = gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact,
+                         advance_direction=direction, engine_flags=gr.FLAG_ASYNC_RETURN)
+        t1 = time.time()
+        gr.bfs(G, src, d, None, ctx, o)  # first call: per-graph preprocessing (symmetry check / transpose, bins), untimed
+        sync()
+        first = time.time() - t1
+        ms = timed(lambda: gr.bfs(G, src, d, None, ctx, o), sync, steps, 1)
+        st = gr.run_stats(ctx)
+        depths[label] = d.cpu().numpy().copy()
+        po = gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact,
+                          advance_direction=direction, engine_flags=gr.FLAG_PROFILE)
+        prof = best_profile(lambda: gr.bfs(G, src, d, None, ctx, po), lambda: gr.level_profile(ctx), tries=2)
+        sizes = [l["frontier_size"] for l in prof] + [0]
+        bu = [dict(l, nxt=sizes[i + 1]) for i, l in enumerate(prof) if l["bottom_up"] == 1]
+        td = [l for l in prof if l["bottom_up"] != 1]
+        r_td = roof(td, lambda l: 12 * l["frontier_size"] + 12 * l["edges"], "top-down level kernels (advance_block / "
+                    "binned scatter + sweep)", "12 B per frontier slot + 12 B per traversed edge (SURVEY 8d)") if td else None
+        r_bu = roof(bu, lambda l: 3 * (V // 8) + 8 * l["bu_open"] + 8 * l["bu_probes"] + 12 * l["nxt"],
+                    "bfs_level_kernel (bottom-up launches)", "3 V/8 + 8 open + 8 probes + 12 found") if bu else None
+        item[label] = {"ms_per_step": round(ms, 4), "mteps": round(st["edges_visited"] / (ms * 1e3), 1),
+                       "edges_visited_per_step": st["edges_visited"], "search_depth": st["search_depth"],
+                       "enact_ms_last": round(st["elapsed_ms"], 4),
+                       "first_call_s_incl_graph_preprocessing": round(first, 3),
+                       "roofline": r_bu if (r_bu and (not r_td or r_bu["kernel_ms_per_step"] >= r_td["kernel_ms_per_step"]))
+                       else r_td,
+                       "roofline_other_direction": r_td if (r_bu and r_td and r_bu["kernel_ms_per_step"] >=
+                                                            r_td["kernel_ms_per_step"]) else (r_bu if r_td else None),
+                       "levels": [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
+                                   round(l["other_ms"], 4)] for l in prof]}
+    item["forward_equals_direction_optimized"] = bool(np.array_equal(depths["forward"], depths["direction_optimized"]))
+    item["setup_s"] = round(t_setup, 1)
+    if cpu_on:
+        g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
+        item["property_check_violations"] = int(O.check_bfs(g, src, depths["direction_optimized"]))
+        d_n, ms_n, ev_n = O.bfs_omp(g, src)
+        item["cpu_baseline_ncore"] = {
+            "value": round(ev_n / (ms_n * 1e3), 2), "unit": "MTEPS", "cores": ncore, "kind": "port",
+            "sample": "1 full level-synchronous BFS on %d host threads (oracle/oracle_omp.c orc_bfs_omp), %.1f s"
+                      % (ncore, ms_n / 1e3),
+            "matches_gpu": bool(np.array_equal(d_n, depths["direction_optimized"]))}
+        d_q, ms_q, ev_q = O.bfs_queue(g, src)
+        item["cpu_baseline"] = {
+            "value": round(ev_q / (ms_q * 1e3), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+            "sample": "1 full BFS of the same workload/source on one core (oracle/oracle.c orc_bfs_queue: FIFO "
+                      "restatement of examples/algorithms/bfs/bfs_cpu.hxx, identical depths), %.1f s" % (ms_q / 1e3),
+            "matches_gpu": bool(np.array_equal(d_q, depths["direction_optimized"]))}
+    del G, d
+    return item
 
 
 def bench_sssp(gr, torch, ctx, dev, sync, pmc, cpu_on, args):
     if cpu_on:
         import oracle_lib as O
         ncore = O.omp_threads()
-    wl = WORKLOADS["road"]
-    res = {"workload": "SSSP on " + wl["name"]}
-    src = (4894 // 2) * 4894 + 4894 // 2
+    res = {}
     for label, weighted in (("unit_weights", False), ("weighted_1_1000", True)):
         t0 = time.time()
-        props, csr = gr.generate("road", wl["V"], 0, wl["a"], 0.0, 1.0 if weighted else 0.0, seed=42)
+        props, csr, src, info = load_workload(gr, "road", args.data_dir, weighted=weighted)
+        res["workload"] = "SSSP on " + info["name"]
         G = gr.build_graph(props, csr, ctx, device=dev)
         V, E = G.get_number_of_vertices(), G.get_number_of_edges()
         d = torch.empty(V, dtype=torch.float32, device=dev)
@@ -352,7 +472,7 @@ def bench_sssp(gr, torch, ctx, dev, sync, pmc, cpu_on, args):
         r["note"] = ("profile run: one record per two-launch iteration (levels absorbed by the LDS-resident tiny-level "
                      "body of the head kernel are accounted to the iteration that ran them)")
         item = {"schedule": "near-far (delta-stepping)" if weighted else "level-synchronous (all weights equal)",
-                "n_vertices": V, "n_edges": E, "source": src, "steps": steps, "ms_per_step": round(ms_step, 3),
+                "data": info["data"], "data_file": info["file"], "n_vertices": V, "n_edges": E, "source": src, "steps": steps, "ms_per_step": round(ms_step, 3),
                 "mteps": round(st["edges_visited"] / (ms_step * 1e3), 1),
                 "edges_relaxed_per_step": st["edges_visited"], "iterations": st["search_depth"],
                 "us_per_iteration": round(ms_step * 1e3 / max(1, st["search_depth"]), 2),
@@ -384,9 +504,9 @@ def bench_pr(gr, torch, ctx, dev, sync, pmc, cpu_on, args):
     if cpu_on:
         import oracle_lib as O
         ncore = O.omp_threads()
-    wl = WORKLOADS["kron"]
     t0 = time.time()
-    props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], wl["c"], seed=42)
+    props, csr, _, info = load_workload(gr, "kron", args.data_dir)
+    pattern = bool(np.all(csr.nonzero_values == 1.0))
     G = gr.build_graph(props, csr, ctx, device=dev)
     V, E = G.get_number_of_vertices(), G.get_number_of_edges()
     p = torch.empty(V, dtype=torch.float32, device=dev)
@@ -402,13 +522,15 @@ def bench_pr(gr, torch, ctx, dev, sync, pmc, cpu_on, args):
     iters = result.iterations
     ppar = gr.pr_param_t(0.85, 1e-6, gr.options_t(engine_flags=gr.FLAG_PROFILE))
     prof = best_profile(lambda: gr.pr_run(G, ppar, result, ctx), lambda: gr.level_profile(ctx))
-    per_iter = 8 * E + 16 * V  # pattern graph: column index + gathered x per edge; offsets, p, x, iweights per vertex
+    # pattern graph: column index + gathered x per edge; offsets, p, x, iweights per vertex; else + the weight stream
+    per_iter = 8 * E + 16 * V if pattern else 12 * E + 20 * V
     r = roof(prof, lambda l: per_iter, "pr pull iteration (pr_pull_xcd_kernel + long-row pieces + pr_combine_kernel)",
-             "8 E + 16 V per iteration on a pattern graph (weights all 1.0 are not read); SURVEY 8d")
+             "8 E + 16 V per iteration on a pattern graph (weights all 1.0 are not read); SURVEY 8d" if pattern else
+             "12 E + 20 V per iteration (SURVEY 8d)")
     attach_traffic(r, pmc, "pr_pull")
     r["prepare_scalar_ms_per_step"] = round(sum(l["other_ms"] for l in prof), 4)
     r["ms_per_iteration_pull"] = round(sum(l["advance_ms"] for l in prof) / max(1, len(prof)), 4)
-    item = {"workload": "PageRank on " + wl["name"], "alpha": 0.85, "tol": 1e-6, "n_vertices": V, "n_edges": E,
+    item = {"workload": "PageRank on " + info["name"], "data": info["data"], "data_file": info["file"], "alpha": 0.85, "tol": 1e-6, "n_vertices": V, "n_edges": E,
             "steps": steps, "ms_per_step": round(ms_step, 4), "iterations": iters,
             "ms_per_iteration": round(ms_step / max(1, iters), 4),
             "mteps": round(E * iters / (ms_step * 1e3), 1), "first_call_s_incl_layout_build": round(t_first, 2),
@@ -416,7 +538,7 @@ def bench_pr(gr, torch, ctx, dev, sync, pmc, cpu_on, args):
     if cpu_on:
         g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
         mine = p.cpu().numpy()
-        delta, err, _ = O.pr_f64_trace(g, max(iters + 1, 8), [mine], pattern=True)
+        delta, err, _ = O.pr_f64_trace(g, max(iters + 1, 8), [mine], pattern=pattern)
         item["max_abs_diff_to_float64_same_iterations"] = float(err[0][iters - 1])
         item["float64_iterations"] = O.pr_iterations_from_trace(delta)
         _, it1, ms1 = O.pr_f32(g, max_iterations=3)
@@ -424,7 +546,7 @@ def bench_pr(gr, torch, ctx, dev, sync, pmc, cpu_on, args):
             "value": round(E * it1 / (ms1 * 1e3), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
             "sample": "oracle/oracle.c orc_pr_f32 (the reference's push iteration, pr.hxx:107-152, fp32), first %d "
                       "iterations, %.1f s" % (it1, ms1 / 1e3)}
-        _, msn = O.pr_omp(g, iterations=5, pattern=True)
+        _, msn = O.pr_omp(g, iterations=5, pattern=pattern)
         item["cpu_baseline_ncore"] = {
             "value": round(E * 5 / (msn * 1e3), 2), "unit": "MTEPS", "cores": ncore, "kind": "port",
             "sample": "oracle/oracle_omp.c orc_pr_omp (the same recurrence as a pull over the transpose on %d host "
@@ -503,6 +625,28 @@ def bench_multi_gpu(args, gr, torch, rank, local_rank, world):
     edges_total, e_total = int(ee[0].item()), int(ee[1].item())
     ms_per_step = elapsed * 1e3 / args.steps
     mteps = edges_total / (ms_per_step * 1e3)
+    check = None
+    if os.environ.get("GRX_BENCH_CHECK", "0") == "1":
+        # parity of the partitioned search (test harness; outside the timed region): the owned label slices are
+        # gathered on rank 0 over a gloo group and checked with the oracle's exact fixed-point characterisation
+        # against the WHOLE graph, which only rank 0 generates
+        gg = dist.new_group(backend="gloo")
+        mine_labels = dist_t.cpu().numpy()[:hi - lo].copy()
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object((lo, hi, mine_labels), parts, dst=0, group=gg)
+        if rank == 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            _, full = gr.generate(wl["kind"], V, entries, wl["a"], wl["b"], wl["c"], seed=42)
+            g = O.Csr(full.row_offsets, full.column_indices, full.nonzero_values)
+            labels = np.full(V, -1, np.int32)
+            for plo, phi, part in parts:
+                labels[plo:phi] = part
+            reached = labels != np.iinfo(np.int32).max
+            check = {"property_check_violations": int(O.check_bfs(g, src, labels)),
+                     "edges_match_reached_out_degrees": bool(int(np.diff(g.row_offsets)[reached].sum()) == edges_total),
+                     "vertices_reached": int(reached.sum())}
+        dist.barrier(group=gg)
     if rank == 0:
         if name == "twitter":
             wname = "BFS on " + wl["name"] + " (BASELINE.json configs[4]), src = max out-degree vertex"
@@ -524,7 +668,7 @@ def bench_multi_gpu(args, gr, torch, rank, local_rank, world):
                        "advance_direction": "forward (top-down)" if topdown_only else "optimized (Beamer, decided on "
                                             "the device from all-reduced statistics)",
                        "edges_visited_per_step": edges_total, "search_depth": st["search_depth"],
-                       "setup_s": round(t_setup, 1)},
+                       "setup_s": round(t_setup, 1), "backend": backend, "parity_check": check},
             "roofline": None, "cpu_baseline": None}))
     dist.barrier()
     dist.destroy_process_group()

@@ -161,6 +161,26 @@ def test_full_size_livejournal_standin_properties(gr, gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_full_size_twitter_standin_properties(gr, gpu_ctx):
+    """BASELINE.json configs[4] size on ONE GPU (C5': 21,297,772 V / ~530 M E after symmetric doubling): forward
+    (binned fat levels) and direction-optimising searches against the oracle's exact fixed-point characterisation,
+    counters against the degrees of the reached set, and the two directions against each other."""
+    _, c = gr.generate("rmat_sym", 21_297_772, 265_025_809, seed=42)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    assert g.n_edges > 520_000_000
+    src = int(np.argmax(np.diff(g.row_offsets)))
+    got = []
+    for opt in (gr.options_t(advance_direction=gr.forward), gr.options_t(advance_direction=gr.optimized)):
+        d, st = run_bfs(gr, gpu_ctx, g.row_offsets, g.column_indices, src, opt)
+        assert O.check_bfs(g, src, d) == 0
+        reached = d != INF
+        assert st["vertices_visited"] == int(reached.sum())
+        assert st["edges_visited"] == int(np.diff(g.row_offsets)[reached].sum())
+        got.append(d)
+    assert np.array_equal(got[0], got[1])
+
+
+@pytest.mark.gpu
 def test_regression_frontier_merge_persisted_in_bottomup(gr, gpu_ctx):
     """Found by tests/tools/fuzz_gpu.py: a vertex discovered top-down sits in the frontier bitmap
     only; the bottom-up level that consumes that frontier must write the merged word back to
