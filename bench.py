@@ -57,7 +57,6 @@ WORKLOADS = {
                   name="R-MAT 262,144 V / 4,000,000 E (smoke size)"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = os.path.join(ROOT, "profiles", "r2_bench_pmc.json")
 
 
 def find_real(key, data_dir):
@@ -109,21 +108,25 @@ def load_workload(gr, key, data_dir=None, weighted=False, seed=42):
 
 
 def source_sha():
-    """Hash of the engine sources: ties committed PMC traffic numbers to the kernels they were taken from."""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "gunrock_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        h.update(f.encode())
-        h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    """Hash of the engine sources, the C-ABI header and the build flags: ties committed PMC traffic numbers to the
+    kernels they were taken from."""
+    from gunrock_amd.build import source_sha as f
+    return f()
 
 
 def load_pmc():
-    try:
-        pmc = json.load(open(PMC_FILE))
-    except Exception:
-        return None
-    return pmc if pmc.get("source_sha") == source_sha() else None
+    """The newest committed profiles/r*_bench_pmc.json whose source_sha is the current one, else None."""
+    import glob
+    sha = source_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except Exception:
+            continue
+        if pmc.get("source_sha") == sha:
+            pmc["_file"] = os.path.relpath(path, ROOT)
+            return pmc
+    return None
 
 
 def roof(levels, bytes_of, kernel, note=None):
@@ -144,17 +147,17 @@ def attach_traffic(r, pmc, cls, per_step=False):
     meaningless there); it is divided by this run's launch count to stay comparable with `achieved`."""
     k = (pmc or {}).get("classes", {}).get(cls)
     if not k or "fetch_bytes_per_launch" not in k:
-        r["traffic_note"] = ("no PMC passes committed for the current engine sources (profiles/r2_bench_pmc.json "
-                             "missing or taken from other sources)")
+        r["traffic_note"] = ("no PMC passes committed for the current engine sources (no profiles/r*_bench_pmc.json "
+                             "carries this source_sha)")
         return
     tr = k["fetch_bytes_per_launch"] + k.get("write_bytes_per_launch", 0.0)
     if per_step:
         r["traffic_per_step"] = int(tr)
         tr /= max(1, r["launches_per_step"])
     r["traffic"] = int(tr)
-    r["traffic_source"] = ("profiles/r2_bench_pmc.json class '%s': FETCH_SIZE + WRITE_SIZE per launch, separate --pmc "
-                           "passes of this command on these sources (raw counters; gfx950 tallies wide coalesced "
-                           "reads at 1/2)" % cls)
+    r["traffic_source"] = ("%s class '%s': FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes of this command on "
+                           "these sources, NOT re-measured in this run (raw counters; gfx950 tallies wide coalesced "
+                           "reads at 1/2)" % (pmc.get("_file", "profiles/"), cls))
     if "duration_us_per_launch" in k:
         r["rocprof_avg_launch_us"] = round(k["duration_us_per_launch"], 2)
 

@@ -24,6 +24,19 @@ FLAGS = ["-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-ato
          "-I" + os.path.join(ROOT, "include")]
 
 
+def source_sha():
+    """Hash of everything that decides what the engine's kernels are: gunrock_amd/csrc/*, the C-ABI header and the
+    compiler flags.  Committed rocprofv3 PMC numbers carry it; bench.py attaches them only while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "grx.h"), "rb").read())
+    h.update(" ".join(f for f in FLAGS if not f.startswith("-I")).encode())
+    return h.hexdigest()[:16]
+
+
 def _deps():
     out = [os.path.join(ROOT, "include", "grx.h")]
     for f in os.listdir(CSRC):

@@ -1,5 +1,7 @@
 // grx_api.hip -- context, graph view, scratch arena and statistics of the C ABI.
 #include "grx_engine.hpp"
+
+#include <algorithm>
 #include "grx_bin.hpp"
 #include "grx_mid.hpp"
 
@@ -91,7 +93,12 @@ __global__ void fingerprint_kernel(const int32_t* ro, const int32_t* ci, const f
 grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   const size_t V = (size_t)g->V, E = (size_t)g->E;
   const size_t grid = (size_t)advance_grid(ctx);
-  const size_t max_tiles = V / TILE + grid * (TILE_RESERVE + 1) + 8;
+  // The multi-level body (grx_mid.hpp, second version -- the only one a default build carries) lays MID_WGS private
+  // regions of MID_SEG entries plus an overflow area of up to V entries over each parity buffer, whatever the grid:
+  // size for it unconditionally (2 MB per buffer), so that a device or partition with few CUs cannot overrun
+  // (the round-2 guard fell back to a body that is not compiled in).
+  const size_t mid_tiles = std::max((size_t)MID_WGS * MID_SEG_TILES + V / TILE + 2, ((size_t)MID_OVF_BASE + V + 2 * TILE) / TILE);
+  const size_t max_tiles = std::max(V / TILE + grid * (TILE_RESERVE + 1) + 8, mid_tiles);
   const size_t max_chunks = E / CHUNK + max_tiles + 8;
   for (int i = 0; i < 2; ++i) GRX_HIP(ctx->frontier[i].reserve(max_tiles * TILE * sizeof(int32_t)));
   GRX_HIP(ctx->tile_chunks.reserve(max_tiles * sizeof(int32_t)));
@@ -127,7 +134,7 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   if (const char* e = getenv("GRX_MID_EXIT_V")) { const int x = atoi(e); if (x >= 1 && x <= MID_EXIT_V) a->mid_exit_v = x; }
   const char* md = getenv("GRX_MID_DEBUG");
   if (md && *md == '1') a->mid_version |= 0x100;  // per-phase clock sums in ctrl.spare (grx_debug_ctrl)
-  if ((size_t)MID_OVF_BASE + V + TILE > max_tiles * TILE || (size_t)MID_WGS * MID_SEG_TILES + V / TILE + 2 > max_tiles) a->mid_version = 1;
+  static_assert(MID_OVF_BASE == MID_WGS * MID_SEG, "regions first, overflow area behind them");
   return GRX_SUCCESS;
 }
 

@@ -106,6 +106,9 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
     c->bu_R = 0;
     c->bu_T = 0;
     c->t_start = (long long)wall_clock64();
+    a.mailbox[0] = 0;
+    a.mailbox[1] = 0;
+    a.mailbox[2] = 0;
     if (source_level && source_level_applies(deg, d)) {
       // what the head of level 0 leaves behind (plan_body / bfs_decide_body on a one-vertex frontier)
       c->level = 0;
@@ -124,9 +127,6 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
     } else if (visited) {
       visited[src >> 5] = 1u << (src & 31);
     }
-    a.mailbox[0] = 0;
-    a.mailbox[1] = 0;
-    a.mailbox[2] = 0;
   }
 }
 

@@ -34,6 +34,14 @@
 // bounded: a barrier that does not complete raises ctrl.mid_err instead of hanging the device.
 #pragma once
 
+// The multi-level bodies and the l2_local claims rely on two gfx950 (CDNA3/4 multi-XCD) facts: s_getreg_b32 0x1814 is
+// HW_REG_XCC_ID, and workgroup-scope atomics / sc1 loads are coherent inside ONE XCD's L2.  Any other target would turn
+// claims silently wrong, so the device pass refuses to compile for it.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "grx_mid.hpp is written for gfx950 (XCC id register, XCD-local L2 coherence); build with --offload-arch=gfx950"
+#endif
+
+
 #include "grx_frontier.hpp"
 
 namespace grx {

@@ -34,12 +34,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def source_sha():
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "gunrock_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        h.update(f.encode())
-        h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    sys.path.insert(0, ROOT)
+    from gunrock_amd.build import source_sha as f
+    return f()
 
 
 def searches_of(rows):
