@@ -392,6 +392,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_bin_kernel(pipe_args a, b
   const level_head h = load_level_head(c);
   if (h.done) return;
   if (h.mode == 2) {
+    if (bn.local_ids) return;  // the scatter of this level is bfs_scatter2_kernel, the next launch of the group
     bin_scatter_block(a, bn, *reinterpret_cast<bin_scatter_smem*>(lds_raw), h.level & 1, h.total_chunks, a.chunk_tile);
   } else if (h.mode == 3) {
     pol.ctrl = c;
@@ -402,6 +403,14 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_bin_kernel(pipe_args a, b
     advance_block<bfs_policy, false>(a, c, pol, reinterpret_cast<td_smem*>(lds_raw)->adv, h.level & 1, blockIdx.x,
                                      gridDim.x, h.total_chunks, a.chunk_tile);
   }
+}
+
+// The scatter phase of a binned level, second version (grx_bin.hpp): 1024 threads, two workgroups = 32 waves per CU.
+__global__ __launch_bounds__(SC2_BLOCK, 8) void bfs_scatter2_kernel(pipe_args a, bin_args bn) {
+  __shared__ __attribute__((aligned(16))) bin_scatter2_smem sm;
+  const level_head h = load_level_head(a.ctrl);
+  if (h.done || h.mode != 2) return;
+  bin_scatter2_block(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
 }
 
 __global__ __launch_bounds__(ADV_BLOCK) void bfs_claim_kernel(pipe_args a, bin_args bn, bfs_policy pol) {
@@ -420,6 +429,16 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void bfs_sweep_kernel(pipe_args a, bin
   const level_head h = load_level_head(c);
   if (h.done || h.mode != 2) return;
   bin_sweep_block(a, bn, c, h.level + 1, sm, h.level & 1);
+}
+
+// The claim phase as a sweep, second version (grx_bin.hpp): 512 threads, <= 64 VGPRs, four workgroups per CU.
+constexpr int SW2_BLOCK = 512;
+__global__ __launch_bounds__(SW2_BLOCK, 8) void bfs_sweep2_kernel(pipe_args a, bin_args bn) {
+  __shared__ __attribute__((aligned(16))) bin_sweep2_smem<SW2_BLOCK> sm;
+  ctrl_t* c = a.ctrl;
+  const level_head h = load_level_head(c);
+  if (h.done || h.mode != 2) return;
+  bin_sweep2_block<SW2_BLOCK>(a, bn, c, h.level + 1, sm, h.level & 1);
 }
 
 }  // namespace grx
@@ -500,13 +519,22 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
     owner[(size_t)b] = (unsigned char)best;
     load[(size_t)best] += cap[(size_t)b] + 1;
   }
-  const size_t tab_bytes = (size_t)BIN_GRAN_MAX + (size_t)BIN_MAX;  // g2b, owner
+  // second scatter: granule -> bin | (index of the granule inside its bin) << 8, one 16-bit LDS read per edge
+  std::vector<unsigned short> g2b16((size_t)BIN_GRAN_MAX, 0);
+  for (int b = 0; b < nb; ++b)
+    for (int i = first[(size_t)b]; i < first[(size_t)b + 1]; ++i)
+      g2b16[(size_t)i] = (unsigned short)(b | ((i - first[(size_t)b]) << 8));
+  static_assert((1 << (BIN_SHIFT_MAX - BIN_GSHIFT_MIN)) <= 256, "granule index inside a bin fits 8 bits");
+  const size_t tab_bytes = (size_t)BIN_GRAN_MAX + (size_t)BIN_MAX + (size_t)BIN_GRAN_MAX * sizeof(unsigned short);  // g2b, owner, g2b16
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_tab8), tab_bytes));
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_off), 2 * ((size_t)BIN_MAX + 1) * sizeof(int32_t)));  // off, v0
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_fill), ((size_t)BIN_MAX + 16) * BIN_PAD * sizeof(int32_t)));  // fill, queue
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bins), ((size_t)g->E + 16) * sizeof(int32_t)));  // + the tail of a 16-byte load
   GRX_HIP(hipMemcpyAsync(g->bin_tab8, g2b.data(), (size_t)BIN_GRAN_MAX, hipMemcpyHostToDevice, s));
   GRX_HIP(hipMemcpyAsync(g->bin_tab8 + BIN_GRAN_MAX, owner.data(), (size_t)BIN_MAX, hipMemcpyHostToDevice, s));
+  static_assert((BIN_GRAN_MAX + BIN_MAX) % 4 == 0, "the 16-bit table is read as 32-bit words");
+  GRX_HIP(hipMemcpyAsync(g->bin_tab8 + BIN_GRAN_MAX + BIN_MAX, g2b16.data(), (size_t)BIN_GRAN_MAX * sizeof(unsigned short),
+                         hipMemcpyHostToDevice, s));
   GRX_HIP(hipMemcpyAsync(g->bin_off, off.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
   GRX_HIP(hipMemcpyAsync(g->bin_off + BIN_MAX + 1, v0.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
   GRX_HIP(hipMemsetAsync(g->bin_fill, 0, ((size_t)BIN_MAX + 16) * BIN_PAD * sizeof(int32_t), s));
@@ -721,7 +749,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.mid_v = env_int("GRX_MID_V", MID_ENTER_V);
     bn.mid_e = env_int("GRX_MID_E", MID_ENTER_E);
   }
-  int grid_scatter = 0, grid_claim = 0;
+  int grid_scatter = 0, grid_claim = 0, grid_scatter2 = 0, grid_sweep2 = 0;
   // claim phase of a binned level: 3 = sweep (one workgroup per bin, vertex-ordered output), 2 = slices claimed in the owning XCD's L2
   const int claim_version = env_int("GRX_BIN_CLAIM", 3);
   if (use_bins) {
@@ -732,6 +760,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.queue = g->bin_fill + (size_t)BIN_MAX * BIN_PAD;
     bn.g2b = g->bin_tab8;
     bn.owner = g->bin_tab8 + BIN_GRAN_MAX;
+    bn.g2b16 = reinterpret_cast<const unsigned short*>(g->bin_tab8 + BIN_GRAN_MAX + BIN_MAX);
     bn.gshift = g->bin_shift;
     bn.n_gran = g->bin_ngran;
     bn.nb = g->bin_nb;
@@ -758,6 +787,28 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.dist = d_dist;
     static const int per_cu_claim = resident_per_cu(bfs_claim_kernel);
     grid_claim = ctx->num_cus * per_cu_claim;
+    // scatter phase: 2 = 1024-thread workgroups in their own launch (bins hold offsets inside the bin), 1 = first
+    // version inside the level kernel.  The slice claim (GRX_BIN_CLAIM=2) reads global ids: first version only.
+    if (env_int("GRX_BIN_SCATTER", 2) == 2 && claim_version != 2) {
+      static const int per_cu_sc2 = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_scatter2_kernel, SC2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
+        return n > 2 ? 2 : n;
+      }();
+      bn.local_ids = 1;
+      grid_scatter2 = ctx->num_cus * env_int("GRX_SC2_WG_PER_CU", per_cu_sc2);
+    }
+    // sweep claim: 2 = 512-thread workgroups, one work item each (GRX_BIN_SWEEP=1: the first version)
+    if (claim_version == 3 && env_int("GRX_BIN_SWEEP", 2) == 2) {
+      static const int per_cu_sw2 = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_sweep2_kernel, SW2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
+        return n > 4 ? 4 : n;
+      }();
+      grid_sweep2 = ctx->num_cus * env_int("GRX_SW2_WG_PER_CU", per_cu_sw2);
+      bn.sweep_items = env_int("GRX_SW2_ITEMS", grid_sweep2);
+      if (bn.sweep_items > grid_sweep2) bn.sweep_items = grid_sweep2;
+    }
   }
   if (!dopt && variant == 0) {
     static const int per_cu_scatter = resident_per_cu(bfs_level_bin_kernel);
@@ -780,8 +831,12 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         // forward-only run.  level = claim-per-edge advance, many mid-size levels (grx_mid.hpp), or the SCATTER phase of
         // a binned level; the CLAIM phase is launched only when levels can be binned (a no-op unless the head did)
         hipLaunchKernelGGL(bfs_level_bin_kernel, dim3(grid_scatter), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
+        if (grid_scatter2 > 0)
+          hipLaunchKernelGGL(bfs_scatter2_kernel, dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
         if (use_bins && claim_version == 2)
           hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_claim), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
+        else if (use_bins && grid_sweep2 > 0)
+          hipLaunchKernelGGL(bfs_sweep2_kernel, dim3(grid_sweep2), dim3(SW2_BLOCK), 0, stream, a, bn);
         else if (use_bins)
           hipLaunchKernelGGL(bfs_sweep_kernel, dim3(ctx->num_cus * 2), dim3(SWEEP_BLOCK), 0, stream, a, bn);
       } else {

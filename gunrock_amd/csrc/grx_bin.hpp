@@ -51,6 +51,9 @@ struct bin_args {
   const unsigned char* g2b;   // granule -> bin (bins are runs of granules: capacity-balanced, variable width)
   const int32_t* v0;          // nb + 1: first vertex of each bin
   const unsigned char* owner; // bin -> dense index of the XCD that claims its vertices
+  const unsigned short* g2b16;  // second scatter: granule -> bin | (index of the granule inside its bin) << 8
+  int32_t local_ids;          // 1: the bins hold ids RELATIVE to the first vertex of their bin (second scatter), 0: global ids
+  int32_t sweep_items;        // second sweep: work items a level is cut into at most (<= its grid: one item per workgroup)
   int32_t gshift;             // granule of vertex n = n >> gshift
   int32_t n_gran;
   int32_t nb;                 // bins in use (<= BIN_MAX)
@@ -650,6 +653,7 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
     const int n_e = min(sm.fillv[b], e0 + SWEEP_PART) - e0;
     const int lo = bn.off[b] + e0, hi = lo + n_e;
     const int vbase = bn.v0[b];
+    const int vsub = bn.local_ids ? 0 : vbase;  // second scatter: the candidates are offsets inside the bin already
     const int words = (bn.v0[b + 1] - vbase) >> 5;
     const int gw0 = vbase >> 5;
     ++dbg_items;
@@ -685,7 +689,7 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
         for (int j = 0; j < 4; ++j) {
           const int gi = g0 + j;
           if (idx <= i4_last && gi >= lo && gi < hi) {
-            const int local = n4[j] - vbase;
+            const int local = n4[j] - vsub;
             const unsigned bit = 1u << (local & 31);
             // plain read first: a visited hub is hit by many lanes at once, and a read broadcasts where an
             // atomic on one word serialises
@@ -764,6 +768,526 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
     d[5] = dbg_words;
     d[6] = dbg_tA;
     d[7] = dbg_tB;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SCATTER, second version (round 3): the same multisplit on workgroups of 1024 threads.
+//
+// What the counters said about the first version (profiles/r2_bench_pmc.json, class topdown_fat): VALU 15 % busy, the
+// LDS array ~45 %, HBM at a quarter of its rate -- and the waves parked in s_waitcnt / s_barrier 59 % of their cycles.
+// Nothing is saturated; the kernel is a chain of ~12 barrier-separated phases per batch executed by THREE workgroups
+// (12 waves) per CU, because a thread carries 32 edges (id + bin/rank) through the sort and a software pipeline four
+// chunks deep: 156 VGPRs, 44 KB of LDS.  Here a batch is still 4 chunks = 8192 edges (one reservation atomic per bin
+// and batch: a counter word sustains ~90 atomics/us), but it is spread over 1024 threads -- quarter q of the
+// workgroup stages chunk q -- so a thread carries 8 edges: <= 64 VGPRs, two workgroups = 32 waves per CU, the
+// hardware maximum, to hide the same round trips.  Changes besides the geometry:
+//   * one barrier less in the owner map: the carry of the running maximum across the four waves of a quarter comes
+//     from three ballots per wave over the slots' row-begin positions (highest slot that begins a row before the
+//     target wave's first atom), written with the degree totals -- no second exchange;
+//   * the granule table yields bin AND the vertex's offset inside its bin in ONE 16-bit LDS read; the sorted entry is
+//     (bin << 24 | offset), so the copy-out finds its bin without a second table lookup, and the bins hold offsets
+//     relative to the bin's first vertex -- which is what the sweep claim indexes its bitmap slice with;
+//   * the owner map no longer shares its LDS with the sort buffer, so the barrier at the end of a batch is gone
+//     (7 per batch instead of ~12).
+// Launched as its own kernel between the level kernel and the sweep (bfs_scatter2_kernel): the other bodies of the
+// level kernel are written for 256-thread workgroups.
+constexpr int SC2_BLOCK = 1024;
+constexpr int SC2_Q = SC2_BLOCK / TILE;  // quarters = chunks per batch
+static_assert(SC2_Q == BIN_BATCH, "a batch is still 4 chunks");
+
+struct bin_scatter2_smem {
+  int dlt[SC2_Q][TILE];            // per staged slot: row start - exclusive degree prefix
+  int wtot[SC2_Q][4];              // degree sums of the four waves of a quarter
+  int cand[SC2_Q][4][4];           // [quarter][target wave][source wave]: highest slot of the source wave that begins a row before the target's first atom
+  int wave[BIN_MAX / 64 + 1];
+  int hist[BIN_MAX];
+  int off[BIN_MAX];
+  int delta[BIN_MAX];
+  int btot;
+  unsigned short g2b[BIN_GRAN_MAX];  // granule -> bin | granule index inside the bin << 8
+  unsigned char own[SC2_Q][CHUNK];   // owner map: staged slot of every atom of the four chunks
+  unsigned sorted[SC2_Q * CHUNK];    // (bin << 24 | offset inside the bin), grouped by bin
+};
+
+__device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin_args& bn, bin_scatter2_smem& sm, int p,
+                                                   int total_chunks, const int* chunk_tile) {
+  const int tid0 = threadIdx.x;
+  int tid = tid0;
+  int q = tid >> 8;          // quarter of the workgroup = chunk of the batch
+  int tq = tid & (TILE - 1); // slot of the staged tile
+  int lane = tid & 63;
+  int wq = (tid >> 6) & 3;   // wave inside the quarter
+  const int32_t* in = a.frontier[p];
+  const int gshift = bn.gshift;
+  const unsigned gmask = (1u << gshift) - 1u;
+  for (int w = tid; w < (bn.n_gran + 1) / 2; w += SC2_BLOCK)
+    reinterpret_cast<unsigned*>(sm.g2b)[w] = reinterpret_cast<const unsigned*>(bn.g2b16)[w];
+  const int boff = tid < bn.nb ? bn.off[tid] : 0;  // static offset of bin `tid`
+  const int n_units = (total_chunks + SC2_Q - 1) / SC2_Q;
+  const int stride = (int)gridDim.x;
+  int vzero;  // keeps the descriptor loads vector loads (a scalar load would be waited for at the next barrier)
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  const int2* map = reinterpret_cast<const int2*>(chunk_tile);
+  auto S1 = [&](int u) -> int2 {
+    const long long cidx = (long long)u * SC2_Q + q;
+    const bool ok = u < n_units && cidx < total_chunks;
+    int2 t = map[(unsigned)((ok ? (int)cidx : 0) + vzero)];
+    if (!ok) t.y = -1;  // not a chunk of this level: contributes no atoms (its tile is a real one)
+    return t;
+  };
+  // software pipeline of the front, as in the first version: descriptor -> slot -> row offsets are three dependent
+  // round trips; iteration i issues the row offsets of unit i + 1, the slot of unit i + 2 and the descriptor of
+  // unit i + 3 together with its own column indices
+  const int u0 = (int)blockIdx.x;
+  // of a descriptor {tile, chunk index inside the tile} the tile is needed only to load the slot: stages A and B
+  // carry the chunk index alone
+  int yA, yB;
+  int2 tlC, tlD;
+  int vA, vB, vC;
+  int rsA, reA, rsB, reB;
+  {
+    const int2 tA = S1(u0), tB = S1(u0 + stride);
+    tlC = S1(u0 + 2 * stride);
+    yA = tA.y;
+    yB = tB.y;
+    vA = in[(unsigned)(tA.x * TILE + tq)];
+    vB = in[(unsigned)(tB.x * TILE + tq)];
+    const unsigned vv = vA >= 0 ? (unsigned)vA : 0u;
+    rsA = a.ro[vv];
+    reA = a.ro[vv + 1u];
+  }
+  for (int u = u0; u < n_units; u += stride) {
+    // Everything derived from the thread index is RE-derived per batch from an opaque copy: left to itself the
+    // compiler hoists two dozen per-thread constants (k * 256 + tq, LDS addresses, ...) out of the loop, runs out
+    // of the 64 VGPRs that two workgroups per CU allow, and spills -- and a scratch reload issued behind the
+    // prefetch loads waits for those loads (in-order vmcnt), which stalls the software pipeline.
+    tid = tid0;
+    asm volatile("" : "+v"(tid));
+    q = tid >> 8;
+    tq = tid & (TILE - 1);
+    lane = tid & 63;
+    wq = (tid >> 6) & 3;
+    unsigned char* own = &sm.own[q][0];
+    // ---- phase 1: degrees, wave scan; clear the owner map and the histogram
+    const bool has = yA >= 0;
+    const int rs = rsA;
+    const int dg = (has && vA >= 0) ? reA - rsA : 0;
+    const int a0 = has ? yA * CHUNK : 0;
+    // the front of the next batches: a whole batch of cover for their round trips
+    {
+      const unsigned vv = vB >= 0 ? (unsigned)vB : 0u;  // unconditional loads from a clamped index (vertex 0 exists)
+      rsB = a.ro[vv];
+      reB = a.ro[vv + 1u];
+    }
+    vC = in[(unsigned)(tlC.x * TILE + tq)];
+    tlD = S1(u + 3 * stride);
+    const int inc = dev::wave_inclusive_sum(dg);
+    if (lane == 63) sm.wtot[q][wq] = inc;
+    reinterpret_cast<uint2*>(own)[tq] = make_uint2(0u, 0u);
+    if (tid < BIN_MAX) sm.hist[tid] = 0;
+    __syncthreads();
+    // ---- phase 2: exclusive prefix inside the tile; rows mark where they begin; carries for the running maximum
+    int base = 0, tot = 0;
+    {
+      const int4 wt = *reinterpret_cast<const int4*>(&sm.wtot[q][0]);
+      const int x[4] = {wt.x, wt.y, wt.z, wt.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < wq) base += x[i];
+        tot += x[i];
+      }
+    }
+    const int ex = base + inc - dg;
+    sm.dlt[q][tq] = rs - ex;
+    const int pos = ex - a0;  // where this slot's row begins inside the chunk's window
+    if (dg > 0) {
+      if (pos > 0) {
+        if (pos < CHUNK) own[pos] = (unsigned char)tq;
+      } else if (pos + dg > 0) {
+        own[0] = (unsigned char)tq;  // the one row that is under way where the window begins
+      }
+    }
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      // highest slot of this wave whose row begins before wave w's first atom (its 512-byte share of the owner map)
+      const unsigned long long m = dev::ballot(dg > 0 && pos < w * (CHUNK / 4));
+      if (lane == 0) sm.cand[q][w][wq] = m ? (wq * 64 + 63 - __builtin_clzll(m)) : 0;
+    }
+    __syncthreads();
+    // ---- phase 3: running maximum over the owner map (8 bytes per thread, wave scan, carry from the ballots)
+    {
+      const uint2 w8 = reinterpret_cast<const uint2*>(own)[tq];
+      unsigned m_k[8];
+      unsigned run = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned b = ((i < 4 ? w8.x : w8.y) >> ((i & 3) * 8)) & 0xffu;
+        run = b > run ? b : run;
+        m_k[i] = run;
+      }
+      const int incm = dev::wave_inclusive_max_nonneg((int)run);
+      unsigned carry = (unsigned)dev::wave_shift_up1(incm);
+      if (wq > 0) {
+        const int4 cd = *reinterpret_cast<const int4*>(&sm.cand[q][wq][0]);
+        const int c4 = max(max(cd.x, cd.y), max(cd.z, cd.w));
+        carry = (unsigned)c4 > carry ? (unsigned)c4 : carry;
+      }
+      uint2 r8 = make_uint2(0u, 0u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned v = m_k[i] > carry ? m_k[i] : carry;
+        if (i < 4) r8.x |= v << (i * 8);
+        else r8.y |= v << ((i - 4) * 8);
+      }
+      reinterpret_cast<uint2*>(own)[tq] = r8;
+    }
+    __syncthreads();
+    // ---- phase 4: edges of the chunk (lanes on consecutive atoms), column indices, bin + rank inside the bin.
+    // Every LDS / global operation of the 8 atoms is issued UNCONDITIONALLY from a clamped index, phase by phase
+    // (owner bytes -> row deltas -> column indices -> granule table -> histogram): under a per-lane condition each
+    // one sits in its own basic block with its consumer and an s_waitcnt behind it -- 8 x 4 serialized round trips.
+    unsigned e_k[ADV_ITEMS];  // first the neighbour id, then bin << 24 | offset inside the bin
+    int r_k[ADV_ITEMS];       // rank inside the bin
+    const int n_at = has ? min(tot - a0, CHUNK) : 0;  // atoms of this chunk; atom k * TILE + tq is real iff < n_at
+    {
+      int ob[ADV_ITEMS];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) ob[k] = own[k * TILE + tq];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) ob[k] = sm.dlt[q][ob[k]];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) {
+        const int al = k * TILE + tq;
+        const int e = al < n_at ? a0 + al + ob[k] : 0;  // lanes past the end read edge 0
+        e_k[k] = (unsigned)a.ci[e];
+      }
+      unsigned t_k[ADV_ITEMS];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) t_k[k] = sm.g2b[e_k[k] >> gshift];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) {
+        const unsigned bb = t_k[k] & 0xffu;
+        e_k[k] = (bb << 24) | ((t_k[k] >> 8) << gshift) | (e_k[k] & gmask);
+        r_k[k] = atomicAdd(&sm.hist[bb], (k * TILE + tq) < n_at ? 1 : 0);
+      }
+    }
+    __syncthreads();
+    // ---- phase 5: one reservation per non-empty bin (its round trip is covered by the scan and the sort), bin offsets
+    int cnt = 0, gbase = 0, inc2 = 0;
+    if (tid < BIN_MAX) {
+      cnt = sm.hist[tid];
+      if (cnt > 0) gbase = atomicAdd(&bn.fill[(unsigned)(tid * BIN_PAD)], cnt);
+      inc2 = dev::wave_inclusive_sum(cnt);
+      if (lane == 63) sm.wave[wq] = inc2;
+    }
+    __syncthreads();
+    int ex2 = 0;
+    if (tid < BIN_MAX) {
+      int b2 = 0;
+#pragma unroll
+      for (int i = 0; i < BIN_MAX / 64; ++i)
+        if (i < wq) b2 += sm.wave[i];
+      ex2 = b2 + inc2 - cnt;
+      sm.off[tid] = ex2;
+      if (tid == BIN_MAX - 1) sm.btot = ex2 + cnt;
+    }
+    __syncthreads();
+    // ---- phase 6: group by bin in LDS (offsets read unconditionally, then the stores)
+    {
+      int o_k[ADV_ITEMS];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) o_k[k] = sm.off[e_k[k] >> 24];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k)
+        if (k * TILE + tq < n_at) sm.sorted[o_k[k] + r_k[k]] = e_k[k];
+    }
+    if (tid < BIN_MAX) sm.delta[tid] = boff + gbase - ex2;  // global slot of sorted position i of this bin: delta + i
+    __syncthreads();
+    // ---- phase 7: runs leave LDS as contiguous segments (no barrier behind it: the next batch touches the sort
+    // buffer and `delta` only after six more barriers).  Positions past the batch's total hold stale entries: their
+    // bin field is < 256 whatever they are, so the table read stays unconditional
+    {
+      const int btot = sm.btot;
+      unsigned s_k[ADV_ITEMS];
+      int d_k[ADV_ITEMS];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) s_k[k] = sm.sorted[k * SC2_BLOCK + tid];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) d_k[k] = sm.delta[s_k[k] >> 24];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) {
+        const int i = k * SC2_BLOCK + tid;
+        if (i < btot) bn.bins[(size_t)(d_k[k] + i)] = (int)(s_k[k] & 0xffffffu);
+      }
+    }
+    yA = yB; yB = tlC.y; tlC = tlD;
+    vA = vB; vB = vC;
+    rsA = rsB; reA = reB;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SWEEP claim, second version (round 3): the same three steps per work item (candidates -> LDS bitmap, one merging
+// atomic per word with new bits, new bits -> ascending vertex ids -> labels + tiles + chunk map) on workgroups of NT
+// = 512 threads and <= 64 VGPRs: FOUR workgroups (32 waves) per CU instead of one of 1024 threads at 128 VGPRs.
+// Why: an item is a chain of ~8 dependent global round trips (bitmap slice, candidate stream, bitmap re-read, merging
+// atomic, row offsets, chunk-map reservation, ...) of ~2 us each under load; the first version ran ONE such chain per
+// CU (timeline of round 2: 23 us of streaming + 26 us of "expand" per item, 216 items on 256 CUs, the other
+// workgroups idle) and ended every workgroup with a separate emission of its last short tile.  Here
+//   * items are smaller: a level is cut into about as many parts as there are RESIDENT workgroups (bin_args::sweep_items,
+//     at least SW2_PART_MIN candidates each), one item per workgroup, so the chains of four items per CU overlap.
+//     (No device-wide queue: a single counter word serves ~88 atomics/us, 1024 workgroups asking at once would wait
+//     12 us for it.)
+//   * a workgroup's last item emits its short tile together with its full ones;
+//   * the emission keeps one group of three passes in flight instead of all nine (registers), and issues the
+//     chunk-map reservation as soon as the degree sums are known, behind the stores of the frontier slots.
+constexpr int SW2_PART_MIN = 1 << 14;
+constexpr int SW2_U = 2;          // 16-byte candidate loads per thread and round
+
+template <int NT>
+struct bin_sweep2_smem {
+  static constexpr int SEG_WORDS = NT / 4;               // a thread expands one byte of a bitmap word
+  static constexpr int LIST = SEG_WORDS * 32 + TILE;
+  static constexpr int MAX_TILES = LIST / TILE + 1;
+  unsigned bm[1 << (BIN_SHIFT_MAX - 5)];
+  int list[LIST];
+  int pre[BIN_MAX + 1];
+  int fillv[BIN_MAX];
+  int wave[NT / 64 + 1];
+  int sum[MAX_TILES][4];   // per tile of an emission and wave of the tile: degree sums
+  int ttot[64];
+  int cpre[64];
+  int tile_base;
+  int chunk_base;
+  int n_chunks;
+};
+
+// Emit list[0 .. n) as ceil(n / TILE) tiles of parity q (only the last one may be short) with their entries of the next
+// level's chunk map and their share of its counters (see sweep_emit).  Block-wide call.
+template <int NT>
+__device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q, bin_sweep2_smem<NT>& sm, int n) {
+  using S = bin_sweep2_smem<NT>;
+  static_assert(S::MAX_TILES <= 64, "one lane per tile of an emission");
+  constexpr int PASSES = (S::LIST + NT - 1) / NT;
+  constexpr int G = 3;  // passes whose row-offset loads travel together
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // (re-derive per call what depends on the thread index: see bin_scatter2_block)
+  const int lane = tid & 63;
+  const int k = (n + TILE - 1) / TILE;
+  if (tid == 0) sm.tile_base = atomicAdd(&c->n_tiles[q], k);  // travels together with the degree loads
+  for (int j0 = 0; j0 < PASSES && j0 * NT < k * TILE; j0 += G) {
+    int x[G], r0[G], r1[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int idx = (j0 + g) * NT + tid;
+      x[g] = idx < n ? sm.list[idx] : -1;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const unsigned xx = x[g] >= 0 ? (unsigned)x[g] : 0u;  // unconditional loads from a clamped index
+      r0[g] = a.ro[xx];
+      r1[g] = a.ro[xx + 1u];
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int idx = (j0 + g) * NT + tid;
+      if (idx - lane < k * TILE) {  // wave-uniform: tiles are multiples of the wave size
+        const int t = dev::wave_sum(x[g] >= 0 ? r1[g] - r0[g] : 0);
+        if (lane == 0) sm.sum[idx >> 8][(idx >> 6) & 3] = t;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {  // k <= MAX_TILES tiles: one lane each
+    int tot = 0, ch = 0;
+    if (lane < k) {
+      tot = sm.sum[lane][0] + sm.sum[lane][1] + sm.sum[lane][2] + sm.sum[lane][3];
+      ch = (tot + CHUNK - 1) / CHUNK;
+    }
+    const int inc = dev::wave_inclusive_sum(ch);
+    long long es = (long long)tot;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) es += __shfl_xor(es, o, 64);
+    sm.ttot[lane] = tot;
+    sm.cpre[lane] = inc - ch;
+    if (lane == 63) {
+      sm.n_chunks = inc;
+      sm.chunk_base = inc > 0 ? atomicAdd(&c->map_chunks, inc) : 0;
+    }
+    if (lane == 0) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(&c->q_edges[q]), (unsigned long long)es);
+      atomicAdd(&c->n_items[q], n);
+    }
+  }
+  // frontier slots first (they need only the tile base, which arrived with the row offsets): the reservation of the
+  // chunk-map entries is on its way meanwhile
+  const int base = __hip_atomic_load(&sm.tile_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int idx = tid; idx < k * TILE; idx += NT)
+    a.frontier[q][(unsigned)((base + (idx >> 8)) * TILE + (idx & (TILE - 1)))] = idx < n ? sm.list[idx] : -1;
+  __syncthreads();
+  for (int t = tid; t < k; t += NT) {
+    const int tot = sm.ttot[t];
+    a.tile_sums[base + t] = tot;
+    a.tile_chunks[base + t] = (tot + CHUNK - 1) / CHUNK;
+    a.tile_count[base + t] = min(TILE, n - t * TILE);
+  }
+  {
+    int2* map = reinterpret_cast<int2*>(a.chunk_tile) + sm.chunk_base;
+    const int nc = sm.n_chunks;
+    for (int ci = tid; ci < nc; ci += NT) {
+      int t = 0;  // largest t with cpre[t] <= ci (tiles without chunks are skipped over): 64 entries, 6 steps
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1)
+        if (t + step < k && sm.cpre[t + step] <= ci) t += step;
+      map[ci] = make_int2(base + t, ci - sm.cpre[t]);
+    }
+  }
+  __syncthreads();
+}
+
+template <int NT>
+__device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_args& bn, ctrl_t* c, int depth,
+                                                 bin_sweep2_smem<NT>& sm, int p) {
+  using S = bin_sweep2_smem<NT>;
+  static_assert(TILE == 256 && NT == 4 * S::SEG_WORDS && NT >= BIN_MAX, "a thread expands one byte of a bitmap word");
+  const int tid0 = threadIdx.x;
+  int tid = tid0;
+  const int q = p ^ 1;
+  if (blockIdx.x == 0 && tid == 0) c->map_level = depth;  // the chunk map and the counters of level `depth` come from this kernel
+  int fill = 0;
+  if (tid < bn.nb) fill = bn.fill[(unsigned)(tid * BIN_PAD)];
+  int tot_fill;
+  (void)dev::block_exclusive_sum<NT>(fill, sm.wave, &tot_fill);
+  // every bin rounds its number of parts up: total / (sweep_items - nb) per part keeps the item count within sweep_items
+  const int parts = max(1, bn.sweep_items - bn.nb);
+  const int PART = max(SW2_PART_MIN, ((tot_fill / parts) + 4) & ~3);
+  int tot_items;
+  const int ex0 = dev::block_exclusive_sum<NT>((fill + PART - 1) / PART, sm.wave, &tot_items);
+  if (tid < BIN_MAX) {
+    sm.pre[tid] = ex0;
+    sm.fillv[tid] = fill;
+  }
+  if (tid == 0) sm.pre[BIN_MAX] = tot_items;
+  __syncthreads();
+  int n_list = 0;  // uniform: entries waiting in sm.list (labels already stored)
+  const int4* src4 = reinterpret_cast<const int4*>(bn.bins);
+  for (int item = (int)blockIdx.x; item < tot_items; item += (int)gridDim.x) {
+    tid = tid0;
+    asm volatile("" : "+v"(tid));  // (per-thread constants are re-derived per item instead of living in VGPRs)
+    int b = 0;  // largest b with pre[b] <= item (bins without items are skipped over)
+#pragma unroll
+    for (int step = BIN_MAX / 2; step >= 1; step >>= 1)
+      if (sm.pre[b + step] <= item) b += step;
+    const int e0 = (item - sm.pre[b]) * PART;
+    const int n_e = min(sm.fillv[b], e0 + PART) - e0;
+    const int lo = bn.off[b] + e0, hi = lo + n_e;
+    const int vbase = bn.v0[b];
+    const int vsub = bn.local_ids ? 0 : vbase;  // second scatter: the candidates are offsets inside the bin already
+    const int words = (bn.v0[b + 1] - vbase) >> 5;
+    const int gw0 = vbase >> 5;
+    // first candidates on their way while the bitmap slice is copied
+    const int i4_first = lo >> 2, i4_last = (hi - 1) >> 2;
+    int4 nx[SW2_U];
+    auto LOAD = [&](int r, int4(&v)[SW2_U]) {
+#pragma unroll
+      for (int u = 0; u < SW2_U; ++u) {
+        const int idx = i4_first + (r * SW2_U + u) * NT + tid;
+        v[u] = src4[idx < i4_last ? idx : i4_last];
+      }
+    };
+    LOAD(0, nx);
+    for (int w = tid; w < words; w += NT) sm.bm[w] = (gw0 + w) < bn.visited_words ? bn.visited[gw0 + w] : ~0u;
+    __syncthreads();
+    // A. candidates -> LDS bitmap (loads one round ahead)
+    const int rounds = (i4_last - i4_first + SW2_U * NT) / (SW2_U * NT);
+    for (int r = 0; r < rounds; ++r) {
+      int4 cur[SW2_U];
+#pragma unroll
+      for (int u = 0; u < SW2_U; ++u) cur[u] = nx[u];
+      LOAD(r + 1, nx);
+#pragma unroll
+      for (int u = 0; u < SW2_U; ++u) {
+        const int idx = i4_first + (r * SW2_U + u) * NT + tid;
+        const int g0 = idx << 2;
+        const int n4[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+        unsigned wv[4];
+        // (unconditional LDS reads from clamped positions first, then the rare atomics)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gi = g0 + j;
+          const bool ok = idx <= i4_last && gi >= lo && gi < hi;
+          const int local = ok ? n4[j] - vsub : 0;
+          wv[j] = ok ? sm.bm[local >> 5] : ~0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int local = n4[j] - vsub;
+          const unsigned bit = 1u << (local & 31);
+          // plain read first: a visited hub is hit by many lanes at once, and a read broadcasts where an atomic on
+          // one word serialises
+          if (!(wv[j] & bit)) atomicOr(&sm.bm[local >> 5], bit);
+        }
+      }
+    }
+    __syncthreads();
+    // B. words with bits the global bitmap lacks: one atomic each; what it returns decides between the parts of a bin
+    for (int w0 = 0; w0 < words; w0 += 4 * NT) {
+      unsigned cand[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = w0 + j * NT + tid;
+        cand[j] = 0u;
+        if (w < words && gw0 + w < bn.visited_words) cand[j] = sm.bm[w] & ~bn.visited[gw0 + w];
+      }
+      unsigned old[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = w0 + j * NT + tid;
+        old[j] = 0u;
+        if (cand[j]) old[j] = atomicOr(&bn.visited[gw0 + w], cand[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = w0 + j * NT + tid;
+        if (w < words) sm.bm[w] = cand[j] & ~old[j];
+      }
+    }
+    __syncthreads();
+    const bool last = item + (int)gridDim.x >= tot_items;  // uniform: this workgroup takes no further item
+    // C. new bits -> ascending vertex ids -> labels, tiles.  The list is emitted when the next segment might not fit and
+    // at the end of the item -- including its short tail when this is the workgroup's last item.
+    auto emit_list = [&](bool all) {
+      const int k = all ? (n_list + TILE - 1) / TILE : n_list / TILE;
+      const int n_emit = all ? n_list : k * TILE;
+      sweep2_emit<NT>(a, c, q, sm, n_emit);
+      const int rem = n_list - n_emit;
+      int keep = 0;
+      if (tid < rem) keep = sm.list[n_emit + tid];
+      __syncthreads();
+      if (tid < rem) sm.list[tid] = keep;
+      n_list = rem;
+      __syncthreads();
+    };
+    for (int s0 = 0; s0 < words; s0 += S::SEG_WORDS) {
+      const int w = s0 + (tid >> 2);
+      unsigned byte = w < words ? (sm.bm[w] >> ((tid & 3) * 8)) & 0xffu : 0u;
+      int tot;
+      const int ex = dev::block_exclusive_sum<NT>(__popc(byte), sm.wave, &tot);
+      if (tot == 0) continue;
+      if (n_list + tot > S::LIST) emit_list(false);  // n_list >= TILE here: tot <= LIST - TILE
+      int pos = n_list + ex;
+      const int v_first = vbase + (w << 5) + (tid & 3) * 8;
+      while (byte) {
+        const int v = v_first + __ffs(byte) - 1;
+        byte &= byte - 1u;
+        sm.list[pos++] = v;
+        bn.dist[v] = depth;  // exactly one winner per vertex (bfs.hxx:117-119 assigns the same depth)
+      }
+      n_list += tot;
+      __syncthreads();
+    }
+    if (last ? n_list > 0 : n_list >= TILE) emit_list(last);
   }
 }
 

@@ -27,15 +27,35 @@ __device__ __forceinline__ unsigned long long ballot(bool p) {
   return __builtin_amdgcn_ballot_w64(p);
 }
 
-// Inclusive prefix sum across the 64 lanes of a wave.
+// Inclusive prefix sum across the 64 lanes of a wave, on the DPP data path of gfx950: four row_shr steps scan each
+// row of 16 lanes, row_bcast:15 / row_bcast:31 carry the row totals across (lanes whose source does not exist, and
+// rows masked off, receive the `old` operand, 0).  Six VALU instructions and no address registers -- the
+// ds_bpermute form (__shfl_up) it replaces went through the LDS crossbar six times and kept six lane-index VGPRs
+// alive in every kernel that scans.
 __device__ __forceinline__ int wave_inclusive_sum(int x) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int o = 1; o < WAVE; o <<= 1) {
-    int y = __shfl_up(x, o, WAVE);
-    if (lane >= o) x += y;
-  }
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
   return x;
+}
+
+// Inclusive running maximum of NON-NEGATIVE values across the wave (same DPP schedule; 0 is the identity).
+__device__ __forceinline__ int wave_inclusive_max_nonneg(int x) {
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
+  return x;
+}
+
+// The value of the lane below (lane 0: 0): wave_shr:1.
+__device__ __forceinline__ int wave_shift_up1(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false);
 }
 
 __device__ __forceinline__ int wave_sum(int x) {
