@@ -406,11 +406,16 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_bin_kernel(pipe_args a, b
 }
 
 // The scatter phase of a binned level, second version (grx_bin.hpp): 1024 threads, two workgroups = 32 waves per CU.
+template <bool DBG>
 __global__ __launch_bounds__(SC2_BLOCK, 8) void bfs_scatter2_kernel(pipe_args a, bin_args bn) {
   __shared__ __attribute__((aligned(16))) bin_scatter2_smem sm;
   const level_head h = load_level_head(a.ctrl);
   if (h.done || h.mode != 2) return;
-  bin_scatter2_block(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
+  if (DBG && h.level != bn.debug_level) {
+    bin_scatter2_block<false>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
+    return;
+  }
+  bin_scatter2_block<DBG>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
 }
 
 __global__ __launch_bounds__(ADV_BLOCK) void bfs_claim_kernel(pipe_args a, bin_args bn, bfs_policy pol) {
@@ -433,12 +438,17 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void bfs_sweep_kernel(pipe_args a, bin
 
 // The claim phase as a sweep, second version (grx_bin.hpp): 512 threads, <= 64 VGPRs, four workgroups per CU.
 constexpr int SW2_BLOCK = 512;
+template <bool DBG>
 __global__ __launch_bounds__(SW2_BLOCK, 8) void bfs_sweep2_kernel(pipe_args a, bin_args bn) {
   __shared__ __attribute__((aligned(16))) bin_sweep2_smem<SW2_BLOCK> sm;
   ctrl_t* c = a.ctrl;
   const level_head h = load_level_head(c);
   if (h.done || h.mode != 2) return;
-  bin_sweep2_block<SW2_BLOCK>(a, bn, c, h.level + 1, sm, h.level & 1);
+  if (DBG && h.level != bn.debug_level) {
+    bin_sweep2_block<SW2_BLOCK, false>(a, bn, c, h.level + 1, sm, h.level & 1);
+    return;
+  }
+  bin_sweep2_block<SW2_BLOCK, DBG>(a, bn, c, h.level + 1, sm, h.level & 1);
 }
 
 }  // namespace grx
@@ -792,7 +802,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (env_int("GRX_BIN_SCATTER", 2) == 2 && claim_version != 2) {
       static const int per_cu_sc2 = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_scatter2_kernel, SC2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_scatter2_kernel<false>, SC2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
         return n > 2 ? 2 : n;
       }();
       bn.local_ids = 1;
@@ -802,7 +812,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (claim_version == 3 && env_int("GRX_BIN_SWEEP", 2) == 2) {
       static const int per_cu_sw2 = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_sweep2_kernel, SW2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_sweep2_kernel<false>, SW2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
         return n > 4 ? 4 : n;
       }();
       grid_sweep2 = ctx->num_cus * env_int("GRX_SW2_WG_PER_CU", per_cu_sw2);
@@ -831,12 +841,16 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         // forward-only run.  level = claim-per-edge advance, many mid-size levels (grx_mid.hpp), or the SCATTER phase of
         // a binned level; the CLAIM phase is launched only when levels can be binned (a no-op unless the head did)
         hipLaunchKernelGGL(bfs_level_bin_kernel, dim3(grid_scatter), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
-        if (grid_scatter2 > 0)
-          hipLaunchKernelGGL(bfs_scatter2_kernel, dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
+        if (grid_scatter2 > 0 && bn.debug)
+          hipLaunchKernelGGL(bfs_scatter2_kernel<true>, dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
+        else if (grid_scatter2 > 0)
+          hipLaunchKernelGGL(bfs_scatter2_kernel<false>, dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
         if (use_bins && claim_version == 2)
           hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_claim), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
+        else if (use_bins && grid_sweep2 > 0 && bn.debug)
+          hipLaunchKernelGGL(bfs_sweep2_kernel<true>, dim3(grid_sweep2), dim3(SW2_BLOCK), 0, stream, a, bn);
         else if (use_bins && grid_sweep2 > 0)
-          hipLaunchKernelGGL(bfs_sweep2_kernel, dim3(grid_sweep2), dim3(SW2_BLOCK), 0, stream, a, bn);
+          hipLaunchKernelGGL(bfs_sweep2_kernel<false>, dim3(grid_sweep2), dim3(SW2_BLOCK), 0, stream, a, bn);
         else if (use_bins)
           hipLaunchKernelGGL(bfs_sweep_kernel, dim3(ctx->num_cus * 2), dim3(SWEEP_BLOCK), 0, stream, a, bn);
       } else {

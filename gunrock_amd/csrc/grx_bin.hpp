@@ -810,8 +810,20 @@ struct bin_scatter2_smem {
   unsigned sorted[SC2_Q * CHUNK];    // (bin << 24 | offset inside the bin), grouped by bin
 };
 
+template <bool DBG>
 __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin_args& bn, bin_scatter2_smem& sm, int p,
                                                    int total_chunks, const int* chunk_tile) {
+  // DBG (GRX_BIN_DEBUG, its own kernel build): wave 0's clock at the end of every phase, summed per workgroup
+  long long dbg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_t = 0, dbg_t0 = 0;
+  int dbg_batches = 0;
+  auto dbg_mark = [&](int i) {
+    if constexpr (DBG) {
+      const long long now = (long long)wall_clock64();
+      dbg_ph[i] += now - dbg_t;
+      dbg_t = now;
+    }
+  };
+  if constexpr (DBG) dbg_t0 = dbg_t = (long long)wall_clock64();
   const int tid0 = threadIdx.x;
   int tid = tid0;
   int q = tid >> 8;          // quarter of the workgroup = chunk of the batch
@@ -887,6 +899,8 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     reinterpret_cast<uint2*>(own)[tq] = make_uint2(0u, 0u);
     if (tid < BIN_MAX) sm.hist[tid] = 0;
     __syncthreads();
+    ++dbg_batches;
+    dbg_mark(0);
     // ---- phase 2: exclusive prefix inside the tile; rows mark where they begin; carries for the running maximum
     int base = 0, tot = 0;
     {
@@ -915,6 +929,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       if (lane == 0) sm.cand[q][w][wq] = m ? (wq * 64 + 63 - __builtin_clzll(m)) : 0;
     }
     __syncthreads();
+    dbg_mark(1);
     // ---- phase 3: running maximum over the owner map (8 bytes per thread, wave scan, carry from the ballots)
     {
       const uint2 w8 = reinterpret_cast<const uint2*>(own)[tq];
@@ -943,6 +958,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       reinterpret_cast<uint2*>(own)[tq] = r8;
     }
     __syncthreads();
+    dbg_mark(2);
     // ---- phase 4: edges of the chunk (lanes on consecutive atoms), column indices, bin + rank inside the bin.
     // Every LDS / global operation of the 8 atoms is issued UNCONDITIONALLY from a clamped index, phase by phase
     // (owner bytes -> row deltas -> column indices -> granule table -> histogram): under a per-lane condition each
@@ -962,6 +978,10 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
         const int e = al < n_at ? a0 + al + ob[k] : 0;  // lanes past the end read edge 0
         e_k[k] = (unsigned)a.ci[e];
       }
+      if constexpr (DBG) {  // split the phase where the column indices have arrived
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg_mark(3);
+      }
       unsigned t_k[ADV_ITEMS];
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) t_k[k] = sm.g2b[e_k[k] >> gshift];
@@ -973,6 +993,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       }
     }
     __syncthreads();
+    dbg_mark(4);
     // ---- phase 5: one reservation per non-empty bin (its round trip is covered by the scan and the sort), bin offsets
     int cnt = 0, gbase = 0, inc2 = 0;
     if (tid < BIN_MAX) {
@@ -993,6 +1014,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       if (tid == BIN_MAX - 1) sm.btot = ex2 + cnt;
     }
     __syncthreads();
+    dbg_mark(5);
     // ---- phase 6: group by bin in LDS (offsets read unconditionally, then the stores)
     {
       int o_k[ADV_ITEMS];
@@ -1004,6 +1026,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     }
     if (tid < BIN_MAX) sm.delta[tid] = boff + gbase - ex2;  // global slot of sorted position i of this bin: delta + i
     __syncthreads();
+    dbg_mark(6);
     // ---- phase 7: runs leave LDS as contiguous segments (no barrier behind it: the next batch touches the sort
     // buffer and `delta` only after six more barriers).  Positions past the batch's total hold stale entries: their
     // bin field is < 256 whatever they are, so the table read stays unconditional
@@ -1021,9 +1044,23 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
         if (i < btot) bn.bins[(size_t)(d_k[k] + i)] = (int)(s_k[k] & 0xffffffu);
       }
     }
+    dbg_mark(7);
     yA = yB; yB = tlC.y; tlC = tlD;
     vA = vB; vB = vC;
     rsA = rsB; reA = reB;
+  }
+  if constexpr (DBG) {
+    if (threadIdx.x == 0 && bn.debug) {
+      long long* d = bn.debug + 8 * (size_t)blockIdx.x;
+      d[0] = (long long)((unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u);
+      d[1] = dbg_batches;
+      d[2] = dbg_t0;
+      d[3] = (long long)wall_clock64();
+      d[4] = dbg_ph[0] | (dbg_ph[1] << 20) | (dbg_ph[2] << 40);
+      d[5] = dbg_ph[3] | (dbg_ph[4] << 20) | (dbg_ph[5] << 40);
+      d[6] = dbg_ph[6] | (dbg_ph[7] << 20);
+      d[7] = -2;  // record of the second scatter
+    }
   }
 }
 
@@ -1146,10 +1183,21 @@ __device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q
   __syncthreads();
 }
 
-template <int NT>
+template <int NT, bool DBG>
 __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_args& bn, ctrl_t* c, int depth,
                                                  bin_sweep2_smem<NT>& sm, int p) {
   using S = bin_sweep2_smem<NT>;
+  // DBG (GRX_BIN_DEBUG, its own kernel build): thread 0's clock per step, summed over the workgroup's items
+  long long dbg_t0 = 0, dbg_t = 0, dbg_ph[4] = {0, 0, 0, 0}, dbg_entries = 0;
+  int dbg_items = 0;
+  auto dbg_mark = [&](int i) {
+    if constexpr (DBG) {
+      const long long now = (long long)wall_clock64();
+      dbg_ph[i] += now - dbg_t;
+      dbg_t = now;
+    }
+  };
+  if constexpr (DBG) dbg_t0 = (long long)wall_clock64();
   static_assert(TILE == 256 && NT == 4 * S::SEG_WORDS && NT >= BIN_MAX, "a thread expands one byte of a bitmap word");
   const int tid0 = threadIdx.x;
   int tid = tid0;
@@ -1175,6 +1223,7 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
   for (int item = (int)blockIdx.x; item < tot_items; item += (int)gridDim.x) {
     tid = tid0;
     asm volatile("" : "+v"(tid));  // (per-thread constants are re-derived per item instead of living in VGPRs)
+    if constexpr (DBG) dbg_t = (long long)wall_clock64();
     int b = 0;  // largest b with pre[b] <= item (bins without items are skipped over)
 #pragma unroll
     for (int step = BIN_MAX / 2; step >= 1; step >>= 1)
@@ -1231,6 +1280,8 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
       }
     }
     __syncthreads();
+    if constexpr (DBG) { ++dbg_items; dbg_entries += n_e; }
+    dbg_mark(0);
     // B. words with bits the global bitmap lacks: one atomic each; what it returns decides between the parts of a bin
     for (int w0 = 0; w0 < words; w0 += 4 * NT) {
       unsigned cand[4];
@@ -1254,6 +1305,7 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
       }
     }
     __syncthreads();
+    dbg_mark(1);
     const bool last = item + (int)gridDim.x >= tot_items;  // uniform: this workgroup takes no further item
     // C. new bits -> ascending vertex ids -> labels, tiles.  The list is emitted when the next segment might not fit and
     // at the end of the item -- including its short tail when this is the workgroup's last item.
@@ -1287,7 +1339,22 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
       n_list += tot;
       __syncthreads();
     }
+    dbg_mark(2);
     if (last ? n_list > 0 : n_list >= TILE) emit_list(last);
+    dbg_mark(3);
+  }
+  if constexpr (DBG) {
+    if (threadIdx.x == 0 && bn.debug && blockIdx.x < 4096) {
+      long long* d = bn.debug + 8 * (4096 + (size_t)blockIdx.x);
+      d[0] = (long long)((unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u);
+      d[1] = dbg_items;
+      d[2] = dbg_t0;
+      d[3] = (long long)wall_clock64();
+      d[4] = dbg_entries;
+      d[5] = dbg_ph[0] | (dbg_ph[1] << 32);   // stream | merge
+      d[6] = dbg_ph[2] | (dbg_ph[3] << 32);   // expand | emit
+      d[7] = -2;
+    }
   }
 }
 

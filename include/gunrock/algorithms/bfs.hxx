@@ -43,6 +43,11 @@ struct relax_depth_t {
   vertex_t* depth;
   vertex_t next;
   __host__ __device__ bool operator()(vertex_t const&, vertex_t const& nbr, edge_t const&, weight_t const&) const {
+    // A plain (possibly stale) read first: labels only decrease, so a label already at or below `next` cannot be improved
+    // by this edge whatever has happened since.  The reference issues the atomic for EVERY edge (bfs.hxx:117-119); on a
+    // multi-XCD part a device-scope atomic is a memory-side operation (~20 G/s for the whole chip), and > 90 % of the
+    // edges of a fat level lead to labelled vertices.  Same result: the atomic still decides among the contenders.
+    if (thread::load(depth + nbr) <= next) return false;
     return next < math::atomic::min(depth + nbr, next);
   }
 };

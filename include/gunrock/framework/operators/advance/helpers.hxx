@@ -41,6 +41,14 @@ __global__ void degrees_kernel(graph_t G, const type_t* input, std::size_t n, ed
 // scan, s_start the first edge id of each slot, s_src the slot's vertex.  Lanes
 // take consecutive atoms, so column-index / weight reads are coalesced inside a
 // row.  `out` points at the output position of window atom 0 (may be null).
+//
+// A thread works on ROUND atoms at a time, phase by phase: the ROUND owner searches step together (ROUND independent LDS
+// probes in flight per step instead of one dependent chain per atom), then all row starts, then all neighbour ids /
+// weights from clamped indices (atoms past the end read the window's first edge), then the user operator, then the stores.
+// Written as one loop over atoms -- search, load, call, store -- every global load sat behind its own search and in
+// front of its own consumer: one round trip at a time per lane (seen in the ISA of round 2's kernels).
+constexpr int ROUND = 8;
+
 template <advance_io_type_t output_type, typename graph_t, typename operator_t, typename type_t>
 __device__ __forceinline__ void expand_window(const graph_t& G, operator_t& op, const int* s_seg,
                                               const int* s_start, const type_t* s_src, int nslots,
@@ -48,21 +56,51 @@ __device__ __forceinline__ void expand_window(const graph_t& G, operator_t& op, 
   using vertex_t = typename graph_t::vertex_type;
   using edge_t = typename graph_t::edge_type;
   using weight_t = typename graph_t::weight_type;
-  for (int atom = atom_lo + (int)threadIdx.x; atom < atom_hi; atom += BLOCK) {
-    int lo = 0;
+  for (int base = atom_lo; base < atom_hi; base += BLOCK * ROUND) {  // uniform over the workgroup
+    int lo[ROUND], atom[ROUND];
 #pragma unroll
-    for (int step = BLOCK / 2; step >= 1; step >>= 1)
-      if (lo + step < nslots && s_seg[lo + step] <= atom) lo += step;
-    // mutable lvalues: user operators may take (vertex_t&, vertex_t&, edge_t const&, weight_t const&)
-    // like the reference's hits.hxx:137
-    edge_t e = (edge_t)(s_start[lo] + (atom - s_seg[lo]));
-    vertex_t src = (vertex_t)s_src[lo];
-    vertex_t nbr = G.get_destination_vertex(e);
-    weight_t w = G.get_edge_weight(e);
-    const bool keep = op(src, nbr, e, w);
-    if constexpr (output_type != advance_io_type_t::none) {
-      const type_t emitted = (output_type == advance_io_type_t::edges) ? (type_t)e : (type_t)nbr;
-      out[atom] = keep ? emitted : gunrock::numeric_limits<type_t>::invalid();
+    for (int k = 0; k < ROUND; ++k) {
+      atom[k] = base + k * BLOCK + (int)threadIdx.x;
+      lo[k] = 0;
+    }
+    // largest slot with s_seg[slot] <= atom, for all ROUND atoms at once (atoms past the end search for atom_hi - 1)
+#pragma unroll
+    for (int step = BLOCK / 2; step >= 1; step >>= 1) {
+      int probe[ROUND];
+#pragma unroll
+      for (int k = 0; k < ROUND; ++k) probe[k] = s_seg[min(lo[k] + step, nslots)];
+#pragma unroll
+      for (int k = 0; k < ROUND; ++k)
+        if (lo[k] + step < nslots && probe[k] <= min(atom[k], atom_hi - 1)) lo[k] += step;
+    }
+    edge_t e[ROUND];
+    vertex_t src[ROUND];
+#pragma unroll
+    for (int k = 0; k < ROUND; ++k) {
+      const int a = min(atom[k], atom_hi - 1);  // a real atom of the window: its edge exists
+      e[k] = (edge_t)(s_start[lo[k]] + (a - s_seg[lo[k]]));
+      src[k] = (vertex_t)s_src[lo[k]];
+    }
+    vertex_t nbr[ROUND];
+    weight_t w[ROUND];
+#pragma unroll
+    for (int k = 0; k < ROUND; ++k) nbr[k] = G.get_destination_vertex(e[k]);
+#pragma unroll
+    for (int k = 0; k < ROUND; ++k) w[k] = G.get_edge_weight(e[k]);
+#pragma unroll
+    for (int k = 0; k < ROUND; ++k) {
+      if (atom[k] < atom_hi) {
+        // mutable lvalues: user operators may take (vertex_t&, vertex_t&, edge_t const&, weight_t const&)
+        // like the reference's hits.hxx:137
+        edge_t ee = e[k];
+        vertex_t ss = src[k], nn = nbr[k];
+        weight_t ww = w[k];
+        const bool keep = op(ss, nn, ee, ww);
+        if constexpr (output_type != advance_io_type_t::none) {
+          const type_t emitted = (output_type == advance_io_type_t::edges) ? (type_t)e[k] : (type_t)nbr[k];
+          out[atom[k]] = keep ? emitted : gunrock::numeric_limits<type_t>::invalid();
+        }
+      }
     }
   }
 }

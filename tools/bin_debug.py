@@ -42,13 +42,28 @@ for phase, lo in (("scatter", 0), ("claim", 4096)):
         q = r[r[:, 0] == x]
         dur = (q[:, 3] - q[:, 2]) * tick_us
         extra = ""
-        if phase == "scatter":
+        if phase == "scatter" and (q[:, 7] == -2).all():  # second scatter: wave 0's clock per phase
+            nb = max(1, q[:, 1].sum())
+            m20 = (1 << 20) - 1
+            parts = (q[:, 4] & m20, (q[:, 4] >> 20) & m20, q[:, 4] >> 40, q[:, 5] & m20, (q[:, 5] >> 20) & m20, q[:, 5] >> 40,
+                     q[:, 6] & m20, (q[:, 6] >> 20) & m20)
+            extra = (" | per batch us: front+scan %.2f prefix+marks %.2f running-max %.2f owners+ci-arrive %.2f table+hist %.2f "
+                     "reserve+bin-scan %.2f sort %.2f copy-out %.2f" % tuple(x.sum() * tick_us / nb for x in parts))
+        elif phase == "claim" and (q[:, 7] == -2).all():  # second sweep
+            m32 = (1 << 32) - 1
+            ni = max(1, q[:, 1].sum())
+            extra = (" entries %d (max %d) | per item us: stream %.1f merge %.1f expand %.1f emit %.1f"
+                     % (q[:, 4].sum(), q[:, 4].max(), (q[:, 5] & m32).sum() * tick_us / ni, (q[:, 5] >> 32).sum() * tick_us / ni,
+                        (q[:, 6] & m32).sum() * tick_us / ni, (q[:, 6] >> 32).sum() * tick_us / ni))
+        elif phase == "scatter":
             nb = max(1, q[:, 1].sum())
             m20 = (1 << 20) - 1
             parts = (q[:, 4], q[:, 5] >> 40, (q[:, 5] >> 20) & m20, q[:, 6] >> 40, q[:, 5] & m20, q[:, 6] & ((1 << 40) - 1), q[:, 7])
             extra = " | per batch us: front %.2f scans %.2f search %.2f ci-arrive %.2f hist %.2f reserve+scan+sort %.2f copy-out %.2f" % tuple(
                 x.sum() * tick_us / nb for x in parts)
-        if phase == "claim" and os.environ.get("GRX_BIN_CLAIM", "3") == "2":
+        if phase == "claim" and (q[:, 7] == -2).all():
+            pass
+        elif phase == "claim" and os.environ.get("GRX_BIN_CLAIM", "3") == "2":
             extra = " entries %d bitmap words %d queue items %d dense %s" % (q[:, 4].sum(), q[:, 5].sum(), q[0, 6], set(q[:, 7].tolist()))
         elif phase == "claim":
             # sweep claim: [6] = clock after the candidate pass, [7] = after the word claims (single-item workgroups)
