@@ -816,7 +816,10 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         return n > 4 ? 4 : n;
       }();
       grid_sweep2 = ctx->num_cus * env_int("GRX_SW2_WG_PER_CU", per_cu_sw2);
-      bn.sweep_items = env_int("GRX_SW2_ITEMS", grid_sweep2);
+      // parts per bin: every part of a bin finds the bin's hubs again and pays the merging atomics for them, so few,
+      // large parts (call 2 of round 3: 1024 items 73 us, 512 items 58 us on the 31 M-edge level); two per bin let the
+      // latency chain of one item's emission overlap the candidate stream of another on the same CU
+      bn.sweep_items = env_int("GRX_SW2_ITEMS", bn.nb * (1 + env_int("GRX_SW2_PARTS_PER_BIN", 2)));
       if (bn.sweep_items > grid_sweep2) bn.sweep_items = grid_sweep2;
     }
   }

@@ -797,18 +797,20 @@ constexpr int SC2_Q = SC2_BLOCK / TILE;  // quarters = chunks per batch
 static_assert(SC2_Q == BIN_BATCH, "a batch is still 4 chunks");
 
 struct bin_scatter2_smem {
-  int dlt[SC2_Q][TILE];            // per staged slot: row start - exclusive degree prefix
-  int wtot[SC2_Q][4];              // degree sums of the four waves of a quarter
-  int cand[SC2_Q][4][4];           // [quarter][target wave][source wave]: highest slot of the source wave that begins a row before the target's first atom
+  alignas(16) int dlt[SC2_Q][TILE];            // per staged slot: row start - exclusive degree prefix
+  alignas(16) int wtot[SC2_Q][4];              // degree sums of the four waves of a quarter (read as one int4)
+  alignas(16) int cand[SC2_Q][4][4];           // [quarter][target wave][source wave]: highest slot of the source wave that begins a row before the target's first atom
   int wave[BIN_MAX / 64 + 1];
   int hist[BIN_MAX];
   int off[BIN_MAX];
   int delta[BIN_MAX];
   int btot;
-  unsigned short g2b[BIN_GRAN_MAX];  // granule -> bin | granule index inside the bin << 8
-  unsigned char own[SC2_Q][CHUNK];   // owner map: staged slot of every atom of the four chunks
-  unsigned sorted[SC2_Q * CHUNK];    // (bin << 24 | offset inside the bin), grouped by bin
+  int tick[4];                                 // units of the pipeline stages (tick[3]: the stage entering next)
+  alignas(4) unsigned short g2b[BIN_GRAN_MAX]; // granule -> bin | granule index inside the bin << 8 (loaded as 32-bit words)
+  alignas(8) unsigned char own[SC2_Q][CHUNK];  // owner map: staged slot of every atom of the four chunks (8 bytes per thread)
+  alignas(16) unsigned sorted[SC2_Q * CHUNK];  // (bin << 24 | offset inside the bin), grouped by bin
 };
+
 
 template <bool DBG>
 __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin_args& bn, bin_scatter2_smem& sm, int p,
@@ -837,7 +839,22 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     reinterpret_cast<unsigned*>(sm.g2b)[w] = reinterpret_cast<const unsigned*>(bn.g2b16)[w];
   const int boff = tid < bn.nb ? bn.off[tid] : 0;  // static offset of bin `tid`
   const int n_units = (total_chunks + SC2_Q - 1) / SC2_Q;
-  const int stride = (int)gridDim.x;
+  // DYNAMIC unit hand-out, one queue per XCD.  With units strided statically over the workgroups the last workgroup of
+  // a fat level finished 17-36 us after the average one (timeline of round 3, call 3: busy mean 79 / 114 us, span 96 /
+  // 150 us): the units are equal, the workgroups' speeds are not.  Unit u belongs to XCD u % n_xcd; ticket k of XCD x
+  // is unit x + n_xcd * k, drawn with an L2-LOCAL atomic (workgroup scope: every taker of that word runs on that XCD;
+  // one device-wide word would serve ~88 tickets/us for ~45 tickets/us of demand).  The head kernel zeroes the words.
+  const int xcd = xcd_index(bn.xcc_mask, bn.n_xcd);
+  const int n_xcd = bn.n_xcd;
+  int* qhead = &bn.queue[(unsigned)(xcd * BIN_PAD)];
+  if (tid0 == 0) {
+    int t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = __hip_atomic_fetch_add(qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm.tick[i] = xcd + n_xcd * t[i];
+  }
+  __syncthreads();
   int vzero;  // keeps the descriptor loads vector loads (a scalar load would be waited for at the next barrier)
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
   const int2* map = reinterpret_cast<const int2*>(chunk_tile);
@@ -851,7 +868,8 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
   // software pipeline of the front, as in the first version: descriptor -> slot -> row offsets are three dependent
   // round trips; iteration i issues the row offsets of unit i + 1, the slot of unit i + 2 and the descriptor of
   // unit i + 3 together with its own column indices
-  const int u0 = (int)blockIdx.x;
+  int uA = __builtin_amdgcn_readfirstlane(sm.tick[0]), uB = __builtin_amdgcn_readfirstlane(sm.tick[1]),
+      uC = __builtin_amdgcn_readfirstlane(sm.tick[2]);  // (tickets of one XCD grow: uA < uB < uC < the later ones)
   // of a descriptor {tile, chunk index inside the tile} the tile is needed only to load the slot: stages A and B
   // carry the chunk index alone
   int yA, yB;
@@ -859,8 +877,8 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
   int vA, vB, vC;
   int rsA, reA, rsB, reB;
   {
-    const int2 tA = S1(u0), tB = S1(u0 + stride);
-    tlC = S1(u0 + 2 * stride);
+    const int2 tA = S1(uA), tB = S1(uB);
+    tlC = S1(uC);
     yA = tA.y;
     yB = tB.y;
     vA = in[(unsigned)(tA.x * TILE + tq)];
@@ -869,7 +887,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     rsA = a.ro[vv];
     reA = a.ro[vv + 1u];
   }
-  for (int u = u0; u < n_units; u += stride) {
+  while (uA < n_units) {
     // Everything derived from the thread index is RE-derived per batch from an opaque copy: left to itself the
     // compiler hoists two dozen per-thread constants (k * 256 + tq, LDS addresses, ...) out of the loop, runs out
     // of the 64 VGPRs that two workgroups per CU allow, and spills -- and a scratch reload issued behind the
@@ -893,12 +911,15 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       reB = a.ro[vv + 1u];
     }
     vC = in[(unsigned)(tlC.x * TILE + tq)];
-    tlD = S1(u + 3 * stride);
+    int ticket = 0;  // drawn now, used at the end of the batch (unit of stage D of the NEXT batch)
+    if (tid == 0) ticket = __hip_atomic_fetch_add(qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const int inc = dev::wave_inclusive_sum(dg);
     if (lane == 63) sm.wtot[q][wq] = inc;
     reinterpret_cast<uint2*>(own)[tq] = make_uint2(0u, 0u);
     if (tid < BIN_MAX) sm.hist[tid] = 0;
     __syncthreads();
+    const int uD = __builtin_amdgcn_readfirstlane(sm.tick[3]);  // written at the end of the previous batch (or at the start)
+    tlD = S1(uD);
     ++dbg_batches;
     dbg_mark(0);
     // ---- phase 2: exclusive prefix inside the tile; rows mark where they begin; carries for the running maximum
@@ -1045,6 +1066,8 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       }
     }
     dbg_mark(7);
+    if (tid == 0) sm.tick[3] = xcd + n_xcd * ticket;  // read after the next batch's first barrier
+    uA = uB; uB = uC; uC = uD;
     yA = yB; yB = tlC.y; tlC = tlD;
     vA = vB; vB = vC;
     rsA = rsB; reA = reB;
@@ -1085,7 +1108,7 @@ constexpr int SW2_U = 2;          // 16-byte candidate loads per thread and roun
 template <int NT>
 struct bin_sweep2_smem {
   static constexpr int SEG_WORDS = NT / 4;               // a thread expands one byte of a bitmap word
-  static constexpr int LIST = SEG_WORDS * 32 + TILE;
+  static constexpr int LIST = 8192 + TILE;               // >= SEG_WORDS * 32 + TILE; sized for ONE emission per item
   static constexpr int MAX_TILES = LIST / TILE + 1;
   unsigned bm[1 << (BIN_SHIFT_MAX - 5)];
   int list[LIST];
