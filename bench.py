@@ -603,21 +603,63 @@ def bench_multi_gpu(args, gr, torch, rank, local_rank, world):
     dist.all_reduce(et)
     overlap = os.environ.get("GRX_BENCH_OVERLAP", "0") == "1"
     eng = D.GrxEngine(props, mine, rank, world, dev, int(et.item()), in_rows=mine_in, overlap=overlap)
-    if os.environ.get("GRX_DIST_RCCL", "0") == "1" and backend == "nccl" and not overlap:
-        eng.enable_library_transport(dist)  # collectives issued by libgrx over its own RCCL communicator
     dist_t = eng.new_labels()
+    optimized = not topdown_only
+
+    def agree(ok):
+        """every rank must take the same branch (a level group carries collectives): MIN over the ranks of a flag"""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    # Transport.  Default on RCCL: the collectives of a level group are issued by libgrx itself over its own
+    # communicator (one C call per batch of levels, one HIP-graph launch per level once recorded) -- AFTER a self-test:
+    # one search through torch.distributed (eager), the same search through the library transport, and the two must
+    # agree on depth and on the global traversed-edge count on every rank.  Anything else (librccl not loadable,
+    # communicator creation fails, results differ) falls back to the torch.distributed transport on all ranks alike.
+    # GRX_DIST_RCCL=0 skips the attempt.
+    transport_note = "torch.distributed transport (backend %s)" % backend
+    want_lib = os.environ.get("GRX_DIST_RCCL", "1") == "1" and backend == "nccl" and not overlap
+    if want_lib:
+        ref_st = D.bfs(eng, dist, src, dist_t, optimized=optimized)
+        ref_e = torch.tensor([ref_st["edges_visited"]], dtype=torch.int64, device=cdev)
+        dist.all_reduce(ref_e)
+        ok, why = True, ""
+        try:
+            eng.enable_library_transport(dist)
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, "communicator setup failed: %s" % str(e)[:200]
+        if agree(ok):
+            try:
+                st_l = D.bfs(eng, dist, src, dist_t, optimized=optimized)
+                got_e = torch.tensor([st_l["edges_visited"]], dtype=torch.int64, device=cdev)
+                dist.all_reduce(got_e)
+                ok = st_l["search_depth"] == ref_st["search_depth"] and int(got_e.item()) == int(ref_e.item())
+                why = "" if ok else "self-test search differs from the torch.distributed search"
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, "self-test search failed: %s" % str(e)[:200]
+            ok = agree(ok)
+        else:
+            ok = False
+        if ok:
+            transport_note = "in-library RCCL transport (self-test passed)"
+        else:
+            eng.disable_library_transport()
+            transport_note = "torch.distributed transport (in-library RCCL transport rejected%s)" % (": " + why if why else " on another rank")
     t_setup = time.time() - t0
 
     def barrier():
         dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(2):  # part of the setup: the first search records the level group as a HIP graph, the second replays it
+        st = D.bfs(eng, dist, src, dist_t, optimized=optimized)
     for _ in range(args.warmup):
-        st = D.bfs(eng, dist, src, dist_t, optimized=not topdown_only)
+        st = D.bfs(eng, dist, src, dist_t, optimized=optimized)
     barrier()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        st = D.bfs(eng, dist, src, dist_t, optimized=not topdown_only)
+        st = D.bfs(eng, dist, src, dist_t, optimized=optimized)
     barrier()
     elapsed = time.perf_counter() - t1
     tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -628,6 +670,28 @@ def bench_multi_gpu(args, gr, torch, rank, local_rank, world):
     edges_total, e_total = int(ee[0].item()), int(ee[1].item())
     ms_per_step = elapsed * 1e3 / args.steps
     mteps = edges_total / (ms_per_step * 1e3)
+    captured = eng.group_captured()
+    cap_t = torch.tensor([1 if captured else 0], dtype=torch.int64, device=cdev)
+    dist.all_reduce(cap_t, op=dist.ReduceOp.MIN)
+    # per-level breakdown (untimed, eager, one extra search): kernels before the exchange | bitmap all-to-all | kernels
+    # after it + statistics all-reduce, per rank; rank 0 reports the max and the mean over the ranks
+    levels_breakdown = None
+    try:
+        recs = D.profile_bfs(eng, dist, src, dist_t, optimized=optimized)
+        n_g = torch.tensor([len(recs)], dtype=torch.int64, device=cdev)
+        dist.all_reduce(n_g, op=dist.ReduceOp.MIN)
+        n_g = int(n_g.item())
+        arr = torch.tensor([[r["pre_ms"], r["exchange_ms"], r["post_ms"]] for r in recs[:n_g]], dtype=torch.float64,
+                           device=cdev).reshape(n_g, 3)
+        mx, sm = arr.clone(), arr.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        levels_breakdown = {"columns": "per level group: kernels before the exchange ms, exchange ms, kernels after + "
+                                       "all-reduce ms (max over ranks | mean over ranks)",
+                            "max_over_ranks": [[round(float(x), 4) for x in row] for row in mx.tolist()],
+                            "mean_over_ranks": [[round(float(x) / world, 4) for x in row] for row in sm.tolist()]}
+    except Exception as e:  # noqa: BLE001  (diagnostics only)
+        levels_breakdown = {"error": str(e)[:200]}
     check = None
     if os.environ.get("GRX_BENCH_CHECK", "0") == "1":
         # parity of the partitioned search (test harness; outside the timed region): the owned label slices are
@@ -671,7 +735,9 @@ def bench_multi_gpu(args, gr, torch, rank, local_rank, world):
                        "advance_direction": "forward (top-down)" if topdown_only else "optimized (Beamer, decided on "
                                             "the device from all-reduced statistics)",
                        "edges_visited_per_step": edges_total, "search_depth": st["search_depth"],
-                       "setup_s": round(t_setup, 1), "backend": backend, "parity_check": check},
+                       "setup_s": round(t_setup, 1), "backend": backend, "transport": transport_note,
+                       "level_group_captured_as_hip_graph_on_all_ranks": bool(cap_t.item()),
+                       "per_level_breakdown": levels_breakdown, "parity_check": check},
             "roofline": None, "cpu_baseline": None}))
     dist.barrier()
     dist.destroy_process_group()

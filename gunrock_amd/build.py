@@ -66,6 +66,35 @@ def _compile(src):
     return obj
 
 
+def build_variant(name, defines, verbose=False):
+    """A second build of the same sources with extra -D flags, as gunrock_amd/libgrx_<name>.so (tuning aids only:
+    e.g. `timers` = -DGRX_MID_TIMERS, the per-phase clocks of the multi-level body).  Loaded through GRX_LIB_PATH."""
+    lib = os.path.join(HERE, "libgrx_%s.so" % name)
+    obj_dir = os.path.join(HERE, "_obj_" + name)
+    if os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in _deps()):
+        return lib
+    os.makedirs(obj_dir, exist_ok=True)
+
+    def one(src):
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(obj_dir, src + ".o")
+        cmd = [HIPCC] + FLAGS + ["-D" + d for d in defines] + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", path, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(one, SOURCES))
+    r = subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + objs + ["-lpthread", "-ldl"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", lib)
+    return lib
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
@@ -83,4 +112,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    if "--timers" in sys.argv:
+        build_variant("timers", ["GRX_MID_TIMERS"], verbose=True)
+    else:
+        build(force="--force" in sys.argv, verbose=True)

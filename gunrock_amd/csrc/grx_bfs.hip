@@ -436,20 +436,25 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void bfs_sweep_kernel(pipe_args a, bin
   bin_sweep_block(a, bn, c, h.level + 1, sm, h.level & 1);
 }
 
-// The claim phase as a sweep, second version (grx_bin.hpp): 512 threads, <= 64 VGPRs, four workgroups per CU.
-constexpr int SW2_BLOCK = 512;
-template <bool DBG>
-__global__ __launch_bounds__(SW2_BLOCK, 8) void bfs_sweep2_kernel(pipe_args a, bin_args bn) {
-  __shared__ __attribute__((aligned(16))) bin_sweep2_smem<SW2_BLOCK> sm;
+// The claim phase as a sweep, second version (grx_bin.hpp), in two geometries:
+//   NT = 512, <= 64 VGPRs, 8448-entry list: up to three workgroups per CU, two parts per bin;
+//   NT = 1024, <= 128 VGPRs, 16128-entry list (82 KB of LDS): one workgroup per CU like the first version, one part per bin
+//   unless it is fat -- what it changes against the first version is ONE emission per item (the first version's 8448-entry
+//   list was emitted up to three times per item on the 31 M-edge level, plus once more for the short tile at the end).
+template <int NT, int LE, int WAVES_PER_SIMD, bool DBG>
+__global__ __launch_bounds__(NT, WAVES_PER_SIMD) void bfs_sweep2_kernel(pipe_args a, bin_args bn) {
+  __shared__ __attribute__((aligned(16))) bin_sweep2_smem<NT, LE> sm;
   ctrl_t* c = a.ctrl;
   const level_head h = load_level_head(c);
   if (h.done || h.mode != 2) return;
   if (DBG && h.level != bn.debug_level) {
-    bin_sweep2_block<SW2_BLOCK, false>(a, bn, c, h.level + 1, sm, h.level & 1);
+    bin_sweep2_block<NT, LE, false>(a, bn, c, h.level + 1, sm, h.level & 1);
     return;
   }
-  bin_sweep2_block<SW2_BLOCK, DBG>(a, bn, c, h.level + 1, sm, h.level & 1);
+  bin_sweep2_block<NT, LE, DBG>(a, bn, c, h.level + 1, sm, h.level & 1);
 }
+constexpr int SW2_BLOCK = 512, SW2_LIST = 8192 + TILE;
+constexpr int SW3_BLOCK = 1024, SW3_LIST = 63 * TILE;
 
 }  // namespace grx
 
@@ -759,7 +764,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.mid_v = env_int("GRX_MID_V", MID_ENTER_V);
     bn.mid_e = env_int("GRX_MID_E", MID_ENTER_E);
   }
-  int grid_scatter = 0, grid_claim = 0, grid_scatter2 = 0, grid_sweep2 = 0;
+  int grid_scatter = 0, grid_claim = 0, grid_scatter2 = 0, grid_sweep2 = 0, grid_sweep3 = 0;
   // claim phase of a binned level: 3 = sweep (one workgroup per bin, vertex-ordered output), 2 = slices claimed in the owning XCD's L2
   const int claim_version = env_int("GRX_BIN_CLAIM", 3);
   if (use_bins) {
@@ -808,19 +813,26 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       bn.local_ids = 1;
       grid_scatter2 = ctx->num_cus * env_int("GRX_SC2_WG_PER_CU", per_cu_sc2);
     }
-    // sweep claim: 2 = 512-thread workgroups, one work item each (GRX_BIN_SWEEP=1: the first version)
-    if (claim_version == 3 && env_int("GRX_BIN_SWEEP", 2) == 2) {
+    // sweep claim: 1 = first version; 2 = second version on 512-thread workgroups, two parts per bin; 3 = second version on
+    // 1024-thread workgroups, one per CU, one emission per item
+    const int sweep_version = claim_version == 3 ? env_int("GRX_BIN_SWEEP", 3) : 0;
+    if (sweep_version == 2) {
       static const int per_cu_sw2 = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_sweep2_kernel<false>, SW2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_sweep2_kernel<SW2_BLOCK, SW2_LIST, 8, false>, SW2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
         return n > 4 ? 4 : n;
       }();
-      grid_sweep2 = ctx->num_cus * env_int("GRX_SW2_WG_PER_CU", per_cu_sw2);
+      grid_sweep2 = ctx->num_cus * env_int("GRX_SW2_WG_PER_CU", per_cu_sw2 > 2 ? 2 : per_cu_sw2);
       // parts per bin: every part of a bin finds the bin's hubs again and pays the merging atomics for them, so few,
-      // large parts (call 2 of round 3: 1024 items 73 us, 512 items 58 us on the 31 M-edge level); two per bin let the
-      // latency chain of one item's emission overlap the candidate stream of another on the same CU
+      // large parts (call 2 of round 3: 1024 items 73 us, 512 items 58 us on the 31 M-edge level)
       bn.sweep_items = env_int("GRX_SW2_ITEMS", bn.nb * (1 + env_int("GRX_SW2_PARTS_PER_BIN", 2)));
       if (bn.sweep_items > grid_sweep2) bn.sweep_items = grid_sweep2;
+    } else if (sweep_version == 3) {
+      // as the first version: a bin with more than 1/160 of the level's candidates is cut into parts, the grid is twice the
+      // resident workgroups (the second half starts as the first finishes)
+      grid_sweep3 = ctx->num_cus * 2;
+      bn.sweep_items = env_int("GRX_SW2_ITEMS", bn.nb + 160);
+      if (bn.sweep_items > grid_sweep3) bn.sweep_items = grid_sweep3;
     }
   }
   if (!dopt && variant == 0) {
@@ -851,9 +863,13 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         if (use_bins && claim_version == 2)
           hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_claim), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
         else if (use_bins && grid_sweep2 > 0 && bn.debug)
-          hipLaunchKernelGGL(bfs_sweep2_kernel<true>, dim3(grid_sweep2), dim3(SW2_BLOCK), 0, stream, a, bn);
+          hipLaunchKernelGGL((bfs_sweep2_kernel<SW2_BLOCK, SW2_LIST, 8, true>), dim3(grid_sweep2), dim3(SW2_BLOCK), 0, stream, a, bn);
         else if (use_bins && grid_sweep2 > 0)
-          hipLaunchKernelGGL(bfs_sweep2_kernel<false>, dim3(grid_sweep2), dim3(SW2_BLOCK), 0, stream, a, bn);
+          hipLaunchKernelGGL((bfs_sweep2_kernel<SW2_BLOCK, SW2_LIST, 8, false>), dim3(grid_sweep2), dim3(SW2_BLOCK), 0, stream, a, bn);
+        else if (use_bins && grid_sweep3 > 0 && bn.debug)
+          hipLaunchKernelGGL((bfs_sweep2_kernel<SW3_BLOCK, SW3_LIST, 4, true>), dim3(grid_sweep3), dim3(SW3_BLOCK), 0, stream, a, bn);
+        else if (use_bins && grid_sweep3 > 0)
+          hipLaunchKernelGGL((bfs_sweep2_kernel<SW3_BLOCK, SW3_LIST, 4, false>), dim3(grid_sweep3), dim3(SW3_BLOCK), 0, stream, a, bn);
         else if (use_bins)
           hipLaunchKernelGGL(bfs_sweep_kernel, dim3(ctx->num_cus * 2), dim3(SWEEP_BLOCK), 0, stream, a, bn);
       } else {

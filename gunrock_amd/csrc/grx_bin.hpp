@@ -1102,13 +1102,14 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
 //   * a workgroup's last item emits its short tile together with its full ones;
 //   * the emission keeps one group of three passes in flight instead of all nine (registers), and issues the
 //     chunk-map reservation as soon as the degree sums are known, behind the stores of the frontier slots.
-constexpr int SW2_PART_MIN = 1 << 14;
+constexpr int SW2_PART_MIN = 1 << 15;
 constexpr int SW2_U = 2;          // 16-byte candidate loads per thread and round
 
-template <int NT>
+template <int NT, int LIST_ENTRIES>
 struct bin_sweep2_smem {
   static constexpr int SEG_WORDS = NT / 4;               // a thread expands one byte of a bitmap word
-  static constexpr int LIST = 8192 + TILE;               // >= SEG_WORDS * 32 + TILE; sized for ONE emission per item
+  static constexpr int LIST = LIST_ENTRIES;              // sized for ONE emission per item on the graphs measured
+  static_assert(LIST_ENTRIES >= NT / 4 * 32 + TILE && LIST_ENTRIES % TILE == 0, "a segment's ids + a carried short tile fit");
   static constexpr int MAX_TILES = LIST / TILE + 1;
   unsigned bm[1 << (BIN_SHIFT_MAX - 5)];
   int list[LIST];
@@ -1125,9 +1126,9 @@ struct bin_sweep2_smem {
 
 // Emit list[0 .. n) as ceil(n / TILE) tiles of parity q (only the last one may be short) with their entries of the next
 // level's chunk map and their share of its counters (see sweep_emit).  Block-wide call.
-template <int NT>
-__device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q, bin_sweep2_smem<NT>& sm, int n) {
-  using S = bin_sweep2_smem<NT>;
+template <int NT, int LE>
+__device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q, bin_sweep2_smem<NT, LE>& sm, int n) {
+  using S = bin_sweep2_smem<NT, LE>;
   static_assert(S::MAX_TILES <= 64, "one lane per tile of an emission");
   constexpr int PASSES = (S::LIST + NT - 1) / NT;
   constexpr int G = 3;  // passes whose row-offset loads travel together
@@ -1206,10 +1207,10 @@ __device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q
   __syncthreads();
 }
 
-template <int NT, bool DBG>
+template <int NT, int LE, bool DBG>
 __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_args& bn, ctrl_t* c, int depth,
-                                                 bin_sweep2_smem<NT>& sm, int p) {
-  using S = bin_sweep2_smem<NT>;
+                                                 bin_sweep2_smem<NT, LE>& sm, int p) {
+  using S = bin_sweep2_smem<NT, LE>;
   // DBG (GRX_BIN_DEBUG, its own kernel build): thread 0's clock per step, summed over the workgroup's items
   long long dbg_t0 = 0, dbg_t = 0, dbg_ph[4] = {0, 0, 0, 0}, dbg_entries = 0;
   int dbg_items = 0;
@@ -1335,7 +1336,7 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
     auto emit_list = [&](bool all) {
       const int k = all ? (n_list + TILE - 1) / TILE : n_list / TILE;
       const int n_emit = all ? n_list : k * TILE;
-      sweep2_emit<NT>(a, c, q, sm, n_emit);
+      sweep2_emit<NT, LE>(a, c, q, sm, n_emit);
       const int rem = n_list - n_emit;
       int keep = 0;
       if (tid < rem) keep = sm.list[n_emit + tid];

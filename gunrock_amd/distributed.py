@@ -114,6 +114,19 @@ class GrxEngine:
     def hi(self):
         return min((self.rank + 1) * self.S, self.V)
 
+    def disable_library_transport(self):
+        """Back to the torch.distributed transport (every rank must take the same decision)."""
+        self.library_transport = False
+
+    def group_captured(self):
+        """True once the level group of the transport in use has been recorded as a HIP graph."""
+        if getattr(self, "library_transport", False):
+            try:
+                return bool(_capi.lib().grx_bfs_dist_group_is_captured(self._h))
+            except Exception:
+                return False
+        return getattr(self, "_graph", None) is not None
+
     def transport_description(self):
         if getattr(self, "library_transport", False):
             return ("level groups (kernels + grouped ncclSend/ncclRecv + ncclAllReduce) enqueued by the library itself "
@@ -229,6 +242,45 @@ def _level_group(engine, dist):
             w.wait()  # stream-level wait, the host does not block
     engine.post()
     _all_reduce_stats(dist, engine)
+
+
+def profile_bfs(engine, dist, source, distances, optimized=True, max_groups=64):
+    """One EAGER search with three stream events per level group -- kernels before the exchange (head, prep,
+    advance), the bitmap all-to-all, kernels after it + the statistics all-reduce -- for the N > 1 bench line's per-level
+    breakdown.  Untimed diagnostics: every group is followed by a host poll, and the exchange goes through
+    torch.distributed whatever transport the timed searches use (same kernels, an equivalent collective).
+    -> list of {"pre_ms", "exchange_ms", "post_ms"} per executed level group."""
+    torch = engine.torch
+    import contextlib
+    on_stream = torch.cuda.stream(engine.stream) if getattr(engine, "stream", None) is not None \
+        else contextlib.nullcontext()
+    recs = []
+    with on_stream:
+        engine.begin(source, distances, optimized)
+        _all_reduce_stats(dist, engine)
+        for _ in range(max_groups):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+            engine.pre(0)
+            ev[1].record()
+            send, recv = engine.part_buffers(0)
+            _all_to_all(dist, send, recv)
+            for part in range(1, engine.parts):
+                engine.pre(part)
+                s2, r2 = engine.part_buffers(part)
+                _all_to_all(dist, s2, r2)
+            ev[2].record()
+            engine.post()
+            _all_reduce_stats(dist, engine)
+            ev[3].record()
+            done, _ = engine.poll()
+            ev[3].synchronize()
+            recs.append({"pre_ms": ev[0].elapsed_time(ev[1]), "exchange_ms": ev[1].elapsed_time(ev[2]),
+                         "post_ms": ev[2].elapsed_time(ev[3])})
+            if done:
+                break
+        engine.end()
+    return recs
 
 
 def _group_graph(engine, dist, key):

@@ -71,10 +71,10 @@ def run(label, direction, env=None):
 
 print("workload", name, "V", V, "E", G.get_number_of_edges(), "src", src, flush=True)
 run("fwd scatter1 sweep1 (round 2)", gr.forward, {"GRX_BIN_SCATTER": 1, "GRX_BIN_SWEEP": 1})
-run("fwd scatter2 sweep1", gr.forward, {"GRX_BIN_SCATTER": 2, "GRX_BIN_SWEEP": 1})
-run("fwd scatter2 sweep2 2 parts/bin (dflt)", gr.forward, {})
-run("fwd scatter2 sweep2 1 part/bin", gr.forward, {"GRX_SW2_PARTS_PER_BIN": 1})
-run("fwd scatter2 sweep2 3 parts/bin", gr.forward, {"GRX_SW2_PARTS_PER_BIN": 3})
-run("fwd scatter2 sweep2 2 parts, 2 wg/cu", gr.forward, {"GRX_SW2_WG_PER_CU": 2})
+run("fwd scatter2 sweep1", gr.forward, {"GRX_BIN_SWEEP": 1})
+run("fwd scatter2 sweep3 (default)", gr.forward, {})
+run("fwd scatter2 sweep2 2 parts, 2 wg/cu", gr.forward, {"GRX_BIN_SWEEP": 2})
+run("fwd scatter2 sweep3 items nb+96", gr.forward, {"GRX_SW2_ITEMS": 320})
+run("fwd scatter2 sweep1 again", gr.forward, {"GRX_BIN_SWEEP": 1})
 run("fwd default again", gr.forward, {})
 run("DO default", gr.optimized, {})
