@@ -76,13 +76,15 @@ def classify(rows):
                 if pos in (1, 2, 3):
                     cls[d] = ("bottom_up", pos)
         elif kind == "bfs":
+            # a level group of a forward run: level kernel (a no-op on a binned level when the second scatter is in use),
+            # scatter kernel (second version), claim / sweep kernel
             lv = [d for d, n in s["kernels"] if "bfs_level_bin_kernel" in n]
-            cl = [d for d, n in s["kernels"] if "bfs_claim_kernel" in n or "bfs_sweep_kernel" in n]
+            sc = [d for d, n in s["kernels"] if "bfs_scatter2_kernel" in n]
+            cl = [d for d, n in s["kernels"] if "bfs_claim_kernel" in n or "bfs_sweep" in n]
             for pos in (1, 2):
-                if pos < len(lv):
-                    cls[lv[pos]] = ("topdown_fat", pos)
-                if pos < len(cl):
-                    cls[cl[pos]] = ("topdown_fat", pos)
+                for group in (lv, sc, cl):
+                    if pos < len(group):
+                        cls[group[pos]] = ("topdown_fat", pos)
         elif kind == "sssp":
             name = "sssp_weighted_1_1000" if nf else "sssp_unit_weights"
             for d, n in s["kernels"]:
