@@ -406,16 +406,16 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_bin_kernel(pipe_args a, b
 }
 
 // The scatter phase of a binned level, second version (grx_bin.hpp): 1024 threads, two workgroups = 32 waves per CU.
-template <bool DBG>
+template <bool DBG, bool E16>
 __global__ __launch_bounds__(SC2_BLOCK, 8) void bfs_scatter2_kernel(pipe_args a, bin_args bn) {
   __shared__ __attribute__((aligned(16))) bin_scatter2_smem sm;
   const level_head h = load_level_head(a.ctrl);
   if (h.done || h.mode != 2) return;
   if (DBG && h.level != bn.debug_level) {
-    bin_scatter2_block<false>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
+    bin_scatter2_block<false, E16>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
     return;
   }
-  bin_scatter2_block<DBG>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
+  bin_scatter2_block<DBG, E16>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
 }
 
 __global__ __launch_bounds__(ADV_BLOCK) void bfs_claim_kernel(pipe_args a, bin_args bn, bfs_policy pol) {
@@ -441,17 +441,17 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void bfs_sweep_kernel(pipe_args a, bin
 //   NT = 1024, <= 128 VGPRs, 16128-entry list (82 KB of LDS): one workgroup per CU like the first version, one part per bin
 //   unless it is fat -- what it changes against the first version is ONE emission per item (the first version's 8448-entry
 //   list was emitted up to three times per item on the 31 M-edge level, plus once more for the short tile at the end).
-template <int NT, int LE, int WAVES_PER_SIMD, bool DBG>
+template <int NT, int LE, int WAVES_PER_SIMD, bool DBG, bool E16>
 __global__ __launch_bounds__(NT, WAVES_PER_SIMD) void bfs_sweep2_kernel(pipe_args a, bin_args bn) {
   __shared__ __attribute__((aligned(16))) bin_sweep2_smem<NT, LE> sm;
   ctrl_t* c = a.ctrl;
   const level_head h = load_level_head(c);
   if (h.done || h.mode != 2) return;
   if (DBG && h.level != bn.debug_level) {
-    bin_sweep2_block<NT, LE, false>(a, bn, c, h.level + 1, sm, h.level & 1);
+    bin_sweep2_block<NT, LE, false, E16>(a, bn, c, h.level + 1, sm, h.level & 1);
     return;
   }
-  bin_sweep2_block<NT, LE, DBG>(a, bn, c, h.level + 1, sm, h.level & 1);
+  bin_sweep2_block<NT, LE, DBG, E16>(a, bn, c, h.level + 1, sm, h.level & 1);
 }
 constexpr int SW2_BLOCK = 512, SW2_LIST = 8192 + TILE;
 constexpr int SW3_BLOCK = 1024, SW3_LIST = 63 * TILE;
@@ -459,6 +459,11 @@ constexpr int SW3_BLOCK = 1024, SW3_LIST = 63 * TILE;
 }  // namespace grx
 
 using namespace grx;
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
 
 // Per-graph static part of the binned levels (cached in the graph handle): the bins -- runs of
 // granules with about equal numbers of in-edges -- their capacities, the XCD that claims each
@@ -471,7 +476,14 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   while (gshift < 31 && (((long long)g->V + (1ll << gshift) - 1) >> gshift) > BIN_GRAN_MAX) ++gshift;
   if (gshift > BIN_SHIFT_MAX) return GRX_SUCCESS;  // a bin's bitmap slice would not fit the claim kernel's LDS
   const int n_gran = (int)(((long long)g->V + (1ll << gshift) - 1) >> gshift);
-  const int max_width = 1 << (BIN_SHIFT_MAX - gshift);  // granules per bin
+  // widest bin: 65536 vertices when BIN_MAX such bins cover the graph -- then an offset inside a bin fits 16 bits and the
+  // bins are written and streamed as 16-bit entries (second scatter + second sweep) -- else 131072 (32-bit entries)
+  int shift_max = BIN_SHIFT_MAX;
+  if (gshift <= 16) {
+    const int mw16 = 1 << (16 - gshift);
+    if ((n_gran + mw16 - 1) / mw16 <= BIN_MAX - 32 && env_int("GRX_BIN_ENTRY16", 1) != 0) shift_max = 16;
+  }
+  const int max_width = 1 << (shift_max - gshift);  // granules per bin
   if ((n_gran + max_width - 1) / max_width > BIN_MAX) return GRX_SUCCESS;
   hipStream_t s = ctx->stream;
   int32_t* d_cnt = nullptr;
@@ -557,6 +569,7 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   g->bin_shift = gshift;
   g->bin_ngran = n_gran;
   g->bin_nb = nb;
+  g->bin_entry16 = shift_max == 16 ? 1 : 0;
   g->bin_state = 1;
   return GRX_SUCCESS;
 }
@@ -564,10 +577,6 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
 // Workgroups of the per-level kernel: exactly what is RESIDENT (persistent workgroups
 // stride over the work with gridDim, so a partial second round would double the time),
 // one per CU on road-like graphs (advance_grid_for).
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
 
 // The per-level kernel comes in two builds: bottom-up chunks in flight per wave
 // (GRX_BU_BATCH = 2 | 4; measured equal on the LJ / kron stand-ins, 8 slower).  Forcing more
@@ -807,7 +816,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (env_int("GRX_BIN_SCATTER", 2) == 2 && claim_version != 2) {
       static const int per_cu_sc2 = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_scatter2_kernel<false>, SC2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_scatter2_kernel<false, false>, SC2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
         return n > 2 ? 2 : n;
       }();
       bn.local_ids = 1;
@@ -819,7 +828,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (sweep_version == 2) {
       static const int per_cu_sw2 = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_sweep2_kernel<SW2_BLOCK, SW2_LIST, 8, false>, SW2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_sweep2_kernel<SW2_BLOCK, SW2_LIST, 8, false, false>, SW2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
         return n > 4 ? 4 : n;
       }();
       grid_sweep2 = ctx->num_cus * env_int("GRX_SW2_WG_PER_CU", per_cu_sw2 > 2 ? 2 : per_cu_sw2);
@@ -835,6 +844,9 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       if (bn.sweep_items > grid_sweep3) bn.sweep_items = grid_sweep3;
     }
   }
+  // 16-bit bin entries need the second scatter (writes them) and the second sweep (reads them)
+  bn.entry16 = (use_bins && g->bin_entry16 && bn.local_ids && (grid_sweep2 > 0 || grid_sweep3 > 0) &&
+                env_int("GRX_BIN_E16", 1) != 0) ? 1 : 0;  // (GRX_BIN_E16=0: 32-bit entries in the same bins, for A/B)
   if (!dopt && variant == 0) {
     static const int per_cu_scatter = resident_per_cu(bfs_level_bin_kernel);
     const int resident = ctx->num_cus * per_cu_scatter;
@@ -856,22 +868,26 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         // forward-only run.  level = claim-per-edge advance, many mid-size levels (grx_mid.hpp), or the SCATTER phase of
         // a binned level; the CLAIM phase is launched only when levels can be binned (a no-op unless the head did)
         hipLaunchKernelGGL(bfs_level_bin_kernel, dim3(grid_scatter), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
-        if (grid_scatter2 > 0 && bn.debug)
-          hipLaunchKernelGGL(bfs_scatter2_kernel<true>, dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
-        else if (grid_scatter2 > 0)
-          hipLaunchKernelGGL(bfs_scatter2_kernel<false>, dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
-        if (use_bins && claim_version == 2)
-          hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_claim), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
-        else if (use_bins && grid_sweep2 > 0 && bn.debug)
-          hipLaunchKernelGGL((bfs_sweep2_kernel<SW2_BLOCK, SW2_LIST, 8, true>), dim3(grid_sweep2), dim3(SW2_BLOCK), 0, stream, a, bn);
-        else if (use_bins && grid_sweep2 > 0)
-          hipLaunchKernelGGL((bfs_sweep2_kernel<SW2_BLOCK, SW2_LIST, 8, false>), dim3(grid_sweep2), dim3(SW2_BLOCK), 0, stream, a, bn);
-        else if (use_bins && grid_sweep3 > 0 && bn.debug)
-          hipLaunchKernelGGL((bfs_sweep2_kernel<SW3_BLOCK, SW3_LIST, 4, true>), dim3(grid_sweep3), dim3(SW3_BLOCK), 0, stream, a, bn);
-        else if (use_bins && grid_sweep3 > 0)
-          hipLaunchKernelGGL((bfs_sweep2_kernel<SW3_BLOCK, SW3_LIST, 4, false>), dim3(grid_sweep3), dim3(SW3_BLOCK), 0, stream, a, bn);
-        else if (use_bins)
-          hipLaunchKernelGGL(bfs_sweep_kernel, dim3(ctx->num_cus * 2), dim3(SWEEP_BLOCK), 0, stream, a, bn);
+        // (four builds of each: tuning clocks on / off x 16-bit / 32-bit bin entries)
+        auto launch2 = [&](auto dbg_c, auto e16_c) {
+          constexpr bool DBG = decltype(dbg_c)::value, E16 = decltype(e16_c)::value;
+          if (grid_scatter2 > 0)
+            hipLaunchKernelGGL((bfs_scatter2_kernel<DBG, E16>), dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
+          if (use_bins && claim_version == 2)
+            hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_claim), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
+          else if (use_bins && grid_sweep2 > 0)
+            hipLaunchKernelGGL((bfs_sweep2_kernel<SW2_BLOCK, SW2_LIST, 8, DBG, E16>), dim3(grid_sweep2), dim3(SW2_BLOCK), 0, stream, a, bn);
+          else if (use_bins && grid_sweep3 > 0)
+            hipLaunchKernelGGL((bfs_sweep2_kernel<SW3_BLOCK, SW3_LIST, 4, DBG, E16>), dim3(grid_sweep3), dim3(SW3_BLOCK), 0, stream, a, bn);
+          else if (use_bins)
+            hipLaunchKernelGGL(bfs_sweep_kernel, dim3(ctx->num_cus * 2), dim3(SWEEP_BLOCK), 0, stream, a, bn);
+        };
+        using std::true_type;
+        using std::false_type;
+        if (bn.debug && bn.entry16) launch2(true_type{}, true_type{});
+        else if (bn.debug) launch2(true_type{}, false_type{});
+        else if (bn.entry16) launch2(false_type{}, true_type{});
+        else launch2(false_type{}, false_type{});
       } else {
         hipLaunchKernelGGL(lbuild->fn, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
       }

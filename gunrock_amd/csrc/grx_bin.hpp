@@ -54,6 +54,7 @@ struct bin_args {
   const unsigned short* g2b16;  // second scatter: granule -> bin | (index of the granule inside its bin) << 8
   int32_t local_ids;          // 1: the bins hold ids RELATIVE to the first vertex of their bin (second scatter), 0: global ids
   int32_t sweep_items;        // second sweep: work items a level is cut into at most (<= its grid: one item per workgroup)
+  int32_t entry16;            // 1: the bins hold 16-BIT offsets (every bin spans <= 65536 vertices; needs local_ids), 0: 32-bit entries
   int32_t gshift;             // granule of vertex n = n >> gshift
   int32_t n_gran;
   int32_t nb;                 // bins in use (<= BIN_MAX)
@@ -812,7 +813,8 @@ struct bin_scatter2_smem {
 };
 
 
-template <bool DBG>
+// E16: the bins hold 16-bit offsets (half the bytes written here and streamed by the sweep)
+template <bool DBG, bool E16>
 __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin_args& bn, bin_scatter2_smem& sm, int p,
                                                    int total_chunks, const int* chunk_tile) {
   // DBG (GRX_BIN_DEBUG, its own kernel build): wave 0's clock at the end of every phase, summed per workgroup
@@ -1062,7 +1064,10 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) {
         const int i = k * SC2_BLOCK + tid;
-        if (i < btot) bn.bins[(size_t)(d_k[k] + i)] = (int)(s_k[k] & 0xffffffu);
+        if (i < btot) {
+          if constexpr (E16) reinterpret_cast<unsigned short*>(bn.bins)[(size_t)(d_k[k] + i)] = (unsigned short)(s_k[k] & 0xffffu);
+          else bn.bins[(size_t)(d_k[k] + i)] = (int)(s_k[k] & 0xffffffu);
+        }
       }
     }
     dbg_mark(7);
@@ -1207,9 +1212,10 @@ __device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q
   __syncthreads();
 }
 
-template <int NT, int LE, bool DBG>
+template <int NT, int LE, bool DBG, bool E16>
 __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_args& bn, ctrl_t* c, int depth,
                                                  bin_sweep2_smem<NT, LE>& sm, int p) {
+  constexpr int EPL = E16 ? 8 : 4;  // entries per 16-byte load
   using S = bin_sweep2_smem<NT, LE>;
   // DBG (GRX_BIN_DEBUG, its own kernel build): thread 0's clock per step, summed over the workgroup's items
   long long dbg_t0 = 0, dbg_t = 0, dbg_ph[4] = {0, 0, 0, 0}, dbg_entries = 0;
@@ -1260,7 +1266,7 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
     const int words = (bn.v0[b + 1] - vbase) >> 5;
     const int gw0 = vbase >> 5;
     // first candidates on their way while the bitmap slice is copied
-    const int i4_first = lo >> 2, i4_last = (hi - 1) >> 2;
+    const int i4_first = lo / EPL, i4_last = (hi - 1) / EPL;
     int4 nx[SW2_U];
     auto LOAD = [&](int r, int4(&v)[SW2_U]) {
 #pragma unroll
@@ -1282,20 +1288,30 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
 #pragma unroll
       for (int u = 0; u < SW2_U; ++u) {
         const int idx = i4_first + (r * SW2_U + u) * NT + tid;
-        const int g0 = idx << 2;
-        const int n4[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
-        unsigned wv[4];
+        const int g0 = idx * EPL;
+        int n_e4[EPL];
+        if constexpr (E16) {
+          const unsigned q4[4] = {(unsigned)cur[u].x, (unsigned)cur[u].y, (unsigned)cur[u].z, (unsigned)cur[u].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            n_e4[2 * j] = (int)(q4[j] & 0xffffu);
+            n_e4[2 * j + 1] = (int)(q4[j] >> 16);
+          }
+        } else {
+          n_e4[0] = cur[u].x; n_e4[1] = cur[u].y; n_e4[2] = cur[u].z; n_e4[3] = cur[u].w;
+        }
+        unsigned wv[EPL];
         // (unconditional LDS reads from clamped positions first, then the rare atomics)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < EPL; ++j) {
           const int gi = g0 + j;
           const bool ok = idx <= i4_last && gi >= lo && gi < hi;
-          const int local = ok ? n4[j] - vsub : 0;
+          const int local = ok ? n_e4[j] - vsub : 0;
           wv[j] = ok ? sm.bm[local >> 5] : ~0u;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int local = n4[j] - vsub;
+        for (int j = 0; j < EPL; ++j) {
+          const int local = n_e4[j] - vsub;
           const unsigned bit = 1u << (local & 31);
           // plain read first: a visited hub is hit by many lanes at once, and a read broadcasts where an atomic on
           // one word serialises

@@ -173,6 +173,7 @@ struct grx_graph {
   int32_t* bin_fill = nullptr;  // per-level fill counters + per-XCD claim queue heads
   unsigned char* bin_tab8 = nullptr;  // granule -> bin, bin -> owning XCD
   int32_t bin_shift = 0, bin_ngran = 0, bin_nb = 0;
+  int32_t bin_entry16 = 0;      // every bin spans <= 65536 vertices: offsets inside a bin fit 16-bit entries
   int32_t bin_state = 0;        // 0: not built, 1: usable, 2: not applicable to this graph
   double weight_sum = -1.0;  // sum of edge weights (lazy; near-far SSSP bucket width)
   bool uniform_weights = false;
