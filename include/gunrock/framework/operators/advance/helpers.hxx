@@ -63,15 +63,30 @@ __device__ __forceinline__ void expand_window(const graph_t& G, operator_t& op, 
       atom[k] = base + k * BLOCK + (int)threadIdx.x;
       lo[k] = 0;
     }
-    // largest slot with s_seg[slot] <= atom, for all ROUND atoms at once (atoms past the end search for atom_hi - 1)
+    // largest slot with s_seg[slot] <= atom, for all ROUND atoms at once (atoms past the end search for atom_hi - 1).
+    // The BLOCK * ROUND atoms of a round are consecutive, so their owners lie between the owner of the first and the
+    // owner of the last one: two uniform searches (broadcast reads) bound the range, and the per-atom search needs
+    // log2(range) steps instead of 8 -- three on a frontier of hubs (hundreds of edges per row).
+    int s_lo = 0, s_hi = 0;
+    {
+      const int a_first = base, a_last = min(base + BLOCK * ROUND, atom_hi) - 1;
 #pragma unroll
-    for (int step = BLOCK / 2; step >= 1; step >>= 1) {
+      for (int step = BLOCK / 2; step >= 1; step >>= 1) {
+        if (s_lo + step < nslots && s_seg[s_lo + step] <= a_first) s_lo += step;
+        if (s_hi + step < nslots && s_seg[s_hi + step] <= a_last) s_hi += step;
+      }
+    }
+    int top = 1;
+    while (top * 2 <= s_hi - s_lo) top *= 2;  // uniform: largest power of two <= the range (1 when the range is 0 or 1)
+#pragma unroll
+    for (int k = 0; k < ROUND; ++k) lo[k] = s_lo;
+    for (int step = top; step >= 1; step >>= 1) {
       int probe[ROUND];
 #pragma unroll
       for (int k = 0; k < ROUND; ++k) probe[k] = s_seg[min(lo[k] + step, nslots)];
 #pragma unroll
       for (int k = 0; k < ROUND; ++k)
-        if (lo[k] + step < nslots && probe[k] <= min(atom[k], atom_hi - 1)) lo[k] += step;
+        if (lo[k] + step <= s_hi && probe[k] <= min(atom[k], atom_hi - 1)) lo[k] += step;
     }
     edge_t e[ROUND];
     vertex_t src[ROUND];
