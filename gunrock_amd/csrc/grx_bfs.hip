@@ -820,7 +820,6 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         return n > 2 ? 2 : n;
       }();
       bn.local_ids = 1;
-      bn.warm_ci = env_int("GRX_SC2_WARM", 1) != 0 ? 1 : 0;
       grid_scatter2 = ctx->num_cus * env_int("GRX_SC2_WG_PER_CU", per_cu_sc2);
     }
     // sweep claim: 1 = first version; 2 = second version on 512-thread workgroups, two parts per bin; 3 = second version on

@@ -54,7 +54,6 @@ struct bin_args {
   const unsigned short* g2b16;  // second scatter: granule -> bin | (index of the granule inside its bin) << 8
   int32_t local_ids;          // 1: the bins hold ids RELATIVE to the first vertex of their bin (second scatter), 0: global ids
   int32_t sweep_items;        // second sweep: work items a level is cut into at most (<= its grid: one item per workgroup)
-  int32_t warm_ci;            // second scatter: touch the next batch's column-index lines half a batch ahead
   int32_t entry16;            // 1: the bins hold 16-BIT offsets (every bin spans <= 65536 vertices; needs local_ids), 0: 32-bit entries
   int32_t gshift;             // granule of vertex n = n >> gshift
   int32_t n_gran;
@@ -1018,17 +1017,10 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     }
     __syncthreads();
     dbg_mark(4);
-    // WARM the column indices of the NEXT batch: its row offsets (rsB, reB: issued at the top of this batch) have arrived
-    // by now, and a level of short rows (18 edges per vertex on the LJ stand-in's second fat level) pays a memory round
-    // trip with a cold line per row at the top of phase 4 -- the waves of a workgroup then reach the histogram skewed by
-    // the slowest line.  One load of the row's first and one of its last column index per staged slot, issued ~5 us
-    // ahead; the values are only kept alive to the end of the batch (GRX_SC2_WARM=0: off, for A/B).
-    int warm0 = 0, warm1 = 0;
-    if (bn.warm_ci) {
-      const bool real = yB >= 0 && vB >= 0 && reB > rsB;
-      warm0 = a.ci[real ? rsB : 0];
-      warm1 = a.ci[real ? reB - 1 : 0];
-    }
+    // (Measured and removed, call 7 of round 3: touching the first and last column-index line of the NEXT batch's rows here,
+    // half a batch ahead -- the fat level of short rows pays a cold line per row at the top of phase 4.  Slower on every
+    // graph (LJ fat levels 136 + 168 -> 157 + 177 us): the reservation atomic below is younger than those loads, and
+    // waiting for its result means waiting for them too -- vmcnt retires in order.)
     // ---- phase 5: one reservation per non-empty bin (its round trip is covered by the scan and the sort), bin offsets
     int cnt = 0, gbase = 0, inc2 = 0;
     if (tid < BIN_MAX) {
@@ -1083,7 +1075,6 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       }
     }
     dbg_mark(7);
-    asm volatile("" ::"v"(warm0), "v"(warm1));  // (the warming loads end here)
     if (tid == 0) sm.tick[3] = xcd + n_xcd * ticket;  // read after the next batch's first barrier
     uA = uB; uB = uC; uC = uD;
     yA = yB; yB = tlC.y; tlC = tlD;
