@@ -476,21 +476,15 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   while (gshift < 31 && (((long long)g->V + (1ll << gshift) - 1) >> gshift) > BIN_GRAN_MAX) ++gshift;
   if (gshift > BIN_SHIFT_MAX) return GRX_SUCCESS;  // a bin's bitmap slice would not fit the claim kernel's LDS
   const int n_gran = (int)(((long long)g->V + (1ll << gshift) - 1) >> gshift);
-  // widest bin: 65536 vertices when BIN2_MAX - 64 such bins cover the graph -- then an offset inside a bin fits 16 bits and
-  // the bins are written and streamed as 16-bit entries (second scatter + second sweep) -- else 131072 (32-bit entries).
-  // More than BIN_MAX (256) bins rule out the first-version kernels, which the caller then does not offer.
+  // widest bin: 65536 vertices when BIN_MAX such bins cover the graph -- then an offset inside a bin fits 16 bits and the
+  // bins are written and streamed as 16-bit entries (second scatter + second sweep) -- else 131072 (32-bit entries)
   int shift_max = BIN_SHIFT_MAX;
-  int bin_limit = BIN_MAX;
   if (gshift <= 16) {
     const int mw16 = 1 << (16 - gshift);
-    const int need16 = (n_gran + mw16 - 1) / mw16;
-    if (need16 <= BIN2_MAX - 64 && env_int("GRX_BIN_ENTRY16", 1) != 0) {
-      shift_max = 16;
-      if (need16 > BIN_MAX - 32) bin_limit = BIN2_MAX - 32;
-    }
+    if ((n_gran + mw16 - 1) / mw16 <= BIN_MAX - 32 && env_int("GRX_BIN_ENTRY16", 1) != 0) shift_max = 16;
   }
   const int max_width = 1 << (shift_max - gshift);  // granules per bin
-  if ((n_gran + max_width - 1) / max_width > bin_limit) return GRX_SUCCESS;
+  if ((n_gran + max_width - 1) / max_width > BIN_MAX) return GRX_SUCCESS;
   hipStream_t s = ctx->stream;
   int32_t* d_cnt = nullptr;
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt), BIN_GRAN_MAX * sizeof(int32_t)));
@@ -516,14 +510,14 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
       ++width;
       if (acc >= target || width == max_width) { acc = 0; width = 0; }
     }
-    if ((int)first.size() <= bin_limit) break;
+    if ((int)first.size() <= BIN_MAX) break;
     target += target / 4 + 1;
   }
   const int nb = (int)first.size();
-  if (nb < 1 || nb > bin_limit) return GRX_SUCCESS;
+  if (nb < 1 || nb > BIN_MAX) return GRX_SUCCESS;
   first.push_back(n_gran);
-  std::vector<unsigned char> g2b((size_t)BIN_GRAN_MAX, 0), owner((size_t)BIN2_MAX, 0);  // (8-bit tables: first-version kernels, nb <= 256)
-  std::vector<int32_t> off((size_t)BIN2_MAX + 1, 0), v0((size_t)BIN2_MAX + 1, 0);
+  std::vector<unsigned char> g2b((size_t)BIN_GRAN_MAX, 0), owner((size_t)BIN_MAX, 0);
+  std::vector<int32_t> off((size_t)BIN_MAX + 1, 0), v0((size_t)BIN_MAX + 1, 0);
   std::vector<long long> cap((size_t)nb, 0);
   for (int b = 0; b < nb; ++b) {
     for (int i = first[(size_t)b]; i < first[(size_t)b + 1]; ++i) {
@@ -534,7 +528,7 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   }
   {
     long long acc = 0;
-    for (int b = 0; b <= BIN2_MAX; ++b) {
+    for (int b = 0; b <= BIN_MAX; ++b) {
       off[(size_t)b] = (int32_t)acc;
       if (b < nb) acc += cap[(size_t)b];
       if (b >= nb) v0[(size_t)b] = (int32_t)((long long)n_gran << gshift);  // bitmap words exist up to the padded end
@@ -556,21 +550,21 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   std::vector<unsigned short> g2b16((size_t)BIN_GRAN_MAX, 0);
   for (int b = 0; b < nb; ++b)
     for (int i = first[(size_t)b]; i < first[(size_t)b + 1]; ++i)
-      g2b16[(size_t)i] = (unsigned short)(b | ((i - first[(size_t)b]) << 9));
-  static_assert((1 << (BIN_SHIFT_MAX - BIN_GSHIFT_MIN)) <= 128 && BIN2_MAX <= 512, "bin: 9 bits, granule index inside a bin: 7 bits");
-  const size_t tab_bytes = (size_t)BIN_GRAN_MAX + (size_t)BIN2_MAX + (size_t)BIN_GRAN_MAX * sizeof(unsigned short);  // g2b, owner, g2b16
+      g2b16[(size_t)i] = (unsigned short)(b | ((i - first[(size_t)b]) << 8));
+  static_assert((1 << (BIN_SHIFT_MAX - BIN_GSHIFT_MIN)) <= 256, "granule index inside a bin fits 8 bits");
+  const size_t tab_bytes = (size_t)BIN_GRAN_MAX + (size_t)BIN_MAX + (size_t)BIN_GRAN_MAX * sizeof(unsigned short);  // g2b, owner, g2b16
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_tab8), tab_bytes));
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_off), 2 * ((size_t)BIN2_MAX + 1) * sizeof(int32_t)));  // off, v0
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_fill), ((size_t)BIN2_MAX + 16) * BIN_PAD * sizeof(int32_t)));  // fill, queue
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_off), 2 * ((size_t)BIN_MAX + 1) * sizeof(int32_t)));  // off, v0
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_fill), ((size_t)BIN_MAX + 16) * BIN_PAD * sizeof(int32_t)));  // fill, queue
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bins), ((size_t)g->E + 16) * sizeof(int32_t)));  // + the tail of a 16-byte load
   GRX_HIP(hipMemcpyAsync(g->bin_tab8, g2b.data(), (size_t)BIN_GRAN_MAX, hipMemcpyHostToDevice, s));
-  GRX_HIP(hipMemcpyAsync(g->bin_tab8 + BIN_GRAN_MAX, owner.data(), (size_t)BIN2_MAX, hipMemcpyHostToDevice, s));
-  static_assert((BIN_GRAN_MAX + BIN2_MAX) % 4 == 0, "the 16-bit table is read as 32-bit words");
-  GRX_HIP(hipMemcpyAsync(g->bin_tab8 + BIN_GRAN_MAX + BIN2_MAX, g2b16.data(), (size_t)BIN_GRAN_MAX * sizeof(unsigned short),
+  GRX_HIP(hipMemcpyAsync(g->bin_tab8 + BIN_GRAN_MAX, owner.data(), (size_t)BIN_MAX, hipMemcpyHostToDevice, s));
+  static_assert((BIN_GRAN_MAX + BIN_MAX) % 4 == 0, "the 16-bit table is read as 32-bit words");
+  GRX_HIP(hipMemcpyAsync(g->bin_tab8 + BIN_GRAN_MAX + BIN_MAX, g2b16.data(), (size_t)BIN_GRAN_MAX * sizeof(unsigned short),
                          hipMemcpyHostToDevice, s));
-  GRX_HIP(hipMemcpyAsync(g->bin_off, off.data(), ((size_t)BIN2_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  GRX_HIP(hipMemcpyAsync(g->bin_off + BIN2_MAX + 1, v0.data(), ((size_t)BIN2_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  GRX_HIP(hipMemsetAsync(g->bin_fill, 0, ((size_t)BIN2_MAX + 16) * BIN_PAD * sizeof(int32_t), s));
+  GRX_HIP(hipMemcpyAsync(g->bin_off, off.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  GRX_HIP(hipMemcpyAsync(g->bin_off + BIN_MAX + 1, v0.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  GRX_HIP(hipMemsetAsync(g->bin_fill, 0, ((size_t)BIN_MAX + 16) * BIN_PAD * sizeof(int32_t), s));
   GRX_HIP(hipStreamSynchronize(s));
   g->bin_shift = gshift;
   g->bin_ngran = n_gran;
@@ -781,18 +775,16 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   }
   int grid_scatter = 0, grid_claim = 0, grid_scatter2 = 0, grid_sweep2 = 0, grid_sweep3 = 0;
   // claim phase of a binned level: 3 = sweep (one workgroup per bin, vertex-ordered output), 2 = slices claimed in the owning XCD's L2
-  // (more than 256 bins -- graphs beyond 16.7 M vertices with 16-bit entries -- leave only the second scatter / sweep)
-  const bool wide_bins = use_bins && g->bin_nb > BIN_MAX;
-  const int claim_version = wide_bins ? 3 : env_int("GRX_BIN_CLAIM", 3);
+  const int claim_version = env_int("GRX_BIN_CLAIM", 3);
   if (use_bins) {
     bn.bins = g->bins;
     bn.off = g->bin_off;
-    bn.v0 = g->bin_off + BIN2_MAX + 1;
+    bn.v0 = g->bin_off + BIN_MAX + 1;
     bn.fill = g->bin_fill;
-    bn.queue = g->bin_fill + (size_t)BIN2_MAX * BIN_PAD;
+    bn.queue = g->bin_fill + (size_t)BIN_MAX * BIN_PAD;
     bn.g2b = g->bin_tab8;
     bn.owner = g->bin_tab8 + BIN_GRAN_MAX;
-    bn.g2b16 = reinterpret_cast<const unsigned short*>(g->bin_tab8 + BIN_GRAN_MAX + BIN2_MAX);
+    bn.g2b16 = reinterpret_cast<const unsigned short*>(g->bin_tab8 + BIN_GRAN_MAX + BIN_MAX);
     bn.gshift = g->bin_shift;
     bn.n_gran = g->bin_ngran;
     bn.nb = g->bin_nb;
@@ -821,7 +813,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     grid_claim = ctx->num_cus * per_cu_claim;
     // scatter phase: 2 = 1024-thread workgroups in their own launch (bins hold offsets inside the bin), 1 = first
     // version inside the level kernel.  The slice claim (GRX_BIN_CLAIM=2) reads global ids: first version only.
-    if ((wide_bins || env_int("GRX_BIN_SCATTER", 2) == 2) && claim_version != 2) {
+    if (env_int("GRX_BIN_SCATTER", 2) == 2 && claim_version != 2) {
       static const int per_cu_sc2 = [] {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_scatter2_kernel<false, false>, SC2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
@@ -832,8 +824,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     }
     // sweep claim: 1 = first version; 2 = second version on 512-thread workgroups, two parts per bin; 3 = second version on
     // 1024-thread workgroups, one per CU, one emission per item
-    int sweep_version = claim_version == 3 ? env_int("GRX_BIN_SWEEP", 3) : 0;
-    if (wide_bins && sweep_version != 2) sweep_version = 3;
+    const int sweep_version = claim_version == 3 ? env_int("GRX_BIN_SWEEP", 3) : 0;
     if (sweep_version == 2) {
       static const int per_cu_sw2 = [] {
         int n = 0;

@@ -34,9 +34,7 @@
 
 namespace grx {
 
-constexpr int BIN_MAX = ADV_BLOCK;   // bins of the first-version kernels: one thread of a 256-thread workgroup per bin
-constexpr int BIN2_MAX = 512;        // bins of the second scatter / sweep (1024- and 512-thread workgroups): a 21 M-vertex graph
-                                     // needs 325 bins of <= 65536 vertices for 16-bit entries
+constexpr int BIN_MAX = ADV_BLOCK;   // bins: one thread of a workgroup per bin
 constexpr int BIN_BATCH = 4;         // chunks sorted together (one reservation atomic per bin and batch:
                                      // a single word sustains only ~90 atomics/us)
 constexpr int BIN_SLICE = 8192;      // entries per claim work item
@@ -53,7 +51,7 @@ struct bin_args {
   const unsigned char* g2b;   // granule -> bin (bins are runs of granules: capacity-balanced, variable width)
   const int32_t* v0;          // nb + 1: first vertex of each bin
   const unsigned char* owner; // bin -> dense index of the XCD that claims its vertices
-  const unsigned short* g2b16;  // second scatter: granule -> bin (9 bits) | (index of the granule inside its bin) << 9
+  const unsigned short* g2b16;  // second scatter: granule -> bin | (index of the granule inside its bin) << 8
   int32_t local_ids;          // 1: the bins hold ids RELATIVE to the first vertex of their bin (second scatter), 0: global ids
   int32_t sweep_items;        // second sweep: work items a level is cut into at most (<= its grid: one item per workgroup)
   int32_t entry16;            // 1: the bins hold 16-BIT offsets (every bin spans <= 65536 vertices; needs local_ids), 0: 32-bit entries
@@ -789,7 +787,7 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
 //     from three ballots per wave over the slots' row-begin positions (highest slot that begins a row before the
 //     target wave's first atom), written with the degree totals -- no second exchange;
 //   * the granule table yields bin AND the vertex's offset inside its bin in ONE 16-bit LDS read; the sorted entry is
-//     (bin << 17 | offset), so the copy-out finds its bin without a second table lookup, and the bins hold offsets
+//     (bin << 24 | offset), so the copy-out finds its bin without a second table lookup, and the bins hold offsets
 //     relative to the bin's first vertex -- which is what the sweep claim indexes its bitmap slice with;
 //   * the owner map no longer shares its LDS with the sort buffer, so the barrier at the end of a batch is gone
 //     (7 per batch instead of ~12).
@@ -797,22 +795,21 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
 // level kernel are written for 256-thread workgroups.
 constexpr int SC2_BLOCK = 1024;
 constexpr int SC2_Q = SC2_BLOCK / TILE;  // quarters = chunks per batch
-constexpr int SC2_BIN_SHIFT = BIN_SHIFT_MAX;  // a sorted entry is bin << 17 | offset inside the bin (< 2^17)
 static_assert(SC2_Q == BIN_BATCH, "a batch is still 4 chunks");
 
 struct bin_scatter2_smem {
   alignas(16) int dlt[SC2_Q][TILE];            // per staged slot: row start - exclusive degree prefix
   alignas(16) int wtot[SC2_Q][4];              // degree sums of the four waves of a quarter (read as one int4)
   alignas(16) int cand[SC2_Q][4][4];           // [quarter][target wave][source wave]: highest slot of the source wave that begins a row before the target's first atom
-  int wave[BIN2_MAX / 64 + 1];
-  int hist[BIN2_MAX];
-  int off[BIN2_MAX];
-  int delta[BIN2_MAX];
+  int wave[BIN_MAX / 64 + 1];
+  int hist[BIN_MAX];
+  int off[BIN_MAX];
+  int delta[BIN_MAX];
   int btot;
   int tick[4];                                 // units of the pipeline stages (tick[3]: the stage entering next)
-  alignas(4) unsigned short g2b[BIN_GRAN_MAX]; // granule -> bin (9 bits) | granule index inside the bin << 9 (loaded as 32-bit words)
+  alignas(4) unsigned short g2b[BIN_GRAN_MAX]; // granule -> bin | granule index inside the bin << 8 (loaded as 32-bit words)
   alignas(8) unsigned char own[SC2_Q][CHUNK];  // owner map: staged slot of every atom of the four chunks (8 bytes per thread)
-  alignas(16) unsigned sorted[SC2_Q * CHUNK];  // (bin << 17 | offset inside the bin), grouped by bin
+  alignas(16) unsigned sorted[SC2_Q * CHUNK];  // (bin << 24 | offset inside the bin), grouped by bin
 };
 
 
@@ -921,7 +918,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     const int inc = dev::wave_inclusive_sum(dg);
     if (lane == 63) sm.wtot[q][wq] = inc;
     reinterpret_cast<uint2*>(own)[tq] = make_uint2(0u, 0u);
-    if (tid < BIN2_MAX) sm.hist[tid] = 0;
+    if (tid < BIN_MAX) sm.hist[tid] = 0;
     __syncthreads();
     const int uD = __builtin_amdgcn_readfirstlane(sm.tick[3]);  // written at the end of the previous batch (or at the start)
     tlD = S1(uD);
@@ -989,7 +986,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     // Every LDS / global operation of the 8 atoms is issued UNCONDITIONALLY from a clamped index, phase by phase
     // (owner bytes -> row deltas -> column indices -> granule table -> histogram): under a per-lane condition each
     // one sits in its own basic block with its consumer and an s_waitcnt behind it -- 8 x 4 serialized round trips.
-    unsigned e_k[ADV_ITEMS];  // first the neighbour id, then bin << 17 | offset inside the bin
+    unsigned e_k[ADV_ITEMS];  // first the neighbour id, then bin << 24 | offset inside the bin
     int r_k[ADV_ITEMS];       // rank inside the bin
     const int n_at = has ? min(tot - a0, CHUNK) : 0;  // atoms of this chunk; atom k * TILE + tq is real iff < n_at
     {
@@ -1013,8 +1010,8 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       for (int k = 0; k < ADV_ITEMS; ++k) t_k[k] = sm.g2b[e_k[k] >> gshift];
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) {
-        const unsigned bb = t_k[k] & 0x1ffu;
-        e_k[k] = (bb << SC2_BIN_SHIFT) | ((t_k[k] >> 9) << gshift) | (e_k[k] & gmask);
+        const unsigned bb = t_k[k] & 0xffu;
+        e_k[k] = (bb << 24) | ((t_k[k] >> 8) << gshift) | (e_k[k] & gmask);
         r_k[k] = atomicAdd(&sm.hist[bb], (k * TILE + tq) < n_at ? 1 : 0);
       }
     }
@@ -1026,22 +1023,22 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     // waiting for its result means waiting for them too -- vmcnt retires in order.)
     // ---- phase 5: one reservation per non-empty bin (its round trip is covered by the scan and the sort), bin offsets
     int cnt = 0, gbase = 0, inc2 = 0;
-    if (tid < BIN2_MAX) {
+    if (tid < BIN_MAX) {
       cnt = sm.hist[tid];
       if (cnt > 0) gbase = atomicAdd(&bn.fill[(unsigned)(tid * BIN_PAD)], cnt);
       inc2 = dev::wave_inclusive_sum(cnt);
-      if (lane == 63) sm.wave[tid >> 6] = inc2;
+      if (lane == 63) sm.wave[wq] = inc2;
     }
     __syncthreads();
     int ex2 = 0;
-    if (tid < BIN2_MAX) {
+    if (tid < BIN_MAX) {
       int b2 = 0;
 #pragma unroll
-      for (int i = 0; i < BIN2_MAX / 64; ++i)
-        if (i < (tid >> 6)) b2 += sm.wave[i];
+      for (int i = 0; i < BIN_MAX / 64; ++i)
+        if (i < wq) b2 += sm.wave[i];
       ex2 = b2 + inc2 - cnt;
       sm.off[tid] = ex2;
-      if (tid == BIN2_MAX - 1) sm.btot = ex2 + cnt;
+      if (tid == BIN_MAX - 1) sm.btot = ex2 + cnt;
     }
     __syncthreads();
     dbg_mark(5);
@@ -1049,12 +1046,12 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     {
       int o_k[ADV_ITEMS];
 #pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) o_k[k] = sm.off[e_k[k] >> SC2_BIN_SHIFT];
+      for (int k = 0; k < ADV_ITEMS; ++k) o_k[k] = sm.off[e_k[k] >> 24];
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k)
         if (k * TILE + tq < n_at) sm.sorted[o_k[k] + r_k[k]] = e_k[k];
     }
-    if (tid < BIN2_MAX) sm.delta[tid] = boff + gbase - ex2;  // global slot of sorted position i of this bin: delta + i
+    if (tid < BIN_MAX) sm.delta[tid] = boff + gbase - ex2;  // global slot of sorted position i of this bin: delta + i
     __syncthreads();
     dbg_mark(6);
     // ---- phase 7: runs leave LDS as contiguous segments (no barrier behind it: the next batch touches the sort
@@ -1067,13 +1064,13 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) s_k[k] = sm.sorted[k * SC2_BLOCK + tid];
 #pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) d_k[k] = sm.delta[s_k[k] >> SC2_BIN_SHIFT];
+      for (int k = 0; k < ADV_ITEMS; ++k) d_k[k] = sm.delta[s_k[k] >> 24];
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) {
         const int i = k * SC2_BLOCK + tid;
         if (i < btot) {
           if constexpr (E16) reinterpret_cast<unsigned short*>(bn.bins)[(size_t)(d_k[k] + i)] = (unsigned short)(s_k[k] & 0xffffu);
-          else bn.bins[(size_t)(d_k[k] + i)] = (int)(s_k[k] & ((1u << SC2_BIN_SHIFT) - 1u));
+          else bn.bins[(size_t)(d_k[k] + i)] = (int)(s_k[k] & 0xffffffu);
         }
       }
     }
@@ -1125,8 +1122,8 @@ struct bin_sweep2_smem {
   static constexpr int MAX_TILES = LIST / TILE + 1;
   unsigned bm[1 << (BIN_SHIFT_MAX - 5)];
   int list[LIST];
-  int pre[BIN2_MAX + 1];
-  int fillv[BIN2_MAX];
+  int pre[BIN_MAX + 1];
+  int fillv[BIN_MAX];
   int wave[NT / 64 + 1];
   int sum[MAX_TILES][4];   // per tile of an emission and wave of the tile: degree sums
   int ttot[64];
@@ -1235,7 +1232,7 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
     }
   };
   if constexpr (DBG) dbg_t0 = (long long)wall_clock64();
-  static_assert(TILE == 256 && NT == 4 * S::SEG_WORDS && NT >= BIN2_MAX, "a thread expands one byte of a bitmap word");
+  static_assert(TILE == 256 && NT == 4 * S::SEG_WORDS && NT >= BIN_MAX, "a thread expands one byte of a bitmap word");
   const int tid0 = threadIdx.x;
   int tid = tid0;
   const int q = p ^ 1;
@@ -1249,11 +1246,11 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
   const int PART = max(SW2_PART_MIN, ((tot_fill / parts) + 4) & ~3);
   int tot_items;
   const int ex0 = dev::block_exclusive_sum<NT>((fill + PART - 1) / PART, sm.wave, &tot_items);
-  if (tid < BIN2_MAX) {
+  if (tid < BIN_MAX) {
     sm.pre[tid] = ex0;
     sm.fillv[tid] = fill;
   }
-  if (tid == 0) sm.pre[BIN2_MAX] = tot_items;
+  if (tid == 0) sm.pre[BIN_MAX] = tot_items;
   __syncthreads();
   int n_list = 0;  // uniform: entries waiting in sm.list (labels already stored)
   const int4* src4 = reinterpret_cast<const int4*>(bn.bins);
@@ -1263,7 +1260,7 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
     if constexpr (DBG) dbg_t = (long long)wall_clock64();
     int b = 0;  // largest b with pre[b] <= item (bins without items are skipped over)
 #pragma unroll
-    for (int step = BIN2_MAX / 2; step >= 1; step >>= 1)
+    for (int step = BIN_MAX / 2; step >= 1; step >>= 1)
       if (sm.pre[b + step] <= item) b += step;
     const int e0 = (item - sm.pre[b]) * PART;
     const int n_e = min(sm.fillv[b], e0 + PART) - e0;

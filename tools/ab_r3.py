@@ -70,10 +70,9 @@ def run(label, direction, env=None):
 
 
 print("workload", name, "V", V, "E", G.get_number_of_edges(), "src", src, flush=True)
-if V <= 16_000_000:
-    run("fwd scatter1 sweep1 (round 2)", gr.forward, {"GRX_BIN_SCATTER": 1, "GRX_BIN_SWEEP": 1})
-run("fwd 32-bit entries", gr.forward, {"GRX_BIN_E16": 0})
-run("fwd default (16-bit entries)", gr.forward, {})
-run("fwd 32-bit entries again", gr.forward, {"GRX_BIN_E16": 0})
+run("fwd scatter1 sweep1 (round 2)", gr.forward, {"GRX_BIN_SCATTER": 1, "GRX_BIN_SWEEP": 1})
+run("fwd default (warm ci)", gr.forward, {})
+run("fwd no warming", gr.forward, {"GRX_SC2_WARM": 0})
 run("fwd default again", gr.forward, {})
+run("fwd no warming again", gr.forward, {"GRX_SC2_WARM": 0})
 run("DO default", gr.optimized, {})
