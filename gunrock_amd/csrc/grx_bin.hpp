@@ -1140,9 +1140,7 @@ __device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q
   using S = bin_sweep2_smem<NT, LE>;
   static_assert(S::MAX_TILES <= 64, "one lane per tile of an emission");
   constexpr int PASSES = (S::LIST + NT - 1) / NT;
-  // passes whose row-offset loads travel together: the groups are dependent round trips (16 passes in groups of 3 were six of
-  // them, ~9 us of a 38 us kernel); the 1024-thread geometry has the registers for 8
-  constexpr int G = NT >= 1024 ? 8 : 3;
+  constexpr int G = 3;  // passes whose row-offset loads travel together
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));  // (re-derive per call what depends on the thread index: see bin_scatter2_block)
   const int lane = tid & 63;
@@ -1222,11 +1220,6 @@ template <int NT, int LE, bool DBG, bool E16>
 __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_args& bn, ctrl_t* c, int depth,
                                                  bin_sweep2_smem<NT, LE>& sm, int p) {
   constexpr int EPL = E16 ? 8 : 4;  // entries per 16-byte load
-  // candidate loads in flight per thread: the 1024-thread geometry is alone on its CU and limited by LDS, not registers --
-  // 4 loads per round, two rounds ahead (an item is only ~5 rounds of 2 loads: with one round ahead the stream was a chain of
-  // round trips, 17-19 us for 300 KB); the 512-thread geometry lives under 64 VGPRs: 2 loads, one round ahead
-  constexpr int U = NT >= 1024 ? 4 : SW2_U;
-  constexpr bool TWO_AHEAD = NT >= 1024;
   using S = bin_sweep2_smem<NT, LE>;
   // DBG (GRX_BIN_DEBUG, its own kernel build): thread 0's clock per step, summed over the workgroup's items
   long long dbg_t0 = 0, dbg_t = 0, dbg_ph[4] = {0, 0, 0, 0}, dbg_entries = 0;
@@ -1278,34 +1271,27 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
     const int gw0 = vbase >> 5;
     // first candidates on their way while the bitmap slice is copied
     const int i4_first = lo / EPL, i4_last = (hi - 1) / EPL;
-    int4 nx[U], nx2[U];
-    auto LOAD = [&](int r, int4(&v)[U]) {
+    int4 nx[SW2_U];
+    auto LOAD = [&](int r, int4(&v)[SW2_U]) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int idx = i4_first + (r * U + u) * NT + tid;
+      for (int u = 0; u < SW2_U; ++u) {
+        const int idx = i4_first + (r * SW2_U + u) * NT + tid;
         v[u] = src4[idx < i4_last ? idx : i4_last];
       }
     };
     LOAD(0, nx);
-    if constexpr (TWO_AHEAD) LOAD(1, nx2);
     for (int w = tid; w < words; w += NT) sm.bm[w] = (gw0 + w) < bn.visited_words ? bn.visited[gw0 + w] : ~0u;
     __syncthreads();
-    // A. candidates -> LDS bitmap
-    const int rounds = (i4_last - i4_first + U * NT) / (U * NT);
+    // A. candidates -> LDS bitmap (loads one round ahead)
+    const int rounds = (i4_last - i4_first + SW2_U * NT) / (SW2_U * NT);
     for (int r = 0; r < rounds; ++r) {
-      int4 cur[U];
+      int4 cur[SW2_U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) cur[u] = nx[u];
-      if constexpr (TWO_AHEAD) {
+      for (int u = 0; u < SW2_U; ++u) cur[u] = nx[u];
+      LOAD(r + 1, nx);
 #pragma unroll
-        for (int u = 0; u < U; ++u) nx[u] = nx2[u];
-        LOAD(r + 2, nx2);
-      } else {
-        LOAD(r + 1, nx);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int idx = i4_first + (r * U + u) * NT + tid;
+      for (int u = 0; u < SW2_U; ++u) {
+        const int idx = i4_first + (r * SW2_U + u) * NT + tid;
         const int g0 = idx * EPL;
         int n_e4[EPL];
         if constexpr (E16) {
