@@ -105,6 +105,13 @@ struct enactor_t : gunrock::enactor_t<problem_t> {
     const options_t& opt = P->param.options;
 
     detail::relax_depth_t<vertex_t, edge_t, weight_t> relax{P->result.distances, (vertex_t)(this->iteration + 1)};
+    const bool mp = opt.advance_load_balance == operators::load_balance_t::merge_path ||
+                    opt.advance_load_balance == operators::load_balance_t::merge_path_v2;
+    if (mp && opt.enable_filter && opt.filter_algorithm == operators::filter_algorithm_t::compact) {
+      // the reference README's tuned command line (merge_path + compact filter): one fused pass, no -1 holes in HBM
+      operators::advance::execute_compact(G, E, relax, context);
+      return;
+    }
     operators::advance::execute_runtime(G, E, relax, opt.advance_load_balance, context);
     if (opt.enable_filter)
       operators::filter::execute_runtime(G, E, detail::keep_valid_t<vertex_t>(), opt.filter_algorithm, context);

@@ -99,6 +99,40 @@ void execute(graph_t& G, enactor_type* E, operator_type op, gcuda::multi_context
   if (swap_buffers && output_type != advance_io_type_t::none) E->swap_frontier_buffers();
 }
 
+// Extension (not in the reference): advance followed by filter_algorithm_t::compact with an always-true predicate, FUSED --
+// the merge-path advance compacts the neighbours `op` keeps on the fly (wave ballot, one atomic per workgroup and round), so
+// the m_F-entry output with its -1 holes is never written and the filter pass never runs.  Same output SET as
+// advance::execute<merge_path> + filter::execute<compact>(keep valid); order across workgroups is unspecified, as for compact.
+// One size read-back instead of two.
+template <advance_io_type_t output_type = advance_io_type_t::vertices, typename graph_t, typename enactor_type,
+          typename operator_type>
+void execute_compact(graph_t& G, enactor_type* E, operator_type op, gcuda::multi_context_t& context,
+                     bool swap_buffers = true) {
+  GUNROCK_TRACE_RANGE("advance+compact");
+  using frontier_t = typename enactor_type::frontier_t;
+  using type_t = typename frontier_t::type_t;
+  using edge_t = typename graph_t::edge_type;
+  error::throw_if_exception(context.size() != 1, "`context.size() != 1` not supported");
+  auto& ctx = *context.get_context(0);
+  frontier_t* input = E->get_input_frontier();
+  frontier_t* output = E->get_output_frontier();
+  const std::size_t n = input->get_number_of_elements();
+  const std::size_t total = compute_output_offsets(G, input, E->scanned_work_domain, ctx, false);
+  const edge_t* seg = memory::raw_pointer_cast(E->scanned_work_domain.data());
+  benchmark::LOG_EDGES_HOST(total);
+  benchmark::LOG_VERTICES_HOST(n);
+  if (output->get_capacity() < total) output->reserve(total);
+  if (total == 0) {
+    output->set_number_of_elements(0);
+  } else {
+    int32_t* counter = ctx.template scratch<int32_t>(2, 4);
+    error::throw_if_exception(hipMemsetAsync(counter, 0, sizeof(int32_t), ctx.stream()), "counter reset");
+    merge_path::launch_compact<output_type>(G, op, input->data(), n, output->data(), seg, total, counter, ctx);
+    output->set_number_of_elements((std::size_t)ctx.read_back(counter)[0]);
+  }
+  if (swap_buffers) E->swap_frontier_buffers();
+}
+
 template <typename graph_t, typename enactor_type, typename operator_type>
 void execute_runtime(graph_t& G, enactor_type* E, operator_type op, load_balance_t lb,
                      gcuda::multi_context_t& context, bool swap_buffers = true) {

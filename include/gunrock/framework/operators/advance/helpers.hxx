@@ -49,10 +49,15 @@ __global__ void degrees_kernel(graph_t G, const type_t* input, std::size_t n, ed
 // front of its own consumer: one round trip at a time per lane (seen in the ISA of round 2's kernels).
 constexpr int ROUND = 8;
 
-template <advance_io_type_t output_type, typename graph_t, typename operator_t, typename type_t>
+// COMPACT (fused advance + compact filter, advance::execute_compact): instead of out[atom] = keep ? nbr : -1 the kept
+// neighbours of a round leave compacted -- wave ballot + mbcnt rank, wave totals in LDS (s_cmp: BLOCK / 64 + 2 ints), ONE
+// atomicAdd on *counter per workgroup and round for the output base -- so the -1 holes never reach HBM and the separate
+// filter pass (read m_F, write the survivors) disappears.  Unordered across workgroups, like filter_algorithm_t::compact.
+template <advance_io_type_t output_type, bool COMPACT = false, typename graph_t, typename operator_t, typename type_t>
 __device__ __forceinline__ void expand_window(const graph_t& G, operator_t& op, const int* s_seg,
                                               const int* s_start, const type_t* s_src, int nslots,
-                                              int atom_lo, int atom_hi, type_t* out) {
+                                              int atom_lo, int atom_hi, type_t* out, int* s_cmp = nullptr,
+                                              int32_t* counter = nullptr) {
   using vertex_t = typename graph_t::vertex_type;
   using edge_t = typename graph_t::edge_type;
   using weight_t = typename graph_t::weight_type;
@@ -102,20 +107,56 @@ __device__ __forceinline__ void expand_window(const graph_t& G, operator_t& op, 
     for (int k = 0; k < ROUND; ++k) nbr[k] = G.get_destination_vertex(e[k]);
 #pragma unroll
     for (int k = 0; k < ROUND; ++k) w[k] = G.get_edge_weight(e[k]);
+    if constexpr (!COMPACT) {
 #pragma unroll
-    for (int k = 0; k < ROUND; ++k) {
-      if (atom[k] < atom_hi) {
-        // mutable lvalues: user operators may take (vertex_t&, vertex_t&, edge_t const&, weight_t const&)
-        // like the reference's hits.hxx:137
-        edge_t ee = e[k];
-        vertex_t ss = src[k], nn = nbr[k];
-        weight_t ww = w[k];
-        const bool keep = op(ss, nn, ee, ww);
-        if constexpr (output_type != advance_io_type_t::none) {
-          const type_t emitted = (output_type == advance_io_type_t::edges) ? (type_t)e[k] : (type_t)nbr[k];
-          out[atom[k]] = keep ? emitted : gunrock::numeric_limits<type_t>::invalid();
+      for (int k = 0; k < ROUND; ++k) {
+        if (atom[k] < atom_hi) {
+          // mutable lvalues: user operators may take (vertex_t&, vertex_t&, edge_t const&, weight_t const&)
+          // like the reference's hits.hxx:137
+          edge_t ee = e[k];
+          vertex_t ss = src[k], nn = nbr[k];
+          weight_t ww = w[k];
+          const bool keep = op(ss, nn, ee, ww);
+          if constexpr (output_type != advance_io_type_t::none) {
+            const type_t emitted = (output_type == advance_io_type_t::edges) ? (type_t)e[k] : (type_t)nbr[k];
+            out[atom[k]] = keep ? emitted : gunrock::numeric_limits<type_t>::invalid();
+          }
         }
       }
+    } else {
+      static_assert(output_type != advance_io_type_t::none, "a compacted advance has an output");
+      const int lane = grx::dev::lane_id();
+      const int wid = (int)threadIdx.x >> 6;
+      int rank[ROUND];
+      int mine = 0;  // kept by this wave so far (wave-uniform)
+#pragma unroll
+      for (int k = 0; k < ROUND; ++k) {
+        bool keep = false;
+        if (atom[k] < atom_hi) {
+          edge_t ee = e[k];
+          vertex_t ss = src[k], nn = nbr[k];
+          weight_t ww = w[k];
+          keep = op(ss, nn, ee, ww);
+        }
+        const unsigned long long m = grx::dev::ballot(keep);
+        rank[k] = keep ? mine + grx::dev::mask_rank(m) : -1;
+        mine += __popcll(m);
+      }
+      if (lane == 0) s_cmp[wid] = mine;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int i = 0; i < BLOCK / 64; ++i) tot += s_cmp[i];
+        s_cmp[BLOCK / 64] = tot ? atomicAdd(counter, tot) : 0;
+      }
+      __syncthreads();
+      int before = s_cmp[BLOCK / 64];
+      for (int i = 0; i < wid; ++i) before += s_cmp[i];
+#pragma unroll
+      for (int k = 0; k < ROUND; ++k)
+        if (rank[k] >= 0) out[before + rank[k]] = (output_type == advance_io_type_t::edges) ? (type_t)e[k] : (type_t)nbr[k];
+      __syncthreads();  // s_cmp is reused by the next round
     }
   }
 }

@@ -18,11 +18,13 @@ namespace operators {
 namespace advance {
 namespace merge_path {
 
-template <advance_io_type_t output_type, typename graph_t, typename operator_t, typename type_t, typename edge_t>
+template <advance_io_type_t output_type, bool COMPACT = false, typename graph_t, typename operator_t, typename type_t,
+          typename edge_t>
 __global__ __launch_bounds__(detail::BLOCK) void kernel(graph_t G, operator_t op, const type_t* input,
                                                         std::size_t n, type_t* output, const edge_t* segments,
-                                                        edge_t total_atoms) {
+                                                        edge_t total_atoms, int32_t* counter = nullptr) {
   using vertex_t = typename graph_t::vertex_type;
+  __shared__ int s_cmp[detail::BLOCK / 64 + 2];
   __shared__ int s_seg[detail::BLOCK + 1];
   __shared__ int s_start[detail::BLOCK];
   __shared__ type_t s_src[detail::BLOCK];
@@ -75,8 +77,9 @@ __global__ __launch_bounds__(detail::BLOCK) void kernel(graph_t G, operator_t op
     const int lo = (int)max((edge_t)0, a0 - base);
     const int hi = (int)min((edge_t)window_total, a1 - base);
     type_t* out = nullptr;
-    if constexpr (output_type != advance_io_type_t::none) out = output + base;
-    if (lo < hi) detail::expand_window<output_type>(G, op, s_seg, s_start, s_src, nslots, lo, hi, out);
+    if constexpr (COMPACT) out = output;  // positions come from the counter, not from the scan
+    else if constexpr (output_type != advance_io_type_t::none) out = output + base;
+    if (lo < hi) detail::expand_window<output_type, COMPACT>(G, op, s_seg, s_start, s_src, nslots, lo, hi, out, s_cmp, counter);
     if (base + window_total >= a1) break;
   }
 }
@@ -86,8 +89,20 @@ void launch(graph_t& G, operator_t op, const type_t* input, std::size_t n, type_
             std::size_t total_atoms, gcuda::standard_context_t& context) {
   if (n == 0 || total_atoms == 0) return;
   const std::size_t blocks = (total_atoms + detail::ATOMS_PER_BLOCK - 1) / detail::ATOMS_PER_BLOCK;
-  hipLaunchKernelGGL((kernel<output_type, graph_t, operator_t, type_t, edge_t>), dim3((unsigned)blocks),
-                     dim3(detail::BLOCK), 0, context.stream(), G, op, input, n, output, segments, (edge_t)total_atoms);
+  hipLaunchKernelGGL((kernel<output_type, false, graph_t, operator_t, type_t, edge_t>), dim3((unsigned)blocks),
+                     dim3(detail::BLOCK), 0, context.stream(), G, op, input, n, output, segments, (edge_t)total_atoms,
+                     (int32_t*)nullptr);
+}
+
+// advance + compact filter in one pass: the kept neighbours land at output[0 .. *counter) (counter zeroed by the caller)
+template <advance_io_type_t output_type, typename graph_t, typename operator_t, typename type_t, typename edge_t>
+void launch_compact(graph_t& G, operator_t op, const type_t* input, std::size_t n, type_t* output, const edge_t* segments,
+                    std::size_t total_atoms, int32_t* counter, gcuda::standard_context_t& context) {
+  if (n == 0 || total_atoms == 0) return;
+  const std::size_t blocks = (total_atoms + detail::ATOMS_PER_BLOCK - 1) / detail::ATOMS_PER_BLOCK;
+  hipLaunchKernelGGL((kernel<output_type, true, graph_t, operator_t, type_t, edge_t>), dim3((unsigned)blocks),
+                     dim3(detail::BLOCK), 0, context.stream(), G, op, input, n, output, segments, (edge_t)total_atoms,
+                     counter);
 }
 
 }  // namespace merge_path

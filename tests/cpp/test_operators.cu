@@ -171,6 +171,23 @@ int main() {
   run_advance(operators::load_balance_t::merge_path, "advance.merge_path");
   run_advance(operators::load_balance_t::merge_path_v2, "advance.merge_path_v2");
   run_advance(operators::load_balance_t::bucketing, "advance.bucketing");
+  // fused advance + compact (extension): the kept neighbours of the same call, as a multiset, and one op call per edge
+  {
+    thrust::fill(calls.begin(), calls.end(), 0);
+    auto* in = E.get_input_frontier();
+    in->set_number_of_elements(0);
+    for (int v : input) in->push_back(v);
+    operators::advance::execute_compact(G, &E, even_neighbors_t{calls.data().get()}, *context);
+    auto out = download(*E.get_input_frontier());
+    std::vector<int> want;
+    for (int x : expect) if (x >= 0) want.push_back(x);
+    std::sort(want.begin(), want.end());
+    std::sort(out.begin(), out.end());
+    thrust::host_vector<int> hc = calls;
+    bool ok = out == want;
+    for (int v = 0; v < V && ok; ++v) ok = hc[v] == expect_calls[v];
+    check("advance.execute_compact", ok);
+  }
   {
     bool threw = false;
     try {
