@@ -277,6 +277,7 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->t_ci) (void)hipFree(g->t_ci);
   if (g->t_w) (void)hipFree(g->t_w);
   if (g->closed0) (void)hipFree(g->closed0);
+  if (g->bu_heads) (void)hipFree(g->bu_heads);
   if (g->bins) (void)hipFree(g->bins);
   if (g->bin_off) (void)hipFree(g->bin_off);
   if (g->bin_fill) (void)hipFree(g->bin_fill);

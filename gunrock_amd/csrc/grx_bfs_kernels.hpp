@@ -171,6 +171,9 @@ struct dobfs_args {
   int32_t ch_lo;               // 0 on a single GPU
   const unsigned* fin_global;  // whole-graph frontier bitmap to probe; null: fbits[level & 1]
   uint32_t xcc_mask;           // hardware XCC ids of this device (grx_mid.hpp)
+  // single GPU, per graph: {first, second in-neighbour} of every vertex (-1: none), so that the first probe group of a
+  // bottom-up level reads ONE coalesced 8-byte stream instead of two column indices per lane from 64 different rows
+  const int2* heads;           // null: probe through t_ci
 };
 
 // Bottom-up level.  A wave owns 64 consecutive vertices (one "chunk") and works on
@@ -336,10 +339,25 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
         // UNCONDITIONAL loads from a clamped index (some lane has an in-edge, so entry 0 exists):
         // a predicated load sits in its own basic block and the compiler then waits for each
         // one before issuing the next -- 2 * BATCH * N serialized round trips instead of 2
+        bool from_heads = false;
+        if constexpr (R0 == 0 && N == 2) {
+          if (d.heads) {  // uniform
+            from_heads = true;
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j)
+            for (int j = 0; j < BATCH; ++j) {
+              const int v = vbase + (ch0 + j) * 64 + lane;
+              const int2 h = d.heads[v < a.V ? v : a.V - 1];  // lanes of a wave read 512 consecutive bytes
+              u[j][0] = h.x;
+              u[j][1] = h.y;
+            }
+          }
+        }
+        if (!from_heads) {
 #pragma unroll
-          for (int q = 0; q < N; ++q) u[j][q] = d.t_ci[act[j][q] ? b[j] + R0 + q : 0];
+          for (int j = 0; j < BATCH; ++j)
+#pragma unroll
+            for (int q = 0; q < N; ++q) u[j][q] = d.t_ci[act[j][q] ? b[j] + R0 + q : 0];
+        }
         unsigned w[BATCH][N];
 #pragma unroll
         for (int j = 0; j < BATCH; ++j)

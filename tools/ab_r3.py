@@ -25,7 +25,7 @@ ctx = gr.multi_context_t(0)
 G = gr.build_graph(props, csr, ctx)
 V = G.get_number_of_vertices()
 d = torch.empty(V, dtype=torch.int32, device="cuda")
-KNOBS = ("GRX_BIN_E16", "GRX_BIN_SCATTER", "GRX_BIN_SWEEP", "GRX_SW2_ITEMS", "GRX_SW2_WG_PER_CU", "GRX_SC2_WG_PER_CU", "GRX_BIN_MIN_EDGES")
+KNOBS = ("GRX_BU_HEADS", "GRX_BIN_E16", "GRX_BIN_SCATTER", "GRX_BIN_SWEEP", "GRX_SW2_ITEMS", "GRX_SW2_WG_PER_CU", "GRX_SC2_WG_PER_CU", "GRX_BIN_MIN_EDGES")
 ref = None
 
 
@@ -70,9 +70,8 @@ def run(label, direction, env=None):
 
 
 print("workload", name, "V", V, "E", G.get_number_of_edges(), "src", src, flush=True)
-run("fwd scatter1 sweep1 (round 2)", gr.forward, {"GRX_BIN_SCATTER": 1, "GRX_BIN_SWEEP": 1})
-run("fwd scatter2 sweep1", gr.forward, {"GRX_BIN_SWEEP": 1, "GRX_BIN_E16": 0})
-run("fwd scatter2 sweep3 32-bit entries", gr.forward, {"GRX_BIN_E16": 0})
-run("fwd default (scatter2 sweep3 16-bit)", gr.forward, {})
-run("fwd default again", gr.forward, {})
-run("DO default", gr.optimized, {})
+run("DO default (heads)", gr.optimized, {})
+run("DO without heads", gr.optimized, {"GRX_BU_HEADS": 0})
+run("DO default again", gr.optimized, {})
+run("DO without heads again", gr.optimized, {"GRX_BU_HEADS": 0})
+run("fwd default", gr.forward, {})
