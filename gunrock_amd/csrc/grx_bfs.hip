@@ -66,12 +66,11 @@ __global__ void bfs_closed0_kernel(const int32_t* t_ro, int32_t V, unsigned* out
   }
 }
 
-// heads[v] = the first four in-neighbours of v (-1: none).  Once per graph (bottom-up probes, dobfs_args::heads).
-__global__ void bfs_heads_kernel(const int32_t* t_ro, const int32_t* t_ci, int32_t V, int4* heads) {
+// heads[v] = {first, second in-neighbour of v} (-1: none).  Once per graph (bottom-up probes, dobfs_args::heads).
+__global__ void bfs_heads_kernel(const int32_t* t_ro, const int32_t* t_ci, int32_t V, int2* heads) {
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
     const int b = t_ro[v], e = t_ro[v + 1];
-    heads[v] = make_int4(b < e ? t_ci[b] : -1, b + 1 < e ? t_ci[b + 1] : -1, b + 2 < e ? t_ci[b + 2] : -1,
-                         b + 3 < e ? t_ci[b + 3] : -1);
+    heads[v] = make_int2(b < e ? t_ci[b] : -1, b + 1 < e ? t_ci[b + 1] : -1);
   }
 }
 
@@ -724,16 +723,16 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
                          (int)bm_words);
     }
     if (env_int("GRX_BU_HEADS", 1) != 0) {
-      // the first four in-neighbours of every vertex as one dense array, built once per graph (16 V bytes)
+      // the first two in-neighbours of every vertex as one dense array, built once per graph (8 V bytes)
       if (!g->bu_heads || g->bu_heads_of != (const void*)d.t_ci) {
         if (g->bu_heads) GRX_HIP(hipFree(g->bu_heads));
         g->bu_heads = nullptr;
-        GRX_HIP(hipMalloc((void**)&g->bu_heads, (size_t)g->V * 4 * sizeof(int32_t)));
+        GRX_HIP(hipMalloc((void**)&g->bu_heads, (size_t)g->V * 2 * sizeof(int32_t)));
         g->bu_heads_of = (const void*)d.t_ci;
         hipLaunchKernelGGL(bfs_heads_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, s, d.t_ro, d.t_ci, g->V,
-                           reinterpret_cast<int4*>(g->bu_heads));
+                           reinterpret_cast<int2*>(g->bu_heads));
       }
-      d.heads = reinterpret_cast<const int4*>(g->bu_heads);
+      d.heads = reinterpret_cast<const int2*>(g->bu_heads);
     }
     d.bu_grid = level_grid(ctx, g, lbuild);
     GRX_HIP(ctx->bu_part.reserve((size_t)d.bu_grid * 4 * sizeof(long long)));

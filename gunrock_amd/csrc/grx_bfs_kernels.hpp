@@ -171,9 +171,9 @@ struct dobfs_args {
   int32_t ch_lo;               // 0 on a single GPU
   const unsigned* fin_global;  // whole-graph frontier bitmap to probe; null: fbits[level & 1]
   uint32_t xcc_mask;           // hardware XCC ids of this device (grx_mid.hpp)
-  // single GPU, per graph: the first FOUR in-neighbours of every vertex (-1: none), so that the first two probe groups of
-  // a bottom-up level read ONE coalesced 16-byte stream instead of column indices per lane from 64 different rows
-  const int4* heads;           // null: probe through t_ci
+  // single GPU, per graph: {first, second in-neighbour} of every vertex (-1: none), so that the first probe group of a
+  // bottom-up level reads ONE coalesced 8-byte stream instead of two column indices per lane from 64 different rows
+  const int2* heads;           // null: probe through t_ci
 };
 
 // Bottom-up level.  A wave owns 64 consecutive vertices (one "chunk") and works on
@@ -340,15 +340,15 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
         // a predicated load sits in its own basic block and the compiler then waits for each
         // one before issuing the next -- 2 * BATCH * N serialized round trips instead of 2
         bool from_heads = false;
-        if constexpr ((R0 == 0 || R0 == 2) && N == 2) {
+        if constexpr (R0 == 0 && N == 2) {
           if (d.heads) {  // uniform
             from_heads = true;
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) {
               const int v = vbase + (ch0 + j) * 64 + lane;
-              const int4 h = d.heads[v < a.V ? v : a.V - 1];  // lanes of a wave read 1024 consecutive bytes (the second
-              u[j][0] = R0 == 0 ? h.x : h.z;                  // group's load hits the lines the first one fetched)
-              u[j][1] = R0 == 0 ? h.y : h.w;
+              const int2 h = d.heads[v < a.V ? v : a.V - 1];  // lanes of a wave read 512 consecutive bytes
+              u[j][0] = h.x;
+              u[j][1] = h.y;
             }
           }
         }
