@@ -314,6 +314,19 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
         ++my_open;
       }
     }
+    // the first two in-neighbours of every vertex of the chunks, issued TOGETHER with the row offsets (both depend only
+    // on the vertex id): the first probe group then waits for one round trip, not for offsets -> column indices
+    int h0[BATCH], h1[BATCH];
+    const bool use_heads = d.heads != nullptr;  // uniform
+    if (use_heads) {
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int v = vbase + (ch0 + j) * 64 + lane;
+        const int2 h = d.heads[v < a.V ? v : a.V - 1];  // lanes of a wave read 512 consecutive bytes
+        h0[j] = h.x;
+        h1[j] = h.y;
+      }
+    }
     // phase A: up to SERIAL probes per lane, the BATCH chunks advance in lock step.
     // Probes are issued SPECULATIVELY in groups (2, 2, 4): a group's column indices are
     // loaded together, then its frontier words together -- two dependent round trips per
@@ -339,25 +352,10 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
         // UNCONDITIONAL loads from a clamped index (some lane has an in-edge, so entry 0 exists):
         // a predicated load sits in its own basic block and the compiler then waits for each
         // one before issuing the next -- 2 * BATCH * N serialized round trips instead of 2
-        bool from_heads = false;
-        if constexpr (R0 == 0 && N == 2) {
-          if (d.heads) {  // uniform
-            from_heads = true;
 #pragma unroll
-            for (int j = 0; j < BATCH; ++j) {
-              const int v = vbase + (ch0 + j) * 64 + lane;
-              const int2 h = d.heads[v < a.V ? v : a.V - 1];  // lanes of a wave read 512 consecutive bytes
-              u[j][0] = h.x;
-              u[j][1] = h.y;
-            }
-          }
-        }
-        if (!from_heads) {
+        for (int j = 0; j < BATCH; ++j)
 #pragma unroll
-          for (int j = 0; j < BATCH; ++j)
-#pragma unroll
-            for (int q = 0; q < N; ++q) u[j][q] = d.t_ci[act[j][q] ? b[j] + R0 + q : 0];
-        }
+          for (int q = 0; q < N; ++q) u[j][q] = d.t_ci[act[j][q] ? b[j] + R0 + q : 0];
         unsigned w[BATCH][N];
 #pragma unroll
         for (int j = 0; j < BATCH; ++j)
@@ -376,7 +374,42 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
       };
       using std::integral_constant;
       static_assert(SERIAL == 8, "probe groups cover 8 probes");
-      if (probe_group(integral_constant<int, 0>{}, integral_constant<int, 2>{}))
+      bool more;
+      if (use_heads) {
+        // first group (2 probes) from the dense array: same rule as probe_group<0, 2>, written out so that h0 / h1 stay in
+        // registers (captured by the generic lambda they ended up on the stack, with a wait right behind their load)
+        bool any = false;
+        unsigned w0[BATCH], w1[BATCH];
+        bool a0[BATCH], a1[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          a0[j] = open[j] && b[j] < e[j];
+          a1[j] = open[j] && b[j] + 1 < e[j];
+          any |= a0[j];
+        }
+        more = dev::ballot(any) != 0ull;
+        if (more) {
+#pragma unroll
+          for (int j = 0; j < BATCH; ++j) {
+            w0[j] = fin[(a0[j] ? h0[j] : 0) >> 5];
+            w1[j] = fin[(a1[j] ? h1[j] : 0) >> 5];
+          }
+#pragma unroll
+          for (int j = 0; j < BATCH; ++j) {
+            if (a0[j]) {
+              ++my_probes;
+              if (w0[j] & (1u << (h0[j] & 31))) found[j] = true;
+            }
+            if (a1[j]) {
+              ++my_probes;
+              if (w1[j] & (1u << (h1[j] & 31))) found[j] = true;
+            }
+          }
+        }
+      } else {
+        more = probe_group(integral_constant<int, 0>{}, integral_constant<int, 2>{});
+      }
+      if (more)
         if (probe_group(integral_constant<int, 2>{}, integral_constant<int, 2>{}))
           (void)probe_group(integral_constant<int, 4>{}, integral_constant<int, 4>{});
     }
