@@ -70,8 +70,11 @@ def run(label, direction, env=None):
 
 
 print("workload", name, "V", V, "E", G.get_number_of_edges(), "src", src, flush=True)
-run("DO default (heads)", gr.optimized, {})
-run("DO without heads", gr.optimized, {"GRX_BU_HEADS": 0})
+run("fwd scatter1 sweep1 (round 2)", gr.forward, {"GRX_BIN_SCATTER": 1, "GRX_BIN_SWEEP": 1})
+run("fwd scatter2 sweep1", gr.forward, {"GRX_BIN_SWEEP": 1, "GRX_BIN_E16": 0})
+run("fwd scatter2 sweep3 32-bit entries", gr.forward, {"GRX_BIN_E16": 0})
+run("fwd default (scatter2 sweep3 16-bit)", gr.forward, {})
+run("fwd default again", gr.forward, {})
+run("DO default", gr.optimized, {})
+run("DO without the two-neighbour array", gr.optimized, {"GRX_BU_HEADS": 0})
 run("DO default again", gr.optimized, {})
-run("DO without heads again", gr.optimized, {"GRX_BU_HEADS": 0})
-run("fwd default", gr.forward, {})
