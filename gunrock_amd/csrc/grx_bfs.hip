@@ -34,6 +34,7 @@
 #include <cstddef>
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace grx {
@@ -66,11 +67,13 @@ __global__ void bfs_closed0_kernel(const int32_t* t_ro, int32_t V, unsigned* out
   }
 }
 
-// heads[v] = {first, second in-neighbour of v} (-1: none).  Once per graph (bottom-up probes, dobfs_args::heads).
+// heads[v] = {first, second in-neighbour of v} (-1: none); bit 30 of the second (BU_MORE) says that v has more than two
+// in-edges, so a bottom-up round needs no row offsets at all (V < 2^29 on this path: direction optimisation asks for
+// E >= 4 V and E < 2^31).  Once per graph (bottom-up probes, dobfs_args::heads).
 __global__ void bfs_heads_kernel(const int32_t* t_ro, const int32_t* t_ci, int32_t V, int2* heads) {
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
     const int b = t_ro[v], e = t_ro[v + 1];
-    heads[v] = make_int2(b < e ? t_ci[b] : -1, b + 1 < e ? t_ci[b + 1] : -1);
+    heads[v] = make_int2(b < e ? t_ci[b] : -1, b + 1 < e ? (t_ci[b + 1] | (b + 2 < e ? BU_MORE : 0)) : -1);
   }
 }
 
@@ -346,11 +349,11 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
 // One level, ONE launch: top-down (advance + fused compaction) or bottom-up, as the
 // head kernel decided.  Direction-optimising runs: every workgroup also clears its share of
 // the frontier bitmap the NEXT level will write into.
-template <int BATCH>
+template <int BATCH, bool BU2 = false, bool DBG = false>
 __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs_args d, bfs_policy pol) {
   // a launch runs ONE of the two bodies: their LDS is overlaid (24 KB instead of 38: 6 workgroups per CU)
   using td_smem = advance_smem<bfs_policy>;
-  using bu_smem = bottomup_smem<BATCH, true>;
+  using bu_smem = typename std::conditional<BU2, bottomup2_smem<BATCH>, bottomup_smem<BATCH, true>>::type;
   constexpr size_t LDS_BYTES = sizeof(td_smem) > sizeof(bu_smem) ? sizeof(td_smem) : sizeof(bu_smem);
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
   td_smem& sm = *reinterpret_cast<td_smem*>(lds_raw);
@@ -384,7 +387,8 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
     pol.set_level(level);
     advance_block<bfs_policy, false>(a, c, pol, sm, level & 1, blockIdx.x, gridDim.x, h.total_chunks, a.chunk_tile);
   } else {
-    bfs_bottomup_block<BATCH, true>(a, d, c, bsm);
+    if constexpr (BU2) bfs_bottomup2_block<BATCH, DBG>(a, d, c, bsm);
+    else bfs_bottomup_block<BATCH, true>(a, d, c, bsm);
   }
 }
 
@@ -593,10 +597,17 @@ using level_kernel_fn = void (*)(pipe_args, dobfs_args, bfs_policy);
 struct level_build {
   level_kernel_fn fn;
   int per_cu;  // resident workgroups per CU (0: not queried yet)
+  int limit;   // ... and how many of them are used at most
 };
 static level_build* level_kernel_build() {
-  static level_build builds[2] = {{bfs_level_kernel<2>, 0}, {bfs_level_kernel<4>, 0}};
+  static level_build builds[2] = {{bfs_level_kernel<2>, 0, 8}, {bfs_level_kernel<4>, 0, 8}};
   return &builds[env_int("GRX_BU_BATCH", 2) == 4 ? 1 : 0];
+}
+// second bottom-up body (grx_bfs_kernels.hpp): one round trip per round, unsettled lanes deferred.  GRX_BU2=0: first version
+static level_build* level_kernel_build2(bool debug) {
+  // 7 workgroups fit a CU; 4-5 measured fastest on all three scale-free stand-ins (profiles/r3_ab_bottomup_second_body.txt)
+  static level_build builds[2] = {{bfs_level_kernel<2, true>, 0, 5}, {bfs_level_kernel<2, true, true>, 0, 5}};
+  return &builds[debug ? 1 : 0];
 }
 using bin_kernel_fn = void (*)(pipe_args, bin_args, bfs_policy);
 static int resident_per_cu(bin_kernel_fn fn) {
@@ -614,8 +625,8 @@ static int level_grid(grx_context_t ctx, grx_graph_t g, level_build* lb) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lb->fn, ADV_BLOCK, 0) != hipSuccess || n < 1) n = 4;
     lb->per_cu = n > 8 ? 8 : n;
   }
-  const int cap = env_int("GRX_LEVEL_WG_PER_CU", 0);  // tuning knob: fewer resident workgroups
-  const int use = (cap > 0 && cap < lb->per_cu) ? cap : lb->per_cu;
+  const int cap = env_int("GRX_LEVEL_WG_PER_CU", 0);  // tuning knob: another number of resident workgroups
+  const int use = (cap > 0 && cap <= lb->per_cu) ? cap : (lb->per_cu < lb->limit ? lb->per_cu : lb->limit);
   const int full = advance_grid_for(ctx, g);
   const int resident = ctx->num_cus * use;
   return full < resident ? full : resident;
@@ -722,7 +733,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       hipLaunchKernelGGL(bfs_closed0_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, d.t_ro, g->V, g->closed0,
                          (int)bm_words);
     }
-    if (env_int("GRX_BU_HEADS", 1) != 0) {
+    if (env_int("GRX_BU_HEADS", 1) != 0 && g->V < (1 << 29)) {
       // the first two in-neighbours of every vertex as one dense array, built once per graph (8 V bytes)
       if (!g->bu_heads || g->bu_heads_of != (const void*)d.t_ci) {
         if (g->bu_heads) GRX_HIP(hipFree(g->bu_heads));
@@ -733,6 +744,19 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
                            reinterpret_cast<int2*>(g->bu_heads));
       }
       d.heads = reinterpret_cast<const int2*>(g->bu_heads);
+    }
+    if (d.heads && env_int("GRX_BU2", 1) != 0) {
+      // second bottom-up body: needs the dense array and all chunks of a wave in 128 slots
+      d.debug_level = env_int("GRX_BU_DEBUG", 0);  // per-wave phase clocks of that level (tools/bu_debug.py)
+      level_build* lb2 = level_kernel_build2(d.debug_level != 0);
+      if (d.debug_level != 0) {
+        GRX_HIP(ctx->far[1].reserve((size_t)8 * 16384 * sizeof(long long)));
+        d.debug = ctx->far[1].as<long long>();
+        GRX_HIP(hipMemsetAsync(d.debug, 0, (size_t)8 * 16384 * sizeof(long long), s));
+      }
+      const int grid2 = level_grid(ctx, g, lb2);
+      const long long chunks = (long long)bm_words / 2, per_round = (long long)grid2 * (ADV_BLOCK / 64) * 2;
+      if ((chunks + per_round - 1) / per_round * 2 <= 128) lbuild = lb2;
     }
     d.bu_grid = level_grid(ctx, g, lbuild);
     GRX_HIP(ctx->bu_part.reserve((size_t)d.bu_grid * 4 * sizeof(long long)));

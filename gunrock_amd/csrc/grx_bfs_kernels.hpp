@@ -16,6 +16,7 @@ __device__ __forceinline__ T* pick3(T* const (&arr)[3], int i) {
   return i == 0 ? arr[0] : (i == 1 ? arr[1] : arr[2]);
 }
 
+constexpr int BU_MORE = 1 << 30;  // dobfs_args::heads: flag in the second entry, "more than two in-edges"
 constexpr int DO_ALPHA = 14;
 constexpr int DO_BETA = 24;
 
@@ -174,6 +175,9 @@ struct dobfs_args {
   // single GPU, per graph: {first, second in-neighbour} of every vertex (-1: none), so that the first probe group of a
   // bottom-up level reads ONE coalesced 8-byte stream instead of two column indices per lane from 64 different rows
   const int2* heads;           // null: probe through t_ci
+  // tuning aid (GRX_BU_DEBUG=<level>): per-wave phase clocks of the second bottom-up body at that level, 8 words per wave
+  long long* debug;
+  int32_t debug_level;
 };
 
 // Bottom-up level.  A wave owns 64 consecutive vertices (one "chunk") and works on
@@ -324,7 +328,7 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
         const int v = vbase + (ch0 + j) * 64 + lane;
         const int2 h = d.heads[v < a.V ? v : a.V - 1];  // lanes of a wave read 512 consecutive bytes
         h0[j] = h.x;
-        h1[j] = h.y;
+        h1[j] = h.y & ~BU_MORE;  // (-1 stays negative; it is never used as an index)
       }
     }
     // phase A: up to SERIAL probes per lane, the BATCH chunks advance in lock step.
@@ -535,6 +539,460 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
     d.bu_part[4 * blockIdx.x + 1] = td;
     d.bu_part[4 * blockIdx.x + 2] = to;
     d.bu_part[4 * blockIdx.x + 3] = tp;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Bottom-up level, second version (round 3, single GPU): ONE dependent round trip per round of chunks.
+//
+// What the counters said about the first version (profiles/r3_bench_pmc.json, class bottom_up): 72 % of the wave cycles
+// waiting, 80 G L2 requests/s, 1.5 TB/s -- neither bandwidth nor request rate, a chain of dependent round trips.  A wave
+// there walks  visited word -> row offsets (+ two first in-neighbours) -> frontier words  per round and then, for the FEW lanes
+// that the first two probes did not settle (5-10 % of the open vertices), two more probe groups (column indices -> frontier
+// words, twice), the whole-wave scan of long lists and the out-degrees of the discoveries: about nine round trips per round,
+// seven of them for a handful of lanes, and 128 / (waves * BATCH) rounds per wave.  Here:
+//  * the visited|frontier words of ALL rounds of a wave are read once, one slot per lane (two per lane: 128 slots), and a
+//    round takes its words from there with v_readlane (the first version did this only to find dead rounds);
+//  * the rows (offsets + first two in-neighbours) of round r + 1 are requested before round r is worked on;
+//  * a round probes only the two first in-neighbours.  Lanes that are still open and have more in-edges are DEFERRED: (slot,
+//    lane, next in-edge) goes to a wave-private LDS list which is worked off 64 entries at a time with every lane busy
+//    (groups of four probes per lane while many lanes are alive, then the whole wave per long list) -- at the end of the wave's
+//    rounds, or when the list is full;
+//  * out-degrees of discoveries are read when a tile of 256 is emitted (four per lane, one round trip per tile), not per round;
+//  * bits of vertices found by the deferred pass are collected per slot in LDS and merged into the wave's own frontier /
+//    visited words at the very end (the words belong to this wave alone: plain read-modify-write).
+// Needs dobfs_args::heads and iters * BATCH <= 128 (else the host launches the first version).
+template <int BATCH>
+struct bottomup2_smem {
+  static constexpr int NW = ADV_BLOCK / 64;
+  static constexpr int STAGE = TILE + 64 * BATCH;  // discoveries staged per wave
+  static constexpr int DEFER = 256;                // deferred entries per wave
+  static constexpr int SLOTS = 128;                // chunks of a wave
+  int cnt[NW];
+  long long deg[NW];
+  int open[NW];
+  long long probe[NW];
+  int sv[NW][STAGE];
+  union {
+    struct {
+      unsigned dv[NW][DEFER];  // (slot << 6) | lane
+    } q;
+    int bv[NW * TILE];         // leftovers of the four waves, merged at the end (the lists are dead by then)
+    unsigned long long pw[NW * SLOTS][2];  // prologue: {visited | frontier, visited} word of every slot of the workgroup
+  } u;
+  unsigned late[NW][2 * SLOTS];  // bits found by the deferred pass, per slot
+  int bcnt;
+  int tix_next;
+  int tiles_out;
+};
+
+// one tile (index tix) of n <= TILE staged vertices src[lo ..], written by ONE wave; out-degrees read here.  Returns their sum.
+__device__ __forceinline__ int wave_emit_tile_deg(const pipe_args& a, int q, int tix, const int* src, int lo, int n) {
+  const int lane = dev::lane_id();
+  int v[TILE / 64], r0[TILE / 64], r1[TILE / 64];
+#pragma unroll
+  for (int i = 0; i < TILE / 64; ++i) {
+    const int k = i * 64 + lane;
+    v[i] = k < n ? src[lo + k] : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < TILE / 64; ++i) {  // unconditional loads from a clamped index: one round trip for all
+    const int vv = v[i] >= 0 ? v[i] : 0;
+    r0[i] = a.ro[vv];
+    r1[i] = a.ro[vv + 1];
+  }
+  int dsum = 0;
+#pragma unroll
+  for (int i = 0; i < TILE / 64; ++i) {
+    a.frontier[q][(size_t)tix * TILE + i * 64 + lane] = v[i];
+    dsum += v[i] >= 0 ? r1[i] - r0[i] : 0;
+  }
+  dsum = dev::wave_sum(dsum);
+  if (lane == 0) {
+    a.tile_sums[tix] = dsum;
+    a.tile_chunks[tix] = (dsum + CHUNK - 1) / CHUNK;
+    a.tile_count[tix] = n;
+  }
+  return dsum;
+}
+
+template <int BATCH, bool DBG = false>
+__device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const dobfs_args& d, ctrl_t* c,
+                                                    bottomup2_smem<BATCH>& sm) {
+  using S = bottomup2_smem<BATCH>;
+  // tuning clocks (DBG builds only): 100 MHz wall clock; `settle` waits for every outstanding load first so that the
+  // round trip is charged to the phase that ends there
+  auto clk = [&](bool settle) -> long long {
+    if constexpr (DBG) {
+      if (settle) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("" ::: "memory");
+      const long long t = (long long)wall_clock64();
+      asm volatile("" ::: "memory");
+      return t;
+    }
+    return 0ll;
+  };
+  long long t_pro = 0, t_probe = 0, t_out = 0, t_drain = 0, t_emit = 0, t_tail = 0;
+  int n_rounds = 0, n_deferred = 0, n_drains = 0;
+  const long long t_start = clk(false);
+  static_assert(64 % BATCH == 0, "the slots of a round sit in one 64-slot word");
+  static_assert(2 * 64 * BATCH <= S::DEFER, "a round's deferred lanes fit behind a half-full list");
+  const int level = c->level;
+  const int p = level & 1;
+  const unsigned* __restrict__ fin = pick3(d.fbits, level % 3);
+  unsigned* fout = pick3(d.fbits, (level + 1) % 3);
+  const int n_chunks = d.n_words / 2;
+  const int iters = (n_chunks + (int)gridDim.x * S::NW * BATCH - 1) / ((int)gridDim.x * S::NW * BATCH);
+  const int tiles_per_wg = BATCH * iters + 1;
+  const int tile_base = (int)blockIdx.x * tiles_per_wg;
+  const int lane = dev::lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wave = (int)blockIdx.x * S::NW + wid;
+  const int n_waves = (int)gridDim.x * S::NW;
+  int* sv = sm.sv[wid];
+  unsigned* dv = sm.u.q.dv[wid];
+  unsigned* late = sm.late[wid];
+  if (threadIdx.x == 0) sm.tix_next = 0;
+#pragma unroll
+  for (int i = 0; i < 2 * S::SLOTS / 64; ++i) late[i * 64 + lane] = 0u;
+  __syncthreads();
+
+  // every slot of this wave: slot s = chunk s % BATCH of round s / BATCH; lane l looks at slots l and l + 64.
+  // The words are fetched by the WORKGROUP: the four waves own 4 * BATCH consecutive chunks per round, so thread t takes
+  // chunk t % (4 * BATCH) of round t / (4 * BATCH) and 8 lanes share a 64-byte line (a wave fetching its own slots touched
+  // one line per lane: 256 line requests per wave and level, a fifth of all L1 misses of a search); exchanged through LDS.
+  {
+    constexpr int PER_ROUND = S::NW * BATCH;
+#pragma unroll
+    for (int k = 0; k < S::NW * S::SLOTS / ADV_BLOCK; ++k) {
+      const int ws = (int)threadIdx.x + ADV_BLOCK * k;
+      const int r = ws / PER_ROUND, cc = ws % PER_ROUND;
+      const int ch = ((int)blockIdx.x * S::NW + r * n_waves) * BATCH + cc;
+      unsigned long long v = ~0ull, vm = ~0ull;
+      if (r < iters && ch < n_chunks) {
+        vm = *reinterpret_cast<const unsigned long long*>(d.visited + 2 * ch);
+        v = vm | *reinterpret_cast<const unsigned long long*>(fin + 2 * ch);
+      }
+      sm.u.pw[ws][0] = v;
+      sm.u.pw[ws][1] = vm;
+    }
+  }
+  __syncthreads();
+  unsigned long long pv0 = ~0ull, pv1 = ~0ull, live0 = 0ull, live1 = 0ull, dirty0 = 0ull, dirty1 = 0ull;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int s = lane + 64 * k;
+    const int r = s / BATCH, j = s % BATCH;
+    const int ch = (wave + r * n_waves) * BATCH + j;
+    const int ws = r * (S::NW * BATCH) + wid * BATCH + j;
+    const unsigned long long v = sm.u.pw[ws][0], vm = sm.u.pw[ws][1];
+    bool live = false, dirty = false;
+    if (r < iters && ch < n_chunks) {
+      unsigned long long in_range = ~0ull;  // lanes of the last chunk beyond V are never open
+      const long long first = (long long)ch * 64;
+      if (first + 64 > (long long)a.V) in_range = first >= (long long)a.V ? 0ull : ((1ull << ((long long)a.V - first)) - 1ull);
+      // the frontier of THIS level may not be in `visited` yet (top-down levels fold a frontier in when they expand it):
+      // such words are written back even if the chunk discovers nothing
+      dirty = v != vm;
+      live = (~v & in_range) != 0ull || dirty;
+    }
+    if (k == 0) { pv0 = v; live0 = dev::ballot(live); dirty0 = dev::ballot(dirty); }
+    else { pv1 = v; live1 = dev::ballot(live); dirty1 = dev::ballot(dirty); }
+  }
+  __syncthreads();  // (the deferred lists overlay the exchange area)
+  // rounds with a live slot, as a mask (iters <= 128 / BATCH <= 64)
+  unsigned long long rounds = 0ull;
+  for (int r = 0; r < iters; ++r) {
+    const int s0 = r * BATCH;
+    if ((((s0 >> 6) ? live1 : live0) >> (s0 & 63)) & ((1ull << BATCH) - 1ull)) rounds |= 1ull << r;
+  }
+  if constexpr (DBG) t_pro = clk(true) - t_start;
+  auto slot_word = [&](int s) -> unsigned long long {  // s is wave-uniform
+    const unsigned long long w = (s >> 6) ? pv1 : pv0;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, s & 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), s & 63);
+    return (unsigned long long)lo | ((unsigned long long)hi << 32);
+  };
+  auto chunk_of = [&](int s) -> int { return (wave + (s / BATCH) * n_waves) * BATCH + s % BATCH; };
+
+  int my_cnt = 0, my_open = 0;
+  long long my_deg = 0, my_probes = 0;
+  int wcnt = 0;  // staged discoveries of this wave
+  int dcnt = 0;  // deferred entries of this wave
+  const int last_edge = d.n_edges > 0 ? d.n_edges - 1 : 0;
+
+  auto emit_from_end = [&]() {  // one full tile leaves the staging area, from the end
+    const long long te0 = clk(false);
+    int k = 0;
+    if (lane == 0) k = atomicAdd(&sm.tix_next, 1);
+    k = __shfl(k, 0, 64);
+    const int dsum = wave_emit_tile_deg(a, p ^ 1, tile_base + k, sv, wcnt - TILE, TILE);
+    if (lane == 0) my_deg += dsum;
+    wcnt -= TILE;
+    if constexpr (DBG) t_emit += clk(false) - te0;
+  };
+
+  // the deferred pass: every lane takes one entry
+  auto drain = [&]() {
+    const long long td0 = clk(false);
+    if constexpr (DBG) { n_deferred += dcnt; ++n_drains; }
+    for (int base = 0; base < dcnt; base += 64) {
+      const int i = base + lane;
+      const bool act = i < dcnt;
+      const unsigned ent = act ? dv[i] : 0u;
+      const int slot = (int)(ent >> 6);
+      const int v = chunk_of(slot) * 64 + (int)(ent & 63u);
+      const int rv = act ? v : 0;
+      const int rb = d.t_ro[rv], e = act ? d.t_ro[rv + 1] : 0;  // (one 8-byte load)
+      int pos = rb + 2;  // the two first in-neighbours were probed in the round
+      bool fnd = false;
+      int it = 0;
+      for (;;) {
+        // four column indices as ONE 16-byte load (one line request per lane instead of four); a list that ends within
+        // three entries of the END OF THE ARRAY is left to the whole-wave scan below, which tests every index
+        const bool go = act && !fnd && pos < e && pos + 3 <= last_edge;
+        const unsigned long long mm = dev::ballot(go);
+        if (mm == 0ull) break;
+        if (it >= 2 && __popcll(mm) <= 8) break;  // a few long lists: the whole wave per list, below
+        struct __attribute__((packed, aligned(4))) quad { int x[4]; };
+        const quad u = *reinterpret_cast<const quad*>(d.t_ci + (go ? pos : 0));
+        unsigned w[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ok[q] = go && pos + q < e;
+          w[q] = fin[(ok[q] ? u.x[q] : 0) >> 5];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          my_probes += ok[q] ? 1 : 0;
+          fnd |= ok[q] && ((w[q] >> (u.x[q] & 31)) & 1u) != 0u;
+        }
+        pos += go ? 4 : 0;
+        ++it;
+      }
+      unsigned long long pend = dev::ballot(act && !fnd && pos < e);
+      while (pend) {
+        const int src_lane = __builtin_ctzll(pend);
+        pend &= pend - 1;
+        const int bb = __shfl(pos, src_lane, 64), ee = __shfl(e, src_lane, 64);
+        bool hit = false;
+        for (int k = bb; k < ee; k += 64) {
+          const int kk = k + lane;
+          bool h = false;
+          if (kk < ee) {
+            const int u = d.t_ci[kk];
+            ++my_probes;
+            h = (fin[u >> 5] & (1u << (u & 31))) != 0u;
+          }
+          if (dev::ballot(h)) { hit = true; break; }
+        }
+        if (lane == src_lane) fnd = hit;
+      }
+      const unsigned long long nw = dev::ballot(fnd);
+      if (nw) {
+        if (fnd) {
+          d.dist[v] = level + 1;
+          my_cnt += 1;
+          atomicOr(&late[2 * slot + (int)((ent >> 5) & 1u)], 1u << (ent & 31u));
+          sv[wcnt + dev::mask_rank(nw)] = v;
+        }
+        wcnt += __popcll(nw);
+        if (wcnt >= TILE) emit_from_end();
+      }
+    }
+    dcnt = 0;
+    if constexpr (DBG) t_drain += clk(true) - td0;
+  };
+
+  auto next_round = [&](int r) -> int {  // first live round after r, -1: none
+    const unsigned long long m = r >= 63 ? 0ull : (rounds & (~0ull << (r + 1)));
+    return m ? (int)__builtin_ctzll(m) : -1;
+  };
+
+  int nh0[BATCH], nh1[BATCH];  // the two first in-neighbours of the round after the current one
+  int ch0[BATCH], ch1[BATCH];  // ... of the current round
+#pragma unroll
+  for (int j = 0; j < BATCH; ++j) nh0[j] = nh1[j] = ch0[j] = ch1[j] = -1;
+  int r = next_round(-1), rc = -1;
+  for (;;) {
+    if (r >= 0) {
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int s = r * BATCH + j;
+        const unsigned long long vis = slot_word(s);
+        const int v = chunk_of(s) * 64 + lane;
+        const bool op = v < a.V && !((vis >> lane) & 1ull);
+        const int2 h = d.heads[op ? v : 0];  // closed lanes read entry 0: one broadcast line
+        nh0[j] = h.x;
+        nh1[j] = h.y;
+      }
+    }
+    if (rc >= 0) {
+      if (dcnt + 64 * BATCH > S::DEFER) drain();
+      const long long tp0 = clk(false);
+      if constexpr (DBG) ++n_rounds;
+      unsigned long long vis[BATCH];
+      bool open[BATCH], found[BATCH], a0[BATCH], a1[BATCH], more[BATCH];
+      int u0[BATCH], u1[BATCH];
+      unsigned w0[BATCH], w1[BATCH];
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int s = rc * BATCH + j;
+        vis[j] = slot_word(s);
+        const int v = chunk_of(s) * 64 + lane;
+        open[j] = v < a.V && !((vis[j] >> lane) & 1ull);
+        my_open += open[j] ? 1 : 0;
+        a0[j] = open[j] && ch0[j] >= 0;
+        a1[j] = open[j] && ch1[j] >= 0;
+        more[j] = a1[j] && (ch1[j] & BU_MORE) != 0;
+        u0[j] = a0[j] ? ch0[j] : 0;
+        u1[j] = a1[j] ? (ch1[j] & ~BU_MORE) : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        w0[j] = fin[u0[j] >> 5];
+        w1[j] = fin[u1[j] >> 5];
+      }
+      // every ballot of the round is taken BEFORE the first store of the round: the compiler otherwise sinks the test of the
+      // later chunks behind the stores of the first one, and its wait for their frontier words then also waits for those
+      // stores (vmcnt retires in order)
+      unsigned long long nwm[BATCH], dfm[BATCH];
+      bool df[BATCH];
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        // (bitwise: a short-circuit here put each frontier word's wait into a branch of its own)
+        const unsigned hit0 = (w0[j] >> (u0[j] & 31)) & (a0[j] ? 1u : 0u);
+        const unsigned hit1 = (w1[j] >> (u1[j] & 31)) & (a1[j] ? 1u : 0u);
+        found[j] = (hit0 | hit1) != 0u;
+        my_probes += (a0[j] ? 1 : 0) + (a1[j] ? 1 : 0);
+        df[j] = more[j] && !found[j];  // still open, more in-edges: deferred
+        nwm[j] = dev::ballot(found[j]);
+        dfm[j] = dev::ballot(df[j]);
+      }
+      const long long tp1 = clk(true);
+      if constexpr (DBG) t_probe += tp1 - tp0;
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int s = rc * BATCH + j;
+        const int ch = chunk_of(s);  // (a slot beyond the last chunk has nothing open: only its word stores need the test)
+        if (dfm[j]) {
+          if (df[j]) {
+            const int at = dcnt + dev::mask_rank(dfm[j]);
+            dv[at] = ((unsigned)s << 6) | (unsigned)lane;
+          }
+          dcnt += __popcll(dfm[j]);
+        }
+        const unsigned long long nw = nwm[j];
+        if (lane == 0 && ch < n_chunks) {
+          fout[2 * ch] = (unsigned)nw;
+          fout[2 * ch + 1] = (unsigned)(nw >> 32);
+          if (nw != 0ull || ((((s >> 6) ? dirty1 : dirty0) >> (s & 63)) & 1ull)) {
+            const unsigned long long nv = vis[j] | nw;
+            d.visited[2 * ch] = (unsigned)nv;
+            d.visited[2 * ch + 1] = (unsigned)(nv >> 32);
+          }
+        }
+        if (nw) {
+          if (found[j]) {
+            const int v = ch * 64 + lane;
+            d.dist[v] = level + 1;
+            my_cnt += 1;
+            sv[wcnt + dev::mask_rank(nw)] = v;
+          }
+          wcnt += __popcll(nw);
+        }
+      }
+      if constexpr (DBG) t_out += clk(false) - tp1;
+      if (wcnt >= TILE) emit_from_end();
+    }
+    if (r < 0) break;
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) { ch0[j] = nh0[j]; ch1[j] = nh1[j]; }
+    rc = r;
+    r = next_round(r);
+  }
+  if (dcnt > 0) drain();
+  const long long t_loop_end = clk(true);
+  // bits found by the deferred pass -> this wave's own words (its earlier plain stores to them have to be performed first)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int s = lane + 64 * k;
+    const unsigned lo = late[2 * s], hi = late[2 * s + 1];
+    if (lo | hi) {
+      const int ch = chunk_of(s);
+      const unsigned f0 = __hip_atomic_load(&fout[2 * ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned f1 = __hip_atomic_load(&fout[2 * ch + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned v0 = __hip_atomic_load(&d.visited[2 * ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned v1 = __hip_atomic_load(&d.visited[2 * ch + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      fout[2 * ch] = f0 | lo;
+      fout[2 * ch + 1] = f1 | hi;
+      d.visited[2 * ch] = v0 | lo;
+      d.visited[2 * ch + 1] = v1 | hi;
+    }
+  }
+  // leftovers (< TILE per wave) of the four waves -> as few tiles as possible
+  if (threadIdx.x == 0) sm.bcnt = 0;
+  __syncthreads();  // (every wave is done with its deferred list: u.bv overlays them)
+  int at = 0;
+  if (lane == 0 && wcnt) at = atomicAdd(&sm.bcnt, wcnt);
+  at = __shfl(at, 0, 64);
+  for (int i = lane; i < wcnt; i += 64) sm.u.bv[at + i] = sv[i];
+  __syncthreads();
+  const int total = sm.bcnt;
+  const int used = sm.tix_next;  // full tiles emitted during the sweep
+  const int extra = (total + TILE - 1) / TILE;
+  if (wid < extra) {
+    const int dsum = wave_emit_tile_deg(a, p ^ 1, tile_base + used + wid, sm.u.bv, wid * TILE, min(TILE, total - wid * TILE));
+    if (lane == 0) my_deg += dsum;
+  }
+  // the rest of the static range: empty tiles
+  for (int t = used + extra + (int)threadIdx.x; t < tiles_per_wg; t += ADV_BLOCK) {
+    a.tile_sums[tile_base + t] = 0;
+    a.tile_chunks[tile_base + t] = 0;
+    a.tile_count[tile_base + t] = 0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    c->n_tiles[p ^ 1] = (int)gridDim.x * tiles_per_wg;
+    c->bu_R = (int)gridDim.x;
+    c->bu_T = tiles_per_wg;
+  }
+  if (threadIdx.x == 0) sm.tiles_out = used + extra;  // read after the barrier of the totals below
+  // per-workgroup totals
+  my_cnt = dev::wave_sum(my_cnt);
+  my_open = dev::wave_sum(my_open);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    my_deg += __shfl_xor(my_deg, o, 64);
+    my_probes += __shfl_xor(my_probes, o, 64);
+  }
+  if (lane == 0) { sm.cnt[wid] = my_cnt; sm.deg[wid] = my_deg; sm.open[wid] = my_open; sm.probe[wid] = my_probes; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tc = 0, to = 0;
+    long long td = 0, tp = 0;
+#pragma unroll
+    for (int i = 0; i < S::NW; ++i) { tc += sm.cnt[i]; td += sm.deg[i]; to += sm.open[i]; tp += sm.probe[i]; }
+    d.bu_part[4 * blockIdx.x] = (long long)tc | ((long long)sm.tiles_out << 40);
+    d.bu_part[4 * blockIdx.x + 1] = td;
+    d.bu_part[4 * blockIdx.x + 2] = to;
+    d.bu_part[4 * blockIdx.x + 3] = tp;
+  }
+  if constexpr (DBG) {
+    const long long t_end = clk(true);
+    t_tail = t_end - t_loop_end;
+    if (lane == 0 && d.debug && level == d.debug_level && wave < 16384) {
+      long long* o = d.debug + 8 * (size_t)wave;
+      o[0] = (long long)blockIdx.x;
+      o[1] = t_start;
+      o[2] = t_end;
+      o[3] = t_pro | (t_tail << 32);
+      o[4] = t_probe | (t_out << 32);
+      o[5] = t_drain | (t_emit << 32);
+      o[6] = (long long)n_rounds | ((long long)n_deferred << 16) | ((long long)n_drains << 40);
+      o[7] = -3;
+    }
   }
 }
 

@@ -11,7 +11,7 @@ OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o p -- "$@" > "$OUT/kt.log" 2>&1
 i=0
-if [ "${PROF_SHORT:-0}" = 1 ]; then GROUPS_FILTER='^FETCH_SIZE|^WRITE_SIZE|^SQ_WAVES|^SQ_INSTS_LDS|^TCC_HIT'; else GROUPS_FILTER='.'; fi
+if [ -n "${PROF_GROUPS_FILTER:-}" ]; then GROUPS_FILTER="$PROF_GROUPS_FILTER"; elif [ "${PROF_SHORT:-0}" = 1 ]; then GROUPS_FILTER='^FETCH_SIZE|^WRITE_SIZE|^SQ_WAVES|^SQ_INSTS_LDS|^TCC_HIT'; else GROUPS_FILTER='.'; fi
 while read -r group; do
   echo "$group" | grep -Eq "$GROUPS_FILTER" || continue
   [ -z "$group" ] && continue
