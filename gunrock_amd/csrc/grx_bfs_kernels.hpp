@@ -543,30 +543,36 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Bottom-up level, second version (round 3, single GPU): ONE dependent round trip per round of chunks.
+// Bottom-up level, second version (round 3, single GPU): dense groups of OPEN vertices, one round trip per group.
 //
 // What the counters said about the first version (profiles/r3_bench_pmc.json, class bottom_up): 72 % of the wave cycles
-// waiting, 80 G L2 requests/s, 1.5 TB/s -- neither bandwidth nor request rate, a chain of dependent round trips.  A wave
-// there walks  visited word -> row offsets (+ two first in-neighbours) -> frontier words  per round and then, for the FEW lanes
+// waiting, 80 G L2 requests/s, 1.5 TB/s -- neither bandwidth nor request rate.  A wave there walks, per round of BATCH
+// 64-vertex chunks,  visited word -> row offsets (+ two first in-neighbours) -> frontier words  and then, for the FEW lanes
 // that the first two probes did not settle (5-10 % of the open vertices), two more probe groups (column indices -> frontier
-// words, twice), the whole-wave scan of long lists and the out-degrees of the discoveries: about nine round trips per round,
-// seven of them for a handful of lanes, and 128 / (waves * BATCH) rounds per wave.  Here:
-//  * the visited|frontier words of ALL rounds of a wave are read once, one slot per lane (two per lane: 128 slots), and a
-//    round takes its words from there with v_readlane (the first version did this only to find dead rounds);
-//  * the rows (offsets + first two in-neighbours) of round r + 1 are requested before round r is worked on;
-//  * a round probes only the two first in-neighbours.  Lanes that are still open and have more in-edges are DEFERRED: (slot,
-//    lane, next in-edge) goes to a wave-private LDS list which is worked off 64 entries at a time with every lane busy
-//    (groups of four probes per lane while many lanes are alive, then the whole wave per long list) -- at the end of the wave's
-//    rounds, or when the list is full;
-//  * out-degrees of discoveries are read when a tile of 256 is emitted (four per lane, one round trip per tile), not per round;
-//  * bits of vertices found by the deferred pass are collected per slot in LDS and merged into the wave's own frontier /
-//    visited words at the very end (the words belong to this wave alone: plain read-modify-write).
+// words, twice), the whole-wave scan of long lists and the out-degrees of the discoveries: about nine dependent round trips
+// and ~300 instructions per round, whatever the share of open vertices in the chunks -- 52 % on the first bottom-up level of
+// the LJ stand-in, 10 % on the second, 0.2 % on the third.  Here:
+//  * the visited|frontier words of ALL chunks ("slots") of a wave are read once (by the workgroup: 8 lanes share a line),
+//    and kept one slot per lane (two per lane: 128 slots);
+//  * the open vertices of the slots are COMPACTED into a wave-private LDS list ((slot, lane): 16 bits each) -- ballots and
+//    LDS stores only -- and worked off in dense groups of 2 x 64: the third level of the LJ stand-in is one group per wave
+//    instead of two rounds of mostly closed lanes, the second one or two instead of eight;
+//  * a group needs no row offsets: the dense two-neighbour array says whether a vertex has a first / second / further
+//    in-neighbour (BU_MORE); the entries of group g + 1 are requested before group g is worked on;
+//  * a group probes only the two first in-neighbours.  Lanes that are still open and have more in-edges are DEFERRED to a
+//    second wave-private list which is worked off 64 entries at a time with every lane busy (four column indices per lane as
+//    one 16-byte load while many lanes are alive, then the whole wave per long list) -- at the end, or when the list is full;
+//  * out-degrees of discoveries are read when a tile of 256 is emitted (four per lane, one round trip per tile);
+//  * discovered bits are collected per slot in LDS and every changed frontier / visited word is written once, at the end,
+//    one slot per lane (the words belong to this wave alone).
 // Needs dobfs_args::heads and iters * BATCH <= 128 (else the host launches the first version).
 template <int BATCH>
 struct bottomup2_smem {
   static constexpr int NW = ADV_BLOCK / 64;
-  static constexpr int STAGE = TILE + 64 * BATCH;  // discoveries staged per wave
-  static constexpr int DEFER = 256;                // deferred entries per wave
+  static constexpr int GROUP = 64 * BATCH;         // open vertices worked on together
+  static constexpr int STAGE = TILE + GROUP;       // discoveries staged per wave
+  static constexpr int DEFER = 2 * GROUP;          // deferred entries per wave
+  static constexpr int OPEN = 2 * GROUP + 64;      // compacted open vertices per wave
   static constexpr int SLOTS = 128;                // chunks of a wave
   int cnt[NW];
   long long deg[NW];
@@ -575,12 +581,13 @@ struct bottomup2_smem {
   int sv[NW][STAGE];
   union {
     struct {
-      unsigned dv[NW][DEFER];  // (slot << 6) | lane
+      unsigned short dv[NW][DEFER];  // (slot << 6) | lane
+      unsigned short ov[NW][OPEN];   // (slot << 6) | lane
     } q;
     int bv[NW * TILE];         // leftovers of the four waves, merged at the end (the lists are dead by then)
     unsigned long long pw[NW * SLOTS][2];  // prologue: {visited | frontier, visited} word of every slot of the workgroup
   } u;
-  unsigned late[NW][2 * SLOTS];  // bits found by the deferred pass, per slot
+  unsigned late[NW][2 * SLOTS];  // bits discovered in this launch, per slot
   int bcnt;
   int tix_next;
   int tiles_out;
@@ -597,9 +604,9 @@ __device__ __forceinline__ int wave_emit_tile_deg(const pipe_args& a, int q, int
   }
 #pragma unroll
   for (int i = 0; i < TILE / 64; ++i) {  // unconditional loads from a clamped index: one round trip for all
-    const int vv = v[i] >= 0 ? v[i] : 0;
+    const unsigned vv = v[i] >= 0 ? (unsigned)v[i] : 0u;
     r0[i] = a.ro[vv];
-    r1[i] = a.ro[vv + 1];
+    r1[i] = a.ro[vv + 1u];
   }
   int dsum = 0;
 #pragma unroll
@@ -620,6 +627,7 @@ template <int BATCH, bool DBG = false>
 __device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const dobfs_args& d, ctrl_t* c,
                                                     bottomup2_smem<BATCH>& sm) {
   using S = bottomup2_smem<BATCH>;
+  static_assert(BATCH == 2, "groups of 2 x 64 open vertices");
   // tuning clocks (DBG builds only): 100 MHz wall clock; `settle` waits for every outstanding load first so that the
   // round trip is charged to the phase that ends there
   auto clk = [&](bool settle) -> long long {
@@ -632,11 +640,9 @@ __device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const do
     }
     return 0ll;
   };
-  long long t_pro = 0, t_probe = 0, t_out = 0, t_drain = 0, t_emit = 0, t_tail = 0;
+  long long t_pro = 0, t_probe = 0, t_out = 0, t_drain = 0, t_emit = 0, t_tail = 0, t_compact = 0;
   int n_rounds = 0, n_deferred = 0, n_drains = 0;
   const long long t_start = clk(false);
-  static_assert(64 % BATCH == 0, "the slots of a round sit in one 64-slot word");
-  static_assert(2 * 64 * BATCH <= S::DEFER, "a round's deferred lanes fit behind a half-full list");
   const int level = c->level;
   const int p = level & 1;
   const unsigned* __restrict__ fin = pick3(d.fbits, level % 3);
@@ -650,17 +656,16 @@ __device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const do
   const int wave = (int)blockIdx.x * S::NW + wid;
   const int n_waves = (int)gridDim.x * S::NW;
   int* sv = sm.sv[wid];
-  unsigned* dv = sm.u.q.dv[wid];
+  unsigned short* dv = sm.u.q.dv[wid];
+  unsigned short* ov = sm.u.q.ov[wid];
   unsigned* late = sm.late[wid];
   if (threadIdx.x == 0) sm.tix_next = 0;
 #pragma unroll
   for (int i = 0; i < 2 * S::SLOTS / 64; ++i) late[i * 64 + lane] = 0u;
-  __syncthreads();
 
   // every slot of this wave: slot s = chunk s % BATCH of round s / BATCH; lane l looks at slots l and l + 64.
   // The words are fetched by the WORKGROUP: the four waves own 4 * BATCH consecutive chunks per round, so thread t takes
-  // chunk t % (4 * BATCH) of round t / (4 * BATCH) and 8 lanes share a 64-byte line (a wave fetching its own slots touched
-  // one line per lane: 256 line requests per wave and level, a fifth of all L1 misses of a search); exchanged through LDS.
+  // chunk t % (4 * BATCH) of round t / (4 * BATCH) and 8 lanes share a 64-byte line; exchanged through LDS.
   {
     constexpr int PER_ROUND = S::NW * BATCH;
 #pragma unroll
@@ -678,48 +683,37 @@ __device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const do
     }
   }
   __syncthreads();
-  unsigned long long pv0 = ~0ull, pv1 = ~0ull, live0 = 0ull, live1 = 0ull, dirty0 = 0ull, dirty1 = 0ull;
+  auto chunk_of = [&](int s) -> int { return (wave + (s / BATCH) * n_waves) * BATCH + s % BATCH; };
+  // lane l keeps the words of slots l (pv0) and l + 64 (pv1), with the vertices beyond V counted as closed; a slot is
+  // LIVE when it has an open vertex, DIRTY when its frontier bits are not in `visited` yet (top-down levels fold a frontier
+  // in when they expand it: such words are written back even if the chunk discovers nothing)
+  unsigned long long pv0 = ~0ull, pv1 = ~0ull, live0 = 0ull, live1 = 0ull;
+  bool dirty0 = false, dirty1 = false;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int s = lane + 64 * k;
-    const int r = s / BATCH, j = s % BATCH;
-    const int ch = (wave + r * n_waves) * BATCH + j;
-    const int ws = r * (S::NW * BATCH) + wid * BATCH + j;
-    const unsigned long long v = sm.u.pw[ws][0], vm = sm.u.pw[ws][1];
-    bool live = false, dirty = false;
-    if (r < iters && ch < n_chunks) {
-      unsigned long long in_range = ~0ull;  // lanes of the last chunk beyond V are never open
-      const long long first = (long long)ch * 64;
-      if (first + 64 > (long long)a.V) in_range = first >= (long long)a.V ? 0ull : ((1ull << ((long long)a.V - first)) - 1ull);
-      // the frontier of THIS level may not be in `visited` yet (top-down levels fold a frontier in when they expand it):
-      // such words are written back even if the chunk discovers nothing
-      dirty = v != vm;
-      live = (~v & in_range) != 0ull || dirty;
-    }
-    if (k == 0) { pv0 = v; live0 = dev::ballot(live); dirty0 = dev::ballot(dirty); }
-    else { pv1 = v; live1 = dev::ballot(live); dirty1 = dev::ballot(dirty); }
+    const int ch = chunk_of(s);
+    const int ws = (s / BATCH) * (S::NW * BATCH) + wid * BATCH + s % BATCH;
+    unsigned long long v = sm.u.pw[ws][0];
+    const unsigned long long vm = sm.u.pw[ws][1];
+    const bool valid = s / BATCH < iters && ch < n_chunks;
+    const bool dirty = valid && v != vm;
+    const long long first = (long long)ch * 64;
+    if (valid && first + 64 > (long long)a.V) v |= first >= (long long)a.V ? ~0ull : (~0ull << ((long long)a.V - first));
+    if (!valid) v = ~0ull;
+    if (k == 0) { pv0 = v; dirty0 = dirty; live0 = dev::ballot(~v != 0ull); }
+    else { pv1 = v; dirty1 = dirty; live1 = dev::ballot(~v != 0ull); }
   }
-  __syncthreads();  // (the deferred lists overlay the exchange area)
-  // rounds with a live slot, as a mask (iters <= 128 / BATCH <= 64)
-  unsigned long long rounds = 0ull;
-  for (int r = 0; r < iters; ++r) {
-    const int s0 = r * BATCH;
-    if ((((s0 >> 6) ? live1 : live0) >> (s0 & 63)) & ((1ull << BATCH) - 1ull)) rounds |= 1ull << r;
-  }
+  __syncthreads();  // (the lists overlay the exchange area)
   if constexpr (DBG) t_pro = clk(true) - t_start;
-  auto slot_word = [&](int s) -> unsigned long long {  // s is wave-uniform
-    const unsigned long long w = (s >> 6) ? pv1 : pv0;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, s & 63);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), s & 63);
-    return (unsigned long long)lo | ((unsigned long long)hi << 32);
-  };
-  auto chunk_of = [&](int s) -> int { return (wave + (s / BATCH) * n_waves) * BATCH + s % BATCH; };
 
-  int my_cnt = 0, my_open = 0;
-  long long my_deg = 0, my_probes = 0;
+  int my_cnt = 0, my_open = 0, my_probes = 0;
+  long long my_deg = 0;
   int wcnt = 0;  // staged discoveries of this wave
   int dcnt = 0;  // deferred entries of this wave
-  const int last_edge = d.n_edges > 0 ? d.n_edges - 1 : 0;
+  int ocnt = 0;  // compacted open vertices of this wave
+  const unsigned last_edge = d.n_edges > 0 ? (unsigned)d.n_edges - 1u : 0u;
+  auto vertex_of = [&](unsigned ent) -> int { return chunk_of((int)(ent >> 6)) * 64 + (int)(ent & 63u); };
 
   auto emit_from_end = [&]() {  // one full tile leaves the staging area, from the end
     const long long te0 = clk(false);
@@ -731,6 +725,19 @@ __device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const do
     wcnt -= TILE;
     if constexpr (DBG) t_emit += clk(false) - te0;
   };
+  // a discovery (call with the ballot of `fnd` over the wave): label, bit, staging
+  auto discovered = [&](bool fnd, unsigned ent, int v) {
+    const unsigned long long nw = dev::ballot(fnd);
+    if (nw) {
+      if (fnd) {
+        d.dist[(unsigned)v] = level + 1;
+        my_cnt += 1;
+        atomicOr(&late[2u * (ent >> 6) + ((ent >> 5) & 1u)], 1u << (ent & 31u));
+        sv[wcnt + dev::mask_rank(nw)] = v;
+      }
+      wcnt += __popcll(nw);
+    }
+  };
 
   // the deferred pass: every lane takes one entry
   auto drain = [&]() {
@@ -739,29 +746,28 @@ __device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const do
     for (int base = 0; base < dcnt; base += 64) {
       const int i = base + lane;
       const bool act = i < dcnt;
-      const unsigned ent = act ? dv[i] : 0u;
-      const int slot = (int)(ent >> 6);
-      const int v = chunk_of(slot) * 64 + (int)(ent & 63u);
-      const int rv = act ? v : 0;
-      const int rb = d.t_ro[rv], e = act ? d.t_ro[rv + 1] : 0;  // (one 8-byte load)
-      int pos = rb + 2;  // the two first in-neighbours were probed in the round
+      const unsigned ent = act ? (unsigned)dv[i] : 0u;
+      const int v = vertex_of(ent);
+      const unsigned rv = act ? (unsigned)v : 0u;
+      const int rb = d.t_ro[rv], e = act ? d.t_ro[rv + 1u] : 0;  // (one 8-byte load)
+      int pos = rb + 2;  // the two first in-neighbours were probed in the group
       bool fnd = false;
       int it = 0;
       for (;;) {
         // four column indices as ONE 16-byte load (one line request per lane instead of four); a list that ends within
         // three entries of the END OF THE ARRAY is left to the whole-wave scan below, which tests every index
-        const bool go = act && !fnd && pos < e && pos + 3 <= last_edge;
+        const bool go = act && !fnd && pos < e && (unsigned)pos + 3u <= last_edge;
         const unsigned long long mm = dev::ballot(go);
         if (mm == 0ull) break;
         if (it >= 2 && __popcll(mm) <= 8) break;  // a few long lists: the whole wave per list, below
         struct __attribute__((packed, aligned(4))) quad { int x[4]; };
-        const quad u = *reinterpret_cast<const quad*>(d.t_ci + (go ? pos : 0));
+        const quad u = *reinterpret_cast<const quad*>(d.t_ci + (go ? (unsigned)pos : 0u));
         unsigned w[4];
         bool ok[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           ok[q] = go && pos + q < e;
-          w[q] = fin[(ok[q] ? u.x[q] : 0) >> 5];
+          w[q] = fin[(unsigned)(ok[q] ? u.x[q] : 0) >> 5];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -783,158 +789,112 @@ __device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const do
           if (kk < ee) {
             const int u = d.t_ci[kk];
             ++my_probes;
-            h = (fin[u >> 5] & (1u << (u & 31))) != 0u;
+            h = (fin[(unsigned)u >> 5] & (1u << (u & 31))) != 0u;
           }
           if (dev::ballot(h)) { hit = true; break; }
         }
         if (lane == src_lane) fnd = hit;
       }
-      const unsigned long long nw = dev::ballot(fnd);
-      if (nw) {
-        if (fnd) {
-          d.dist[v] = level + 1;
-          my_cnt += 1;
-          atomicOr(&late[2 * slot + (int)((ent >> 5) & 1u)], 1u << (ent & 31u));
-          sv[wcnt + dev::mask_rank(nw)] = v;
-        }
-        wcnt += __popcll(nw);
-        if (wcnt >= TILE) emit_from_end();
-      }
+      discovered(fnd, ent, v);
+      if (wcnt >= TILE) emit_from_end();
     }
     dcnt = 0;
     if constexpr (DBG) t_drain += clk(true) - td0;
   };
 
-  auto next_round = [&](int r) -> int {  // first live round after r, -1: none
-    const unsigned long long m = r >= 63 ? 0ull : (rounds & (~0ull << (r + 1)));
-    return m ? (int)__builtin_ctzll(m) : -1;
-  };
-
-  int nh0[BATCH], nh1[BATCH];  // the two first in-neighbours of the round after the current one
-  int ch0[BATCH], ch1[BATCH];  // ... of the current round
-#pragma unroll
-  for (int j = 0; j < BATCH; ++j) nh0[j] = nh1[j] = ch0[j] = ch1[j] = -1;
-  int r = next_round(-1), rc = -1;
+  // live slots, in order: one 64-bit mask after the other
+  unsigned long long todo0 = live0, todo1 = live1;
+  constexpr unsigned NONE = 0xffffu;
+  unsigned ne0 = NONE, ne1 = NONE, ce0 = NONE, ce1 = NONE;  // entries of the group in flight / of the current group
+  int nh00 = -1, nh01 = -1, nh10 = -1, nh11 = -1;          // their two first in-neighbours
+  int ch00 = -1, ch01 = -1, ch10 = -1, ch11 = -1;
+  bool have_cur = false;
   for (;;) {
-    if (r >= 0) {
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        const int s = r * BATCH + j;
-        const unsigned long long vis = slot_word(s);
-        const int v = chunk_of(s) * 64 + lane;
-        const bool op = v < a.V && !((vis >> lane) & 1ull);
-        const int2 h = d.heads[op ? v : 0];  // closed lanes read entry 0: one broadcast line
-        nh0[j] = h.x;
-        nh1[j] = h.y;
-      }
+    // 1. compact open vertices until a group is full or the slots are used up
+    const long long tc0 = clk(false);
+    while (ocnt < S::GROUP && (todo0 | todo1) != 0ull) {
+      int s;
+      if (todo0) { s = (int)__builtin_ctzll(todo0); todo0 &= todo0 - 1ull; }
+      else { s = 64 + (int)__builtin_ctzll(todo1); todo1 &= todo1 - 1ull; }
+      const unsigned long long w = (s >> 6) ? pv1 : pv0;
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, s & 63);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), s & 63);
+      const unsigned long long m = ~((unsigned long long)lo | ((unsigned long long)hi << 32));  // open lanes of slot s
+      if ((m >> lane) & 1ull) ov[ocnt + dev::mask_rank(m)] = (unsigned short)((s << 6) | lane);
+      ocnt += __popcll(m);
     }
-    if (rc >= 0) {
-      if (dcnt + 64 * BATCH > S::DEFER) drain();
+    if constexpr (DBG) t_compact += clk(false) - tc0;
+    // 2. the next group: its entries leave the list (from the end), its two-neighbour records are requested
+    const int n_new = ocnt < S::GROUP ? ocnt : S::GROUP;
+    const bool have_new = n_new > 0;
+    if (have_new) {
+      const int base = ocnt - n_new;
+      ne0 = lane < n_new ? (unsigned)ov[base + lane] : NONE;
+      ne1 = 64 + lane < n_new ? (unsigned)ov[base + 64 + lane] : NONE;
+      ocnt = base;
+      my_open += (ne0 != NONE ? 1 : 0) + (ne1 != NONE ? 1 : 0);
+      const int2 h0 = d.heads[ne0 != NONE ? (unsigned)vertex_of(ne0) : 0u];  // (idle lanes read entry 0: one broadcast line)
+      const int2 h1 = d.heads[ne1 != NONE ? (unsigned)vertex_of(ne1) : 0u];
+      nh00 = h0.x; nh01 = h0.y; nh10 = h1.x; nh11 = h1.y;
+    }
+    // 3. the current group: frontier words of its first two in-neighbours
+    if (have_cur) {
+      if (dcnt + S::GROUP > S::DEFER) drain();
       const long long tp0 = clk(false);
       if constexpr (DBG) ++n_rounds;
-      unsigned long long vis[BATCH];
-      bool open[BATCH], found[BATCH], a0[BATCH], a1[BATCH], more[BATCH];
-      int u0[BATCH], u1[BATCH];
-      unsigned w0[BATCH], w1[BATCH];
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        const int s = rc * BATCH + j;
-        vis[j] = slot_word(s);
-        const int v = chunk_of(s) * 64 + lane;
-        open[j] = v < a.V && !((vis[j] >> lane) & 1ull);
-        my_open += open[j] ? 1 : 0;
-        a0[j] = open[j] && ch0[j] >= 0;
-        a1[j] = open[j] && ch1[j] >= 0;
-        more[j] = a1[j] && (ch1[j] & BU_MORE) != 0;
-        u0[j] = a0[j] ? ch0[j] : 0;
-        u1[j] = a1[j] ? (ch1[j] & ~BU_MORE) : 0;
-      }
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        w0[j] = fin[u0[j] >> 5];
-        w1[j] = fin[u1[j] >> 5];
-      }
-      // every ballot of the round is taken BEFORE the first store of the round: the compiler otherwise sinks the test of the
-      // later chunks behind the stores of the first one, and its wait for their frontier words then also waits for those
-      // stores (vmcnt retires in order)
-      unsigned long long nwm[BATCH], dfm[BATCH];
-      bool df[BATCH];
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        // (bitwise: a short-circuit here put each frontier word's wait into a branch of its own)
-        const unsigned hit0 = (w0[j] >> (u0[j] & 31)) & (a0[j] ? 1u : 0u);
-        const unsigned hit1 = (w1[j] >> (u1[j] & 31)) & (a1[j] ? 1u : 0u);
-        found[j] = (hit0 | hit1) != 0u;
-        my_probes += (a0[j] ? 1 : 0) + (a1[j] ? 1 : 0);
-        df[j] = more[j] && !found[j];  // still open, more in-edges: deferred
-        nwm[j] = dev::ballot(found[j]);
-        dfm[j] = dev::ballot(df[j]);
-      }
+      const bool o0 = ce0 != NONE, o1 = ce1 != NONE;
+      const bool a00 = o0 && ch00 >= 0, a01 = o0 && ch01 >= 0, a10 = o1 && ch10 >= 0, a11 = o1 && ch11 >= 0;
+      const unsigned u00 = a00 ? (unsigned)ch00 : 0u, u01 = a01 ? (unsigned)(ch01 & ~BU_MORE) : 0u;
+      const unsigned u10 = a10 ? (unsigned)ch10 : 0u, u11 = a11 ? (unsigned)(ch11 & ~BU_MORE) : 0u;
+      const unsigned w00 = fin[u00 >> 5], w01 = fin[u01 >> 5], w10 = fin[u10 >> 5], w11 = fin[u11 >> 5];
+      // (bitwise: a short-circuit here put each frontier word's wait into a branch of its own)
+      const bool f0 = (((w00 >> (u00 & 31u)) & (a00 ? 1u : 0u)) | ((w01 >> (u01 & 31u)) & (a01 ? 1u : 0u))) != 0u;
+      const bool f1 = (((w10 >> (u10 & 31u)) & (a10 ? 1u : 0u)) | ((w11 >> (u11 & 31u)) & (a11 ? 1u : 0u))) != 0u;
+      my_probes += (a00 ? 1 : 0) + (a01 ? 1 : 0) + (a10 ? 1 : 0) + (a11 ? 1 : 0);
+      // still open, more in-edges: deferred.  Every ballot of the group is taken BEFORE its first store: the compiler
+      // otherwise sinks the test of the second half behind the stores of the first, and its wait for the frontier words
+      // then also waits for those stores (vmcnt retires in order)
+      const bool df0 = a01 && (ch01 & BU_MORE) != 0 && !f0, df1 = a11 && (ch11 & BU_MORE) != 0 && !f1;
+      const unsigned long long dm0 = dev::ballot(df0), dm1 = dev::ballot(df1);
       const long long tp1 = clk(true);
       if constexpr (DBG) t_probe += tp1 - tp0;
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        const int s = rc * BATCH + j;
-        const int ch = chunk_of(s);  // (a slot beyond the last chunk has nothing open: only its word stores need the test)
-        if (dfm[j]) {
-          if (df[j]) {
-            const int at = dcnt + dev::mask_rank(dfm[j]);
-            dv[at] = ((unsigned)s << 6) | (unsigned)lane;
-          }
-          dcnt += __popcll(dfm[j]);
-        }
-        const unsigned long long nw = nwm[j];
-        if (lane == 0 && ch < n_chunks) {
-          fout[2 * ch] = (unsigned)nw;
-          fout[2 * ch + 1] = (unsigned)(nw >> 32);
-          if (nw != 0ull || ((((s >> 6) ? dirty1 : dirty0) >> (s & 63)) & 1ull)) {
-            const unsigned long long nv = vis[j] | nw;
-            d.visited[2 * ch] = (unsigned)nv;
-            d.visited[2 * ch + 1] = (unsigned)(nv >> 32);
-          }
-        }
-        if (nw) {
-          if (found[j]) {
-            const int v = ch * 64 + lane;
-            d.dist[v] = level + 1;
-            my_cnt += 1;
-            sv[wcnt + dev::mask_rank(nw)] = v;
-          }
-          wcnt += __popcll(nw);
-        }
+      if (dm0 | dm1) {
+        if (df0) dv[dcnt + dev::mask_rank(dm0)] = (unsigned short)ce0;
+        dcnt += __popcll(dm0);
+        if (df1) dv[dcnt + dev::mask_rank(dm1)] = (unsigned short)ce1;
+        dcnt += __popcll(dm1);
       }
+      discovered(f0, ce0, f0 ? vertex_of(ce0) : 0);
+      discovered(f1, ce1, f1 ? vertex_of(ce1) : 0);
       if constexpr (DBG) t_out += clk(false) - tp1;
       if (wcnt >= TILE) emit_from_end();
     }
-    if (r < 0) break;
-#pragma unroll
-    for (int j = 0; j < BATCH; ++j) { ch0[j] = nh0[j]; ch1[j] = nh1[j]; }
-    rc = r;
-    r = next_round(r);
+    if (!have_new) break;
+    ce0 = ne0; ce1 = ne1;
+    ch00 = nh00; ch01 = nh01; ch10 = nh10; ch11 = nh11;
+    have_cur = true;
   }
   if (dcnt > 0) drain();
   const long long t_loop_end = clk(true);
-  // bits found by the deferred pass -> this wave's own words (its earlier plain stores to them have to be performed first)
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  // every changed word of this wave, one slot per lane: the next frontier (cleared by the previous level's sweep, so only
+  // non-zero words are written) and `visited`
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int s = lane + 64 * k;
-    const unsigned lo = late[2 * s], hi = late[2 * s + 1];
-    if (lo | hi) {
+    const unsigned long long nw = (unsigned long long)late[2 * s] | ((unsigned long long)late[2 * s + 1] << 32);
+    const bool dirty = k == 0 ? dirty0 : dirty1;
+    if (nw != 0ull || dirty) {  // (an invalid slot is neither)
       const int ch = chunk_of(s);
-      const unsigned f0 = __hip_atomic_load(&fout[2 * ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned f1 = __hip_atomic_load(&fout[2 * ch + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned v0 = __hip_atomic_load(&d.visited[2 * ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned v1 = __hip_atomic_load(&d.visited[2 * ch + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      fout[2 * ch] = f0 | lo;
-      fout[2 * ch + 1] = f1 | hi;
-      d.visited[2 * ch] = v0 | lo;
-      d.visited[2 * ch + 1] = v1 | hi;
+      const long long first = (long long)ch * 64;
+      unsigned long long keep = ~0ull;  // the bits beyond V were set above to close them: not part of `visited`
+      if (first + 64 > (long long)a.V) keep = first >= (long long)a.V ? 0ull : (1ull << ((long long)a.V - first)) - 1ull;
+      if (nw != 0ull) *reinterpret_cast<unsigned long long*>(fout + 2 * ch) = nw;
+      *reinterpret_cast<unsigned long long*>(d.visited + 2 * ch) = ((k == 0 ? pv0 : pv1) & keep) | nw;
     }
   }
   // leftovers (< TILE per wave) of the four waves -> as few tiles as possible
   if (threadIdx.x == 0) sm.bcnt = 0;
-  __syncthreads();  // (every wave is done with its deferred list: u.bv overlays them)
+  __syncthreads();  // (every wave is done with its lists: u.bv overlays them)
   int at = 0;
   if (lane == 0 && wcnt) at = atomicAdd(&sm.bcnt, wcnt);
   at = __shfl(at, 0, 64);
@@ -962,11 +922,9 @@ __device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const do
   // per-workgroup totals
   my_cnt = dev::wave_sum(my_cnt);
   my_open = dev::wave_sum(my_open);
+  my_probes = dev::wave_sum(my_probes);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    my_deg += __shfl_xor(my_deg, o, 64);
-    my_probes += __shfl_xor(my_probes, o, 64);
-  }
+  for (int o = 32; o > 0; o >>= 1) my_deg += __shfl_xor(my_deg, o, 64);
   if (lane == 0) { sm.cnt[wid] = my_cnt; sm.deg[wid] = my_deg; sm.open[wid] = my_open; sm.probe[wid] = my_probes; }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -984,7 +942,7 @@ __device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const do
     t_tail = t_end - t_loop_end;
     if (lane == 0 && d.debug && level == d.debug_level && wave < 16384) {
       long long* o = d.debug + 8 * (size_t)wave;
-      o[0] = (long long)blockIdx.x;
+      o[0] = (long long)blockIdx.x | (t_compact << 32);
       o[1] = t_start;
       o[2] = t_end;
       o[3] = t_pro | (t_tail << 32);

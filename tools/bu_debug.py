@@ -36,14 +36,14 @@ t0 = r[:, 1].min()
 dur = (r[:, 2] - r[:, 1]) * tick
 print("level %s of %s: %d waves, kernel span %.1f us, wave start %.1f..%.1f, wave busy mean %.1f / max %.1f us"
       % (os.environ.get("GRX_BU_DEBUG"), name, len(r), (r[:, 2].max() - t0) * tick, 0.0, (r[:, 1].max() - t0) * tick, dur.mean(), dur.max()))
-cols = {"prologue (slot words)": r[:, 3] & m32, "probe (rows wait + frontier words)": r[:, 4] & m32, "outputs": r[:, 4] >> 32,
+cols = {"prologue (slot words)": r[:, 3] & m32, "compaction of open vertices": r[:, 0] >> 32, "probe (records wait + frontier words)": r[:, 4] & m32, "outputs": r[:, 4] >> 32,
         "deferred pass": r[:, 5] & m32, "tile emission": r[:, 5] >> 32, "late merge + leftovers + totals": r[:, 3] >> 32}
 for k, v in cols.items():
     print("  %-38s mean %6.2f us  max %6.2f us" % (k, v.mean() * tick, v.max() * tick))
 rounds = r[:, 6] & 0xffff
 deferred = (r[:, 6] >> 16) & 0xffffff
 drains = r[:, 6] >> 40
-print("  rounds per wave mean %.1f max %d; deferred entries per wave mean %.1f max %d; deferred passes mean %.2f"
+print("  groups per wave mean %.1f max %d; deferred entries per wave mean %.1f max %d; deferred passes mean %.2f"
       % (rounds.mean(), rounds.max(), deferred.mean(), deferred.max(), drains.mean()))
-print("  per round: probe %.2f us, outputs %.2f us" % ((cols["probe (rows wait + frontier words)"].sum() / max(1, rounds.sum())) * tick,
+print("  per group: probe %.2f us, outputs %.2f us" % ((cols["probe (records wait + frontier words)"].sum() / max(1, rounds.sum())) * tick,
                                                        (cols["outputs"].sum() / max(1, rounds.sum())) * tick))
