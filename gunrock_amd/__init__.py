@@ -228,7 +228,14 @@ class options_t:
         self.advance_direction = advance_direction
         self.max_iterations = max_iterations
 
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        object.__setattr__(self, "_cached", None)
+
     def _c(self):
+        o = self._cached
+        if o is not None:
+            return o  # (the engine reads the struct, it never writes it)
         o = grx_options_t()
         o.advance_load_balance = int(self.advance_load_balance)
         o.filter_algorithm = int(self.filter_algorithm)
@@ -240,6 +247,7 @@ class options_t:
         o.engine_flags = int(self.engine_flags)
         o.advance_direction = int(self.advance_direction)
         o.max_iterations = int(self.max_iterations)
+        object.__setattr__(self, "_cached", o)
         return o
 
 
@@ -305,19 +313,28 @@ def build_graph(properties, csr, context=None, device="cuda:0"):
     return graph_t(properties, csr.to_device(device), ctx)
 
 
+def _raw_current_stream(index):
+    import torch
+    try:
+        return torch._C._cuda_getCurrentRawStream(index)  # no Stream object: ~0.3 us
+    except AttributeError:
+        return torch.cuda.current_stream(index).cuda_stream
+
+
 def _order_after_producer(ctx, *tensors):
     """The engine works on ITS context's stream (non-blocking, like the reference's
     standard_context_t).  Work queued on torch's current stream that produces the
     tensors handed in (e.g. `torch.full` just before the call) must be finished first;
-    when the context was created on that very stream nothing needs to be done."""
+    when the context was created on that very stream, or that stream is idle, nothing
+    needs to be done -- else the context's stream waits for an event recorded there
+    (grx_context_order_after; the host does not block)."""
     for t in tensors:
         dev = getattr(t, "device", None)
         if dev is None or getattr(dev, "type", "") != "cuda":
             continue
-        import torch
-        cur = torch.cuda.current_stream(dev)
-        if getattr(ctx, "_stream_handle", None) != cur.cuda_stream:
-            cur.synchronize()
+        raw = _raw_current_stream(dev.index if dev.index is not None else 0)
+        if ctx._stream_handle != raw:
+            _capi.check(_capi.lib().grx_context_order_after(ctx._h, C.c_void_p(raw)))
         return
 
 

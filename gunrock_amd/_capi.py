@@ -90,6 +90,7 @@ def lib():
         "grx_version_string": (C.c_char_p, []),
         "grx_context_create": (i32, [i32, vp, P(vp)]),
         "grx_context_synchronize": (i32, [vp]),
+        "grx_context_order_after": (i32, [vp, vp]),
         "grx_context_destroy": (i32, [vp]),
         "grx_context_stream": (vp, [vp]),
         "grx_graph_create_csr": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, P(vp)]),

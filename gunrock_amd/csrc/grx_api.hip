@@ -225,6 +225,19 @@ grx_status_t grx_context_synchronize(grx_context_t ctx) {
 
 void* grx_context_stream(grx_context_t ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+grx_status_t grx_context_order_after(grx_context_t ctx, void* producer_stream) {
+  if (!ctx) return fail(GRX_ERROR_INVALID_ARGUMENT, "null context");
+  hipStream_t ps = reinterpret_cast<hipStream_t>(producer_stream);
+  if (ps == ctx->stream) return GRX_SUCCESS;
+  const hipError_t q = hipStreamQuery(ps);
+  if (q == hipSuccess) return GRX_SUCCESS;  // idle: nothing to be ordered after
+  if (q != hipErrorNotReady) GRX_HIP(q);
+  if (!ctx->ev_order) GRX_HIP(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+  GRX_HIP(hipEventRecord(ctx->ev_order, ps));
+  GRX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_order, 0));
+  return GRX_SUCCESS;
+}
+
 grx_status_t grx_context_destroy(grx_context_t ctx) {
   if (!ctx) return GRX_SUCCESS;
   (void)hipSetDevice(ctx->device);
@@ -246,6 +259,7 @@ grx_status_t grx_context_destroy(grx_context_t ctx) {
   if (ctx->h_mailbox) (void)hipHostFree((void*)ctx->h_mailbox);
   if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
   if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+  if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return GRX_SUCCESS;

@@ -107,6 +107,7 @@ __global__ void bfs_init_kernel(pipe_args a, int32_t* dist, unsigned* visited, i
     c->edges_visited = 0;
     c->vertices_visited = 0;
     c->spare[0] = 0;
+    c->bin_want = 0;
     c->mode = 0;
     c->frontier_bitmap = 0;
     c->convert = 0;
@@ -333,6 +334,8 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
     in.bin_queue = bn.queue;
     in.bin_nb = bn.nb;
     in.bin_pad = BIN_PAD;
+    in.bin_allowed = bn.allowed;
+    in.seq = seq;
     plan_body<PLAN_BLOCK>(a, c, 0, s_wave, &s_red[0], in);
     return;
   }
@@ -902,8 +905,18 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   const int pace = (dense && variant == 0) ? env_int("GRX_PACE_DEPTH", 3) : 0;
   int64_t prof_v = 0, prof_e = 0, prof_open = 0, prof_probe = 0;
   int launches = 0;
+  // The scatter and sweep kernels of a binned level are launched blindly with every group and cost a launch each where the
+  // level is thin (two no-op kernels, ~4 us each, on four of the six levels of the LJ stand-in).  The head kernels
+  // record in which groups they met a fat level (ctrl_t::bin_want, published with `done`); the next forward search on the
+  // graph leaves the two kernels out of the other groups, one group of slack either side.  A fat level in a group
+  // without them runs on the claim-per-edge advance (the head is told: bin_args::allowed) and is recorded for the next
+  // search.  GRX_BIN_HINT=0: every group carries them.
+  const uint32_t hint0 = (use_bins && env_int("GRX_BIN_HINT", 1) != 0) ? g->bin_hint : 0u;
+  const uint32_t bin_groups = hint0 ? (hint0 | (hint0 << 1) | (hint0 >> 1)) : ~0u;
   st = run_levels(ctx, opt, [&](hipStream_t stream, int seq) {
     if (profile) (void)hipEventRecord(pe[0], stream);
+    const bool bins_here = use_bins && (seq >= 32 || ((bin_groups >> seq) & 1u) != 0u);
+    bn.allowed = bins_here ? 1 : 0;
     if (variant == 0) {
       // head (tiny levels + decide + plan) -> level
       hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, lp, (profile || strict_mp) ? 0 : 1, seq, bn);
@@ -928,7 +941,8 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         };
         using std::true_type;
         using std::false_type;
-        if (bn.debug && bn.entry16) launch2(true_type{}, true_type{});
+        if (!bins_here) { /* thin level expected */ }
+        else if (bn.debug && bn.entry16) launch2(true_type{}, true_type{});
         else if (bn.debug) launch2(true_type{}, false_type{});
         else if (bn.entry16) launch2(false_type{}, true_type{});
         else launch2(false_type{}, false_type{});
@@ -991,6 +1005,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     return fail(GRX_ERROR_HIP, "grx_bfs: a device-side barrier timed out (grx_mid.hpp)");
   }
 
+  if (use_bins) g->bin_hint = returned_fast ? (uint32_t)ctx->h_mailbox[11] : (uint32_t)ctx->h_ctrl->bin_want;
   float ms = 0;
   if (returned_fast) {
     // enact() time on the device's own clock: seed (init kernel) -> the kernel that found the

@@ -66,6 +66,7 @@ struct bin_args {
   int32_t* dist;
   long long* debug;           // tuning aid (GRX_BIN_DEBUG=<level>): 8 words per workgroup and phase for that level, else null
   int32_t debug_level;
+  int32_t allowed;            // this launch group carries the scatter / sweep kernels
   int32_t max_degree;         // ... and whose frontier averages at most this many out-edges per vertex
   int32_t mid_v, mid_e;       // thresholds of the many-levels-per-launch body (grx_mid.hpp), 0: off (carried here for the head kernel)
 };

@@ -102,7 +102,7 @@ struct ctrl_t {
   int32_t mid_err;          // a barrier timed out (the host reports an error)
   uint32_t mid_reg;         // registrations of workgroups on the home XCD (bit 31: window closed)
   int32_t mid_G;            // number of workgroups taking part (published by the leader)
-  int32_t pad3[1];
+  int32_t bin_want;         // bit g: the head of launch group g found a level fat enough to be binned (grx_bin.hpp)
 };
 
 struct level_rec {
@@ -122,6 +122,7 @@ struct grx_context {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_order = nullptr;  // grx_context_order_after
   int32_t num_cus = 256;
   uint32_t xcc_mask = 1u;  // hardware XCC ids seen by a census at context creation
   int32_t n_xcd = 1;
@@ -175,6 +176,7 @@ struct grx_graph {
   int32_t* bin_fill = nullptr;  // per-level fill counters + per-XCD claim queue heads
   unsigned char* bin_tab8 = nullptr;  // granule -> bin, bin -> owning XCD
   int32_t bin_shift = 0, bin_ngran = 0, bin_nb = 0;
+  uint32_t bin_hint = 0;        // ctrl_t::bin_want of the last forward search on this graph (0: none yet)
   int32_t bin_entry16 = 0;      // every bin spans <= 65536 vertices: offsets inside a bin fit 16-bit entries
   int32_t bin_state = 0;        // 0: not built, 1: usable, 2: not applicable to this graph
   double weight_sum = -1.0;  // sum of edge weights (lazy; near-far SSSP bucket width)

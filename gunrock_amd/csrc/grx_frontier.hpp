@@ -70,6 +70,7 @@ __device__ __forceinline__ void publish_done(const pipe_args& a, ctrl_t* c, int 
   mb64[1] = c->vertices_visited;
   mb64[2] = (long long)wall_clock64() - c->t_start;
   a.mailbox[1] = level;
+  a.mailbox[11] = c->bin_want;
   __threadfence_system();
   a.mailbox[0] = 1;
 }
@@ -147,6 +148,9 @@ struct plan_in {
   // many mid-size levels in one launch (grx_mid.hpp; external_control == 0 only): a level with at most mid_v
   // frontier vertices and mid_e out-edges runs as mode 3 (0: off)
   int mid_v = 0, mid_e = 0;
+  // the launch group of this level carries the scatter / sweep kernels (the host leaves them out of groups where the
+  // previous search on the graph had no fat level); seq: index of the group
+  int bin_allowed = 1, seq = 0;
   int32_t* bin_fill = nullptr;
   int32_t* bin_queue = nullptr;  // per-XCD claim queue heads (16 slots, bin_pad apart), zeroed with the fill counters
   int bin_nb = 0, bin_pad = 0;
@@ -286,13 +290,15 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
       c->q_edges[p] = edges;
       if (in.bin_min > 0 || in.mid_v > 0) {
         int mode = 0;
-        if (in.bin_min > 0 && edges >= in.bin_min &&
-            (in.bin_max_degree <= 0 || edges <= (long long)in.bin_max_degree * nitems))
+        const bool fat = in.bin_min > 0 && edges >= in.bin_min &&
+                         (in.bin_max_degree <= 0 || edges <= (long long)in.bin_max_degree * nitems);
+        if (fat && in.seq < 32) c->bin_want |= 1 << in.seq;
+        if (fat && in.bin_allowed)
           mode = 2;
         // (the tile queue must be reasonably dense too: the few workgroups of that body walk it themselves, and a
         // level of the regular kernels on a wide grid leaves thousands of nearly empty tiles behind -- such a level
         // is expanded by the regular kernels once more, which compacts it)
-        else if (in.mid_v > 0 && nitems > 0 && nitems <= in.mid_v && edges <= (long long)in.mid_e &&
+        else if (!fat && in.mid_v > 0 && nitems > 0 && nitems <= in.mid_v && edges <= (long long)in.mid_e &&
                  nt <= 4 * ((nitems + TILE - 1) / TILE) + 256)
           mode = 3;
         c->mode = mode;

@@ -121,6 +121,11 @@ grx_status_t grx_context_create(int32_t device, void* stream, grx_context_t* out
 grx_status_t grx_context_synchronize(grx_context_t ctx); /* context.hxx:124-128 */
 grx_status_t grx_context_destroy(grx_context_t ctx);
 void* grx_context_stream(grx_context_t ctx);
+/* Order the context's stream after the work queued so far on `producer_stream` (another stream of the same device, e.g.
+ * the one a caller filled an input array on) without blocking the host: nothing is done when that stream is the
+ * context's own or already idle, else an event is recorded there and waited for on the context's stream.  The reference
+ * has no counterpart (its algorithms run on the stream the caller's thrust calls use). */
+grx_status_t grx_context_order_after(grx_context_t ctx, void* producer_stream);
 
 /* graph::build<memory_space_t::device>(properties, csr),
  * include/gunrock/graph/build.hxx:29-36 + graph/csr.hxx:218-226: a NON-OWNING

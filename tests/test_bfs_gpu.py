@@ -238,6 +238,36 @@ def test_binned_forward_levels(gr, gpu_ctx, monkeypatch, golden):
                         assert all(l["bottom_up"] == 2 for l in prof if l["edges"] > 0), "a level did not run binned"
 
 
+def test_binned_kernels_follow_the_previous_search(gr, gpu_ctx, monkeypatch):
+    """The scatter / sweep kernels of the binned levels are launched only in the groups where the PREVIOUS forward search
+    on the graph handle met a fat level (one group of slack): searches from other sources, whose fat levels fall elsewhere,
+    must still give the oracle's depths (such a level runs on the claim-per-edge advance) and re-train the hint."""
+    import torch
+    _, c = gr.generate("rmat_sym", 1 << 18, 6_000_000, seed=11)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    G = gr.build_graph(gr.graph_properties_t(directed=True, weighted=False, symmetric=False),
+                       gr.csr_t.from_arrays(g.row_offsets, g.column_indices, None), gpu_ctx)
+    deg = np.diff(g.row_offsets)
+    hub = int(np.argmax(deg))
+    # a chain hung onto the graph would be nicer; low-degree sources shift the fat levels by one or two groups
+    lows = [int(v) for v in np.nonzero(deg == 1)[0][:2]] + [int(np.nonzero(deg > 0)[0][-1])]
+    monkeypatch.setenv("GRX_BIN_MIN_EDGES", "100000")
+    dist = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda:0")
+    binned = {}
+    for src in [hub, hub, lows[0], lows[0], hub, lows[1], lows[2], hub, hub]:
+        want, _, ev = O.bfs_queue(g, src)
+        for flags in (0, gr.FLAG_PROFILE):
+            gr.bfs(G, src, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.forward, engine_flags=flags))
+            assert np.array_equal(dist.cpu().numpy(), want), (src, flags)
+            assert gr.run_stats(gpu_ctx)["edges_visited"] == ev
+        binned.setdefault(src, []).append(sum(1 for l in gr.level_profile(gpu_ctx) if l["bottom_up"] == 2))
+    # the same source twice in a row: the second search bins every level the first one wanted binned
+    assert binned[hub][1] >= 1 and binned[hub][-1] == binned[hub][1], binned
+    monkeypatch.setenv("GRX_BIN_HINT", "0")
+    gr.bfs(G, hub, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.forward, engine_flags=gr.FLAG_PROFILE))
+    assert sum(1 for l in gr.level_profile(gpu_ctx) if l["bottom_up"] == 2) == binned[hub][1]
+
+
 def test_symmetric_property_is_verified(gr, gpu_ctx):
     """graph_properties_t defaults to symmetric=true (inert in the reference).  Here it lets the
     bottom-up step use the CSR as its own in-edge list -- so the engine must notice a DIRECTED CSR
