@@ -204,14 +204,25 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_source_kernel(pipe_args a, dobf
       ok_k[k] = i < deg;
       n_k[k] = a.ci[rs + (ok_k[k] ? i : 0)];
     }
+    // Runs that keep bitmaps claim ON THE BITMAP: the bit every discovery has to set in the next frontier (or, forward-only
+    // runs, in `visited`) is set with a returning atomic and decides -- nothing but the source is visited at level 0 -- and the
+    // label is a plain store: one atomic per edge where the label claim + the bit took two (571 k out-edges of the kron
+    // stand-in's source: the level is bound by the rate of those atomics).
+    const bool by_bit = pol.bm_visited != nullptr;  // uniform
 #pragma unroll
     for (int k = 0; k < ADV_ITEMS; ++k) {
       r_k[k] = 0;
-      if (ok_k[k]) r_k[k] = pol.claim(n_k[k], 0);
+      if (ok_k[k]) {
+        if (!by_bit) r_k[k] = pol.claim(n_k[k], 0);
+        else if (n_k[k] == src) r_k[k] = -1;  // a self loop: the source is visited, and no bit of the next frontier
+        else r_k[k] = (int)__hip_atomic_fetch_or(&pol.bm_next[n_k[k] >> 5], 1u << (n_k[k] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
 #pragma unroll
     for (int k = 0; k < ADV_ITEMS; ++k) {
-      const bool keep = ok_k[k] && pol.code(r_k[k], 0, n_k[k], 0) == 1;
+      bool keep;
+      if (by_bit) keep = ok_k[k] && (((unsigned)r_k[k] >> (n_k[k] & 31)) & 1u) == 0u;
+      else keep = ok_k[k] && pol.code(r_k[k], 0, n_k[k], 0) == 1;
       const unsigned long long m = dev::ballot(keep);
       if (m) {
         int at = 0;
@@ -219,7 +230,8 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_source_kernel(pipe_args a, dobf
         at = __shfl(at, 0, 64);
         if (keep) {
           sm.out[at + dev::mask_rank(m)] = n_k[k];
-          pol.on_accept(n_k[k]);
+          if (by_bit) pol.dist[n_k[k]] = pol.next_depth;
+          else pol.on_accept(n_k[k]);
         }
       }
     }
@@ -841,7 +853,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   else
     hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, visited, src, d, source_level);
   if (source_level)
-    hipLaunchKernelGGL(bfs_source_kernel, dim3(ctx->num_cus), dim3(ADV_BLOCK), 0, s, a, d, lp, src);
+    hipLaunchKernelGGL(bfs_source_kernel, dim3(ctx->num_cus * env_int("GRX_SOURCE_WG_PER_CU", 4)), dim3(ADV_BLOCK), 0, s, a, d, lp, src);
   bin_args bn{};
   bn.xcc_mask = ctx->xcc_mask;
   bn.n_xcd = ctx->n_xcd;

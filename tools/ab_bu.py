@@ -24,7 +24,7 @@ ctx = gr.multi_context_t(0)
 G = gr.build_graph(props, csr, ctx)
 V = G.get_number_of_vertices()
 d = torch.empty(V, dtype=torch.int32, device="cuda")
-KNOBS = ("GRX_BU2", "GRX_BU_HEADS", "GRX_LEVEL_WG_PER_CU", "GRX_BU_BATCH", "GRX_PACE_DEPTH", "GRX_SEED_IN_RESET")
+KNOBS = ("GRX_BU2", "GRX_BU_HEADS", "GRX_LEVEL_WG_PER_CU", "GRX_BU_BATCH", "GRX_PACE_DEPTH", "GRX_SEED_IN_RESET", "GRX_SOURCE_WG_PER_CU")
 ref = None
 
 
@@ -69,9 +69,9 @@ run("DO first bottom-up body", gr.optimized, {"GRX_BU2": 0})
 run("DO second body (default)", gr.optimized, {})
 run("DO second body, 5 workgroups per CU", gr.optimized, {"GRX_LEVEL_WG_PER_CU": 5})
 run("DO second body, reset and seed as two launches", gr.optimized, {"GRX_SEED_IN_RESET": 0})
-run("DO second body, pacing depth 1", gr.optimized, {"GRX_PACE_DEPTH": 1})
-run("DO second body, pacing depth 3", gr.optimized, {"GRX_PACE_DEPTH": 3})
-run("DO second body, pacing depth 4", gr.optimized, {"GRX_PACE_DEPTH": 4})
+run("DO second body, source level on 1 workgroup per CU", gr.optimized, {"GRX_SOURCE_WG_PER_CU": 1})
+run("DO second body, source level on 2 workgroups per CU", gr.optimized, {"GRX_SOURCE_WG_PER_CU": 2})
+run("DO second body, source level on 8 workgroups per CU", gr.optimized, {"GRX_SOURCE_WG_PER_CU": 8})
 run("DO first body again", gr.optimized, {"GRX_BU2": 0})
 run("DO second body again", gr.optimized, {})
 # other sources: depths against the forward search from the same source

@@ -43,10 +43,13 @@ def searches_of(rows):
     """rows: [(id, kernel name)] in launch order -> list of searches {kind, do, kernels: [(id, name)]}"""
     out, cur, reset_seen = [], None, False
     for did, name in rows:
-        if "bfs_reset_kernel" in name:
+        if "bfs_reset_kernel" in name:  # (GRX_SEED_IN_RESET=0)
             reset_seen = True
         kind = None
-        if "bfs_init_kernel" in name:
+        if "bfs_reset_seed_kernel" in name:  # problem.reset() + seed of a direction-optimising search, one launch
+            kind = "bfs"
+            reset_seen = True
+        elif "bfs_init_kernel" in name:
             kind = "bfs"
         elif "sssp_init_kernel" in name:
             kind = "sssp"
