@@ -25,7 +25,7 @@ ctx = gr.multi_context_t(0)
 G = gr.build_graph(props, csr, ctx)
 V = G.get_number_of_vertices()
 d = torch.empty(V, dtype=torch.int32, device="cuda")
-KNOBS = ("GRX_BU_HEADS", "GRX_BIN_E16", "GRX_BIN_SCATTER", "GRX_BIN_SWEEP", "GRX_SW2_ITEMS", "GRX_SW2_WG_PER_CU", "GRX_SC2_WG_PER_CU", "GRX_BIN_MIN_EDGES")
+KNOBS = ("GRX_BU2", "GRX_BIN_HINT", "GRX_BU_HEADS", "GRX_BIN_E16", "GRX_BIN_SCATTER", "GRX_BIN_SWEEP", "GRX_SW2_ITEMS", "GRX_SW2_WG_PER_CU", "GRX_SC2_WG_PER_CU", "GRX_BIN_MIN_EDGES")
 ref = None
 
 
@@ -75,6 +75,8 @@ run("fwd scatter2 sweep1", gr.forward, {"GRX_BIN_SWEEP": 1, "GRX_BIN_E16": 0})
 run("fwd scatter2 sweep3 32-bit entries", gr.forward, {"GRX_BIN_E16": 0})
 run("fwd default (scatter2 sweep3 16-bit)", gr.forward, {})
 run("fwd default again", gr.forward, {})
+run("fwd, every group with scatter + sweep", gr.forward, {"GRX_BIN_HINT": 0})
 run("DO default", gr.optimized, {})
-run("DO without the two-neighbour array", gr.optimized, {"GRX_BU_HEADS": 0})
+run("DO first bottom-up body", gr.optimized, {"GRX_BU2": 0})
+run("DO first body, no two-neighbour array", gr.optimized, {"GRX_BU_HEADS": 0})
 run("DO default again", gr.optimized, {})

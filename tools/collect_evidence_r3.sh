@@ -17,3 +17,4 @@ grep -v amdgpu.ids $G/final_fuzz.log | tail -12 > $P/r3_fuzz_sweep.txt
 cat $G/final_pytest_gpu.log | grep -E "passed|failed|rc " > $P/r3_pytest_gpu.log
 tail -3 $G/final_smoke.log | grep -v amdgpu.ids > $P/r3_smoke.log
 ls -la $P | grep r3_ | wc -l
+{ echo "# tools/ab_bu.py on the final sources: first vs second bottom-up body, knobs of the second, other sources"; cat $G/final_ab_bu_lj.log $G/final_ab_bu_kron.log $G/final_ab_bu_twitter.log | cut -c1-420; echo; echo "# per-wave phase clocks of the second body, LJ stand-in"; cat $G/final_bu_debug_lj.log; } > $P/r3_ab_bottomup_final_sources.txt

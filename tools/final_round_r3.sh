@@ -15,6 +15,8 @@ if [ "${FINAL_SHORT:-0}" != 1 ]; then
   timeout 300 python tools/ab_r3.py lj 20 > gpurun_out/final_ab_lj.log 2>&1
   timeout 300 python tools/ab_r3.py kron 10 > gpurun_out/final_ab_kron.log 2>&1
   timeout 400 python tools/ab_r3.py twitter 5 > gpurun_out/final_ab_twitter.log 2>&1
+  for g in lj kron twitter; do timeout 400 python tools/ab_bu.py $g 20 2>&1 | grep -v amdgpu.ids > gpurun_out/final_ab_bu_$g.log; done
+  for l in 1 2 3; do GRX_BU_DEBUG=$l timeout 200 python tools/bu_debug.py lj 2>&1 | grep -v amdgpu.ids; done > gpurun_out/final_bu_debug_lj.log
   GRX_BIN_DEBUG=1 timeout 200 python tools/bin_debug.py lj > gpurun_out/final_bin_debug_l1.log 2>&1
   GRX_BIN_DEBUG=2 timeout 200 python tools/bin_debug.py lj > gpurun_out/final_bin_debug_l2.log 2>&1
   timeout 1200 python tests/tools/bench_all.py bfs_lj bfs_kron bfs_road sssp_road ssspu_road pr_kron bfs_twitter > gpurun_out/final_bench_all.log 2>&1
