@@ -298,6 +298,13 @@ def main():
     edges_rank = st["edges_visited"]
     mteps = edges_rank / (ms_per_step * 1e3)
     bfs_gpu_depths = dist_t.cpu().numpy().copy()
+    # (the forward-only section is timed HERE, before the CPU legs: its timed region right behind the 128-thread leg once
+    # measured 4.3 ms per step with 0.44 on both repetitions -- the host thread that enqueues the level groups was
+    # competing with the runtime's spinning worker threads)
+    fwd = None
+    if "bfs_forward" in only and not args.topdown_only:
+        ms_f, st_f, rep_f = bfs_section(gr.forward)
+        fwd = (ms_f, st_f, rep_f, bool(np.array_equal(dist_t.cpu().numpy(), bfs_gpu_depths)))
 
     roofline_td = forward_roofline()
     if args.topdown_only:
@@ -367,9 +374,8 @@ def main():
            "roofline": roofline, "roofline_topdown_advance": roofline_other,
            "cpu_baseline": cpu, "cpu_baseline_ncore": cpu_n}
 
-    if "bfs_forward" in only and not args.topdown_only:
-        ms_f, st_f, rep_f = bfs_section(gr.forward)
-        ok = bool(np.array_equal(dist_t.cpu().numpy(), bfs_gpu_depths))
+    if fwd is not None:
+        ms_f, st_f, rep_f, ok = fwd
         out["bfs_forward"] = {
             "config": "BASELINE configs[1] as written: merge-path advance + compact filter, advance_direction=forward, "
                       "same graph/source",

@@ -457,6 +457,7 @@ GRX_MID_FN void mid_levels_body(const pipe_args& a, ctrl_t* c, Policy& pol, mid_
                                              __HIP_MEMORY_SCOPE_AGENT);
       mb64[2] = (long long)wall_clock64() - c->t_start;
       a.mailbox[1] = level;
+      a.mailbox[11] = c->bin_want;  // (as publish_done: the host's hint for the next forward search on the graph)
       __threadfence_system();
       a.mailbox[0] = 1;
     }
@@ -889,6 +890,7 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
                                              __HIP_MEMORY_SCOPE_AGENT);
       mb64[2] = (long long)wall_clock64() - c->t_start;
       a.mailbox[1] = level;
+      a.mailbox[11] = c->bin_want;  // (as publish_done: the host's hint for the next forward search on the graph)
       __threadfence_system();
       a.mailbox[0] = 1;
     }
