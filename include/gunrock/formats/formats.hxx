@@ -2,3 +2,4 @@
 #pragma once
 #include <gunrock/formats/coo.hxx>
 #include <gunrock/formats/csr.hxx>
+#include <gunrock/formats/csc.hxx>

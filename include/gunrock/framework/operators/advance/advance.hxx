@@ -29,6 +29,19 @@ namespace gunrock {
 namespace operators {
 namespace advance {
 
+namespace detail {
+// advance_direction_t::backward: the operator still sees an edge as (source, destination, edge, weight) although the walk
+// starts from the destination
+template <typename operator_t>
+struct swap_ends_t {
+  operator_t op;
+  template <typename vertex_t, typename edge_t, typename weight_t>
+  __host__ __device__ bool operator()(vertex_t const& dst, vertex_t const& src, edge_t const& e, weight_t const& w) const {
+    return op(src, dst, e, w);
+  }
+};
+}  // namespace detail
+
 template <load_balance_t lb = load_balance_t::merge_path,
           advance_direction_t direction = advance_direction_t::forward,
           advance_io_type_t input_type = advance_io_type_t::vertices,
@@ -40,6 +53,20 @@ void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, w
   using type_t = typename frontier_t::type_t;
   using edge_t = typename graph_t::edge_type;
   error::throw_if_exception(context.size() != 1, "`context.size() != 1` not supported");
+  if constexpr (direction == advance_direction_t::backward) {
+    // Pull: for every vertex v of the input, visit the IN-edges (u -> v) of v -- the graph's CSC view -- call
+    // op(u, v, e, w) (e indexes the CSC arrays) and emit u, or -1, at the slot of that in-edge: the forward advance of the
+    // reversed graph with the operator's ends swapped back, on the same load-balanced kernels.  The reference declares the
+    // enum (operators/configs.hxx:78-82) and passes the template argument down without ever reading it.
+    // advance_direction_t::optimized stays forward here: when to pull is the algorithm's decision (the BFS engine takes it
+    // per level), not something an operator can know from a functor.
+    static_assert(graph_t::has_csc_view,
+                  "advance_direction_t::backward needs a graph with a CSC view: graph::build(properties, csr, csc)");
+    auto R = G.reverse_view();
+    execute<lb, advance_direction_t::forward, input_type, output_type>(R, detail::swap_ends_t<operator_t>{op}, input, output,
+                                                                       segments, context);
+    return;
+  }
   static_assert(input_type != advance_io_type_t::edges && input_type != advance_io_type_t::none,
                 "advance input must be `vertices` or `graph`");
   static_assert(lb != load_balance_t::work_stealing, "Load balance type not supported.");

@@ -11,6 +11,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <gunrock/graph/properties.hxx>
 #include <gunrock/memory.hxx>
 #include <gunrock/util/load_store.hxx>
@@ -40,6 +42,27 @@ struct graph_csr_t {
   }
 };
 
+// The in-edges of every vertex (reference: graph/csc.hxx:23-142): column_offsets[v] .. column_offsets[v + 1] index
+// row_indices = the SOURCES of the edges that end in v.  A graph may carry it beside the CSR view
+// (graph::build(properties, csr, csc)); it is what advance_direction_t::backward walks.
+template <memory_space_t space, typename vertex_t, typename edge_t, typename weight_t>
+struct graph_csc_t {
+  vertex_t c_number_of_vertices = 0;
+  edge_t c_number_of_edges = 0;
+  const edge_t* c_offsets = nullptr;
+  const vertex_t* c_indices = nullptr;
+  const weight_t* c_values = nullptr;
+
+  template <typename csc_like_t>
+  void set(csc_like_t& csc) {
+    c_number_of_vertices = csc.number_of_columns;
+    c_number_of_edges = csc.number_of_nonzeros;
+    c_offsets = memory::raw_pointer_cast(csc.column_offsets.data());
+    c_indices = memory::raw_pointer_cast(csc.row_indices.data());
+    c_values = memory::raw_pointer_cast(csc.nonzero_values.data());
+  }
+};
+
 template <memory_space_t space, typename vertex_t, typename edge_t, typename weight_t, typename... views_t>
 class graph_t : public views_t... {
   using first_view_t = graph_csr_t<space, vertex_t, edge_t, weight_t>;
@@ -51,6 +74,10 @@ class graph_t : public views_t... {
   using vertex_pointer_t = vertex_t*;
   using edge_pointer_t = edge_t*;
   using weight_pointer_t = weight_t*;
+
+  using graph_csr_view_t = first_view_t;
+  using graph_csc_view_t = graph_csc_t<space, vertex_t, edge_t, weight_t>;
+  static constexpr bool has_csc_view = (std::is_same<views_t, graph_csc_view_t>::value || ...);
 
   graph_properties_t properties;
 
@@ -101,6 +128,39 @@ class graph_t : public views_t... {
   __host__ __device__ __forceinline__ auto get_column_indices() const { return first_view_t::indices; }
   template <typename view_t = first_view_t>
   __host__ __device__ __forceinline__ auto get_nonzero_values() const { return first_view_t::values; }
+
+  // ---- CSC view (graphs built with one): in-degree, in-edges and their sources ----------------------------------
+  // (the reference spells these G.template get_number_of_neighbors<graph_csc_view_t>(v) etc.; its multi-view dispatch is
+  // by template argument on every accessor -- here the in-edge accessors have names of their own and the whole reversed
+  // graph is available as an ordinary CSR-shaped view, which is what the operators consume)
+  __host__ __device__ __forceinline__ edge_t get_number_of_in_neighbors(vertex_t const& v) const {
+    static_assert(has_csc_view, "this graph was built without a CSC view: graph::build(properties, csr, csc)");
+    return thread::load(&graph_csc_view_t::c_offsets[v + 1]) - thread::load(&graph_csc_view_t::c_offsets[v]);
+  }
+  __host__ __device__ __forceinline__ edge_t get_starting_in_edge(vertex_t const& v) const {
+    static_assert(has_csc_view, "this graph was built without a CSC view: graph::build(properties, csr, csc)");
+    return thread::load(&graph_csc_view_t::c_offsets[v]);
+  }
+  // source of in-edge e (an index into the CSC arrays, NOT a CSR edge id)
+  __host__ __device__ __forceinline__ vertex_t get_in_edge_source(edge_t const& e) const {
+    static_assert(has_csc_view, "this graph was built without a CSC view: graph::build(properties, csr, csc)");
+    return thread::load(&graph_csc_view_t::c_indices[e]);
+  }
+  __host__ __device__ __forceinline__ auto get_column_offsets() const { return graph_csc_view_t::c_offsets; }
+  __host__ __device__ __forceinline__ auto get_row_indices() const { return graph_csc_view_t::c_indices; }
+  // The reversed graph as a CSR-shaped view over the CSC arrays: row v lists the in-neighbours of v.  Non-owning, by value.
+  __host__ __device__ auto reverse_view() const {
+    static_assert(has_csc_view, "this graph was built without a CSC view: graph::build(properties, csr, csc)");
+    graph_t<space, vertex_t, edge_t, weight_t, first_view_t> R;
+    R.properties = properties;
+    first_view_t& r = R;
+    r.number_of_vertices = graph_csc_view_t::c_number_of_vertices;
+    r.number_of_edges = graph_csc_view_t::c_number_of_edges;
+    r.offsets = graph_csc_view_t::c_offsets;
+    r.indices = graph_csc_view_t::c_indices;
+    r.values = graph_csc_view_t::c_values;
+    return R;
+  }
 };
 
 }  // namespace graph

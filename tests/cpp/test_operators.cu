@@ -31,6 +31,13 @@ struct even_neighbors_t {  // keep neighbours with even id, count calls per sour
     return (n & 1) == 0;
   }
 };
+struct even_sources_t {  // backward advance: (source, destination) keep the edge's orientation; count calls per DESTINATION
+  int* calls;
+  __host__ __device__ bool operator()(vertex_t const& s, vertex_t const& n, edge_t const&, weight_t const&) const {
+    math::atomic::add(calls + n, 1);
+    return (s & 1) == 0;
+  }
+};
 struct less_than_t {
   vertex_t bound;
   int* seen_invalid;
@@ -187,6 +194,52 @@ int main() {
     bool ok = out == want;
     for (int v = 0; v < V && ok; ++v) ok = hc[v] == expect_calls[v];
     check("advance.execute_compact", ok);
+  }
+  // ---- advance_direction_t::backward over a CSC view: in-neighbours of the input, in CSC order ----------
+  {
+    format::csc_t<memory_space_t::device, vertex_t, edge_t, weight_t> csc;
+    csc.from_csr(csr);
+    auto G2 = graph::build<memory_space_t::device>(props, csr, csc);
+    std::vector<std::vector<int>> radj(V);
+    for (int r = 0; r < V; ++r)
+      for (int n : adj[r]) radj[n].push_back(r);  // rows ascending, file order inside a row: what from_csr produces
+    std::vector<int> want;
+    std::vector<int> want_calls(V, 0);
+    for (int v : input) {
+      if (v < 0) continue;
+      for (int u : radj[v]) { want.push_back((u & 1) == 0 ? u : -1); want_calls[v]++; }
+    }
+    auto run_backward = [&](auto lb_c, const char* name) {
+      constexpr operators::load_balance_t lb = decltype(lb_c)::value;
+      thrust::fill(calls.begin(), calls.end(), 0);
+      auto* in = E.get_input_frontier();
+      auto* out = E.get_output_frontier();
+      in->set_number_of_elements(0);
+      for (int v : input) in->push_back(v);
+      operators::advance::execute<lb, operators::advance_direction_t::backward, operators::advance_io_type_t::vertices,
+                                  operators::advance_io_type_t::vertices>(G2, even_sources_t{calls.data().get()}, in, out,
+                                                                          E.scanned_work_domain, *context);
+      auto got = download(*out);
+      thrust::host_vector<int> hc = calls;
+      bool ok = got == want;
+      for (int v = 0; v < V && ok; ++v) ok = hc[v] == want_calls[v];
+      check(name, ok);
+    };
+    run_backward(std::integral_constant<operators::load_balance_t, operators::load_balance_t::thread_mapped>{}, "advance.backward.thread_mapped");
+    run_backward(std::integral_constant<operators::load_balance_t, operators::load_balance_t::block_mapped>{}, "advance.backward.block_mapped");
+    run_backward(std::integral_constant<operators::load_balance_t, operators::load_balance_t::merge_path>{}, "advance.backward.merge_path");
+    // forward on the same two-view graph is the CSR advance it always was
+    {
+      thrust::fill(calls.begin(), calls.end(), 0);
+      auto* in = E.get_input_frontier();
+      auto* out = E.get_output_frontier();
+      in->set_number_of_elements(0);
+      for (int v : input) in->push_back(v);
+      operators::advance::execute<operators::load_balance_t::merge_path, operators::advance_direction_t::forward,
+                                  operators::advance_io_type_t::vertices, operators::advance_io_type_t::vertices>(
+          G2, even_neighbors_t{calls.data().get()}, in, out, E.scanned_work_domain, *context);
+      check("advance.forward_on_two_view_graph", download(*out) == expect);
+    }
   }
   {
     bool threw = false;
