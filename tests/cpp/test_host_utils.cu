@@ -1,7 +1,8 @@
-// Host-only checks of the header utilities that need no GPU: operators::batch::execute and
-// generate::random (reference: framework/operators/batch/batch.hxx:70-94,
-// algorithms/generate/random.hxx:20-52).  Built with hipcc, runs on the CPU.
+// Host-only checks of the header utilities that need no GPU: operators::batch::execute,
+// generate::random and format::csc_t::from_csr (reference: framework/operators/batch/batch.hxx:70-94,
+// algorithms/generate/random.hxx:20-52, formats/csc.hxx:62-101).  Built with hipcc, runs on the CPU.
 #include <gunrock/algorithms/generate/random.hxx>
+#include <gunrock/formats/formats.hxx>
 #include <gunrock/framework/operators/batch/batch.hxx>
 
 #include <atomic>
@@ -70,6 +71,26 @@ int main() {
     CHECK(a == b);
     const float r = generate::random::get_random<float>(5.0f, 6.0f);
     CHECK(r >= 5.0f && r <= 6.0f);
+  }
+  // csc_t::from_csr: the transpose, entries of a column in row order (duplicates and self loops kept), values carried along
+  {
+    using csr_h = format::csr_t<memory_space_t::host, int, int, float>;
+    using coo_h = format::coo_t<memory_space_t::host, int, int, float>;
+    const int I[] = {0, 0, 2, 2, 2, 3, 1, 0}, J[] = {1, 3, 0, 3, 3, 3, 1, 1};  // file order; (2,3) twice, loops (3,3), (1,1)
+    coo_h coo(4, 4, 8);
+    for (int k = 0; k < 8; ++k) { coo.row_indices[k] = I[k]; coo.column_indices[k] = J[k]; coo.nonzero_values[k] = 10.0f * I[k] + J[k]; }
+    csr_h csr;
+    csr.from_coo(coo);
+    format::csc_t<memory_space_t::host, int, int, float> csc;
+    csc.from_csr(csr);
+    const std::vector<int> want_off = {0, 1, 4, 4, 8};
+    const std::vector<int> want_rows = {2, 0, 0, 1, 0, 2, 2, 3};  // column 1: rows 0 (file order: two entries), 1; column 3: 0, 2, 2, 3
+    bool ok = csc.number_of_rows == 4 && csc.number_of_columns == 4 && csc.number_of_nonzeros == 8;
+    for (int c = 0; c <= 4 && ok; ++c) ok = csc.column_offsets[c] == want_off[c];
+    for (int k = 0; k < 8 && ok; ++k) ok = csc.row_indices[k] == want_rows[k];
+    for (int c = 0; c < 4 && ok; ++c)
+      for (int k = want_off[c]; k < want_off[c + 1] && ok; ++k) ok = csc.nonzero_values[k] == 10.0f * csc.row_indices[k] + c;
+    CHECK(ok);
   }
   std::printf(failures ? "FAILED\n" : "ALL CHECKS PASSED\n");
   return failures ? 1 : 0;
