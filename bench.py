@@ -85,14 +85,8 @@ def load_workload(gr, key, data_dir=None, weighted=False, seed=42):
         csr = gr.csr_t().from_coo(coo)
         info = {"data": "real", "file": path, "name": "%s (%s)" % (wl["file"], os.path.basename(path))}
         if weighted and not props.weighted:
-            # a weight per UNORDERED pair, so that w(u, v) == w(v, u) on a symmetric file: a hash of (min, max, seed)
-            u = np.repeat(np.arange(csr.number_of_rows, dtype=np.uint64), np.diff(csr.row_offsets).astype(np.int64))
-            v = csr.column_indices.astype(np.uint64)
-            h = np.minimum(u, v) * np.uint64(2654435761) + np.maximum(u, v) * np.uint64(2246822519) + np.uint64(seed)
-            h ^= h >> np.uint64(13)
-            h *= np.uint64(0x9E3779B1)
-            h ^= h >> np.uint64(17)
-            csr.nonzero_values = (1 + (h % np.uint64(1000))).astype(np.float32)
+            csr.nonzero_values = pair_hash_weights(csr, seed)
+            csr._device = None
             props.weighted = True
             info["data"] = "real topology, synthetic U{1..1000} weights"
         src = int(np.argmax(np.diff(csr.row_offsets)))
@@ -193,6 +187,28 @@ def timed(run, sync, steps, warmup):
             gc.enable()
 
 
+def pair_hash_weights(csr, seed=42):
+    """U{1..1000} integer weights, one per UNORDERED vertex pair (w(u, v) == w(v, u) on a symmetric graph): a hash of
+    (min, max, seed).  Drawn onto pattern topologies (the published LJ / kron / road / twitter files are all pattern
+    matrices; the reference loader gives them 1.0 everywhere, io/matrix_market.hxx:170-171) for the weighted SSSP sections."""
+    u = np.repeat(np.arange(csr.number_of_rows, dtype=np.uint64), np.diff(csr.row_offsets).astype(np.int64))
+    v = csr.column_indices.astype(np.uint64)
+    h = np.minimum(u, v) * np.uint64(2654435761) + np.maximum(u, v) * np.uint64(2246822519) + np.uint64(seed)
+    h ^= h >> np.uint64(13)
+    h *= np.uint64(0x9E3779B1)
+    h ^= h >> np.uint64(17)
+    return (1 + (h % np.uint64(1000))).astype(np.float32)
+
+
+def slim(r, keys=("frac", "achieved", "peak", "unit", "bound", "traffic", "avg_launch_us", "launches_per_step",
+                  "alg_bytes_per_step", "kernel_ms_per_step", "fat_levels_frac", "rocprof_avg_launch_us")):
+    return None if r is None else {k: r[k] for k in keys if k in r}
+
+
+def cpu_slim(c):
+    return None if c is None else {k: c[k] for k in ("value", "unit", "cores", "kind", "matches_gpu") if k in c}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,18 +216,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="lj", choices=sorted(WORKLOADS),
                     help="graph of the top-level BFS line (default: BASELINE configs[1])")
-    ap.add_argument("--only", default="bfs,bfs_forward,sssp,pr,c5",
-                    help="comma list of the sections to run at N = 1 (bfs is always run)")
+    ap.add_argument("--only", default="bfs,bfs_do,multi,sssp,sssp_lj,sssp_kron,pr,pr_lj,c5",
+                    help="comma list of the sections to run at N = 1 (bfs = the top-level forward search, always run)")
     ap.add_argument("--data-dir", default=os.environ.get("GRX_DATA_DIR", ""),
                     help="directory holding the published graphs (soc-LiveJournal1.mtx, road_usa.mtx, "
                          "kron_g500-logn21.mtx, soc-twitter-2010.mtx, flat or one folder each): every section whose "
                          "file is present runs on it (data: real) instead of its seeded stand-in")
     ap.add_argument("--lb", default="merge_path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--topdown-only", action="store_true",
-                    help="top-level line with advance_direction=forward (every level runs the top-down advance)")
+    ap.add_argument("--detail", default=os.environ.get("GRX_BENCH_DETAIL", ""),
+                    help="file that receives the FULL objects of every section (per-level arrays, kernel names, samples); "
+                         "default gpurun_out/bench_detail.json when that directory exists.  stdout carries ONE compact line")
+    ap.add_argument("--topdown-only", action="store_true", help="(kept for old command lines: the top level IS forward now)")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
+    if "bfs_forward" in only:  # round-3 name of what is now the top level
+        only.add("bfs_do")
 
     import torch
     import gunrock_amd as gr
@@ -227,6 +247,8 @@ def main():
     ctx = gr.multi_context_t(local_rank)
     pmc = load_pmc()
     cpu_on = not args.no_cpu_baseline
+    O = None
+    ncore = 0
     if cpu_on:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O  # checker / timed CPU baseline only
@@ -236,10 +258,11 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    env = dict(gr=gr, torch=torch, ctx=ctx, dev=dev, sync=sync, pmc=pmc, cpu_on=cpu_on, O=O, ncore=ncore, args=args)
     lb = getattr(gr, args.lb)
+    INF = np.iinfo(np.int32).max
 
-    # ------------------------------------------------------------------ BFS (top level) + bfs_forward
-    wl = WORKLOADS[args.workload]
+    # ------------------------------------------------------------------ BFS on the configs[1] graph
     t0 = time.time()
     props, csr, src, info = load_workload(gr, args.workload, args.data_dir)
     G = gr.build_graph(props, csr, ctx, device=dev)
@@ -251,21 +274,26 @@ def main():
         return gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact,
                             advance_direction=direction, engine_flags=flags)
 
-    # the first search with a direction builds what the graph handle caches for it (direction-optimising: the symmetry
-    # check or the transpose + the "no in-edges" bitmap; forward: the bin table + the E-entry bin array): untimed, like the
-    # CSR build, and disclosed in `config`
-    first_call_s = {}
-    for direction0 in ((gr.forward,) if args.topdown_only else (gr.optimized, gr.forward)):
-        t1 = time.perf_counter()
-        gr.bfs(G, src, dist_t, None, ctx, bfs_opts(direction0))
+    # ONE-SHOT cost: the first search on a fresh graph handle builds what the handle caches for its direction (forward: bin
+    # table + E-entry bin array; direction-optimising: symmetry check or transpose, no-in-edges bitmap, two-neighbour
+    # array) and then searches.  Untimed for `value` (like the CSR build), reported per direction.
+    first_call_ms = {}
+    do_dirs = (gr.forward, gr.optimized) if "bfs_do" in only else (gr.forward,)
+    for direction0 in do_dirs:
+        G0 = gr.build_graph(props, csr, ctx, device=dev) if direction0 != gr.forward else G
         sync()
-        first_call_s[direction0] = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        gr.bfs(G0, src, dist_t, None, ctx, bfs_opts(direction0))
+        sync()
+        first_call_ms[direction0] = (time.perf_counter() - t1) * 1e3
+        if G0 is not G:
+            gr.bfs(G, src, dist_t, None, ctx, bfs_opts(direction0))  # the handle the timed steps use
+            del G0
 
     def bfs_section(direction):
         o = bfs_opts(direction, gr.FLAG_ASYNC_RETURN)
         ms_step = timed(lambda: gr.bfs(G, src, dist_t, None, ctx, o), sync, args.steps, args.warmup)
         st = gr.run_stats(ctx)
-        # run-to-run spread of the same K-step measurement (two more repetitions; `value` is the FIRST one)
         rep = [round(timed(lambda: gr.bfs(G, src, dist_t, None, ctx, o), sync, args.steps, 0), 4) for _ in range(2)]
         return ms_step, st, rep
 
@@ -278,54 +306,64 @@ def main():
         po = bfs_opts(direction, gr.FLAG_PROFILE)
         return best_profile(lambda: gr.bfs(G, src, dist_t, None, ctx, po), lambda: gr.level_profile(ctx))
 
-    def forward_roofline():
-        prof = bfs_profile(gr.forward)
-        r = roof(prof, td_bytes, "bfs level kernels, forward-only run: claim-per-edge advance (advance_block) on the "
-                 "thin levels, binned advance (scatter kernel + sweep claim kernel, grx_bin.hpp) on the fat ones",
-                 "12 B per frontier slot + 12 B per traversed edge (SURVEY 8d)")
-        attach_traffic(r, pmc, "topdown_fat")
-        fat = sorted(prof, key=lambda l: -l["edges"])[:2]
-        r["fat_levels_avg_launch_us"] = round(sum(l["advance_ms"] for l in fat) * 1e3 / max(1, len(fat)), 2)
-        r["fat_levels_frac"] = round(sum(td_bytes(l) for l in fat) / max(1e-9, sum(l["advance_ms"] for l in fat) * 1e-3)
-                                     / 1e9 / HBM_PEAK_GBS, 4)
-        r["levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
-                        round(l["other_ms"], 4)] for l in prof]
-        r["levels_columns"] = "frontier vertices, out-edges, mode (2 = binned), level kernel(s) ms, head kernel ms"
-        return r
-
-    direction = gr.forward if args.topdown_only else gr.optimized
-    ms_per_step, st, rep_ms = bfs_section(direction)
+    # --- top level: configs[1] AS WRITTEN -- forward merge-path advance + compact filter
+    ms_per_step, st, rep_ms = bfs_section(gr.forward)
     edges_rank = st["edges_visited"]
     mteps = edges_rank / (ms_per_step * 1e3)
     bfs_gpu_depths = dist_t.cpu().numpy().copy()
-    # (the forward-only section is timed HERE, before the CPU legs: its timed region right behind the 128-thread leg once
-    # measured 4.3 ms per step with 0.44 on both repetitions -- the host thread that enqueues the level groups was
-    # competing with the runtime's spinning worker threads)
-    fwd = None
-    if "bfs_forward" in only and not args.topdown_only:
-        ms_f, st_f, rep_f = bfs_section(gr.forward)
-        fwd = (ms_f, st_f, rep_f, bool(np.array_equal(dist_t.cpu().numpy(), bfs_gpu_depths)))
+    prof = bfs_profile(gr.forward)
+    roofline = roof(prof, td_bytes, "forward BFS level kernels: advance_block on thin levels; bfs_scatter2_kernel + "
+                    "bfs_sweep2_kernel (grx_bin.hpp) on fat ones", "12 B per frontier slot + 12 B per traversed edge (SURVEY 8d)")
+    attach_traffic(roofline, pmc, "topdown_fat")
+    fat = sorted(prof, key=lambda l: -l["edges"])[:2]
+    roofline["fat_levels_avg_launch_us"] = round(sum(l["advance_ms"] for l in fat) * 1e3 / max(1, len(fat)), 2)
+    roofline["fat_levels_frac"] = round(sum(td_bytes(l) for l in fat) / max(1e-9, sum(l["advance_ms"] for l in fat) * 1e-3)
+                                        / 1e9 / HBM_PEAK_GBS, 4)
+    roofline["levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
+                           round(l["other_ms"], 4)] for l in prof]
+    roofline["levels_columns"] = "frontier vertices, out-edges, mode (2 = binned), level kernel(s) ms, head kernel ms"
 
-    roofline_td = forward_roofline()
-    if args.topdown_only:
-        roofline, roofline_other = roofline_td, None
-    else:
+    # --- direction-optimising search on the same graph (engine extension)
+    do = None
+    if "bfs_do" in only:
+        ms_d, st_d, rep_d = bfs_section(gr.optimized)
+        same = bool(np.array_equal(dist_t.cpu().numpy(), bfs_gpu_depths))
         prof_do = bfs_profile(gr.optimized)
         sizes = [l["frontier_size"] for l in prof_do] + [0]
         bu = [dict(l, nxt=sizes[i + 1]) for i, l in enumerate(prof_do) if l["bottom_up"] == 1]
         td = [l for l in prof_do if l["bottom_up"] != 1]
-        t_bu = sum(l["advance_ms"] for l in bu)
-        t_td = sum(l["advance_ms"] for l in td)
         r_bu = roof(bu, lambda l: bu_bytes(l, l["nxt"]), "bfs_level_kernel (bottom-up launches)",
                     "3 V/8 + 8 open + 8 probes + 12 found (DESIGN.md 5)")
-        r_bu["levels"] = [[l["frontier_size"], l["edges"], l["bu_open"], l["bu_probes"], round(l["advance_ms"], 4),
-                           round(l["other_ms"], 4)] for l in bu]
+        t_bu, t_td = sum(l["advance_ms"] for l in bu), sum(l["advance_ms"] for l in td)
         r_bu["share_of_step_kernel_time"] = round(t_bu / max(t_bu + t_td, 1e-9), 3)
         if bu:
             attach_traffic(r_bu, pmc, "bottom_up")
-        roofline, roofline_other = (r_bu, roofline_td) if t_bu >= t_td or not td else (roofline_td, r_bu)
-        roofline["all_levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
-                                   round(l["other_ms"], 4)] for l in prof_do]
+        r_bu["all_levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), l["bu_open"], l["bu_probes"],
+                               round(l["advance_ms"], 4), round(l["other_ms"], 4)] for l in prof_do]
+        # what a direction-optimising search really reads: out-edges of the top-down levels + in-edges probed bottom-up
+        scanned = int(sum(l["edges"] for l in td) + sum(l["bu_probes"] for l in bu))
+        do = {"config": "same graph / source, advance_direction = optimized (Beamer switch decided per level on the device)",
+              "ms_per_step": round(ms_d, 4), "mteps": round(st_d["edges_visited"] / (ms_d * 1e3), 1),
+              "mteps_convention": "Graph500 / reference edges_visited: sum of out-degrees of the reached vertices",
+              "edges_actually_scanned": scanned, "mteps_edges_actually_scanned": round(scanned / (ms_d * 1e3), 1),
+              "ms_per_step_repeated": rep_d, "steps": args.steps, "search_depth": st_d["search_depth"],
+              "enact_ms_last": round(st_d["elapsed_ms"], 4), "equal_to_forward_depths": same,
+              "first_call_ms": round(first_call_ms[gr.optimized], 3), "one_shot_ms": round(first_call_ms[gr.optimized], 3),
+              "roofline": r_bu}
+
+    # --- other sources: 16 vertices of the giant component, each searched ONCE, on a handle whose launch-group hint was
+    # trained by a different source (reference: io/parameters.hxx:192-223 -- several / random sources)
+    multi = None
+    if "multi" in only:
+        multi = bench_multi_source(env, G, csr, src, dist_t, bfs_gpu_depths, bfs_opts, do is not None)
+
+    # --- SSSP and PageRank on the same graph (north_star: BFS / SSSP / PR on soc-LiveJournal1 and kron_g500-logn21)
+    tag = args.workload
+    extra = {}
+    if tag != "kron" and ("sssp_" + tag) in only:
+        extra["sssp_" + tag] = bench_sssp_on(env, tag, props, csr, src, info, G_unit=G)
+    if tag != "kron" and ("pr_" + tag) in only:
+        extra["pr_" + tag] = bench_pr_on(env, tag, props, csr, info)
 
     cpu = cpu_n = None
     if cpu_on:
@@ -350,53 +388,311 @@ def main():
                            "reference's advance with atomicMin, bfs.hxx:105-146, per level), %.1f s"
                            % (runs_n, ncore, t_n / 1e3),
                  "matches_gpu": bool(np.array_equal(d_n, bfs_gpu_depths))}
-
-    out = {"metric": "MTEPS (million traversed edges/sec) BFS", "value": round(mteps, 1), "unit": "MTEPS",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": info["data"],
-           "config": {"workload": "BFS on " + info["name"], "data_file": info["file"], "n_vertices": V, "n_edges": E, "source": src,
-                      "advance_load_balance": args.lb + " (engine: tile/chunk merge-path decomposition; a per-level "
-                                              "choice between claim-per-edge, binned and bottom-up bodies is made on "
-                                              "the device)",
-                      "filter": "compact (fused into advance)",
-                      "advance_direction": "forward" if args.topdown_only else "optimized",
-                      "completion": "GRX_FLAG_ASYNC_RETURN (return when the device publishes the end of the search; "
-                                    "the K steps are bracketed by stream synchronisation)",
-                      "kernel_launch_groups_per_step": int(st["aux"]), "parallelism": "single GPU",
-                      "edges_visited_per_step": edges_rank, "search_depth": st["search_depth"],
-                      "enact_ms_last": round(st["elapsed_ms"], 4), "setup_s": round(t_setup, 1),
-                      "ms_per_step_repeated": rep_ms,
-                      "first_call_s_incl_graph_preprocessing": round(first_call_s[direction], 4),
-                      "graph_preprocessing_note": "untimed, once per graph handle: direction-optimising = symmetry check or "
-                                                  "transpose build + no-in-edges bitmap; forward = bin table + E-entry bin "
-                                                  "array; box-to-box spread of `value` is about +-4 % (BASELINE.md)",
-                      "engine_source_sha": source_sha()},
-           "roofline": roofline, "roofline_topdown_advance": roofline_other,
-           "cpu_baseline": cpu, "cpu_baseline_ncore": cpu_n}
-
-    if fwd is not None:
-        ms_f, st_f, rep_f, ok = fwd
-        out["bfs_forward"] = {
-            "config": "BASELINE configs[1] as written: merge-path advance + compact filter, advance_direction=forward, "
-                      "same graph/source",
-            "ms_per_step": round(ms_f, 4), "mteps": round(st_f["edges_visited"] / (ms_f * 1e3), 1),
-            "ms_per_step_repeated": rep_f,
-            "first_call_s_incl_graph_preprocessing": round(first_call_s[gr.forward], 4),
-            "steps": args.steps, "edges_visited_per_step": st_f["edges_visited"], "search_depth": st_f["search_depth"],
-            "enact_ms_last": round(st_f["elapsed_ms"], 4), "equal_to_direction_optimized_depths": ok,
-            "roofline": roofline_td, "cpu_baseline": cpu, "cpu_baseline_ncore": cpu_n}
+        del g
     del G, dist_t
 
-    # ------------------------------------------------------------------ SSSP on the road stand-in
+    detail = {"metric": "MTEPS (million traversed edges/sec) BFS", "value": round(mteps, 1), "unit": "MTEPS",
+              "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": info["data"],
+              "config": {"workload": "BFS on " + info["name"] + " -- BASELINE.json configs[1] as written: merge-path "
+                                     "advance + compact filter, advance_direction = forward",
+                         "data_file": info["file"], "n_vertices": V, "n_edges": E, "source": src,
+                         "advance_load_balance": args.lb, "filter": "compact (fused into the advance)",
+                         "advance_direction": "forward", "completion": "GRX_FLAG_ASYNC_RETURN, K steps bracketed by syncs",
+                         "parallelism": "single GPU (the single-GPU engine; the partitioned path is used for N > 1 only)",
+                         "edges_visited_per_step": edges_rank, "search_depth": st["search_depth"],
+                         "enact_ms_last": round(st["elapsed_ms"], 4), "ms_per_step_repeated": rep_ms,
+                         "first_call_ms": round(first_call_ms[gr.forward], 3),
+                         "one_shot_ms": round(first_call_ms[gr.forward], 3),
+                         "one_shot_note": "fresh graph handle: per-graph preprocessing + one search",
+                         "setup_s": round(t_setup, 1), "engine_source_sha": source_sha()},
+              "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_ncore": cpu_n,
+              "bfs_direction_optimized": do, "multi_source": multi}
+    detail.update(extra)
+    del csr
+
+    # ------------------------------------------------------------------ the other graphs
     if "sssp" in only:
-        out["sssp"] = bench_sssp(gr, torch, ctx, dev, sync, pmc, cpu_on, args)
-    # ------------------------------------------------------------------ PageRank on the kron stand-in
-    if "pr" in only:
-        out["pr"] = bench_pr(gr, torch, ctx, dev, sync, pmc, cpu_on, args)
-    # ------------------------------------------------------------------ configs[4] graph (C5') on ONE GPU
+        detail["sssp_road"] = bench_sssp_on(env, "road", None, None, None, None)
+    if "pr" in only or "sssp_kron" in only:
+        props_k, csr_k, src_k, info_k = load_workload(gr, "kron", args.data_dir)
+        if "pr" in only:
+            detail["pr_kron"] = bench_pr_on(env, "kron", props_k, csr_k, info_k)
+        if "sssp_kron" in only:
+            detail["sssp_kron"] = bench_sssp_on(env, "kron", props_k, csr_k, src_k, info_k)
+        del csr_k
     if "c5" in only:
-        out["c5_single_gpu"] = bench_c5(gr, torch, ctx, dev, sync, cpu_on, args)
-    print(json.dumps(out))
+        detail["c5_single_gpu"] = bench_c5(gr, torch, ctx, dev, sync, cpu_on, args)
+
+    # ------------------------------------------------------------------ output: the full objects to a file, ONE compact line to stdout
+    path = args.detail or (os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+                           if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "")
+    if path:
+        try:
+            with open(path, "w") as f:
+                json.dump(detail, f)
+        except OSError:
+            path = ""
+    line = {k: detail[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                   "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = dict(detail["config"])
+    sec = {}
+    if do:
+        sec["bfs_do"] = {"ms": do["ms_per_step"], "mteps": do["mteps"], "mteps_scanned": do["mteps_edges_actually_scanned"],
+                         "frac": do["roofline"]["frac"], "first_call_ms": do["first_call_ms"], "eq_fwd": do["equal_to_forward_depths"]}
+    if multi:
+        sec["multi_source"] = {k: multi[k] for k in ("n_sources", "forward_mteps", "forward_vs_single_source",
+                                                      "forward_cold_mteps", "do_mteps", "violations") if k in multi}
+    for name, it in detail.items():
+        if name.startswith("sssp_") and it:
+            for lab in ("unit_weights", "weighted_1_1000"):
+                x = it.get(lab)
+                if x:
+                    sec["%s_%s" % (name, "unit" if lab == "unit_weights" else "w")] = {
+                        "ms": x["ms_per_step"], "mteps": x["mteps"], "frac": x["roofline"]["frac"],
+                        "cpu1_mteps": (x["cpu_baseline"] or {}).get("value"), "eq_cpu": (x["cpu_baseline"] or {}).get("matches_gpu"),
+                        "viol": x.get("property_check_violations")}
+        if name.startswith("pr_") and it:
+            sec[name] = {"ms": it["ms_per_step"], "iters": it["iterations"], "ms_per_iter": it["ms_per_iteration"],
+                         "mteps": it["mteps"], "frac": it["roofline"]["frac"], "first_call_ms": it["first_call_ms"],
+                         "d_f64": it.get("max_abs_diff_to_float64_same_iterations"),
+                         "cpu1_mteps": (it["cpu_baseline"] or {}).get("value")}
+    c5 = detail.get("c5_single_gpu")
+    if c5:
+        sec["c5_1gpu"] = {"fwd_ms": c5["forward"]["ms_per_step"], "fwd_mteps": c5["forward"]["mteps"],
+                          "fwd_frac": (c5["forward"]["roofline"] or {}).get("frac"),
+                          "do_ms": c5["direction_optimized"]["ms_per_step"], "do_mteps": c5["direction_optimized"]["mteps"],
+                          "viol": c5.get("property_check_violations")}
+    cfg["sections"] = sec
+    cfg["sections_note"] = ("ms = ms per step (search / run), frac = roofline fraction of the section's dominant kernels, "
+                            "cpu1 = 1-core oracle on the same workload, eq_cpu = GPU result == oracle's, viol = oracle "
+                            "fixed-point violations; full objects: " + (os.path.relpath(path, ROOT) if path else "--detail FILE"))
+    line["config"] = cfg
+    r = slim(roofline)
+    r["kernel"] = "forward BFS level kernels (advance_block; bfs_scatter2 + bfs_sweep2 on fat levels)"
+    r["traffic_class"] = "topdown_fat (per fat level)" if roofline.get("traffic") else None
+    line["roofline"] = r
+    line["cpu_baseline"] = None if cpu is None else dict(cpu_slim(cpu), sample=cpu["sample"][:120])
+    line["cpu_baseline_ncore"] = cpu_slim(cpu_n)
+    print(json.dumps(line))
+
+
+def bench_multi_source(env, G, csr, src, dist_t, depths, bfs_opts, with_do):
+    """Sources other than the one the handle's launch-group hint was trained on: 16 seeded vertices of
+    the main source's component with out-edges, each searched ONCE in random order, every search timed on its own between
+    two synchronisations; harmonic-mean rate = sum of edges / sum of times.  `forward_cold`: the same with GRX_BIN_HINT=0
+    (every launch group carries the scatter / sweep kernels -- no dependence on history at all)."""
+    gr, ctx, sync, O = env["gr"], env["ctx"], env["sync"], env["O"]
+    INF = np.iinfo(np.int32).max
+    deg = np.diff(csr.row_offsets)
+    cand = np.nonzero((depths != INF) & (deg > 0))[0]
+    rng = np.random.default_rng(7)
+    srcs = [int(x) for x in rng.choice(cand, size=min(16, len(cand)), replace=False)]
+    res = {"n_sources": len(srcs), "sources": srcs,
+           "protocol": "hint trained on the bench source, then each source once, random order, per-search wall time"}
+
+    def sweep(direction, cold=False):
+        if cold:
+            os.environ["GRX_BIN_HINT"] = "0"
+        try:
+            o = bfs_opts(direction, gr.FLAG_ASYNC_RETURN)
+            gr.bfs(G, src, dist_t, None, ctx, o)  # (re)train on the bench source
+            sync()
+            tot_e, tot_t, per = 0, 0.0, []
+            for s in srcs:
+                t1 = time.perf_counter()
+                gr.bfs(G, s, dist_t, None, ctx, o)
+                sync()
+                dt = time.perf_counter() - t1
+                e = gr.run_stats(ctx)["edges_visited"]
+                tot_e += e
+                tot_t += dt
+                per.append(round(e / (dt * 1e9), 1))
+            return tot_e / (tot_t * 1e6), per
+        finally:
+            if cold:
+                os.environ.pop("GRX_BIN_HINT", None)
+
+    single = timed(lambda: gr.bfs(G, src, dist_t, None, ctx, bfs_opts(gr.forward, gr.FLAG_ASYNC_RETURN)), sync, 5, 1)
+    e_single = gr.run_stats(ctx)["edges_visited"]
+    f, per_f = sweep(gr.forward)
+    fc, _ = sweep(gr.forward, cold=True)
+    res.update({"forward_mteps": round(f, 1), "forward_per_source_gteps": per_f, "forward_cold_mteps": round(fc, 1),
+                "forward_single_source_mteps_sync_each": None})
+    # the single-source figure measured the same way (one search per sync) for a like-for-like ratio
+    t1 = time.perf_counter()
+    for _ in range(5):
+        gr.bfs(G, src, dist_t, None, ctx, bfs_opts(gr.forward, gr.FLAG_ASYNC_RETURN))
+        sync()
+    like = e_single * 5 / ((time.perf_counter() - t1) * 1e6)
+    res["forward_single_source_mteps_sync_each"] = round(like, 1)
+    res["forward_vs_single_source"] = round(f / like, 3)
+    if with_do:
+        d, per_d = sweep(gr.optimized)
+        res.update({"do_mteps": round(d, 1), "do_per_source_gteps": per_d})
+    if O is not None:
+        g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
+        viol = 0
+        for s in srcs[:4]:
+            gr.bfs(G, s, dist_t, None, ctx, bfs_opts(gr.forward))
+            viol += int(O.check_bfs(g, s, dist_t.cpu().numpy()))
+        res["violations"] = viol
+        res["violations_note"] = "oracle fixed-point check of the first 4 sources (forward)"
+    del single
+    return res
+
+
+def bench_sssp_on(env, tag, props, csr, src, info, G_unit=None):
+    """SSSP on workload `tag`: unit weights -- what the reference loader makes of the published pattern file
+    (io/matrix_market.hxx:170-171) -- and a U{1..1000} weighted variant.  road: generated per variant (the weighted
+    lattice comes from the generator); R-MAT graphs: weights drawn per unordered pair onto the topology."""
+    gr, torch, ctx, dev, sync, pmc, cpu_on, O, ncore, args = (env[k] for k in (
+        "gr", "torch", "ctx", "dev", "sync", "pmc", "cpu_on", "O", "ncore", "args"))
+    res = {}
+    for label, weighted in (("unit_weights", False), ("weighted_1_1000", True)):
+        t0 = time.time()
+        if tag == "road":
+            props_v, csr_v, src_v, info_v = load_workload(gr, "road", args.data_dir, weighted=weighted)
+        else:
+            props_v, csr_v, src_v, info_v = props, csr, src, info
+            if weighted:
+                import copy
+                csr_v = copy.copy(csr)
+                csr_v.nonzero_values = pair_hash_weights(csr)
+                csr_v._device = None
+                props_v = copy.copy(props)
+                props_v.weighted = True
+        res["workload"] = "SSSP on " + info_v["name"]
+        G = G_unit if (G_unit is not None and not weighted) else gr.build_graph(props_v, csr_v, ctx, device=dev)
+        V, E = G.get_number_of_vertices(), G.get_number_of_edges()
+        d = torch.empty(V, dtype=torch.float32, device=dev)
+        t_setup = time.time() - t0
+        o = gr.options_t(advance_load_balance=gr.merge_path)
+        sync()
+        t1 = time.perf_counter()
+        gr.sssp(G, src_v, d, None, ctx, o)
+        sync()
+        first_ms = (time.perf_counter() - t1) * 1e3
+        road = tag == "road"
+        steps = (3 if weighted else 5) if road else 10
+        ms_step = timed(lambda: gr.sssp(G, src_v, d, None, ctx, o), sync, steps, 1)
+        st = gr.run_stats(ctx)
+        po = gr.options_t(advance_load_balance=gr.merge_path, engine_flags=gr.FLAG_PROFILE)
+        prof = best_profile(lambda: gr.sssp(G, src_v, d, None, ctx, po), lambda: gr.level_profile(ctx), tries=1 if road else 2)
+        # near-far: records with bottom_up == 2 only pull a bucket out of the far pile; unit weights run on the BFS engine,
+        # whose records carry the body (2 = binned there) -- all of them are advance launches
+        adv = [l for l in prof if not (weighted and l["bottom_up"] == 2)]
+        per_edge = 16 if weighted else 12  # weighted: + 4 B weight; all-equal weights are never read
+        r = roof(adv, lambda l: 12 * l["frontier_size"] + per_edge * l["edges"],
+                 "SSSP relaxation kernels (advance_block<sssp policies>, near-far on road-like graphs)" if weighted else
+                 "BFS engine level kernels (all weights equal: depths -> k-fold sums of w)",
+                 "12 B per frontier slot + %d B per relaxed edge (SURVEY 8d)" % per_edge)
+        if road:
+            attach_traffic(r, pmc, "sssp_" + label, per_step=True)
+        r["head_kernel_ms_per_step"] = round(sum(l["other_ms"] for l in prof), 3)
+        if weighted:
+            r["bucket_pull_launches"] = len(prof) - len(adv)
+            r["bucket_pull_ms_per_step"] = round(sum(l["advance_ms"] for l in prof if l["bottom_up"] == 2), 3)
+        if not road:
+            r["levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
+                            round(l["other_ms"], 4)] for l in prof]
+        mean_deg = E / max(1, V)
+        item = {"schedule": ("all weights equal: BFS engine + one pass depths -> distances (grx_sssp.hip)" if not weighted
+                             else ("near-far (delta-stepping)" if mean_deg < 6 else "label-correcting levels (frontier "
+                                   "Bellman-Ford, the reference's schedule)")),
+                "data": info_v["data"] if not (weighted and tag != "road") else "synthetic U{1..1000} weights on " + info_v["data"] + " topology",
+                "data_file": info_v["file"], "n_vertices": V, "n_edges": E, "source": src_v, "steps": steps,
+                "ms_per_step": round(ms_step, 4), "mteps": round(st["edges_visited"] / (ms_step * 1e3), 1),
+                "mteps_note": "edges RELAXED (re-relaxations included) / time; mteps_useful_edges divides the out-edges of "
+                              "the reached vertices, each counted once",
+                "edges_relaxed_per_step": st["edges_visited"], "iterations": st["search_depth"],
+                "first_call_ms": round(first_ms, 3), "setup_s": round(t_setup, 1), "roofline": r,
+                "cpu_baseline": None, "cpu_baseline_ncore": None}
+        mine = d.cpu().numpy()
+        reached = mine < np.float32(3.0e38)
+        useful = int(np.diff(csr_v.row_offsets)[reached].sum())
+        item["useful_edges_per_step"] = useful
+        item["mteps_useful_edges"] = round(useful / (ms_step * 1e3), 1)
+        if cpu_on:
+            g = O.Csr(csr_v.row_offsets, csr_v.column_indices, csr_v.nonzero_values)
+            item["property_check_violations"] = int(O.check_sssp(g, src_v, mine))
+            d1, ms1, ev1, fin1 = O.sssp_budget(g, src_v, 12e3)
+            item["cpu_baseline"] = {
+                "value": round(ev1 / (ms1 * 1e3), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+                "sample": "oracle/oracle.c orc_sssp (priority-queue Dijkstra of examples/algorithms/sssp/sssp_cpu.hxx) "
+                          "from the same source, %s after %.1f s: %d edges scanned"
+                          % ("finished" if fin1 else "stopped", ms1 / 1e3, ev1),
+                "matches_gpu": bool(np.array_equal(d1, mine)) if fin1 else None}
+            dn, msn, evn, itn, finn = O.sssp_omp(g, src_v, budget_ms=10e3 if road else 5e3)
+            item["cpu_baseline_ncore"] = {
+                "value": round(evn / (msn * 1e3), 2), "unit": "MTEPS", "cores": ncore, "kind": "port",
+                "sample": "oracle/oracle_omp.c orc_sssp_omp (the reference's frontier relaxation, sssp.hxx:116-151, on "
+                          "%d host threads), %s after %.1f s: %d iterations, %d edges relaxed"
+                          % (ncore, "finished" if finn else "stopped", msn / 1e3, itn, evn),
+                "matches_gpu": bool(np.array_equal(dn, mine)) if finn else None}
+            del g
+        res[label] = item
+        if G is not G_unit:
+            del G
+        del d
+    return res
+
+
+def bench_pr_on(env, tag, props, csr, info):
+    gr, torch, ctx, dev, sync, pmc, cpu_on, O, ncore, args = (env[k] for k in (
+        "gr", "torch", "ctx", "dev", "sync", "pmc", "cpu_on", "O", "ncore", "args"))
+    t0 = time.time()
+    pattern = bool(np.all(csr.nonzero_values == 1.0))
+    G = gr.build_graph(props, csr, ctx, device=dev)  # a FRESH handle: the first call below is the one-shot cost
+    V, E = G.get_number_of_vertices(), G.get_number_of_edges()
+    p = torch.empty(V, dtype=torch.float32, device=dev)
+    result = gr.pr_result_t(p)
+    par = gr.pr_param_t(0.85, 1e-6)
+    sync()
+    t1 = time.perf_counter()
+    gr.pr_run(G, par, result, ctx)  # first call: builds the pull layout (transpose, partitions, XCD-blocked copy) and runs
+    sync()
+    first_ms = (time.perf_counter() - t1) * 1e3
+    t_setup = time.time() - t0
+    steps = 5
+    ms_step = timed(lambda: gr.pr_run(G, par, result, ctx), sync, steps, 1)
+    iters = result.iterations
+    ppar = gr.pr_param_t(0.85, 1e-6, gr.options_t(engine_flags=gr.FLAG_PROFILE))
+    prof = best_profile(lambda: gr.pr_run(G, ppar, result, ctx), lambda: gr.level_profile(ctx))
+    # pattern graph: column index + gathered x per edge; offsets, p, x, iweights per vertex; else + the weight stream
+    per_iter = 8 * E + 16 * V if pattern else 12 * E + 20 * V
+    r = roof(prof, lambda l: per_iter, "pr pull iteration (pr_pull[_xcd]_kernel + long-row pieces + pr_combine_kernel)",
+             "8 E + 16 V per iteration on a pattern graph (weights all 1.0 are not read); SURVEY 8d" if pattern else
+             "12 E + 20 V per iteration (SURVEY 8d)")
+    if tag == "kron":
+        attach_traffic(r, pmc, "pr_pull")
+    r["prepare_scalar_ms_per_step"] = round(sum(l["other_ms"] for l in prof), 4)
+    r["ms_per_iteration_pull"] = round(sum(l["advance_ms"] for l in prof) / max(1, len(prof)), 4)
+    item = {"workload": "PageRank on " + info["name"], "data": info["data"], "data_file": info["file"], "alpha": 0.85,
+            "tol": 1e-6, "n_vertices": V, "n_edges": E, "steps": steps, "ms_per_step": round(ms_step, 4), "iterations": iters,
+            "ms_per_iteration": round(ms_step / max(1, iters), 4), "mteps": round(E * iters / (ms_step * 1e3), 1),
+            "first_call_ms": round(first_ms, 2), "one_shot_ms": round(first_ms, 2),
+            "one_shot_note": "fresh graph handle: transpose + pull partitions (+ XCD-blocked layout) + one full run",
+            "setup_s": round(t_setup, 1), "roofline": r, "cpu_baseline": None, "cpu_baseline_ncore": None}
+    if cpu_on:
+        g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
+        mine = p.cpu().numpy()
+        delta, err, _ = O.pr_f64_trace(g, max(iters + 1, 8), [mine], pattern=pattern)
+        item["max_abs_diff_to_float64_same_iterations"] = float(err[0][iters - 1])
+        item["float64_iterations"] = O.pr_iterations_from_trace(delta)
+        _, it1, ms1 = O.pr_f32(g, max_iterations=3)
+        item["cpu_baseline"] = {
+            "value": round(E * it1 / (ms1 * 1e3), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+            "sample": "oracle/oracle.c orc_pr_f32 (the reference's push iteration, pr.hxx:107-152, fp32), first %d "
+                      "iterations, %.1f s" % (it1, ms1 / 1e3)}
+        _, msn = O.pr_omp(g, iterations=5, pattern=pattern)
+        item["cpu_baseline_ncore"] = {
+            "value": round(E * 5 / (msn * 1e3), 2), "unit": "MTEPS", "cores": ncore, "kind": "port",
+            "sample": "oracle/oracle_omp.c orc_pr_omp (the same recurrence as a pull over the transpose on %d host "
+                      "threads), 5 iterations, %.1f s" % (ncore, msn / 1e3)}
+        del g
+    del G, p
+    return item
 
 
 def bench_c5(gr, torch, ctx, dev, sync, cpu_on, args):
@@ -466,126 +762,6 @@ def bench_c5(gr, torch, ctx, dev, sync, cpu_on, args):
                       "restatement of examples/algorithms/bfs/bfs_cpu.hxx, identical depths), %.1f s" % (ms_q / 1e3),
             "matches_gpu": bool(np.array_equal(d_q, depths["direction_optimized"]))}
     del G, d
-    return item
-
-
-def bench_sssp(gr, torch, ctx, dev, sync, pmc, cpu_on, args):
-    if cpu_on:
-        import oracle_lib as O
-        ncore = O.omp_threads()
-    res = {}
-    for label, weighted in (("unit_weights", False), ("weighted_1_1000", True)):
-        t0 = time.time()
-        props, csr, src, info = load_workload(gr, "road", args.data_dir, weighted=weighted)
-        res["workload"] = "SSSP on " + info["name"]
-        G = gr.build_graph(props, csr, ctx, device=dev)
-        V, E = G.get_number_of_vertices(), G.get_number_of_edges()
-        d = torch.empty(V, dtype=torch.float32, device=dev)
-        t_setup = time.time() - t0
-        o = gr.options_t(advance_load_balance=gr.merge_path)
-        steps = 3 if weighted else 5
-        ms_step = timed(lambda: gr.sssp(G, src, d, None, ctx, o), sync, steps, 1)
-        st = gr.run_stats(ctx)
-        po = gr.options_t(advance_load_balance=gr.merge_path, engine_flags=gr.FLAG_PROFILE)
-        prof = best_profile(lambda: gr.sssp(G, src, d, None, ctx, po), lambda: gr.level_profile(ctx), tries=1)
-        adv = [l for l in prof if l["bottom_up"] != 2]  # 2: iterations that only pull a bucket out of the far pile
-        per_edge = 16 if weighted else 12  # weighted: + 4 B weight; all-1.0 weights are never read
-        r = roof(adv, lambda l: 12 * l["frontier_size"] + per_edge * l["edges"],
-                 "sssp_nf_level_kernel (near-far advance)" if weighted else "advance_kernel<sssp_policy>",
-                 "12 B per frontier slot + %d B per relaxed edge (SURVEY 8d)" % per_edge)
-        attach_traffic(r, pmc, "sssp_" + label, per_step=True)
-        r["head_kernel_ms_per_step"] = round(sum(l["other_ms"] for l in prof), 3)
-        r["bucket_pull_launches"] = len(prof) - len(adv)
-        r["bucket_pull_ms_per_step"] = round(sum(l["advance_ms"] for l in prof if l["bottom_up"] == 2), 3)
-        r["note"] = ("profile run: one record per two-launch iteration (levels absorbed by the LDS-resident tiny-level "
-                     "body of the head kernel are accounted to the iteration that ran them)")
-        item = {"schedule": "near-far (delta-stepping)" if weighted else "level-synchronous (all weights equal)",
-                "data": info["data"], "data_file": info["file"], "n_vertices": V, "n_edges": E, "source": src, "steps": steps, "ms_per_step": round(ms_step, 3),
-                "mteps": round(st["edges_visited"] / (ms_step * 1e3), 1),
-                "mteps_note": "edges RELAXED (re-relaxations of the near-far schedule included) / time; "
-                              "mteps_useful_edges divides the out-edges of the reached vertices, each counted once",
-                "edges_relaxed_per_step": st["edges_visited"], "iterations": st["search_depth"],
-                "us_per_iteration": round(ms_step * 1e3 / max(1, st["search_depth"]), 2),
-                "setup_s": round(t_setup, 1), "roofline": r, "cpu_baseline": None, "cpu_baseline_ncore": None}
-        reached = d.cpu().numpy() < np.float32(3.0e38)
-        useful = int(np.diff(csr.row_offsets)[reached].sum())
-        item["useful_edges_per_step"] = useful
-        item["mteps_useful_edges"] = round(useful / (ms_step * 1e3), 1)
-        if cpu_on:
-            g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
-            mine = d.cpu().numpy()
-            item["property_check_violations"] = int(O.check_sssp(g, src, mine))
-            d1, ms1, ev1, fin1 = O.sssp_budget(g, src, 12e3)
-            item["cpu_baseline"] = {
-                "value": round(ev1 / (ms1 * 1e3), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
-                "sample": "oracle/oracle.c orc_sssp (priority-queue Dijkstra of examples/algorithms/sssp/sssp_cpu.hxx) "
-                          "from the same source, %s after %.1f s: %d edges scanned"
-                          % ("finished" if fin1 else "stopped", ms1 / 1e3, ev1),
-                "matches_gpu": bool(np.array_equal(d1, mine)) if fin1 else None}
-            dn, msn, evn, itn, finn = O.sssp_omp(g, src, budget_ms=10e3)
-            item["cpu_baseline_ncore"] = {
-                "value": round(evn / (msn * 1e3), 2), "unit": "MTEPS", "cores": ncore, "kind": "port",
-                "sample": "oracle/oracle_omp.c orc_sssp_omp (the reference's frontier relaxation, sssp.hxx:116-151, on "
-                          "%d host threads), %s after %.1f s: %d iterations, %d edges relaxed"
-                          % (ncore, "finished" if finn else "stopped", msn / 1e3, itn, evn),
-                "matches_gpu": bool(np.array_equal(dn, mine)) if finn else None}
-        res[label] = item
-        del G, d
-    return res
-
-
-def bench_pr(gr, torch, ctx, dev, sync, pmc, cpu_on, args):
-    if cpu_on:
-        import oracle_lib as O
-        ncore = O.omp_threads()
-    t0 = time.time()
-    props, csr, _, info = load_workload(gr, "kron", args.data_dir)
-    pattern = bool(np.all(csr.nonzero_values == 1.0))
-    G = gr.build_graph(props, csr, ctx, device=dev)
-    V, E = G.get_number_of_vertices(), G.get_number_of_edges()
-    p = torch.empty(V, dtype=torch.float32, device=dev)
-    result = gr.pr_result_t(p)
-    par = gr.pr_param_t(0.85, 1e-6)
-    t1 = time.time()
-    gr.pr_run(G, par, result, ctx)  # first call: builds the pull layout (graph preparation, untimed like the CSR build)
-    sync()
-    t_first = time.time() - t1
-    t_setup = time.time() - t0
-    steps = 5
-    ms_step = timed(lambda: gr.pr_run(G, par, result, ctx), sync, steps, 1)
-    iters = result.iterations
-    ppar = gr.pr_param_t(0.85, 1e-6, gr.options_t(engine_flags=gr.FLAG_PROFILE))
-    prof = best_profile(lambda: gr.pr_run(G, ppar, result, ctx), lambda: gr.level_profile(ctx))
-    # pattern graph: column index + gathered x per edge; offsets, p, x, iweights per vertex; else + the weight stream
-    per_iter = 8 * E + 16 * V if pattern else 12 * E + 20 * V
-    r = roof(prof, lambda l: per_iter, "pr pull iteration (pr_pull_xcd_kernel + long-row pieces + pr_combine_kernel)",
-             "8 E + 16 V per iteration on a pattern graph (weights all 1.0 are not read); SURVEY 8d" if pattern else
-             "12 E + 20 V per iteration (SURVEY 8d)")
-    attach_traffic(r, pmc, "pr_pull")
-    r["prepare_scalar_ms_per_step"] = round(sum(l["other_ms"] for l in prof), 4)
-    r["ms_per_iteration_pull"] = round(sum(l["advance_ms"] for l in prof) / max(1, len(prof)), 4)
-    item = {"workload": "PageRank on " + info["name"], "data": info["data"], "data_file": info["file"], "alpha": 0.85, "tol": 1e-6, "n_vertices": V, "n_edges": E,
-            "steps": steps, "ms_per_step": round(ms_step, 4), "iterations": iters,
-            "ms_per_iteration": round(ms_step / max(1, iters), 4),
-            "mteps": round(E * iters / (ms_step * 1e3), 1), "first_call_s_incl_layout_build": round(t_first, 2),
-            "setup_s": round(t_setup, 1), "roofline": r, "cpu_baseline": None, "cpu_baseline_ncore": None}
-    if cpu_on:
-        g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
-        mine = p.cpu().numpy()
-        delta, err, _ = O.pr_f64_trace(g, max(iters + 1, 8), [mine], pattern=pattern)
-        item["max_abs_diff_to_float64_same_iterations"] = float(err[0][iters - 1])
-        item["float64_iterations"] = O.pr_iterations_from_trace(delta)
-        _, it1, ms1 = O.pr_f32(g, max_iterations=3)
-        item["cpu_baseline"] = {
-            "value": round(E * it1 / (ms1 * 1e3), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
-            "sample": "oracle/oracle.c orc_pr_f32 (the reference's push iteration, pr.hxx:107-152, fp32), first %d "
-                      "iterations, %.1f s" % (it1, ms1 / 1e3)}
-        _, msn = O.pr_omp(g, iterations=5, pattern=pattern)
-        item["cpu_baseline_ncore"] = {
-            "value": round(E * 5 / (msn * 1e3), 2), "unit": "MTEPS", "cores": ncore, "kind": "port",
-            "sample": "oracle/oracle_omp.c orc_pr_omp (the same recurrence as a pull over the transpose on %d host "
-                      "threads), 5 iterations, %.1f s" % (ncore, msn / 1e3)}
-    del G, p
     return item
 
 

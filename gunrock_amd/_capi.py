@@ -26,6 +26,9 @@ FLAG_PROFILE = 0x2
 FLAG_SYNC_EACH_LEVEL = 0x4
 FLAG_ASYNC_RETURN = 0x8
 FLAG_LB_STRICT = 0x1000
+FLAG_SSSP_PLAIN = 0x10
+FLAG_SSSP_NEAR_FAR = 0x20
+FLAG_SSSP_NO_BFS = 0x40
 
 
 class grx_options_t(C.Structure):

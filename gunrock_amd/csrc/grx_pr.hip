@@ -645,9 +645,9 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   // buckets (8 partial sums per row are cheap next to E gathers); sparse graphs (the 8 V
   // row visits would rival E) and small ones keep the plain transpose.
   // engine_flags: 0x40 = never, 0x80 = always (tests / A-B runs)
-  const bool xcd_blocked = (opt.engine_flags & 0x80) != 0 ||
+  const bool xcd_blocked = (opt.engine_flags & GRX_FLAG_PR_XCD_LAYOUT) != 0 ||
                            ((long long)g->E >= 16ll * g->V && (size_t)g->V * sizeof(float) > ((size_t)3 << 20) &&
-                            !(opt.engine_flags & 0x40));
+                            !(opt.engine_flags & GRX_FLAG_PR_NO_XCD_LAYOUT));
   grx_status_t st = graph_weight_stats(ctx, g);
   if (st != GRX_SUCCESS) return st;
   // all weights exactly 1.0 (a pattern .mtx as the reference loads it): x * 1.0f == x, so the

@@ -28,7 +28,9 @@
 
 #include <cfloat>
 #include <cmath>
+#include <climits>
 #include <cstdlib>
+#include <vector>
 
 namespace grx {
 
@@ -517,11 +519,26 @@ __global__ void weight_sum_kernel(const float* w, int64_t n, double* out, unsign
   }
 }
 
+// Uniform weights: the search is a BFS and a vertex of depth k carries the label fl(...fl(fl(0 + w) + w)... + w), k additions
+// (the sum every shortest path gives the reference's relaxation, sssp.hxx:121-123).  Depths -> distances, in place (the
+// caller's float buffer held the int32 depths of the BFS engine).  table == nullptr: w is exactly 1.0, the k-fold sum is
+// min(k, 2^24) (16777216 + 1 rounds back to 16777216: the additions stall there, as the reference's do).
+__global__ void sssp_depth_to_dist_kernel(float* dist, int64_t n, const float* table, int32_t table_n) {
+  int32_t* as_int = reinterpret_cast<int32_t*>(dist);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t k = as_int[i];
+    float d = FLT_MAX;  // unreached (sssp.hxx:72-73)
+    if (k != INT_MAX) {
+      if (table) d = table[k < table_n ? k : table_n - 1];
+      else d = (float)(k < (1 << 24) ? k : (1 << 24));
+    }
+    dist[i] = d;
+  }
+}
+
 }  // namespace grx
 
 using namespace grx;
-
-#define GRX_FLAG_SSSP_PLAIN 0x10
 
 // Sum / min / max of the edge weights, once per graph handle (near-far bucket width; graphs whose
 // weights are all 1.0 -- what the reference loader makes of a pattern .mtx, io/matrix_market.hxx:170-171
@@ -658,6 +675,46 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
   return GRX_SUCCESS;
 }
 
+static grx_status_t sssp_uniform_as_bfs(grx_context_t ctx, grx_graph_t g, int32_t src, const grx_options_t& opt,
+                                        float* d_dist, float w, float* elapsed_ms) {
+  grx_options_t bo = opt;
+  bo.engine_flags &= ~GRX_FLAG_ASYNC_RETURN;  // the conversion pass below is ordered behind the search on the stream anyway,
+                                               // but the table of a non-unit weight needs the depth on the host
+  float bfs_ms = 0.0f;
+  grx_status_t st = grx_bfs(ctx, g, src, &bo, reinterpret_cast<int32_t*>(d_dist), nullptr, &bfs_ms);
+  if (st != GRX_SUCCESS) return st;
+  hipStream_t s = ctx->stream;
+  const int32_t depth = ctx->stats.search_depth;
+  const float* d_table = nullptr;
+  int32_t table_n = 0;
+  if (w != 1.0f) {
+    // t[k] = fl(t[k-1] + w), capped at FLT_MAX: a tentative distance that is not < FLT_MAX never replaces the initial label
+    // (sssp.hxx:121-126), so such a vertex keeps FLT_MAX
+    std::vector<float> t((size_t)std::max(depth, 0) + 2);
+    t[0] = 0.0f;
+    for (size_t k = 1; k < t.size(); ++k) {
+      const float nd = t[k - 1] + w;
+      t[k] = nd < FLT_MAX ? nd : FLT_MAX;
+    }
+    GRX_HIP(ctx->misc.reserve(t.size() * sizeof(float) + 64));
+    float* dt = reinterpret_cast<float*>(ctx->misc.as<unsigned char>() + 64);
+    GRX_HIP(hipMemcpyAsync(dt, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    GRX_HIP(hipStreamSynchronize(s));  // t is a local
+    d_table = dt;
+    table_n = (int32_t)t.size();
+  }
+  hipEvent_t e0 = ctx->ev_begin, e1 = ctx->ev_end;
+  GRX_HIP(hipEventRecord(e0, s));
+  hipLaunchKernelGGL(sssp_depth_to_dist_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, s, d_dist, (int64_t)g->V, d_table, table_n);
+  GRX_HIP(hipEventRecord(e1, s));
+  GRX_HIP(hipEventSynchronize(e1));
+  float conv_ms = 0.0f;
+  GRX_HIP(hipEventElapsedTime(&conv_ms, e0, e1));
+  ctx->stats.elapsed_ms = bfs_ms + conv_ms;  // enact() scope: the search and the pass that writes the distances
+  if (elapsed_ms) *elapsed_ms = ctx->stats.elapsed_ms;
+  return GRX_SUCCESS;
+}
+
 extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
                                  const grx_options_t* options, float* d_dist, int32_t* d_pred,
                                  float* elapsed_ms) {
@@ -678,6 +735,20 @@ extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
     grx_status_t wst = graph_weight_stats(ctx, g);
     if (wst != GRX_SUCCESS) return wst;
   }
+  // All weights equal and non-negative -- what the reference loader makes of every pattern .mtx (io/matrix_market.hxx:170-171:
+  // soc-LiveJournal1, kron_g500-logn21, road_usa, soc-twitter-2010 as distributed) -- : the search IS a breadth-first
+  // search and a vertex of depth k gets the k-fold fp32 sum of w.  It runs on the BFS engine (binned fat levels, many
+  // mid-size levels per launch, bottom-up levels with advance_direction = optimized) writing int32 depths into the
+  // caller's buffer, and one streaming pass turns them into distances.  GRX_FLAG_SSSP_NO_BFS / GRX_SSSP_UNIFORM_BFS=0:
+  // the relaxation kernels below, as for any other weights.
+  {
+    const char* ub = getenv("GRX_SSSP_UNIFORM_BFS");
+    const bool all_equal = !g->w || (g->E > 0 && g->uniform_weights && g->weight_min == g->weight_max &&
+                                     (g->weight_min > 0.0f || g->weight_sum == 0.0));
+    if (all_equal && !(opt.engine_flags & (GRX_FLAG_SSSP_NO_BFS | GRX_FLAG_SSSP_PLAIN | GRX_FLAG_UNFUSED)) &&
+        !(ub && *ub == '0'))
+      return sssp_uniform_as_bfs(ctx, g, src, opt, d_dist, g->w ? g->weight_min : 1.0f, elapsed_ms);
+  }
   if (near_far) {
     // all weights equal (e.g. a pattern .mtx loaded with 1.0 everywhere): the search is
     // level-synchronous already, nothing is ever re-relaxed
@@ -696,7 +767,7 @@ extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (!(mean_w > 0.0) || !std::isfinite(dlt) || dlt <= 0.0) near_far = false;  // zero / negative weights
     // dense, low-diameter graphs finish in a dozen levels: label-correcting wastes little
     // there and the pile handling only costs (measured: LJ stand-in 4.8 ms plain vs 7.2 ms)
-    if (mean_deg >= 6.0 && !(opt.engine_flags & 0x20)) near_far = false;
+    if (mean_deg >= 6.0 && !(opt.engine_flags & GRX_FLAG_SSSP_NEAR_FAR)) near_far = false;
     else delta = (float)dlt;
   }
   bool overflow = false;

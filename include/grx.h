@@ -105,6 +105,15 @@ typedef struct grx_options {
                                         see grx_bfs.  Off by default: the reference's run() returns after a
                                         stream synchronisation (enactor.hxx:280-282) */
 
+/* bits 0x10 .. 0x80 are per algorithm (tests / A-B runs): */
+#define GRX_FLAG_PR_NO_XCD_LAYOUT 0x40 /* grx_pr: never use the XCD-blocked copy of the in-edges */
+#define GRX_FLAG_PR_XCD_LAYOUT 0x80    /* grx_pr: always use it */
+#define GRX_FLAG_SSSP_PLAIN 0x10     /* grx_sssp: label-correcting levels only, no near-far (delta-stepping) buckets */
+#define GRX_FLAG_SSSP_NEAR_FAR 0x20  /* grx_sssp: near-far buckets also on dense graphs (mean degree >= 6) */
+#define GRX_FLAG_SSSP_NO_BFS 0x40    /* grx_sssp: relax with the SSSP kernels even when all weights are equal.  By default
+                                        such a graph (every pattern .mtx: the reference loader stores 1.0, io/matrix_market.hxx:
+                                        170-171) is searched by the BFS engine and the depths become k-fold fp32 sums of w */
+
 typedef struct grx_context* grx_context_t;
 typedef struct grx_graph* grx_graph_t;
 

@@ -86,8 +86,10 @@ def test_growing_frontier_bfs_and_unit_sssp(gr, gpu_ctx):
             assert st["edges_visited"] == ev, env
         fwant = want.astype(np.float64)
         fwant[want == np.iinfo(np.int32).max] = np.finfo(np.float32).max
-        for env, d, st in run_sssp(gr, gpu_ctx, ro, ci, g.values, src):
-            assert np.array_equal(d, fwant.astype(np.float32)), env
+        # unit weights: the BFS engine + depths -> distances (default), and the SSSP relaxation kernels' own multi-level body
+        for flags in (0, gr.FLAG_SSSP_NO_BFS):
+            for env, d, st in run_sssp(gr, gpu_ctx, ro, ci, g.values, src, flags):
+                assert np.array_equal(d, fwant.astype(np.float32)), (flags, env)
 
 
 def test_lattice_all_paths(gr, gpu_ctx):

@@ -139,13 +139,15 @@ def test_full_size_road_standin_unit_weights(gr, gpu_ctx):
     assert np.all(c.nonzero_values == 1.0)
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
     src = (4894 // 2) * 4894 + 4894 // 2
-    d, st = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src)
-    assert O.check_sssp(g, src, d) == 0
     depths, _, ev = O.bfs_queue(g, src)
     reached = depths != np.iinfo(np.int32).max
-    assert np.array_equal(d[reached], depths[reached].astype(np.float32))
-    assert np.all(d[~reached] == FMAX)
-    assert st["edges_visited"] == ev  # level-synchronous: every reached vertex relaxed exactly once
+    # default: the BFS engine + one pass depths -> distances; GRX_FLAG_SSSP_NO_BFS: the relaxation kernels (grx_sssp.hip)
+    for o in (None, gr.options_t(engine_flags=gr.FLAG_SSSP_NO_BFS)):
+        d, st = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src, o)
+        assert O.check_sssp(g, src, d) == 0
+        assert np.array_equal(d[reached], depths[reached].astype(np.float32))
+        assert np.all(d[~reached] == FMAX)
+        assert st["edges_visited"] == ev  # level-synchronous: every reached vertex relaxed exactly once
 
 
 def test_regression_late_workgroups_of_a_multi_level_launch(gr, gpu_ctx):

@@ -1,7 +1,8 @@
 """All BASELINE.json single-GPU configs in one run: ours (engine) and, when
 oracle/_ref/libgunrock_ref_gpu.so is present, the reference's own GPU path on the same
 arrays (test infrastructure; reporting only).  Prints one JSON object per config.
-    python tests/tools/bench_all.py [bfs_lj] [sssp_road] [ssspu_road] [pr_kron] [bfs_road] [sssp_lj] [bfs_kron]"""
+    python tests/tools/bench_all.py [bfs_lj] [sssp_road] [ssspu_road] [pr_kron] [bfs_road] [sssp_lj] [ssspu_lj] [sssp_kron]
+        [ssspu_kron] [pr_lj] [bfs_kron] [bfs_twitter]      (ssspu = unit weights, what the reference loader makes of a pattern file)"""
 import json
 import os
 import sys
@@ -15,7 +16,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gunrock_amd as gr  # noqa: E402
 import oracle_lib as O  # noqa: E402
-from bench import WORKLOADS  # noqa: E402
+from bench import WORKLOADS, pair_hash_weights  # noqa: E402
 
 which = sys.argv[1:] or ["bfs_lj", "sssp_road", "pr_kron"]
 ctx = gr.multi_context_t(0)
@@ -26,8 +27,8 @@ def graph(name, weighted=False):
     c_par = 1.0 if (weighted and wl["kind"] == "road") else wl["c"]
     props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], c_par, seed=42)
     if weighted and wl["kind"] != "road":
-        rng = np.random.default_rng(1)
-        csr.nonzero_values = rng.integers(1, 1001, csr.number_of_nonzeros).astype(np.float32)
+        csr.nonzero_values = pair_hash_weights(csr)  # the weights bench.py and the full-size tests draw
+        csr._device = None
         props.weighted = True
     return wl, props, csr
 
