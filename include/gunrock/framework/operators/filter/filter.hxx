@@ -172,33 +172,79 @@ std::size_t stable_compact(operator_t op, const type_t* in, std::size_t n, type_
 
 }  // namespace detail
 
+// Per-algorithm entry points with the reference's names and signatures (filter/predicated.hxx:12-39, remove.hxx:11-44,
+// bypass.hxx:13-69, compact.hxx:13-25): filter::<algorithm>::execute(G, op, input, output, standard_context).  The
+// headers of those names forward here.
+namespace detail {
+template <typename frontier_t>
+bool prepare_output(frontier_t* input, frontier_t* output) {
+  const std::size_t n = input->get_number_of_elements();
+  if (output != input && output->get_capacity() < n) output->reserve(n);
+  if (n == 0) output->set_number_of_elements(0);
+  return n != 0;
+}
+}  // namespace detail
+
+namespace predicated {
+template <typename graph_t, typename operator_t, typename frontier_t>
+void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, gcuda::standard_context_t& context) {
+  (void)G;
+  if (!detail::prepare_output(input, output)) return;
+  error::throw_if_exception(output == input, "stable filter cannot run in place");
+  output->set_number_of_elements(
+      detail::stable_compact(op, input->data(), input->get_number_of_elements(), output->data(), context));
+}
+}  // namespace predicated
+
+namespace remove {  // identical result: the same stable compaction
+template <typename graph_t, typename operator_t, typename frontier_t>
+void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, gcuda::standard_context_t& context) {
+  predicated::execute(G, op, input, output, context);
+}
+}  // namespace remove
+
+namespace compact {  // throws in the reference (filter/compact.hxx:21-24); real here
+template <typename graph_t, typename operator_t, typename frontier_t>
+void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, gcuda::standard_context_t& context) {
+  (void)G;
+  using type_t = typename frontier_t::type_t;
+  if (!detail::prepare_output(input, output)) return;
+  error::throw_if_exception(output == input, "compact filter cannot run in place");
+  const std::size_t n = input->get_number_of_elements();
+  int32_t* counter = context.template scratch<int32_t>(2, 4);
+  error::throw_if_exception(hipMemsetAsync(counter, 0, sizeof(int32_t), context.stream()), "counter reset");
+  hipLaunchKernelGGL((detail::compact_kernel<operator_t, type_t>), dim3(detail::strided_grid(n, detail::TILE, context)),
+                     dim3(detail::BLOCK), 0, context.stream(), op, input->data(), n, output->data(), counter);
+  output->set_number_of_elements((std::size_t)context.read_back(counter)[0]);
+}
+}  // namespace compact
+
+namespace bypass {
+template <typename graph_t, typename operator_t, typename frontier_t>
+void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, gcuda::standard_context_t& context) {
+  (void)G;
+  using type_t = typename frontier_t::type_t;
+  if (!detail::prepare_output(input, output)) return;
+  const std::size_t n = input->get_number_of_elements();
+  hipLaunchKernelGGL((detail::bypass_kernel<operator_t, type_t>), dim3(detail::strided_grid(n, detail::BLOCK, context)),
+                     dim3(detail::BLOCK), 0, context.stream(), op, input->data(), output->data(), n);
+  output->set_number_of_elements(n);
+}
+template <typename graph_t, typename operator_t, typename frontier_t>
+void execute(graph_t& G, operator_t op, frontier_t* input, gcuda::standard_context_t& context) {  // in place
+  execute(G, op, input, input, context);
+}
+}  // namespace bypass
+
 template <filter_algorithm_t alg_type, typename graph_t, typename operator_t, typename frontier_t>
 void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, gcuda::multi_context_t& context) {
   GUNROCK_TRACE_RANGE("filter");
-  using type_t = typename frontier_t::type_t;
   error::throw_if_exception(context.size() != 1, "`context.size() != 1` not supported");
   auto& ctx = *context.get_context(0);
-  const std::size_t n = input->get_number_of_elements();
-  if (output != input && output->get_capacity() < n) output->reserve(n);
-  if (n == 0) {
-    output->set_number_of_elements(0);
-    return;
-  }
-  if constexpr (alg_type == filter_algorithm_t::bypass) {
-    hipLaunchKernelGGL((detail::bypass_kernel<operator_t, type_t>), dim3(detail::strided_grid(n, detail::BLOCK, ctx)),
-                       dim3(detail::BLOCK), 0, ctx.stream(), op, input->data(), output->data(), n);
-    output->set_number_of_elements(n);
-  } else if constexpr (alg_type == filter_algorithm_t::compact) {
-    error::throw_if_exception(output == input, "compact filter cannot run in place");
-    int32_t* counter = ctx.scratch<int32_t>(2, 4);
-    error::throw_if_exception(hipMemsetAsync(counter, 0, sizeof(int32_t), ctx.stream()), "counter reset");
-    hipLaunchKernelGGL((detail::compact_kernel<operator_t, type_t>), dim3(detail::strided_grid(n, detail::TILE, ctx)),
-                       dim3(detail::BLOCK), 0, ctx.stream(), op, input->data(), n, output->data(), counter);
-    output->set_number_of_elements((std::size_t)ctx.read_back(counter)[0]);
-  } else {  // predicated, remove: identical result (stable)
-    error::throw_if_exception(output == input, "stable filter cannot run in place");
-    output->set_number_of_elements(detail::stable_compact(op, input->data(), n, output->data(), ctx));
-  }
+  if constexpr (alg_type == filter_algorithm_t::bypass) bypass::execute(G, op, input, output, ctx);
+  else if constexpr (alg_type == filter_algorithm_t::compact) compact::execute(G, op, input, output, ctx);
+  else if constexpr (alg_type == filter_algorithm_t::remove) remove::execute(G, op, input, output, ctx);
+  else predicated::execute(G, op, input, output, ctx);
 }
 
 // in-place bypass overload (filter/bypass.hxx:62-69 of the reference)

@@ -15,6 +15,7 @@
 #include <gunrock/cuda/context.hxx>
 #include <gunrock/error.hxx>
 #include <gunrock/framework/operators/configs.hxx>
+#include <gunrock/framework/frontier/frontier.hxx>
 #include <gunrock/framework/operators/filter/filter.hxx>
 
 namespace gunrock {
@@ -39,27 +40,46 @@ struct keep_all_t {
 
 }  // namespace detail
 
-template <uniquify_algorithm_t type, typename frontier_t>
-void execute(frontier_t* input, frontier_t* output, gcuda::multi_context_t& context,
-             bool best_effort_uniquification = false, const float uniquification_percent = 100) {
+// Per-algorithm entry points with the reference's names (uniquify/unique.hxx:21-38, unique_copy.hxx:22-36):
+// uniquify::<algorithm>::execute(input, output, standard_context) -- one element of every run of equal neighbours of
+// `input` (invalid slots dropped), written to `output`.  Both names share one implementation; the headers of those names
+// forward here.
+namespace unique_copy {
+template <typename frontier_t>
+void execute(frontier_t* input, frontier_t* output, gcuda::standard_context_t& ctx) {
   using type_t = typename frontier_t::type_t;
-  error::throw_if_exception(context.size() != 1, "`context.size() != 1` not supported");
-  error::throw_if_exception(type != uniquify_algorithm_t::unique && type != uniquify_algorithm_t::unique_copy,
-                            "Unique type not supported.");
-  auto& ctx = *context.get_context(0);
   const std::size_t n = input->get_number_of_elements();
   if (output->get_capacity() < n) output->reserve(n);
   if (n == 0) {
     output->set_number_of_elements(0);
     return;
   }
-  if (!best_effort_uniquification && uniquification_percent == 100)
-    input->sort(sort::order_t::ascending, ctx.stream());
   type_t* marked = ctx.template scratch<type_t>(3, n);
   hipLaunchKernelGGL((detail::mark_runs_kernel<type_t>), dim3(filter::detail::strided_grid(n, 256, ctx)), dim3(256), 0,
                      ctx.stream(), input->data(), n, marked);
   output->set_number_of_elements(
       filter::detail::stable_compact(detail::keep_all_t(), (const type_t*)marked, n, output->data(), ctx));
+}
+}  // namespace unique_copy
+
+namespace unique {
+template <typename frontier_t>
+void execute(frontier_t* input, frontier_t* output, gcuda::standard_context_t& ctx) {
+  unique_copy::execute(input, output, ctx);
+}
+}  // namespace unique
+
+template <uniquify_algorithm_t type, typename frontier_t>
+void execute(frontier_t* input, frontier_t* output, gcuda::multi_context_t& context,
+             bool best_effort_uniquification = false, const float uniquification_percent = 100) {
+  error::throw_if_exception(context.size() != 1, "`context.size() != 1` not supported");
+  error::throw_if_exception(type != uniquify_algorithm_t::unique && type != uniquify_algorithm_t::unique_copy,
+                            "Unique type not supported.");
+  auto& ctx = *context.get_context(0);
+  if (input->get_number_of_elements() != 0 && !best_effort_uniquification && uniquification_percent == 100)
+    input->sort(sort::order_t::ascending, ctx.stream());
+  if constexpr (type == uniquify_algorithm_t::unique) unique::execute(input, output, ctx);
+  else unique_copy::execute(input, output, ctx);
 }
 
 template <uniquify_algorithm_t type = uniquify_algorithm_t::unique, typename enactor_type>

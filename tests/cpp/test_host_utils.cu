@@ -2,9 +2,12 @@
 // generate::random and format::csc_t::from_csr (reference: framework/operators/batch/batch.hxx:70-94,
 // algorithms/generate/random.hxx:20-52, formats/csc.hxx:62-101).  Built with hipcc, runs on the CPU.
 #include <gunrock/algorithms/generate/random.hxx>
+#include <gunrock/algorithms/search/binary_search.hxx>
 #include <gunrock/formats/formats.hxx>
+#include <gunrock/io/sample.hxx>
 #include <gunrock/framework/operators/batch/batch.hxx>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <stdexcept>
@@ -90,6 +93,30 @@ int main() {
     for (int k = 0; k < 8 && ok; ++k) ok = csc.row_indices[k] == want_rows[k];
     for (int c = 0; c < 4 && ok; ++c)
       for (int k = want_off[c]; k < want_off[c + 1] && ok; ++k) ok = csc.nonzero_values[k] == 10.0f * csc.row_indices[k] + c;
+    CHECK(ok);
+  }
+  // io::sample::csr: the reference's 4 x 4 unit-test matrix (io/sample.hxx:47-78; SURVEY 8c golden vector 2)
+  {
+    auto m = io::sample::csr<memory_space_t::host>();
+    const int ro[5] = {0, 0, 2, 3, 4}, ci[4] = {0, 1, 2, 1};
+    const float w[4] = {5, 8, 3, 6};
+    bool ok = m.number_of_rows == 4 && m.number_of_columns == 4 && m.number_of_nonzeros == 4;
+    for (int i = 0; i < 5 && ok; ++i) ok = m.row_offsets[i] == ro[i];
+    for (int i = 0; i < 4 && ok; ++i) ok = m.column_indices[i] == ci[i] && m.nonzero_values[i] == w[i];
+    CHECK(ok);
+  }
+  // search::binary::execute: upper bound by default, lower bound on request (algorithms/search/binary_search.hxx:41-60)
+  {
+    const std::vector<int> keys = {0, 0, 2, 3, 3, 3, 9};
+    const int* k = keys.data();
+    bool ok = true;
+    for (int key = -1; key <= 10; ++key) {
+      const int up = (int)(std::upper_bound(keys.begin(), keys.end(), key) - keys.begin());
+      const int lo = (int)(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin());
+      ok = ok && search::binary::execute(k, key, 0, (int)keys.size()) == up;
+      ok = ok && search::binary::execute(k, key, 0, (int)keys.size(), search::bound_t::lower) == lo;
+    }
+    ok = ok && search::binary::execute(k, 3, 4, 4) == 4;  // empty range
     CHECK(ok);
   }
   std::printf(failures ? "FAILED\n" : "ALL CHECKS PASSED\n");

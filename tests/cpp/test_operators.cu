@@ -6,6 +6,12 @@
 //            bypass keeps positions and writes -1, `op` is never called on -1;
 //   uniquify, parallel_for, frontier_t host API, bucketing's kernel choice.
 // Prints "CHECK <name> ok|FAILED" lines and exits non-zero on any failure.
+#include <gunrock/framework/operators/filter/predicated.hxx>
+#include <gunrock/framework/operators/filter/remove.hxx>
+#include <gunrock/framework/operators/filter/bypass.hxx>
+#include <gunrock/framework/operators/filter/compact.hxx>
+#include <gunrock/framework/operators/uniquify/unique.hxx>
+#include <gunrock/framework/operators/uniquify/unique_copy.hxx>
 #include <gunrock/algorithms/algorithms.hxx>
 
 #include <algorithm>
@@ -309,6 +315,36 @@ int main() {
     bool ok = got.size() == fin.size();
     for (size_t i = 0; i < fin.size() && ok; ++i) ok = got[i] == ((fin[i] >= 0 && fin[i] < 400) ? fin[i] : -1);
     check("filter.bypass_keeps_positions", ok && invalid_seen[0] == 0);
+  }
+  // the reference's per-algorithm entry points (filter/predicated.hxx:12-39 etc.): filter::<algorithm>::execute(G, op, in*, out*,
+  // standard_context) and the same for uniquify -- called directly, as a user TU that includes only those headers would
+  {
+    auto* in = E.get_input_frontier();
+    auto* out = E.get_output_frontier();
+    in->resize(fin.size());
+    hipMemcpy(in->data(), fin.data(), fin.size() * sizeof(int), hipMemcpyHostToDevice);
+    auto& sctx = *context->get_context(0);
+    invalid_seen[0] = 0;
+    operators::filter::predicated::execute(G, less_than_t{400, invalid_seen.data().get()}, in, out, sctx);
+    bool ok = download(*out) == stable;
+    operators::filter::remove::execute(G, less_than_t{400, invalid_seen.data().get()}, in, out, sctx);
+    ok = ok && download(*out) == stable;
+    operators::filter::compact::execute(G, less_than_t{400, invalid_seen.data().get()}, in, out, sctx);
+    auto a = download(*out), b = stable;
+    std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+    ok = ok && a == b;
+    operators::filter::bypass::execute(G, less_than_t{400, invalid_seen.data().get()}, in, sctx);  // in place
+    auto got = download(*in);
+    ok = ok && got.size() == fin.size();
+    for (size_t i = 0; i < fin.size() && ok; ++i) ok = got[i] == ((fin[i] >= 0 && fin[i] < 400) ? fin[i] : -1);
+    check("filter.per_algorithm_namespaces", ok && invalid_seen[0] == 0);
+    std::vector<int> runs = {5, 5, -1, 5, 1, 1, 9};
+    in->resize(runs.size());
+    hipMemcpy(in->data(), runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice);
+    operators::uniquify::unique::execute(in, out, sctx);
+    bool uok = download(*out) == std::vector<int>({5, 5, 1, 9});
+    operators::uniquify::unique_copy::execute(in, out, sctx);
+    check("uniquify.per_algorithm_namespaces", uok && download(*out) == std::vector<int>({5, 5, 1, 9}));
   }
   // ---- uniquify -------------------------------------------------------------------
   {
