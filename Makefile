@@ -6,10 +6,13 @@ FLAGS = -std=c++17 -O3 --offload-arch=gfx950 -munsafe-fp-atomics -ffp-contract=o
 LINK = -Lgunrock_amd -lgrx -Wl,-rpath,'$$ORIGIN/../gunrock_amd'
 HDRS = $(shell find include -name '*.hxx' -o -name '*.h') $(wildcard examples/algorithms/*.hxx examples/algorithms/*/*.hxx)
 
-all: lib bin/bfs bin/sssp bin/pr
+all: lib bin/bfs bin/sssp bin/pr bin/test_engine_cache
 lib:
 	python -m gunrock_amd.build
 bin/%: examples/algorithms/%/*.cu $(HDRS) | lib
+	@mkdir -p bin
+	$(HIPCC) $(FLAGS) $< -o $@ $(LINK)
+bin/test_engine_cache: tests/cpp/test_engine_cache.cu $(HDRS) | lib
 	@mkdir -p bin
 	$(HIPCC) $(FLAGS) $< -o $@ $(LINK)
 bin/test_operators: tests/cpp/test_operators.cu $(HDRS)

@@ -90,6 +90,37 @@ __global__ void fingerprint_kernel(const int32_t* ro, const int32_t* ci, const f
   if ((t & 63) == 0) atomicAdd(out, acc);
 }
 
+// FULL content hash of one 32-bit array (grx_csr_hash): a position-keyed 64-bit mix of every element, summed (the sum is
+// order independent, so any grid works).  One streaming pass, 16-byte loads when the base is aligned.
+__device__ __forceinline__ unsigned long long hash_mix(unsigned long long pos, unsigned v) {
+  unsigned long long x = (pos * 0x9e3779b97f4a7c15ull) ^ ((unsigned long long)v * 0xc2b2ae3d27d4eb4full);
+  x = (x ^ (x >> 29)) * 0xbf58476d1ce4e5b9ull;
+  return x ^ (x >> 32);
+}
+__global__ __launch_bounds__(256) void content_hash_kernel(const unsigned* __restrict__ p, long long n, unsigned long long salt,
+                                                           unsigned long long* out) {
+  unsigned long long acc = 0ull;
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long long)gridDim.x * blockDim.x;
+  if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+    const uint4* p4 = reinterpret_cast<const uint4*>(p);
+    const long long n4 = n >> 2;
+    for (long long i = tid; i < n4; i += nt) {
+      const uint4 v = p4[i];
+      const unsigned long long b = salt + 4ull * (unsigned long long)i;
+      acc += hash_mix(b, v.x) + hash_mix(b + 1, v.y) + hash_mix(b + 2, v.z) + hash_mix(b + 3, v.w);
+    }
+    for (long long i = (n4 << 2) + tid; i < n; i += nt) acc += hash_mix(salt + (unsigned long long)i, p[i]);
+  } else {
+    for (long long i = tid; i < n; i += nt) acc += hash_mix(salt + (unsigned long long)i, p[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  __shared__ unsigned long long s_part[4];
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
 grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   const size_t V = (size_t)g->V, E = (size_t)g->E;
   const size_t grid = (size_t)advance_grid(ctx);
@@ -229,9 +260,11 @@ grx_status_t grx_context_order_after(grx_context_t ctx, void* producer_stream) {
   if (!ctx) return fail(GRX_ERROR_INVALID_ARGUMENT, "null context");
   hipStream_t ps = reinterpret_cast<hipStream_t>(producer_stream);
   if (ps == ctx->stream) return GRX_SUCCESS;
+  GRX_HIP(hipSetDevice(ctx->device));  // the event below belongs to the context's device, whatever the caller's current one is
   const hipError_t q = hipStreamQuery(ps);
   if (q == hipSuccess) return GRX_SUCCESS;  // idle: nothing to be ordered after
-  if (q != hipErrorNotReady) GRX_HIP(q);
+  // anything but "idle" -- still busy, or a stream under capture (the query itself is an error there) -- : record and wait
+  if (q != hipErrorNotReady) (void)hipGetLastError();
   if (!ctx->ev_order) GRX_HIP(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
   GRX_HIP(hipEventRecord(ctx->ev_order, ps));
   GRX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_order, 0));
@@ -254,6 +287,8 @@ grx_status_t grx_context_destroy(grx_context_t ctx) {
   for (auto& b : ctx->fbuf) b.release();
   ctx->misc.release();
   ctx->mid_aux.release();
+  ctx->bins.release();
+  ctx->bin_fill.release();
   if (ctx->d_ctrl) (void)hipFree(ctx->d_ctrl);
   if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
   if (ctx->h_mailbox) (void)hipHostFree((void*)ctx->h_mailbox);
@@ -292,9 +327,7 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->t_w) (void)hipFree(g->t_w);
   if (g->closed0) (void)hipFree(g->closed0);
   if (g->bu_heads) (void)hipFree(g->bu_heads);
-  if (g->bins) (void)hipFree(g->bins);
   if (g->bin_off) (void)hipFree(g->bin_off);
-  if (g->bin_fill) (void)hipFree(g->bin_fill);
   if (g->bin_tab8) (void)hipFree(g->bin_tab8);
   if (g->pr_blocks) (void)hipFree(g->pr_blocks);
   if (g->pr_piece) (void)hipFree(g->pr_piece);
@@ -323,6 +356,32 @@ grx_status_t grx_csr_fingerprint(grx_context_t ctx, int32_t V, int32_t E, const 
   GRX_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   GRX_HIP(hipStreamSynchronize(ctx->stream));
   *out = (uint64_t)h;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_csr_hash(grx_context_t ctx, int32_t V, int32_t E, const int32_t* ro, const int32_t* ci, const float* w,
+                          uint64_t* out) {
+  if (!ctx || !ro || !out || V < 0 || E < 0 || (E > 0 && !ci))
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_csr_hash: bad argument");
+  GRX_HIP(hipSetDevice(ctx->device));
+  GRX_HIP(ctx->misc.reserve(64));
+  unsigned long long* d = ctx->misc.as<unsigned long long>();
+  hipStream_t s = ctx->stream;
+  GRX_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), s));
+  auto pass = [&](const void* p, long long n, unsigned long long salt) {
+    if (!p || n <= 0) return;
+    const long long blocks = std::min<long long>((n / 4 + 255) / 256 + 1, (long long)ctx->num_cus * 8);
+    hipLaunchKernelGGL(content_hash_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const unsigned*>(p), n, salt, d);
+  };
+  pass(ro, (long long)V + 1, 0x1000000000000000ull);
+  pass(ci, (long long)E, 0x2000000000000000ull);
+  pass(w, (long long)E, 0x3000000000000000ull);
+  unsigned long long h = 0;
+  GRX_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s));
+  GRX_HIP(hipStreamSynchronize(s));
+  GRX_HIP(hipGetLastError());
+  // (V, E, presence of weights) are part of the identity a caller keys on; fold them in so that a hash is never 0 by accident
+  *out = (uint64_t)(h ^ ((unsigned long long)(unsigned)V << 32) ^ (unsigned long long)(unsigned)E ^ (w ? 0x8000000000000000ull : 0ull));
   return GRX_SUCCESS;
 }
 

@@ -519,6 +519,7 @@ static int env_int(const char* name, int dflt) {
 // granules with about equal numbers of in-edges -- their capacities, the XCD that claims each
 // bin (longest-processing-time assignment by capacity), the E-entry bin array and the counters.
 static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
+  if (g->bin_state == 3) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: a column index lies outside [0, V)");
   if (g->bin_state != 0) return GRX_SUCCESS;
   g->bin_state = 2;  // unusable until proven otherwise
   if (g->V <= 0 || g->E <= 0 || ctx->n_xcd < 1) return GRX_SUCCESS;
@@ -546,7 +547,10 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   (void)hipFree(d_cnt);
   long long total = 0;
   for (int i = 0; i < n_gran; ++i) total += cnt[(size_t)i];
-  if (total != (long long)g->E) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: a column index lies outside [0, V)");
+  if (total != (long long)g->E) {
+    g->bin_state = 3;  // reported by every call, not only the first
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: a column index lies outside [0, V)");
+  }
   // cut the granule sequence into <= BIN_MAX bins of about `target` in-edges each, no wider than max_width
   std::vector<int> first;  // first granule of each bin
   long long target = (total + 223) / 224;
@@ -605,8 +609,6 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   const size_t tab_bytes = (size_t)BIN_GRAN_MAX + (size_t)BIN_MAX + (size_t)BIN_GRAN_MAX * sizeof(unsigned short);  // g2b, owner, g2b16
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_tab8), tab_bytes));
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_off), 2 * ((size_t)BIN_MAX + 1) * sizeof(int32_t)));  // off, v0
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_fill), ((size_t)BIN_MAX + 16) * BIN_PAD * sizeof(int32_t)));  // fill, queue
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bins), ((size_t)g->E + 16) * sizeof(int32_t)));  // + the tail of a 16-byte load
   GRX_HIP(hipMemcpyAsync(g->bin_tab8, g2b.data(), (size_t)BIN_GRAN_MAX, hipMemcpyHostToDevice, s));
   GRX_HIP(hipMemcpyAsync(g->bin_tab8 + BIN_GRAN_MAX, owner.data(), (size_t)BIN_MAX, hipMemcpyHostToDevice, s));
   static_assert((BIN_GRAN_MAX + BIN_MAX) % 4 == 0, "the 16-bit table is read as 32-bit words");
@@ -614,7 +616,6 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
                          hipMemcpyHostToDevice, s));
   GRX_HIP(hipMemcpyAsync(g->bin_off, off.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
   GRX_HIP(hipMemcpyAsync(g->bin_off + BIN_MAX + 1, v0.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  GRX_HIP(hipMemsetAsync(g->bin_fill, 0, ((size_t)BIN_MAX + 16) * BIN_PAD * sizeof(int32_t), s));
   GRX_HIP(hipStreamSynchronize(s));
   g->bin_shift = gshift;
   g->bin_ngran = n_gran;
@@ -723,6 +724,19 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     st = graph_build_bins(ctx, g);
     if (st != GRX_SUCCESS) return st;
     use_bins = g->bin_state == 1;
+  }
+  if (use_bins) {
+    // per-SEARCH scratch of the binned levels, owned by the context: the E-entry candidate array (+ the tail of a 16-byte
+    // load) and the fill / ticket words.  When the big array cannot be had (4 E bytes: 2 GB on the 530 M-edge graph) the
+    // search runs without binned levels -- slower fat levels, same result -- instead of failing.
+    const size_t fill_bytes = ((size_t)BIN_MAX + 16) * BIN_PAD * sizeof(int32_t);
+    const bool fresh = ctx->bin_fill.bytes < fill_bytes;
+    if (ctx->bins.reserve(((size_t)g->E + 16) * sizeof(int32_t)) != hipSuccess || ctx->bin_fill.reserve(fill_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      use_bins = false;
+    } else if (fresh) {
+      GRX_HIP(hipMemsetAsync(ctx->bin_fill.ptr, 0, ctx->bin_fill.bytes, ctx->stream));
+    }
   }
 
   dobfs_args d{};
@@ -867,11 +881,11 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   // claim phase of a binned level: 3 = sweep (one workgroup per bin, vertex-ordered output), 2 = slices claimed in the owning XCD's L2
   const int claim_version = env_int("GRX_BIN_CLAIM", 3);
   if (use_bins) {
-    bn.bins = g->bins;
+    bn.bins = ctx->bins.as<int32_t>();
     bn.off = g->bin_off;
     bn.v0 = g->bin_off + BIN_MAX + 1;
-    bn.fill = g->bin_fill;
-    bn.queue = g->bin_fill + (size_t)BIN_MAX * BIN_PAD;
+    bn.fill = ctx->bin_fill.as<int32_t>();
+    bn.queue = ctx->bin_fill.as<int32_t>() + (size_t)BIN_MAX * BIN_PAD;
     bn.g2b = g->bin_tab8;
     bn.owner = g->bin_tab8 + BIN_GRAN_MAX;
     bn.g2b16 = reinterpret_cast<const unsigned short*>(g->bin_tab8 + BIN_GRAN_MAX + BIN_MAX);
@@ -911,6 +925,11 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       }();
       bn.local_ids = 1;
       grid_scatter2 = ctx->num_cus * env_int("GRX_SC2_WG_PER_CU", per_cu_sc2);
+      if (grid_scatter2 < 1) grid_scatter2 = ctx->num_cus;
+      // per-XCD ticket queues need a workgroup on every XCD: a grid that cannot be trusted to give that (fewer than four
+      // workgroups per XCD), a context whose coverage check failed once, or GRX_SC2_STATIC=1 -> statically strided units
+      bn.static_units = (ctx->sc2_static || grid_scatter2 < 4 * ctx->n_xcd || env_int("GRX_SC2_STATIC", 0) != 0) ? 1 : 0;
+      bn.fault_xcd = ctx->sc2_static ? 0 : env_int("GRX_SC2_FAULT_XCD", 0);
     }
     // sweep claim: 1 = first version; 2 = second version on 512-thread workgroups, two parts per bin; 3 = second version on
     // 1024-thread workgroups, one per CU, one emission per item
@@ -954,7 +973,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   // graph leaves the two kernels out of the other groups, one group of slack either side.  A fat level in a group
   // without them runs on the claim-per-edge advance (the head is told: bin_args::allowed) and is recorded for the next
   // search.  GRX_BIN_HINT=0: every group carries them.
-  const uint32_t hint0 = (use_bins && env_int("GRX_BIN_HINT", 1) != 0) ? g->bin_hint : 0u;
+  const uint32_t hint0 = (use_bins && env_int("GRX_BIN_HINT", 1) != 0) ? g->bin_hint.load(std::memory_order_relaxed) : 0u;
   const uint32_t bin_groups = hint0 ? (hint0 | (hint0 << 1) | (hint0 >> 1)) : ~0u;
   st = run_levels(ctx, opt, [&](hipStream_t stream, int seq) {
     if (profile) (void)hipEventRecord(pe[0], stream);
@@ -1044,11 +1063,32 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   if (st != GRX_SUCCESS) return st;
   if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));
   if (ctx->h_mailbox[10] != 0 || (!returned_fast && ctx->h_ctrl->mid_err != 0)) {
+    const int code = ctx->h_mailbox[10] != 0 ? (int)ctx->h_mailbox[10] : (int)ctx->h_ctrl->mid_err;
     ctx->h_mailbox[10] = 0;
+    if (code == 2) {
+      // The sweep found that the bins did not receive exactly the level's out-edges: the per-XCD ticket queues of the
+      // second scatter lost units (no workgroup of the launch ran on some XCD of the census).  Nothing wrong was
+      // returned -- the search stopped there.  Repeat it with statically strided units, and keep that mode.
+      GRX_HIP(hipStreamSynchronize(s));
+      GRX_HIP(hipMemsetAsync(&ctx->d_ctrl->mid_err, 0, sizeof(int32_t), s));
+      if (profile) for (auto& e : pe) (void)hipEventDestroy(e);
+      if (!ctx->sc2_static) {
+        ctx->sc2_static = true;
+        return grx_bfs(ctx, g, src, options, d_dist, d_pred, elapsed_ms);
+      }
+      return fail(GRX_ERROR_HIP, "grx_bfs: the binned scatter did not cover the level's edges (grx_bin.hpp)");
+    }
     return fail(GRX_ERROR_HIP, "grx_bfs: a device-side barrier timed out (grx_mid.hpp)");
   }
 
-  if (use_bins) g->bin_hint = returned_fast ? (uint32_t)ctx->h_mailbox[11] : (uint32_t)ctx->h_ctrl->bin_want;
+  // OR-ed over the searches: a search from another source whose fat levels fall into other groups adds them
+  // instead of replacing the set, so alternating sources do not keep evicting each other's groups.  A set bit costs
+  // two no-op launches (~8 us) in a search that has no fat level there; GRX_BIN_HINT_REPLACE=1: the round-3 behaviour.
+  if (use_bins) {
+    const uint32_t want = returned_fast ? (uint32_t)ctx->h_mailbox[11] : (uint32_t)ctx->h_ctrl->bin_want;
+    if (env_int("GRX_BIN_HINT_REPLACE", 0) != 0) g->bin_hint.store(want, std::memory_order_relaxed);
+    else g->bin_hint.fetch_or(want, std::memory_order_relaxed);
+  }
   float ms = 0;
   if (returned_fast) {
     // enact() time on the device's own clock: seed (init kernel) -> the kernel that found the

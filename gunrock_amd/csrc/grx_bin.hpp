@@ -69,6 +69,9 @@ struct bin_args {
   int32_t allowed;            // this launch group carries the scatter / sweep kernels
   int32_t max_degree;         // ... and whose frontier averages at most this many out-edges per vertex
   int32_t mid_v, mid_e;       // thresholds of the many-levels-per-launch body (grx_mid.hpp), 0: off (carried here for the head kernel)
+  int32_t static_units;       // second scatter: units strided statically over the workgroups instead of drawn from per-XCD ticket
+                              // queues (the fallback when a launch cannot be trusted to put a workgroup on every XCD)
+  int32_t fault_xcd;          // test aid (GRX_SC2_FAULT_XCD=k): workgroups on dense XCD index k - 1 take no units (0: off)
 };
 
 struct bin_scatter_smem {
@@ -847,15 +850,24 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
   // 150 us): the units are equal, the workgroups' speeds are not.  Unit u belongs to XCD u % n_xcd; ticket k of XCD x
   // is unit x + n_xcd * k, drawn with an L2-LOCAL atomic (workgroup scope: every taker of that word runs on that XCD;
   // one device-wide word would serve ~88 tickets/us for ~45 tickets/us of demand).  The head kernel zeroes the words.
+  // SAFETY NET: the queues only work if every XCD of the census runs at least one workgroup of this launch
+  // (CU masks, another partition mode, a tiny grid ...).  The sweep that follows checks that the bins received EXACTLY the
+  // level's out-edges (bin_sweep2_block) and raises ctrl.mid_err = 2 otherwise; the host then repeats the search with
+  // bin_args::static_units = 1 -- unit k of workgroup w is w + k * gridDim.x, no queue, no assumption -- and keeps that
+  // mode for the context.
   const int xcd = xcd_index(bn.xcc_mask, bn.n_xcd);
-  const int n_xcd = bn.n_xcd;
+  if (bn.fault_xcd == xcd + 1) return;  // (test aid: this XCD's units are lost on purpose)
+  const bool stat = bn.static_units != 0;  // uniform
+  const int n_xcd = stat ? (int)gridDim.x : bn.n_xcd;   // unit of ticket k: first + n_xcd * k
+  const int first_unit = stat ? (int)blockIdx.x : xcd;
+  int next_static = 4;  // uniform: the static "ticket" counter
   int* qhead = &bn.queue[(unsigned)(xcd * BIN_PAD)];
   if (tid0 == 0) {
     int t[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = __hip_atomic_fetch_add(qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int i = 0; i < 4; ++i) t[i] = stat ? i : __hip_atomic_fetch_add(qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sm.tick[i] = xcd + n_xcd * t[i];
+    for (int i = 0; i < 4; ++i) sm.tick[i] = first_unit + n_xcd * t[i];
   }
   __syncthreads();
   int vzero;  // keeps the descriptor loads vector loads (a scalar load would be waited for at the next barrier)
@@ -915,7 +927,8 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     }
     vC = in[(unsigned)(tlC.x * TILE + tq)];
     int ticket = 0;  // drawn now, used at the end of the batch (unit of stage D of the NEXT batch)
-    if (tid == 0) ticket = __hip_atomic_fetch_add(qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (stat) ticket = next_static++;
+    else if (tid == 0) ticket = __hip_atomic_fetch_add(qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const int inc = dev::wave_inclusive_sum(dg);
     if (lane == 63) sm.wtot[q][wq] = inc;
     reinterpret_cast<uint2*>(own)[tq] = make_uint2(0u, 0u);
@@ -1076,7 +1089,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       }
     }
     dbg_mark(7);
-    if (tid == 0) sm.tick[3] = xcd + n_xcd * ticket;  // read after the next batch's first barrier
+    if (tid == 0) sm.tick[3] = first_unit + n_xcd * ticket;  // read after the next batch's first barrier
     uA = uB; uB = uC; uC = uD;
     yA = yB; yB = tlC.y; tlC = tlD;
     vA = vB; vB = vC;
@@ -1242,6 +1255,19 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
   if (tid < bn.nb) fill = bn.fill[(unsigned)(tid * BIN_PAD)];
   int tot_fill;
   (void)dev::block_exclusive_sum<NT>(fill, sm.wave, &tot_fill);
+  // every out-edge of the level's frontier is one candidate: the bins must hold EXACTLY q_edges[p] entries.  Anything else
+  // means the scatter lost or repeated work units (see bin_scatter2_block: per-XCD ticket queues) -- the search is
+  // abandoned with an error code the host acts on instead of returning wrong depths.
+  if (bn.local_ids && (long long)tot_fill != c->q_edges[p]) {
+    if (blockIdx.x == 0 && tid == 0) {
+      c->mid_err = 2;
+      c->done = 1;
+      a.mailbox[10] = 2;
+      __threadfence_system();
+      a.mailbox[0] = 1;
+    }
+    return;
+  }
   // every bin rounds its number of parts up: total / (sweep_items - nb) per part keeps the item count within sweep_items
   const int parts = max(1, bn.sweep_items - bn.nb);
   const int PART = max(SW2_PART_MIN, ((tot_fill / parts) + 4) & ~3);

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -148,6 +149,11 @@ struct grx_context {
   grx::dbuf fbuf[4];       // float per vertex (PR plast, iweights, x, ...)
   grx::dbuf misc;          // reductions etc.
   grx::dbuf mid_aux;       // grx_mid.hpp: row start / degree carried with the flat queue entries
+  grx::dbuf bins;          // binned forward BFS levels (grx_bin.hpp): the candidate array of the level, E + 16 entries
+  grx::dbuf bin_fill;      // ... its per-bin fill counters and per-XCD ticket words (per SEARCH state: lives with the context,
+                           // so that two contexts may search one graph handle concurrently)
+
+  bool sc2_static = false;  // the binned scatter draws its units statically (set for good once a search failed the coverage check)
 
   grx_run_stats_t stats{};
   std::vector<grx::level_rec> levels;
@@ -171,14 +177,13 @@ struct grx_graph {
   int32_t* bu_heads = nullptr;     // {first, second in-neighbour} per vertex (bottom-up probes), built lazily; owned
   const void* bu_heads_of = nullptr;  // the in-edge array it was built from (CSR of a symmetric graph, or the transpose)
   // binned top-down levels (grx_bin.hpp), built lazily; owned
-  int32_t* bins = nullptr;      // E entries
   int32_t* bin_off = nullptr;   // static bin offsets (in-edges per vertex range)
-  int32_t* bin_fill = nullptr;  // per-level fill counters + per-XCD claim queue heads
   unsigned char* bin_tab8 = nullptr;  // granule -> bin, bin -> owning XCD
   int32_t bin_shift = 0, bin_ngran = 0, bin_nb = 0;
-  uint32_t bin_hint = 0;        // ctrl_t::bin_want of the last forward search on this graph (0: none yet)
+  std::atomic<uint32_t> bin_hint{0};  // launch groups in which forward searches on this graph met a fat level (ctrl_t::bin_want,
+                                      // OR-ed over the searches; 0: none yet)
   int32_t bin_entry16 = 0;      // every bin spans <= 65536 vertices: offsets inside a bin fit 16-bit entries
-  int32_t bin_state = 0;        // 0: not built, 1: usable, 2: not applicable to this graph
+  int32_t bin_state = 0;        // 0: not built, 1: usable, 2: not applicable to this graph, 3: a column index lies outside [0, V)
   double weight_sum = -1.0;  // sum of edge weights (lazy; near-far SSSP bucket width)
   bool uniform_weights = false;
   float weight_min = 0.0f, weight_max = 0.0f;

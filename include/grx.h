@@ -166,6 +166,13 @@ grx_status_t grx_graph_destroy(grx_graph_t graph);
 grx_status_t grx_csr_fingerprint(grx_context_t ctx, int32_t n_vertices, int32_t n_edges,
                                  const int32_t* d_row_offsets, const int32_t* d_column_indices,
                                  const float* d_values, uint64_t* out);
+/* The FULL content hash of the three arrays (every element, position-keyed; one streaming pass at HBM rate, one
+ * 8-byte read-back and stream synchronisation): what a caller that must tolerate in-place edits compares per use.
+ * include/gunrock/algorithms/engine.hxx does by default, because upstream's graph view is non-owning and editing the
+ * arrays between two run() calls is legal there (graph/graph.hxx:187-214). */
+grx_status_t grx_csr_hash(grx_context_t ctx, int32_t n_vertices, int32_t n_edges,
+                          const int32_t* d_row_offsets, const int32_t* d_column_indices,
+                          const float* d_values, uint64_t* out);
 int32_t grx_graph_number_of_vertices(grx_graph_t graph); /* graph_t::get_number_of_vertices */
 int32_t grx_graph_number_of_edges(grx_graph_t graph);    /* graph_t::get_number_of_edges */
 

@@ -288,3 +288,73 @@ def test_symmetric_property_is_verified(gr, gpu_ctx):
     ci = ((np.arange(n) + 1) % n).astype(np.int32)
     d, _ = run_bfs(gr, gpu_ctx, ro, ci, 0, gr.options_t(advance_direction=gr.optimized))
     assert np.array_equal(d, np.arange(n))
+
+
+def test_binned_scatter_unit_hand_out_safety_net(gr, monkeypatch):
+    """The second scatter draws its work units from per-XCD ticket queues, which is only complete when every XCD runs a
+    workgroup of the launch.  (a) GRX_SC2_STATIC=1: statically strided units give the same depths.
+    (b) GRX_SC2_FAULT_XCD=1 makes the workgroups of one XCD take no units: the sweep's coverage check (bins must hold
+    exactly the level's out-edges) stops the search, the host repeats it with static units -- the caller sees correct
+    depths, and the context stays in static mode (the fault knob is ignored from then on)."""
+    import torch
+    _, c = gr.generate("rmat", 1 << 18, 6_000_000, seed=13)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    src = int(np.argmax(np.diff(g.row_offsets)))
+    want, _, ev = O.bfs_queue(g, src)
+    monkeypatch.setenv("GRX_BIN_MIN_EDGES", "100000")
+    o = gr.options_t(advance_load_balance=gr.merge_path, enable_filter=True, filter_algorithm=gr.compact)
+    for env in ({"GRX_SC2_STATIC": "1"}, {"GRX_SC2_FAULT_XCD": "1"}, {"GRX_SC2_FAULT_XCD": "3"}):
+        ctx = gr.multi_context_t(0)  # a fresh context: the static mode is sticky per context
+        G = gr.build_graph(gr.graph_properties_t(True, False, False), gr.csr_t.from_arrays(g.row_offsets, g.column_indices), ctx)
+        d = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda:0")
+        for k in ("GRX_SC2_STATIC", "GRX_SC2_FAULT_XCD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for rep in range(3):
+            for flags in (0, gr.FLAG_ASYNC_RETURN):
+                o.engine_flags = flags
+                gr.bfs(G, src, d, None, ctx, o)
+                ctx.synchronize()
+                assert np.array_equal(d.cpu().numpy(), want), (env, rep, flags)
+                assert gr.run_stats(ctx)["edges_visited"] == ev
+        del G, ctx
+
+
+def test_two_contexts_search_one_graph_handle_concurrently(gr, gpu_ctx):
+    """Per-search scratch (bin candidate array, fill / ticket words, bitmaps, queues) belongs to the CONTEXT; a graph handle
+    only carries immutable per-graph tables.  Two host threads, two contexts (two streams), one handle: forward (binned fat
+    levels) and direction-optimising searches from different sources at the same time must both give the oracle's depths
+    (the reference's batch operator runs run() from N host threads, operators/batch/batch.hxx:70-75)."""
+    import threading
+    import torch
+    _, c = gr.generate("rmat_sym", 1 << 18, 5_000_000, seed=17)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    G = gr.build_graph(gr.graph_properties_t(True, False, True), gr.csr_t.from_arrays(g.row_offsets, g.column_indices), gpu_ctx)
+    deg = np.diff(g.row_offsets)
+    srcs = [int(v) for v in np.argsort(deg)[-4:]]
+    want = {s: O.bfs_queue(g, s)[0] for s in srcs}
+    warm = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda:0")
+    for direction in (gr.forward, gr.optimized):  # per-graph preprocessing once, before the threads start
+        gr.bfs(G, srcs[0], warm, None, gpu_ctx, gr.options_t(advance_direction=direction))
+    errors = []
+
+    def worker(idx):
+        try:
+            ctx = gr.multi_context_t(0)
+            d = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda:0")
+            for rep in range(12):
+                s = srcs[(idx * 2 + rep) % len(srcs)]
+                direction = gr.forward if (rep + idx) % 3 else gr.optimized
+                gr.bfs(G, s, d, None, ctx, gr.options_t(advance_load_balance=gr.merge_path, advance_direction=direction))
+                if not np.array_equal(d.cpu().numpy(), want[s]):
+                    errors.append((idx, rep, s, int(direction)))
+        except Exception as e:  # noqa: BLE001
+            errors.append((idx, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

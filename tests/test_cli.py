@@ -146,6 +146,15 @@ def test_operator_level_semantics(binaries):
 
 
 @pytest.mark.gpu
+def test_engine_handle_cache_sees_in_place_edits(binaries):
+    """tests/cpp/test_engine_cache.cu: the C++ bridge's cached graph handles under in-place edits of the (non-owning) CSR
+    arrays -- full validation by default, identity + engine::invalidate on request."""
+    r = run([os.path.join(BIN, "test_engine_cache")], check=False)
+    assert "ALL CHECKS PASSED" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("CHECK ") >= 8
+
+
+@pytest.mark.gpu
 def test_export_metrics_json(binaries, tmp_path):
     import json
     run([os.path.join(BIN, "bfs"), "--market", CHES, "--src", "0,5", "--export_metrics", "--json_dir", str(tmp_path),
