@@ -57,6 +57,7 @@ constexpr int MID_WGS = 32;          // workgroups that stay (the rest of the gr
 constexpr int MID_ENTER_V = 8192;    // a level enters with at most this many frontier vertices ...
 constexpr int MID_ENTER_E = 65536;   // ... and out-edges
 constexpr int MID_EXIT_V = 131072;   // a frontier beyond this goes back to the regular kernels
+constexpr int MID_EXIT_E = 4 * MID_ENTER_E;  // ... and so does one with more out-edges than this (8 chunks per workgroup)
 constexpr int MID_SPIN_LIMIT = 1 << 22;
 constexpr int MID_AUX_CAP = MID_EXIT_V + TILE;  // queue entries that carry their row start / degree along
 // second version (mid_levels_body2): every workgroup appends to a PRIVATE region of the next queue -- no reservation
@@ -91,6 +92,8 @@ struct mid_smem {
   int n_ovf;
   int ok;
   int rank;
+  int out_edges;      // second version: out-degree sum of the entries this workgroup appended this level
+  int next_edges;     // ... and (in units of 128, from the exchange words) of the whole next level
 };
 
 
@@ -526,13 +529,17 @@ __device__ __forceinline__ bool mid_exchange(const pipe_args& a, int G, int w, i
       __builtin_amdgcn_s_sleep(1);
       if (++spins > MID_SPIN_LIMIT) { ok = 0; break; }
     }
-    const int cnt = lane < G ? (int)(v & 0x7fffffffull) : 0;
+    // word: entries appended (15 bits: <= MID_SEG) | out-degree sum of those entries >> 7, saturating (16 bits) | overflow flag
+    const int cnt = lane < G ? (int)(v & 0x7fffull) : 0;
+    const int e128 = lane < G ? (int)((v >> 15) & 0xffffull) : 0;
     const bool ovf = lane < G && ((v >> 31) & 1ull) != 0ull;
     const int inc = dev::wave_inclusive_sum(cnt);
     if (lane <= MID_WGS) sm.seg_pre[lane] = inc - cnt;  // lanes >= G: the total
     const bool any_ovf = dev::ballot(ovf) != 0ull;
+    const int e_next = dev::wave_sum(e128);
     if (lane == 0) {
       sm.ok = ok;
+      sm.next_edges = e_next;
       sm.n_ovf = any_ovf ? __hip_atomic_load(ovf_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     }
   }
@@ -619,7 +626,7 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
     int* ovf_cnt = &c->mid_cnt[(level + 1) % 3];
     if (w == 0 && tid == 0) __hip_atomic_store(&c->mid_cnt[(level + 2) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     pol.set_level(level);
-    if (tid == 0) { ad.cnt = 0; sm.side_cnt = 0; }
+    if (tid == 0) { ad.cnt = 0; sm.side_cnt = 0; sm.out_edges = 0; }
     __syncthreads();
     int my_out = 0;     // entries appended to my region this level (uniform)
     unsigned my_ovf = 0u;
@@ -635,11 +642,15 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
         base = MID_OVF_BASE + sm.base;
         my_ovf = 0x80000000u;
       }
+      int dsum = 0;
       for (int i = tid; i < k; i += ADV_BLOCK) {
         qout[base + i] = ad.out[lo + i];
+        dsum += sm.out_deg[lo + i];
         if (base + i < MID_AUX2_CAP)
           aux_out[base + i] = make_int4(sm.out_rs[lo + i], sm.out_deg[lo + i], CARRY ? sm.out_st[CARRY ? lo + i : 0] : 0, 0);
       }
+      dsum = dev::wave_sum(dsum);
+      if (lane == 0 && dsum) atomicAdd(&sm.out_edges, dsum);
       __syncthreads();
     };
     const int n_blocks = (n_in + TILE - 1) / TILE;
@@ -846,7 +857,9 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
       }
     }
     dbg_mark(2);
-    if (!mid_exchange(a, G, w, epoch, (unsigned)my_out | my_ovf, ovf_cnt, sm)) { fail_out(); return; }
+    static_assert(MID_SEG <= 0x7fff, "the entry count of a region fits 15 bits of the exchange word");
+    const unsigned e128 = (unsigned)min(sm.out_edges >> 7, 0xffff);  // (every flush ended with a barrier)
+    if (!mid_exchange(a, G, w, epoch, (unsigned)my_out | (e128 << 15) | my_ovf, ovf_cnt, sm)) { fail_out(); return; }
     dbg_mark(3);
     ++dbg_levels;
     n_priv = sm.seg_pre[MID_WGS];
@@ -855,7 +868,10 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
     first = false;
     ++level;
     __syncthreads();
-    if (n_in == 0 || n_in > a.mid_exit_v) break;
+    // A level that has outgrown this body goes back to the regular kernels: too many vertices, or -- scale-free graphs: a
+    // few thousand vertices a level before the hubs -- too many out-edges for the 32 workgroups of one XCD (round 4: three of
+    // 16 random sources of the LJ stand-in spent 5 ms in here on levels of 10^5 vertices / 10^6 edges).
+    if (n_in == 0 || n_in > a.mid_exit_v || sm.next_edges > (a.mid_exit_e >> 7)) break;
   }
   // ---- leaving
   if (dbg) {
