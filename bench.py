@@ -452,6 +452,8 @@ def main():
                         "ms": x["ms_per_step"], "mteps": x["mteps"], "frac": x["roofline"]["frac"],
                         "cpu1_mteps": (x["cpu_baseline"] or {}).get("value"), "eq_cpu": (x["cpu_baseline"] or {}).get("matches_gpu"),
                         "viol": x.get("property_check_violations")}
+                    if x.get("block_async"):
+                        sec["%s_%s" % (name, "unit" if lab == "unit_weights" else "w")]["supersteps"] = x["block_async"]["supersteps"]
         if name.startswith("pr_") and it:
             sec[name] = {"ms": it["ms_per_step"], "iters": it["iterations"], "ms_per_iter": it["ms_per_iteration"],
                          "mteps": it["mteps"], "frac": it["roofline"]["frac"], "first_call_ms": it["first_call_ms"],
@@ -577,6 +579,7 @@ def bench_sssp_on(env, tag, props, csr, src, info, G_unit=None):
         steps = (3 if weighted else 5) if road else 10
         ms_step = timed(lambda: gr.sssp(G, src_v, d, None, ctx, o), sync, steps, 1)
         st = gr.run_stats(ctx)
+        bs = gr.block_stats(ctx)  # road-like graphs: block-asynchronous relaxation (grx_block.hip)
         po = gr.options_t(advance_load_balance=gr.merge_path, engine_flags=gr.FLAG_PROFILE)
         prof = best_profile(lambda: gr.sssp(G, src_v, d, None, ctx, po), lambda: gr.level_profile(ctx), tries=1 if road else 2)
         # near-far: records with bottom_up == 2 only pull a bucket out of the far pile; unit weights run on the BFS engine,
@@ -597,9 +600,12 @@ def bench_sssp_on(env, tag, props, csr, src, info, G_unit=None):
             r["levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
                             round(l["other_ms"], 4)] for l in prof]
         mean_deg = E / max(1, V)
-        item = {"schedule": ("all weights equal: BFS engine + one pass depths -> distances (grx_sssp.hip)" if not weighted
-                             else ("near-far (delta-stepping)" if mean_deg < 6 else "label-correcting levels (frontier "
-                                   "Bellman-Ford, the reference's schedule)")),
+        blocky = bs["supersteps"] > 0
+        item = {"schedule": (("all weights equal: BFS engine + one pass depths -> distances (grx_sssp.hip)" if not weighted
+                              else ("near-far (delta-stepping)" if mean_deg < 6 else "label-correcting levels (frontier "
+                                    "Bellman-Ford, the reference's schedule)")) +
+                             ("; road-like graph: block-asynchronous relaxation (grx_block.hip), supersteps between blocks "
+                              "of %d vertices inside global label buckets" % bs["block_vertices"] if blocky else "")),
                 "data": info_v["data"] if not (weighted and tag != "road") else "synthetic U{1..1000} weights on " + info_v["data"] + " topology",
                 "data_file": info_v["file"], "n_vertices": V, "n_edges": E, "source": src_v, "steps": steps,
                 "ms_per_step": round(ms_step, 4), "mteps": round(st["edges_visited"] / (ms_step * 1e3), 1),
@@ -608,9 +614,14 @@ def bench_sssp_on(env, tag, props, csr, src, info, G_unit=None):
                 "edges_relaxed_per_step": st["edges_visited"], "iterations": st["search_depth"],
                 "first_call_ms": round(first_ms, 3), "setup_s": round(t_setup, 1), "roofline": r,
                 "cpu_baseline": None, "cpu_baseline_ncore": None}
+        if blocky:
+            item["block_async"] = dict(bs, us_per_superstep=round(ms_step * 1e3 / max(1, bs["supersteps"]), 2),
+                                       relaxations_per_useful_edge=None)
         mine = d.cpu().numpy()
         reached = mine < np.float32(3.0e38)
         useful = int(np.diff(csr_v.row_offsets)[reached].sum())
+        if blocky:
+            item["block_async"]["relaxations_per_useful_edge"] = round(bs["edges_relaxed"] / max(1, useful), 3)
         item["useful_edges_per_step"] = useful
         item["mteps_useful_edges"] = round(useful / (ms_step * 1e3), 1)
         if cpu_on:

@@ -16,12 +16,12 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (GrxError, grx_options_t, grx_run_stats_t, grx_level_profile_t,
+from ._capi import (GrxError, grx_options_t, grx_run_stats_t, grx_level_profile_t, grx_block_stats_t,
                     thread_mapped, warp_mapped, block_mapped, bucketing, merge_path,
                     merge_path_v2, work_stealing, remove, predicated, compact, bypass,
                     unique, unique_copy, forward, backward, optimized,
                     FLAG_UNFUSED, FLAG_PROFILE, FLAG_SYNC_EACH_LEVEL, FLAG_ASYNC_RETURN, FLAG_LB_STRICT,
-                    FLAG_SSSP_PLAIN, FLAG_SSSP_NEAR_FAR, FLAG_SSSP_NO_BFS)
+                    FLAG_SSSP_PLAIN, FLAG_SSSP_NEAR_FAR, FLAG_SSSP_NO_BFS, FLAG_NO_BLOCK_ASYNC)
 
 __all__ = ["memory_space_t", "graph_properties_t", "coo_t", "csr_t", "graph_t",
            "matrix_market_t", "build_graph", "multi_context_t", "options_t",
@@ -422,6 +422,14 @@ def run_stats(context):
     _capi.check(_capi.lib().grx_get_run_stats(context._h, C.byref(s)))
     return {"edges_visited": s.edges_visited, "vertices_visited": s.vertices_visited,
             "search_depth": s.search_depth, "elapsed_ms": s.elapsed_ms, "aux": s.reserved}
+
+
+def block_stats(context):
+    """Statistics of the last block-asynchronous search on the context (road-like graphs, grx_block.hip);
+    supersteps == 0: the last search took another path."""
+    s = grx_block_stats_t()
+    _capi.check(_capi.lib().grx_get_block_stats(context._h, C.byref(s)))
+    return {k: getattr(s, k) for k, _ in grx_block_stats_t._fields_}
 
 
 def level_profile(context, capacity=65536):

@@ -29,6 +29,7 @@ FLAG_LB_STRICT = 0x1000
 FLAG_SSSP_PLAIN = 0x10
 FLAG_SSSP_NEAR_FAR = 0x20
 FLAG_SSSP_NO_BFS = 0x40
+FLAG_NO_BLOCK_ASYNC = 0x2000
 
 
 class grx_options_t(C.Structure):
@@ -52,6 +53,17 @@ class grx_run_stats_t(C.Structure):
                 ("n_levels_recorded", C.c_int32),
                 ("elapsed_ms", C.c_float),
                 ("reserved", C.c_float)]
+
+
+class grx_block_stats_t(C.Structure):
+    _fields_ = [("edges_relaxed", C.c_int64),
+                ("activations", C.c_int64),
+                ("cross_edges", C.c_int64),
+                ("supersteps", C.c_int32),
+                ("buckets", C.c_int32),
+                ("blocks", C.c_int32),
+                ("block_vertices", C.c_int32),
+                ("build_ms", C.c_double)]
 
 
 class grx_level_profile_t(C.Structure):
@@ -106,6 +118,9 @@ def lib():
         "grx_pr": (i32, [vp, vp, f32, f32, P(grx_options_t), vp, P(i32), P(f32)]),
         "grx_get_run_stats": (i32, [vp, P(grx_run_stats_t)]),
         "grx_get_level_profile": (i32, [vp, P(grx_level_profile_t), i32, P(i32)]),
+        "grx_get_block_stats": (i32, [vp, P(grx_block_stats_t)]),
+        "grx_csr_hash": (i32, [vp, i32, i32, vp, vp, vp, P(C.c_uint64)]),
+        "grx_debug_block_search_host": (i32, [vp, i32, i32, i32, C.c_uint32, vp, P(grx_block_stats_t)]),
         "grx_host_csr_load_mtx": (i32, [C.c_char_p, P(vp)]),
         "grx_host_csr_read_binary": (i32, [C.c_char_p, P(vp)]),
         "grx_host_csr_write_binary": (i32, [vp, C.c_char_p]),

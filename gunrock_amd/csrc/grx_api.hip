@@ -291,6 +291,7 @@ grx_status_t grx_context_destroy(grx_context_t ctx) {
   ctx->mid_aux.release();
   ctx->bins.release();
   ctx->bin_fill.release();
+  for (auto& b : ctx->blk_buf) b.release();
   if (ctx->d_ctrl) (void)hipFree(ctx->d_ctrl);
   if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
   if (ctx->h_mailbox) (void)hipHostFree((void*)ctx->h_mailbox);
@@ -331,6 +332,7 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->bu_heads) (void)hipFree(g->bu_heads);
   if (g->bin_off) (void)hipFree(g->bin_off);
   if (g->bin_tab8) (void)hipFree(g->bin_tab8);
+  for (void* b : g->blk) blk_graph_free(b);
   if (g->pr_blocks) (void)hipFree(g->pr_blocks);
   if (g->pr_piece) (void)hipFree(g->pr_piece);
   if (g->pr_long) (void)hipFree(g->pr_long);
@@ -393,6 +395,12 @@ int32_t grx_graph_number_of_edges(grx_graph_t g) { return g ? g->E : 0; }
 grx_status_t grx_get_run_stats(grx_context_t ctx, grx_run_stats_t* out) {
   if (!ctx || !out) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_get_run_stats: null argument");
   *out = ctx->stats;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_get_block_stats(grx_context_t ctx, grx_block_stats_t* out) {
+  if (!ctx || !out) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_get_block_stats: null argument");
+  *out = ctx->block_stats;
   return GRX_SUCCESS;
 }
 

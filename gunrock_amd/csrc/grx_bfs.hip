@@ -702,10 +702,21 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     return fail(GRX_ERROR_UNSUPPORTED, "Load balance type not supported.");
 
   GRX_HIP(hipSetDevice(ctx->device));
-  pipe_args a;
-  grx_status_t st = pipeline_prepare(ctx, g, &a);
-  if (st != GRX_SUCCESS) return st;
+  ctx->block_stats = grx_block_stats_t{};
   const int variant = (opt.engine_flags >> 8) & 7;
+  grx_status_t st;
+  // road-like graphs: block-asynchronous relaxation (grx_block.hip) instead of thousands of nearly empty levels
+  if (variant == 0 && opt.max_iterations == 0 &&
+      !(opt.engine_flags & (GRX_FLAG_NO_BLOCK_ASYNC | GRX_FLAG_UNFUSED | GRX_FLAG_SYNC_EACH_LEVEL | GRX_FLAG_LB_STRICT)) &&
+      env_int("GRX_LB_STRICT", 0) == 0) {
+    bool use = false;
+    st = blk_prepare(ctx, g, false, &use);
+    if (st != GRX_SUCCESS) return st;
+    if (use) return blk_search(ctx, g, src, opt, false, d_dist, elapsed_ms);
+  }
+  pipe_args a;
+  st = pipeline_prepare(ctx, g, &a);
+  if (st != GRX_SUCCESS) return st;
   // bottom-up pays off on low-diameter graphs; with fewer than 4 edges per vertex the
   // frontier never gets heavy enough to switch and the extra per-level kernels only cost
   const bool dopt = opt.advance_direction == GRX_DIR_OPTIMIZED && variant == 0 && (long long)g->E >= 4ll * g->V;

@@ -153,6 +153,8 @@ struct grx_context {
   grx::dbuf bin_fill;      // ... its per-bin fill counters and per-XCD ticket words (per SEARCH state: lives with the context,
                            // so that two contexts may search one graph handle concurrently)
 
+  grx::dbuf blk_buf[3];    // block-asynchronous searches (grx_block.hip): dist, expd in the block numbering; bmin + queue
+  grx_block_stats_t block_stats{};  // of the last search (supersteps == 0: it did not take that path)
   bool sc2_static = false;  // the binned scatter draws its units statically (set for good once a search failed the coverage check)
 
   grx_run_stats_t stats{};
@@ -184,6 +186,8 @@ struct grx_graph {
                                       // OR-ed over the searches; 0: none yet)
   int32_t bin_entry16 = 0;      // every bin spans <= 65536 vertices: offsets inside a bin fit 16-bit entries
   int32_t bin_state = 0;        // 0: not built, 1: usable, 2: not applicable to this graph, 3: a column index lies outside [0, V)
+  void* blk[2] = {nullptr, nullptr};  // block structure of the block-asynchronous searches: [0] BFS depths, [1] weighted; owned
+  int32_t blk_state[2] = {0, 0};      // 0: not tried, 1: built, 2: not applicable to this graph
   double weight_sum = -1.0;  // sum of edge weights (lazy; near-far SSSP bucket width)
   bool uniform_weights = false;
   float weight_min = 0.0f, weight_max = 0.0f;

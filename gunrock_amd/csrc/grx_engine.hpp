@@ -34,6 +34,13 @@ inline bool graph_unit_weights(grx_graph_t g) {
   return !g->w || (g->weight_sum >= 0.0 && g->uniform_weights && g->weight_min == 1.0f);
 }
 
+// Block-asynchronous relaxation for road-like graphs (grx_block.hip): is it to be used for this graph (weighted: float
+// labels relaxed with the edge weights; else BFS depths)?  Builds the per-graph block structure on first use.
+grx_status_t blk_prepare(grx_context_t ctx, grx_graph_t g, bool weighted, bool* usable);
+grx_status_t blk_search(grx_context_t ctx, grx_graph_t g, int32_t src, const grx_options_t& opt, bool weighted, void* d_out,
+                        float* elapsed_ms);
+void blk_graph_free(void* p);
+
 // Launch configuration of the advance kernel (persistent workgroups striding over chunks).
 // Upper bound used for sizing scratch:
 inline int advance_grid(grx_context_t ctx) { return ctx->num_cus * 8; }

@@ -749,6 +749,19 @@ extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
         !(ub && *ub == '0'))
       return sssp_uniform_as_bfs(ctx, g, src, opt, d_dist, g->w ? g->weight_min : 1.0f, elapsed_ms);
   }
+  // weighted road-like graphs: block-asynchronous relaxation (grx_block.hip) instead of the near-far schedule
+  ctx->block_stats = grx_block_stats_t{};
+  if (g->w && g->E > 0 && opt.max_iterations == 0 &&
+      !(opt.engine_flags & (GRX_FLAG_NO_BLOCK_ASYNC | GRX_FLAG_SSSP_PLAIN | GRX_FLAG_SSSP_NEAR_FAR | GRX_FLAG_UNFUSED |
+                            GRX_FLAG_SYNC_EACH_LEVEL | GRX_FLAG_LB_STRICT))) {
+    const char* strict = getenv("GRX_LB_STRICT");
+    bool use = false;
+    if (!(strict && *strict == '1')) {
+      grx_status_t bst = blk_prepare(ctx, g, true, &use);
+      if (bst != GRX_SUCCESS) return bst;
+    }
+    if (use) return blk_search(ctx, g, src, opt, true, d_dist, elapsed_ms);
+  }
   if (near_far) {
     // all weights equal (e.g. a pattern .mtx loaded with 1.0 everywhere): the search is
     // level-synchronous already, nothing is ever re-relaxed

@@ -100,6 +100,7 @@ typedef struct grx_options {
                                         With this flag and MERGE_PATH every level runs the chunked merge-path advance (the
                                         reference pipeline of BASELINE configs[1] as written); with BLOCK_MAPPED the
                                         block-staged bodies are preferred wherever the frontier fits them */
+#define GRX_FLAG_NO_BLOCK_ASYNC 0x2000 /* road-like graphs: keep the level-synchronous kernels (see grx_get_block_stats) */
 #define GRX_FLAG_ASYNC_RETURN 0x8    /* grx_bfs may return as soon as the device has PUBLISHED the end
                                         of the search (results final) instead of after its stream drained;
                                         see grx_bfs.  Off by default: the reference's run() returns after a
@@ -232,6 +233,32 @@ typedef struct grx_run_stats {
   float reserved;
 } grx_run_stats_t;
 grx_status_t grx_get_run_stats(grx_context_t ctx, grx_run_stats_t* out);
+
+/* Road-like graphs (fewer than 4 edges per vertex, >= 65536 vertices) are searched BLOCK-ASYNCHRONOUSLY by default
+ * (gunrock_amd/csrc/grx_block.hip; GRX_FLAG_NO_BLOCK_ASYNC / GRX_BLOCK=0: the level-synchronous kernels): blocks of a few
+ * thousand vertices relax to their local fixed point in LDS, supersteps synchronise only between blocks, global buckets
+ * keep wrong labels from flooding.  Statistics of the last such search on the context (supersteps == 0: the last search
+ * took another path).  For these searches grx_run_stats_t::edges_visited is the reference's count for BFS (out-edges of
+ * the reached vertices) and the edges relaxed for weighted SSSP; edges_relaxed below always counts every relaxation. */
+typedef struct grx_block_stats {
+  int64_t edges_relaxed;   /* intra-block + boundary relaxations, re-relaxations included */
+  int64_t activations;     /* block activations summed over the supersteps */
+  int64_t cross_edges;     /* edges of the graph that leave their block */
+  int32_t supersteps;      /* head + block launch pairs that had work */
+  int32_t buckets;         /* global label buckets opened */
+  int32_t blocks;          /* blocks the graph was cut into ... */
+  int32_t block_vertices;  /* ... of at most this many vertices */
+  double build_ms;         /* one-time cost of the block structure of this graph (host partitioner + upload) */
+} grx_block_stats_t;
+grx_status_t grx_get_block_stats(grx_context_t ctx, grx_block_stats_t* out);
+
+/* HOST emulation of that schedule on a host CSR (the partitioner, the block structure and the superstep / bucket / local
+ * round logic of grx_block.hip, executed serially): test infrastructure of the CPU suite, never called by a product path.
+ * out_keys[V]: depths (weighted == 0; INT32_MAX unreached) or the bit patterns of float distances (FLT_MAX unreached);
+ * delta_bits: bucket width in hops, or the bits of a float. */
+typedef struct grx_host_csr* grx_host_csr_t;
+grx_status_t grx_debug_block_search_host(grx_host_csr_t csr, int32_t weighted, int32_t block_vertices, int32_t source,
+                                         uint32_t delta_bits, uint32_t* out_keys, grx_block_stats_t* stats);
 
 /* Per-level profile of the last run with GRX_FLAG_PROFILE: up to `capacity`
  * levels are copied; fields below. */
@@ -367,7 +394,6 @@ int32_t grx_bfs_dist_group_is_captured(grx_bfs_dist_t h);
 /* io::matrix_market_t::load + format::csr_t::from_coo,
  * include/gunrock/io/matrix_market.hxx:99-254, include/gunrock/formats/csr.hxx:81-140.
  * Produces host CSR arrays owned by the returned handle. */
-typedef struct grx_host_csr* grx_host_csr_t;
 grx_status_t grx_host_csr_load_mtx(const char* filename, grx_host_csr_t* out);
 /* format::csr_t::read_binary / write_binary, formats/csr.hxx:142-228 */
 grx_status_t grx_host_csr_read_binary(const char* filename, grx_host_csr_t* out);

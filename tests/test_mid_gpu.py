@@ -51,7 +51,9 @@ def run_bfs(gr, ctx, ro, ci, src, direction):
     import torch
     G = gr.build_graph(gr.graph_properties_t(True, False, False), gr.csr_t.from_arrays(ro, ci), ctx)
     d = torch.empty(len(ro) - 1, dtype=torch.int32, device="cuda:0")
-    o = gr.options_t(advance_load_balance=gr.merge_path, advance_direction=direction)
+    # (these graphs are road-like: by default they would be searched block-asynchronously, grx_block.hip -- this file is
+    # about the level-synchronous multi-level body)
+    o = gr.options_t(advance_load_balance=gr.merge_path, advance_direction=direction, engine_flags=gr.FLAG_NO_BLOCK_ASYNC)
     out = []
     for env in CONFIGS:
         for k in KNOBS:
@@ -71,7 +73,7 @@ def run_sssp(gr, ctx, ro, ci, w, src, flags=0):
         for k in KNOBS:
             os.environ.pop(k, None)
         os.environ.update(env)
-        gr.sssp(G, src, d, None, ctx, gr.options_t(engine_flags=flags))
+        gr.sssp(G, src, d, None, ctx, gr.options_t(engine_flags=flags | gr.FLAG_NO_BLOCK_ASYNC))
         out.append((env, d.cpu().numpy().copy(), gr.run_stats(ctx)))
     return out
 

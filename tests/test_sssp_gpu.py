@@ -87,7 +87,9 @@ def test_near_far_schedule_equals_plain_and_does_less_work(gr, gpu_ctx):
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
     src = 150 * 300 + 150
     want = O.sssp(g, src)[0]
-    d_nf, st_nf = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src)
+    # (this lattice is big enough for the block-asynchronous path, the default for road-like graphs: ask for near-far)
+    d_nf, st_nf = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src,
+                           gr.options_t(engine_flags=gr.FLAG_SSSP_NEAR_FAR))
     d_pl, st_pl = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src, gr.options_t(engine_flags=0x10))
     assert np.array_equal(d_nf, want) and np.array_equal(d_pl, want)
     assert st_nf["aux"] > 1  # several buckets were opened
@@ -125,9 +127,15 @@ def test_full_size_road_standin_properties(gr, gpu_ctx):
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
     assert 55_000_000 < g.n_edges < 60_000_000
     src = (4894 // 2) * 4894 + 4894 // 2
-    d, st = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src)
-    assert (d < FMAX).sum() > g.n_vertices // 2
-    assert O.check_sssp(g, src, d) == 0
+    # default: block-asynchronous relaxation (grx_block.hip); GRX_FLAG_NO_BLOCK_ASYNC: the near-far schedule
+    got = []
+    for o in (None, gr.options_t(engine_flags=gr.FLAG_NO_BLOCK_ASYNC)):
+        d, st = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src, o)
+        assert (d < FMAX).sum() > g.n_vertices // 2
+        assert O.check_sssp(g, src, d) == 0
+        assert (gr.block_stats(gpu_ctx)["supersteps"] > 0) == (o is None)
+        got.append(d)
+    assert np.array_equal(got[0], got[1])
 
 
 def test_full_size_road_standin_unit_weights(gr, gpu_ctx):
@@ -141,13 +149,18 @@ def test_full_size_road_standin_unit_weights(gr, gpu_ctx):
     src = (4894 // 2) * 4894 + 4894 // 2
     depths, _, ev = O.bfs_queue(g, src)
     reached = depths != np.iinfo(np.int32).max
-    # default: the BFS engine + one pass depths -> distances; GRX_FLAG_SSSP_NO_BFS: the relaxation kernels (grx_sssp.hip)
-    for o in (None, gr.options_t(engine_flags=gr.FLAG_SSSP_NO_BFS)):
-        d, st = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src, o)
+    # default: the BFS engine (block-asynchronous on this road-like graph) + one pass depths -> distances;
+    # GRX_FLAG_SSSP_NO_BFS: the SSSP paths (block-asynchronous with the weight array; with GRX_FLAG_NO_BLOCK_ASYNC the
+    # level-synchronous relaxation kernels of grx_sssp.hip); GRX_FLAG_NO_BLOCK_ASYNC alone: the level-synchronous BFS engine
+    for flags in (0, gr.FLAG_SSSP_NO_BFS, gr.FLAG_SSSP_NO_BFS | gr.FLAG_NO_BLOCK_ASYNC, gr.FLAG_NO_BLOCK_ASYNC):
+        d, st = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src, gr.options_t(engine_flags=flags))
         assert O.check_sssp(g, src, d) == 0
-        assert np.array_equal(d[reached], depths[reached].astype(np.float32))
+        assert np.array_equal(d[reached], depths[reached].astype(np.float32)), flags
         assert np.all(d[~reached] == FMAX)
-        assert st["edges_visited"] == ev  # level-synchronous: every reached vertex relaxed exactly once
+        if flags != gr.FLAG_SSSP_NO_BFS:  # (the weighted block schedule reports every relaxation, re-relaxations included)
+            assert st["edges_visited"] == ev, flags  # every reached vertex's out-edges exactly once
+        else:
+            assert st["edges_visited"] >= ev
 
 
 def test_regression_late_workgroups_of_a_multi_level_launch(gr, gpu_ctx):

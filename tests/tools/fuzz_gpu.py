@@ -48,6 +48,9 @@ def sweep(budget_s, seed=1234, log=print, max_vertices=600_000):
                 c.nonzero_values = rng.integers(1, 200, nnz).astype(np.float32) / 4.0
                 props.weighted = True
             g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+            # sparse graphs: every other one small enough to stay on the level-synchronous kernels takes the
+            # block-asynchronous path anyway (grx_block.hip; the threshold is read when the handle first searches)
+            os.environ["GRX_BLOCK_MIN_V"] = "512" if int(rng.integers(0, 2)) else "65536"
             G = gr.build_graph(props, c, ctx)
             deg = np.diff(c.row_offsets)
             sources = [int(np.argmax(deg))] + [int(x) for x in rng.integers(0, V, 3)]
@@ -88,6 +91,7 @@ def sweep(budget_s, seed=1234, log=print, max_vertices=600_000):
             log("%-8s V %7d E %9d weighted %d  %s" % (kind, V, nnz, weighted, "ok" if not bad else "BAD x%d" % bad))
             del G
     finally:
+        os.environ.pop("GRX_BLOCK_MIN_V", None)
         os.environ.pop("GRX_BIN_MAX_DEGREE", None)
         if saved_env is None:
             os.environ.pop("GRX_BIN_MIN_EDGES", None)
