@@ -954,6 +954,9 @@ def bench_multi_gpu(args, gr, torch, rank, local_rank, world):
                                             "the device from all-reduced statistics)",
                        "edges_visited_per_step": edges_total, "search_depth": st["search_depth"],
                        "setup_s": round(t_setup, 1), "backend": backend, "transport": transport_note,
+                       "rccl_ranks_seen": int(dist.get_world_size()),
+                       "n1_path": "python bench.py --gpus 1 runs the single-GPU engine (no partition, no collective); "
+                                  "this line is the partitioned path",
                        "level_group_captured_as_hip_graph_on_all_ranks": bool(cap_t.item()),
                        "per_level_breakdown": levels_breakdown, "parity_check": check},
             "roofline": None, "cpu_baseline": None}))

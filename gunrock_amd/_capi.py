@@ -163,6 +163,7 @@ def lib():
         "grx_pr_dist_poll": (i32, [vp, vp, vp]),
         "grx_pr_dist_end": (i32, [vp, vp]),
         "grx_pr_dist_destroy": (i32, [vp]),
+        "grx_debug_radix_sort": (i32, [vp, vp, vp, vp, i64, i32]),
         "grx_debug_read": (i32, [vp, vp, i64]),
         "grx_debug_ctrl": (i32, [vp, vp, i32]),
     }

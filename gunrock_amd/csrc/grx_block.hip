@@ -50,6 +50,9 @@
 namespace grx {
 
 constexpr uint32_t BLK_NONE = 0xffffffffu;
+#ifndef GRX_BLOCK_DEFAULT
+#define GRX_BLOCK_DEFAULT 0  // round 4, call 2: correct everywhere, but 120-160 ms against 40 ms level-synchronous on the road stand-in
+#endif
 
 // per graph (device arrays; built once, cached in the graph handle)
 struct blk_graph {
@@ -67,6 +70,7 @@ struct blk_graph {
   int32_t* xci = nullptr;         // targets (new ids)
   float* xw = nullptr;
   uint32_t* bnd = nullptr;        // [nb][nv / 32]: the vertex has an in-edge from another block
+  uint32_t* xout = nullptr;       // [nb][nv / 32]: the vertex has an out-edge that leaves its block
   double host_ms = 0.0;           // what the build cost (reported, not timed)
 };
 
@@ -81,6 +85,7 @@ struct blk_dev {
   const int32_t* xci;
   const float* xw;
   const uint32_t* bnd;
+  const uint32_t* xout;
 };
 
 struct blk_run {
@@ -218,6 +223,7 @@ struct blk_smem {
   uint32_t chg[WORDS];
   uint32_t pend[WORDS];
   uint32_t bnd[WORDS];
+  uint32_t xout[WORDS];
   int flag[3];
   unsigned left;
   int nrelax;
@@ -247,21 +253,43 @@ __global__ __launch_bounds__(NV / 32) void blk_kernel(blk_run r, blk_dev g) {
       sm.left = BLK_NONE;
       sm.nrelax = 0;
     }
-    // ---- ... then the immutable part of the block: offsets, local targets, weights, boundary bitmap
-    const int neb = g.nedge[b];
+    // ---- ... then the immutable part of the block: offsets, local targets, weights, the two boundary bitmaps.  Whole
+    // capacity (the unused tail is zeros), so that no load waits for the block's edge count, and all of a thread's loads
+    // in flight together (a copy loop waits for every load before it issues the next: 12+ serialized round trips in the
+    // first version's ISA)
     {
+      constexpr int N_OFF = (S::OFFS / 8 + T - 1) / T, N_TGT = NE / 8 / T, N_WT = W ? NE / 4 / T : 0;
+      static_assert(NE % (8 * T) == 0, "whole 16-byte pieces per thread");
       const uint4* s4 = reinterpret_cast<const uint4*>(g.off + (size_t)b * S::OFFS);
-      uint4* d4 = reinterpret_cast<uint4*>(sm.off);
-      for (int i = tid; i < S::OFFS / 8; i += T) d4[i] = s4[i];
       const uint4* t4 = reinterpret_cast<const uint4*>(g.tgt + (size_t)b * NE);
+      uint4 vo[N_OFF], vt[N_TGT];
+#pragma unroll
+      for (int j = 0; j < N_OFF; ++j) vo[j] = s4[min(j * T + tid, S::OFFS / 8 - 1)];
+#pragma unroll
+      for (int j = 0; j < N_TGT; ++j) vt[j] = t4[j * T + tid];
+      const uint32_t vb = g.bnd[(size_t)b * S::WORDS + tid], vx = g.xout[(size_t)b * S::WORDS + tid];
+      uint4* d4 = reinterpret_cast<uint4*>(sm.off);
       uint4* td4 = reinterpret_cast<uint4*>(sm.tgt);
-      for (int i = tid; i < (neb + 7) / 8; i += T) td4[i] = t4[i];
+#pragma unroll
+      for (int j = 0; j < N_OFF; ++j)
+        if (j * T + tid < S::OFFS / 8) d4[j * T + tid] = vo[j];
+#pragma unroll
+      for (int j = 0; j < N_TGT; ++j) td4[j * T + tid] = vt[j];
       if constexpr (W) {
         const uint4* w4 = reinterpret_cast<const uint4*>(g.wt + (size_t)b * NE);
         uint4* wd4 = reinterpret_cast<uint4*>(sm.wt);
-        for (int i = tid; i < (neb + 3) / 4; i += T) wd4[i] = w4[i];
+#pragma unroll
+        for (int h0 = 0; h0 < N_WT; h0 += 12) {
+          uint4 vw[12];
+#pragma unroll
+          for (int j = 0; j < 12; ++j) vw[j] = w4[min(h0 + j, N_WT - 1) * T + tid];
+#pragma unroll
+          for (int j = 0; j < 12; ++j)
+            if (h0 + j < N_WT) wd4[(h0 + j) * T + tid] = vw[j];
+        }
       }
-      sm.bnd[tid] = g.bnd[(size_t)b * S::WORDS + tid];
+      sm.bnd[tid] = vb;
+      sm.xout[tid] = vx;
       sm.fb[1][tid] = 0u;
     }
     __syncthreads();  // thread 0 is past its exchange (it stored the answer)
@@ -269,24 +297,35 @@ __global__ __launch_bounds__(NV / 32) void blk_kernel(blk_run r, blk_dev g) {
     {
       const uint32_t* dg = r.dist + base;
       const uint32_t* eg = r.expd + base;
-#pragma unroll 4
-      for (int k = 0; k < 32; ++k) {
-        const int v = k * T + tid;
-        const uint32_t d = dg[v], e = eg[v];
-        sm.lab[v] = d;
-        const bool pnd = d < e;
-        const bool sd = pnd && d < hi;
-        const unsigned long long bp = dev::ballot(pnd), bs = dev::ballot(sd);
-        const int w0 = v >> 5;  // lanes 0..31: word w0, lanes 32..63: the next one
-        if (lane == 0) {
-          sm.pend[w0] = (uint32_t)bp;
-          sm.fb[0][w0] = (uint32_t)bs;
-          sm.chg[w0] = (uint32_t)bs;
-          if (bs) sm.flag[0] = 1;
-        } else if (lane == 32) {
-          sm.pend[w0] = (uint32_t)(bp >> 32);
-          sm.fb[0][w0] = (uint32_t)(bs >> 32);
-          sm.chg[w0] = (uint32_t)(bs >> 32);
+      // (eight labels and eight expansion marks per thread in flight: written iteration by iteration the loop waited for
+      // every pair of loads before it issued the next -- 32 serialized round trips per activation in the first version's ISA)
+#pragma unroll 1
+      for (int k0 = 0; k0 < 32; k0 += 8) {
+        uint32_t dv[8], ev[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          dv[j] = dg[(k0 + j) * T + tid];
+          ev[j] = eg[(k0 + j) * T + tid];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int v = (k0 + j) * T + tid;
+          const uint32_t d = dv[j], e = ev[j];
+          sm.lab[v] = d;
+          const bool pnd = d < e;
+          const bool sd = pnd && d < hi;
+          const unsigned long long bp = dev::ballot(pnd), bs = dev::ballot(sd);
+          const int w0 = v >> 5;  // lanes 0..31: word w0, lanes 32..63: the next one
+          if (lane == 0) {
+            sm.pend[w0] = (uint32_t)bp;
+            sm.fb[0][w0] = (uint32_t)bs;
+            sm.chg[w0] = (uint32_t)bs;
+            if (bs) sm.flag[0] = 1;
+          } else if (lane == 32) {
+            sm.pend[w0] = (uint32_t)(bp >> 32);
+            sm.fb[0][w0] = (uint32_t)(bs >> 32);
+            sm.chg[w0] = (uint32_t)(bs >> 32);
+          }
         }
       }
     }
@@ -294,38 +333,56 @@ __global__ __launch_bounds__(NV / 32) void blk_kernel(blk_run r, blk_dev g) {
     int nrel = 0;
     for (int rd = 0;; ++rd) {
       __syncthreads();
-      if (!sm.flag[rd % 3]) break;
+      const int go = sm.flag[rd % 3];
+      uint32_t wv = sm.fb[rd & 1][tid];  // (issued together with the flag: one round trip)
+      if (!go) break;
       if (tid == 0) sm.flag[(rd + 2) % 3] = 0;  // read last two rounds ago, written next round
-      uint32_t wv = sm.fb[rd & 1][tid];
       sm.fb[rd & 1][tid] = 0u;  // written again from the next round on (behind the next barrier)
       uint32_t* nxt = sm.fb[(rd + 1) & 1];
       while (wv) {
         const int v = tid * 32 + __builtin_ctz(wv);
         wv &= wv - 1u;
-        const uint32_t lu = sm.lab[v];
+        // A round is a chain of DEPENDENT LDS round trips (~100+ cycles each with two to four waves on the CU): label +
+        // offsets -> targets -> atomic min -> (fire-and-forget marks).  The first version walked the edges one by one
+        // (target, min, marks: three trips per edge, 2.2 us per round on the road stand-in); here the operations of up
+        // to four edges are issued together, from clamped indices, so a vertex costs one chain whatever its degree.
+        uint32_t lu = sm.lab[v];
         const int e0 = sm.off[v], e1 = sm.off[v + 1];
+        asm volatile("" : "+v"(lu));  // (the label travels with the offsets, not behind the branch on them)
         nrel += e1 - e0;
-        for (int e = e0; e < e1; ++e) {
-          const int t = sm.tgt[e];
-          uint32_t cand;
-          if constexpr (W) cand = __float_as_uint(__uint_as_float(lu) + sm.wt[e]);
-          else cand = lu + 1u;
-          const uint32_t old = atomicMin(&sm.lab[t], cand);
-          if (cand < old) {
-            const uint32_t bit = 1u << (t & 31);
-            atomicOr(&sm.chg[t >> 5], bit);
-            if (cand < hi) {
-              atomicOr(&nxt[t >> 5], bit);
-              sm.flag[(rd + 1) % 3] = 1;
+        for (int eb = e0; eb < e1; eb += 4) {
+          int t[4];
+          uint32_t cand[4], old[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = min(eb + j, e1 - 1);
+            t[j] = sm.tgt[e];
+            if constexpr (W) cand[j] = __float_as_uint(__uint_as_float(lu) + sm.wt[e]);
+            else cand[j] = lu + 1u;
+            if (eb + j >= e1) cand[j] = BLK_NONE;  // no edge: a min with the largest key changes nothing
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) old[j] = atomicMin(&sm.lab[t[j]], cand[j]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (cand[j] < old[j]) {
+              const uint32_t bit = 1u << (t[j] & 31);
+              atomicOr(&sm.chg[t[j] >> 5], bit);
+              if (cand[j] < hi) {
+                atomicOr(&nxt[t[j] >> 5], bit);
+                sm.flag[(rd + 1) % 3] = 1;
+              }
             }
           }
         }
       }
     }
-    // ---- out: boundary edges of what was expanded, labels back, the smallest label left pending
+    // ---- out.  First what needs no load: expansion marks and labels back (stores / fire-and-forget atomics), the
+    // smallest label left pending.  Then the edges that leave the block -- only the vertices that have any (bitmap): the
+    // first version looked the offsets of EVERY changed vertex up, a chain of dependent global round trips per thread.
     {
       const uint32_t cw = sm.chg[tid], pw = sm.pend[tid], bw = sm.bnd[tid];
-      uint32_t m = cw | pw;
+      uint32_t m = cw | pw, xm = 0u;
       unsigned left = BLK_NONE;
       while (m) {
         const int j = __builtin_ctz(m);
@@ -337,24 +394,42 @@ __global__ __launch_bounds__(NV / 32) void blk_kernel(blk_run r, blk_dev g) {
         if (cw & bit) {
           if (L < hi) {
             r.expd[vg] = L;
-            const int x0 = g.xro[vg], x1 = g.xro[vg + 1];
-            nrel += x1 - x0;
-            for (int e = x0; e < x1; ++e) {
-              const int t = g.xci[e];
-              uint32_t cand;
-              if constexpr (W) cand = __float_as_uint(__uint_as_float(L) + g.xw[e]);
-              else cand = L + 1u;
-              const uint32_t old = __hip_atomic_fetch_min(&r.dist[t], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              // (issued behind the answer of the atomic above: the label is lowered BEFORE its block is notified)
-              if (cand < old)
-                (void)__hip_atomic_fetch_min(&r.bmin[t >> g.nv_shift], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            xm |= bit;
           }
           // a boundary vertex may have been lowered by a neighbour since it was loaded: min, not store
           if (bw & bit) (void)__hip_atomic_fetch_min(&r.dist[vg], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           else __hip_atomic_store(&r.dist[vg], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (L >= hi) left = min(left, L);  // pending: it was when it came in, or its label fell in here
+      }
+      xm &= sm.xout[tid];
+      while (xm) {
+        const int v = tid * 32 + __builtin_ctz(xm);
+        xm &= xm - 1u;
+        const uint32_t L = sm.lab[v];
+        const size_t vg = base + (size_t)v;
+        const int x0 = g.xro[vg], x1 = g.xro[vg + 1];
+        nrel += x1 - x0;
+        for (int eb = x0; eb < x1; eb += 4) {
+          int t[4];
+          uint32_t cand[4], old[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = min(eb + j, x1 - 1);
+            t[j] = g.xci[e];
+            if constexpr (W) cand[j] = __float_as_uint(__uint_as_float(L) + g.xw[e]);
+            else cand[j] = L + 1u;
+            if (eb + j >= x1) cand[j] = BLK_NONE;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            old[j] = __hip_atomic_fetch_min(&r.dist[t[j]], cand[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // (issued behind the answers of the atomics above: a label is lowered BEFORE its block is notified)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (cand[j] < old[j])
+              (void)__hip_atomic_fetch_min(&r.bmin[t[j] >> g.nv_shift], cand[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
@@ -418,7 +493,7 @@ static int blk_env(const char* name, int dflt) {
 void grx::blk_graph_free(void* p) {
   blk_graph* b = reinterpret_cast<blk_graph*>(p);
   if (!b) return;
-  void* ptrs[] = {b->perm, b->inv, b->off, b->tgt, b->wt, b->nedge, b->xro, b->xci, b->xw, b->bnd};
+  void* ptrs[] = {b->perm, b->inv, b->off, b->tgt, b->wt, b->nedge, b->xro, b->xci, b->xw, b->bnd, b->xout};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete b;
@@ -462,7 +537,7 @@ struct blk_host {
   std::vector<int32_t> perm, inv, nedge, xro, xci;
   std::vector<unsigned short> off, tgt;
   std::vector<float> wt, xw;
-  std::vector<uint32_t> bnd;
+  std::vector<uint32_t> bnd, xout;
 };
 
 // Cut the graph (host CSR) into blocks.  false: not applicable (a row that does not fit a block, negative weights, too much
@@ -582,6 +657,7 @@ static bool blk_partition_host(int32_t V, int64_t E, const int32_t* ro, const in
   h.xci.assign((size_t)h.n_cross, 0);
   if (weighted) h.xw.assign((size_t)h.n_cross, 0.0f);
   h.bnd.assign((size_t)nb * WORDS, 0u);
+  h.xout.assign((size_t)nb * WORDS, 0u);
   parallel_chunks(nb, [&](int b) {
     for (int i = 0; i < NV; ++i) {
       const size_t id = (size_t)b * NV + i;
@@ -589,6 +665,7 @@ static bool blk_partition_host(int32_t V, int64_t E, const int32_t* ro, const in
       const int32_t v = h.inv[id];
       if (v < 0) continue;
       int32_t at = h.xro[id];
+      if (h.xro[id + 1] > at) h.xout[(size_t)b * WORDS + (i >> 5)] |= 1u << (i & 31);
       for (int32_t e = ro[(size_t)v]; e < ro[(size_t)v + 1]; ++e) {
         const int32_t t = h.perm[(size_t)ci[(size_t)e]];
         if (t / NV == b) continue;
@@ -627,7 +704,7 @@ static grx_status_t blk_build(grx_context_t ctx, grx_graph_t g, bool weighted, i
   hipError_t e = hipSuccess;
   auto up = [&](auto** dst, const auto& src) { if (e == hipSuccess) e = upload(dst, src, s); };
   up(&bg->perm, h.perm); up(&bg->inv, h.inv); up(&bg->off, h.off); up(&bg->tgt, h.tgt); up(&bg->nedge, h.nedge);
-  up(&bg->xro, h.xro); up(&bg->xci, h.xci); up(&bg->bnd, h.bnd);
+  up(&bg->xro, h.xro); up(&bg->xci, h.xci); up(&bg->bnd, h.bnd); up(&bg->xout, h.xout);
   if (weighted) { up(&bg->wt, h.wt); up(&bg->xw, h.xw); }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) {
@@ -777,7 +854,7 @@ extern "C" grx_status_t grx_debug_block_search_host(grx_host_csr_t csr, int32_t 
 grx_status_t grx::blk_prepare(grx_context_t ctx, grx_graph_t g, bool weighted, bool* usable) {
   *usable = false;
   const int k = weighted ? 1 : 0;
-  if (blk_env("GRX_BLOCK", 1) == 0) return GRX_SUCCESS;
+  if (blk_env("GRX_BLOCK", GRX_BLOCK_DEFAULT) == 0) return GRX_SUCCESS;
   if (g->blk_state[k] == 2) return GRX_SUCCESS;
   if (g->blk_state[k] == 1) { *usable = true; return GRX_SUCCESS; }
   g->blk_state[k] = 2;
@@ -829,7 +906,7 @@ grx_status_t grx::blk_search(grx_context_t ctx, grx_graph_t g, int32_t src, cons
   d.nv_shift = bg->nv == 8192 ? 13 : (bg->nv == 4096 ? 12 : 11);
   d.n_new = bg->n_new;
   d.inv = bg->inv; d.off = bg->off; d.tgt = bg->tgt; d.wt = bg->wt; d.nedge = bg->nedge;
-  d.xro = bg->xro; d.xci = bg->xci; d.xw = bg->xw; d.bnd = bg->bnd;
+  d.xro = bg->xro; d.xci = bg->xci; d.xw = bg->xw; d.bnd = bg->bnd; d.xout = bg->xout;
 
   // problem.reset(), outside the timed region like the reference's
   hipLaunchKernelGGL(blk_reset_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, s, r, (int64_t)bg->n_new, bg->nb);

@@ -14,6 +14,7 @@
 // The problem is bandwidth bound (~0.17 flop/byte); MFMA has nothing to offer
 // at one multiply-add per 12 gathered bytes and is deliberately not used.
 #include "grx_engine.hpp"
+#include "grx_sort.hpp"
 #include <gunrock/hip/scan.hxx>
 
 #include <algorithm>
@@ -414,33 +415,23 @@ __global__ __launch_bounds__(256) void pr_combine_kernel(pr_args a, int iter) {
   if (threadIdx.x == 0) a.partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// bucket in-edges by (source block, destination): counts, then fill with cursors
-// `perm` (may be null) relabels the SOURCES: in-edges are bucketed by, and store, perm[u].
-__global__ void xb_count_kernel(const int32_t* __restrict__ ro, const int32_t* __restrict__ ci, int32_t V,
-                                int32_t per_block, const int32_t* __restrict__ perm, int32_t* cnt) {
-  const int lane = dev::lane_id();
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t u = wave; u < V; u += nwaves) {
-    const int s = (int)((perm ? perm[u] : (int32_t)u) / per_block);
-    const int b = ro[u], e = ro[u + 1];
-    for (int k = b + lane; k < e; k += 64) atomicAdd(&cnt[(size_t)s * ((size_t)V + 1) + ci[k]], 1);
-  }
-}
-__global__ void xb_fill_kernel(const int32_t* __restrict__ ro, const int32_t* __restrict__ ci,
-                               const float* __restrict__ w, int32_t V, int32_t per_block,
-                               const int32_t* __restrict__ perm, int32_t* cursor, int32_t* out_ci, float* out_w) {
+// The XCD-blocked layout is the edge list sorted by (source block, destination): key = block * (V + 1) + destination,
+// value = the (relabelled) source [, weight].  `perm` (may be null) relabels the SOURCES: in-edges are bucketed by, and
+// store, perm[u].  One wave per row, lanes on consecutive edges.
+__global__ void xb_expand_kernel(const int32_t* __restrict__ ro, const int32_t* __restrict__ ci, const float* __restrict__ w,
+                                 int32_t V, int32_t per_block, const int32_t* __restrict__ perm, uint32_t* keys, uint32_t* vals,
+                                 uint32_t* vals2) {
   const int lane = dev::lane_id();
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t u = wave; u < V; u += nwaves) {
     const int32_t pu = perm ? perm[u] : (int32_t)u;
-    const int s = (int)(pu / per_block);
+    const uint32_t kb = (uint32_t)(pu / per_block) * ((uint32_t)V + 1u);
     const int b = ro[u], e = ro[u + 1];
     for (int k = b + lane; k < e; k += 64) {
-      const int pos = atomicAdd(&cursor[(size_t)s * ((size_t)V + 1) + ci[k]], 1);
-      out_ci[pos] = pu;
-      if (out_w) out_w[pos] = w[k];
+      keys[k] = kb + (uint32_t)ci[k];
+      vals[k] = (uint32_t)pu;
+      if (vals2) vals2[k] = __float_as_uint(w[k]);
     }
   }
 }
@@ -533,7 +524,6 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   const size_t n_off = (size_t)XB * ((size_t)V + 1);
   const int32_t per_block = (V + XB - 1) / XB;
   hipStream_t s = ctx->stream;
-  int32_t *cnt = nullptr, *bs = nullptr;
   // HUB-FIRST RELABELLING OF THE SOURCES.  The gathers of a bucket go to one slice of x[] (V/8
   // floats); on a scale-free graph most of them go to a few thousand hub vertices, which the
   // Graph500 permutation scatters one per cache line.  Sources are ranked by out-degree (= how
@@ -572,22 +562,26 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
     GRX_HIP(hipMemcpy(g->xb_perm, perm.data(), (size_t)V * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ro), (n_off + 2) * sizeof(int32_t)));
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ci), (size_t)E * sizeof(int32_t)));
   const bool unit = graph_unit_weights(g);  // no weight stream needed (graph_weight_stats ran)
-  if (!unit) GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_w), (size_t)E * sizeof(float)));
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&cnt), (n_off + 2) * sizeof(int32_t)));
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&bs), ((size_t)scan_num_blocks((int64_t)n_off) + 2) * sizeof(int32_t)));
-  GRX_HIP(hipMemsetAsync(cnt, 0, (n_off + 2) * sizeof(int32_t), s));
-  hipLaunchKernelGGL(xb_count_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, V, per_block, g->xb_perm, cnt);
-  exclusive_scan_i32(s, cnt, (int64_t)n_off, g->xb_ro, bs);
-  GRX_HIP(hipMemcpyAsync(cnt, g->xb_ro, n_off * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(xb_fill_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, unit ? nullptr : g->w, V, per_block,
-                     g->xb_perm, cnt, g->xb_ci, g->xb_w);
+  // stable radix sort of the edges by (source block, destination) (grx_sort.hpp): the round 1-3 version counted and filled
+  // with one global atomic per edge -- 124 ms for the 182 M edges of the kron stand-in
+  sort_buffers sb;
+  if ((uint64_t)n_off >= (1ull << 31) || sb.alloc(E, !unit) != hipSuccess) {
+    sb.release();
+    (void)hipGetLastError();
+    return fail(GRX_ERROR_OUT_OF_MEMORY, "pagerank: scratch for the XCD-blocked layout");
+  }
+  hipLaunchKernelGGL(xb_expand_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, unit ? nullptr : g->w, V, per_block, g->xb_perm,
+                     sb.keys[0], sb.vals[0], sb.vals2[0]);
+  const int res = radix_sort_pairs(s, sb, bits_for((uint64_t)n_off));
+  hipLaunchKernelGGL(sort_boundaries_kernel, dim3(2048), dim3(256), 0, s, sb.keys[res], E, 0, (int32_t)n_off, g->xb_ro);
   std::vector<int32_t> off(n_off + 1);
   GRX_HIP(hipMemcpyAsync(off.data(), g->xb_ro, (n_off + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   GRX_HIP(hipStreamSynchronize(s));
-  (void)hipFree(cnt);
-  (void)hipFree(bs);
+  GRX_HIP(hipGetLastError());
+  g->xb_ci = reinterpret_cast<int32_t*>(sb.vals[res]);
+  if (!unit) g->xb_w = reinterpret_cast<float*>(sb.vals2[res]);
+  sb.release(g->xb_ci, g->xb_w);
   // static partition, one list per source block (same packing rule as the plain layout)
   std::vector<int4> blocks;
   std::vector<int32_t> piece, longrows;

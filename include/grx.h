@@ -278,6 +278,10 @@ typedef struct grx_level_profile {
 grx_status_t grx_get_level_profile(grx_context_t ctx, grx_level_profile_t* out,
                                    int32_t capacity, int32_t* n_levels);
 
+/* Test hook: the stable LSD radix sort behind the per-graph preprocessing (gunrock_amd/csrc/grx_sort.hpp) on caller
+ * device arrays, in place: n (key, value[, value2]) triples ordered by the low key_bits bits of the key, ties in input order. */
+grx_status_t grx_debug_radix_sort(grx_context_t ctx, uint32_t* d_keys, uint32_t* d_vals, uint32_t* d_vals2_or_null, int64_t n,
+                                  int32_t key_bits);
 /* Tuning aid: copies `n` 64-bit words of the context's debug scratch (per-workgroup timeline of the binned BFS
  * kernels, recorded when GRX_BIN_DEBUG=<level> is set; tools/bin_debug.py). */
 grx_status_t grx_debug_read(grx_context_t ctx, long long* out, int64_t n);

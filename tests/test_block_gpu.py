@@ -18,6 +18,7 @@ KNOBS = ("GRX_BLOCK_NV", "GRX_BLOCK_NV_W", "GRX_BLOCK_DELTA", "GRX_BLOCK_DELTA_W
 @pytest.fixture(autouse=True)
 def _clean_env():
     saved = {k: os.environ.pop(k, None) for k in KNOBS}
+    os.environ["GRX_BLOCK"] = "1"  # (whatever the library's default is: this file is about that path)
     yield
     for k, v in saved.items():
         os.environ.pop(k, None)
@@ -42,7 +43,7 @@ def test_bfs_lattice_every_block_size_and_bucket(gr, gpu_ctx):
                 {"GRX_BLOCK_DELTA": "100000"}, {"GRX_BLOCK_WG_PER_CU": "1"}):
         for k in KNOBS:
             os.environ.pop(k, None)
-        os.environ.update(env)
+        os.environ.update(dict(env, GRX_BLOCK="1"))
         # a fresh handle per configuration: the block structure is cached in it
         G = gr.build_graph(gr.graph_properties_t(True, False, False), gr.csr_t.from_arrays(g.row_offsets, g.column_indices), gpu_ctx)
         for rep in range(2):
@@ -75,7 +76,7 @@ def test_weighted_and_unit_sssp_lattice(gr, gpu_ctx):
                     {"GRX_BLOCK_DELTA_W": "100000"}):
             for k in KNOBS:
                 os.environ.pop(k, None)
-            os.environ.update(env)
+            os.environ.update(dict(env, GRX_BLOCK="1"))
             G = gr.build_graph(gr.graph_properties_t(True, True, False),
                                gr.csr_t.from_arrays(g.row_offsets, g.column_indices, g.values), gpu_ctx)
             for s in sources:

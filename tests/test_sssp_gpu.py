@@ -120,14 +120,15 @@ def test_medium_weighted_rmat(gr, gpu_ctx):
     assert O.check_sssp(g, src, d) == 0
 
 
-def test_full_size_road_standin_properties(gr, gpu_ctx):
+def test_full_size_road_standin_properties(gr, gpu_ctx, monkeypatch):
     """BASELINE.json configs[2] size: 4894x4894 lattice (23,951,236 V, ~57.7 M E),
     weighted variant U{1..1000}; exact fixed-point characterisation by the oracle."""
     _, c = gr.generate("road", 4894 * 4894, a=0.602, c=1.0, seed=42)
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
     assert 55_000_000 < g.n_edges < 60_000_000
     src = (4894 // 2) * 4894 + 4894 // 2
-    # default: block-asynchronous relaxation (grx_block.hip); GRX_FLAG_NO_BLOCK_ASYNC: the near-far schedule
+    # block-asynchronous relaxation (grx_block.hip, GRX_BLOCK=1); GRX_FLAG_NO_BLOCK_ASYNC: the near-far schedule
+    monkeypatch.setenv("GRX_BLOCK", "1")
     got = []
     for o in (None, gr.options_t(engine_flags=gr.FLAG_NO_BLOCK_ASYNC)):
         d, st = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src, o)
@@ -138,7 +139,7 @@ def test_full_size_road_standin_properties(gr, gpu_ctx):
     assert np.array_equal(got[0], got[1])
 
 
-def test_full_size_road_standin_unit_weights(gr, gpu_ctx):
+def test_full_size_road_standin_unit_weights(gr, gpu_ctx, monkeypatch):
     """BASELINE.json configs[2] as the reference loader produces it from the pattern file road_usa.mtx:
     every weight 1.0 (io/matrix_market.hxx:170-171).  Full size; distances must equal the BFS depths of
     the same run (bit-exact, as floats) and pass the oracle's exact fixed-point check."""
@@ -149,7 +150,8 @@ def test_full_size_road_standin_unit_weights(gr, gpu_ctx):
     src = (4894 // 2) * 4894 + 4894 // 2
     depths, _, ev = O.bfs_queue(g, src)
     reached = depths != np.iinfo(np.int32).max
-    # default: the BFS engine (block-asynchronous on this road-like graph) + one pass depths -> distances;
+    monkeypatch.setenv("GRX_BLOCK", "1")
+    # default: the BFS engine (block-asynchronous on this road-like graph with GRX_BLOCK=1) + one pass depths -> distances;
     # GRX_FLAG_SSSP_NO_BFS: the SSSP paths (block-asynchronous with the weight array; with GRX_FLAG_NO_BLOCK_ASYNC the
     # level-synchronous relaxation kernels of grx_sssp.hip); GRX_FLAG_NO_BLOCK_ASYNC alone: the level-synchronous BFS engine
     for flags in (0, gr.FLAG_SSSP_NO_BFS, gr.FLAG_SSSP_NO_BFS | gr.FLAG_NO_BLOCK_ASYNC, gr.FLAG_NO_BLOCK_ASYNC):

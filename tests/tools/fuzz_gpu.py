@@ -51,6 +51,7 @@ def sweep(budget_s, seed=1234, log=print, max_vertices=600_000):
             # sparse graphs: every other one small enough to stay on the level-synchronous kernels takes the
             # block-asynchronous path anyway (grx_block.hip; the threshold is read when the handle first searches)
             os.environ["GRX_BLOCK_MIN_V"] = "512" if int(rng.integers(0, 2)) else "65536"
+            os.environ["GRX_BLOCK"] = "1"
             G = gr.build_graph(props, c, ctx)
             deg = np.diff(c.row_offsets)
             sources = [int(np.argmax(deg))] + [int(x) for x in rng.integers(0, V, 3)]
@@ -92,6 +93,7 @@ def sweep(budget_s, seed=1234, log=print, max_vertices=600_000):
             del G
     finally:
         os.environ.pop("GRX_BLOCK_MIN_V", None)
+        os.environ.pop("GRX_BLOCK", None)
         os.environ.pop("GRX_BIN_MAX_DEGREE", None)
         if saved_env is None:
             os.environ.pop("GRX_BIN_MIN_EDGES", None)
