@@ -522,6 +522,7 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   if (g->bin_state == 3) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: a column index lies outside [0, V)");
   if (g->bin_state != 0) return GRX_SUCCESS;
   g->bin_state = 2;  // unusable until proven otherwise
+  prep_timer tm("bfs: bin table (granule counts + cut)", ctx->stream);
   if (g->V <= 0 || g->E <= 0 || ctx->n_xcd < 1) return GRX_SUCCESS;
   int gshift = BIN_GSHIFT_MIN;
   while (gshift < 31 && (((long long)g->V + (1ll << gshift) - 1) >> gshift) > BIN_GRAN_MAX) ++gshift;

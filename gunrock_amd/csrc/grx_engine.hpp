@@ -4,6 +4,7 @@
 
 #include "grx_frontier.hpp"
 
+#include <chrono>
 #include <cstdlib>
 
 namespace grx {
@@ -40,6 +41,29 @@ grx_status_t blk_prepare(grx_context_t ctx, grx_graph_t g, bool weighted, bool* 
 grx_status_t blk_search(grx_context_t ctx, grx_graph_t g, int32_t src, const grx_options_t& opt, bool weighted, void* d_out,
                         float* elapsed_ms);
 void blk_graph_free(void* p);
+
+// GRX_PREP_TIMING=1: wall time of every per-graph preprocessing step (stream drained at both ends) on stderr --
+// what `first_call_ms` of bench.py is made of.
+struct prep_timer {
+  const char* what;
+  hipStream_t s;
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  prep_timer(const char* w, hipStream_t stream) : what(w), s(stream) {
+    const char* v = getenv("GRX_PREP_TIMING");
+    on = v && *v == '1';
+    if (on) {
+      (void)hipStreamSynchronize(s);
+      t0 = std::chrono::steady_clock::now();
+    }
+  }
+  ~prep_timer() {
+    if (!on) return;
+    (void)hipStreamSynchronize(s);
+    fprintf(stderr, "[grx prep] %-40s %9.3f ms\n", what,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
 
 // Launch configuration of the advance kernel (persistent workgroups striding over chunks).
 // Upper bound used for sizing scratch:

@@ -15,6 +15,9 @@
 // at one multiply-add per 12 gathered bytes and is deliberately not used.
 #include "grx_engine.hpp"
 #include "grx_sort.hpp"
+
+#include <atomic>
+#include <thread>
 #include <gunrock/hip/scan.hxx>
 
 #include <algorithm>
@@ -457,16 +460,19 @@ struct pr_partition {
   int32_t* longrows = nullptr;
   int32_t n_blocks = 0, n_pieces = 0, n_long = 0;
 };
-// rows [lo, hi) of the matrix whose (host) row offsets are `ro`
-static grx_status_t build_pr_partition_rows(const std::vector<int32_t>& ro, int32_t lo, int32_t hi, pr_partition* out) {
+// The packing of rows [lo, hi) of the matrix whose (host) row offsets are `ro`, as host vectors.  `row_id_base` is added to
+// the row ids recorded for long rows (the XCD-blocked lists number them block-major).
+struct pr_pack {
   std::vector<int4> blocks;
-  std::vector<int32_t> piece, longrows;
+  std::vector<int32_t> piece, longrows;  // piece: -1 or the piece number LOCAL to this pack; longrows: {row, first piece (local), n}
   int32_t n_pieces = 0;
+};
+static void pack_rows(const int32_t* ro, int32_t lo, int32_t hi, int64_t row_id_base, pr_pack& out) {
   int32_t row0 = lo;
   auto flush = [&](int32_t row_end) {
     if (row_end > row0) {
-      blocks.push_back(make_int4(row0, row_end - row0, ro[row0], ro[row_end]));
-      piece.push_back(-1);
+      out.blocks.push_back(make_int4(row0, row_end - row0, ro[row0], ro[row_end]));
+      out.piece.push_back(-1);
     }
     row0 = row_end;
   };
@@ -474,23 +480,58 @@ static grx_status_t build_pr_partition_rows(const std::vector<int32_t>& ro, int3
     const int32_t deg = ro[v + 1] - ro[v];
     if (deg > PR_LONG) {
       flush(v);
-      longrows.push_back(v);
-      longrows.push_back(n_pieces);
+      out.longrows.push_back((int32_t)(row_id_base + v));
+      out.longrows.push_back(out.n_pieces);
       int32_t np = 0;
       for (int32_t e = ro[v]; e < ro[v + 1]; e += PR_NNZ) {
-        blocks.push_back(make_int4(v, 0, e, std::min(ro[v + 1], e + PR_NNZ)));
-        piece.push_back(n_pieces++);
+        out.blocks.push_back(make_int4(v, 0, e, std::min(ro[v + 1], e + PR_NNZ)));
+        out.piece.push_back(out.n_pieces++);
         ++np;
       }
-      longrows.push_back(np);
+      out.longrows.push_back(np);
       row0 = v + 1;
       continue;
     }
     if (ro[v + 1] - ro[row0] > PR_NNZ || v - row0 >= PR_MAXROWS) flush(v);
   }
   flush(hi);
+}
+// The same packing over FIXED chunks of the row range, the chunks packed by host threads in parallel and concatenated in
+// order.  The chunk boundaries depend on nothing but (lo, hi): the partition -- and with it every fp32 row sum -- is the same
+// on every machine and every handle.  (One thread walked 16.8 M rows of the kron stand-in's eight lists in ~50 ms.)
+constexpr int32_t PR_PACK_CHUNK = 1 << 16;
+static void pack_rows_parallel(const int32_t* ro, int32_t lo, int32_t hi, int64_t row_id_base, pr_pack& out) {
+  const int n_chunks = std::max(1, (hi - lo + PR_PACK_CHUNK - 1) / PR_PACK_CHUNK);
+  std::vector<pr_pack> parts((size_t)n_chunks);
+  std::atomic<int> next{0};
+  const int nt = std::max(1, std::min(n_chunks, std::min(32, (int)std::thread::hardware_concurrency())));
+  auto work = [&] {
+    for (int c; (c = next.fetch_add(1)) < n_chunks;)
+      pack_rows(ro, lo + c * PR_PACK_CHUNK, std::min(hi, lo + (c + 1) * PR_PACK_CHUNK), row_id_base, parts[(size_t)c]);
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
+  for (auto& p : parts) {
+    const int32_t piece0 = out.n_pieces;
+    out.blocks.insert(out.blocks.end(), p.blocks.begin(), p.blocks.end());
+    for (int32_t x : p.piece) out.piece.push_back(x < 0 ? -1 : x + piece0);
+    for (size_t i = 0; i < p.longrows.size(); i += 3) {
+      out.longrows.push_back(p.longrows[i]);
+      out.longrows.push_back(p.longrows[i + 1] + piece0);
+      out.longrows.push_back(p.longrows[i + 2]);
+    }
+    out.n_pieces += p.n_pieces;
+  }
+}
+static grx_status_t build_pr_partition_rows(const std::vector<int32_t>& ro, int32_t lo, int32_t hi, pr_partition* out) {
+  pr_pack pk;
+  pack_rows_parallel(ro.data(), lo, hi, 0, pk);
+  const std::vector<int4>& blocks = pk.blocks;
+  const std::vector<int32_t>&piece = pk.piece, &longrows = pk.longrows;
   out->n_blocks = (int32_t)blocks.size();
-  out->n_pieces = n_pieces;
+  out->n_pieces = pk.n_pieces;
   out->n_long = (int32_t)(longrows.size() / 3);
   GRX_HIP(hipMalloc(&out->blocks, std::max<size_t>(1, blocks.size()) * sizeof(int4)));
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&out->piece), std::max<size_t>(1, piece.size()) * sizeof(int32_t)));
@@ -505,6 +546,11 @@ static grx_status_t build_pr_partition_rows(const std::vector<int32_t>& ro, int3
 }
 static grx_status_t build_pr_partition(grx_graph_t g) {
   if (g->pr_blocks) return GRX_SUCCESS;
+  prep_timer tm("pagerank: static partition (host)", g->ctx ? g->ctx->stream : nullptr);
+  if (g->h_t_ro.size() != (size_t)g->V + 1) {  // host copy of the transpose offsets, taken once
+    g->h_t_ro.resize((size_t)g->V + 1);
+    GRX_HIP(hipMemcpy(g->h_t_ro.data(), g->t_ro, ((size_t)g->V + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
   pr_partition pt;
   grx_status_t st = build_pr_partition_rows(g->h_t_ro, 0, g->V, &pt);
   if (st != GRX_SUCCESS) return st;
@@ -519,6 +565,7 @@ static grx_status_t build_pr_partition(grx_graph_t g) {
 
 static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   if (g->has_xb) return GRX_SUCCESS;
+  prep_timer tm("pagerank: XCD-blocked layout (rank + sort + partition)", ctx->stream);
   const int32_t V = g->V;
   const int64_t E = g->E;
   const size_t n_off = (size_t)XB * ((size_t)V + 1);
@@ -583,40 +630,14 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   if (!unit) g->xb_w = reinterpret_cast<float*>(sb.vals2[res]);
   sb.release(g->xb_ci, g->xb_w);
   // static partition, one list per source block (same packing rule as the plain layout)
-  std::vector<int4> blocks;
-  std::vector<int32_t> piece, longrows;
-  int32_t n_pieces = 0;
+  pr_pack pk;
   for (int sb = 0; sb < XB; ++sb) {
-    g->xb_begin[sb] = (int32_t)blocks.size();
-    const int32_t* ro = off.data() + (size_t)sb * ((size_t)V + 1);
-    int32_t row0 = 0;
-    auto flush = [&](int32_t row_end) {
-      if (row_end > row0) {
-        blocks.push_back(make_int4(row0, row_end - row0, ro[row0], ro[row_end]));
-        piece.push_back(-1);
-      }
-      row0 = row_end;
-    };
-    for (int32_t v = 0; v < V; ++v) {
-      const int32_t deg = ro[v + 1] - ro[v];
-      if (deg > PR_LONG) {
-        flush(v);
-        longrows.push_back((int32_t)((size_t)sb * (size_t)V + (size_t)v));
-        longrows.push_back(n_pieces);
-        int32_t np = 0;
-        for (int32_t e = ro[v]; e < ro[v + 1]; e += PR_NNZ) {
-          blocks.push_back(make_int4(v, 0, e, std::min(ro[v + 1], e + PR_NNZ)));
-          piece.push_back(n_pieces++);
-          ++np;
-        }
-        longrows.push_back(np);
-        row0 = v + 1;
-        continue;
-      }
-      if (ro[v + 1] - ro[row0] > PR_NNZ || v - row0 >= PR_MAXROWS) flush(v);
-    }
-    flush(V);
+    g->xb_begin[sb] = (int32_t)pk.blocks.size();
+    pack_rows_parallel(off.data() + (size_t)sb * ((size_t)V + 1), 0, V, (int64_t)sb * (int64_t)V, pk);
   }
+  const std::vector<int4>& blocks = pk.blocks;
+  const std::vector<int32_t>&piece = pk.piece, &longrows = pk.longrows;
+  const int32_t n_pieces = pk.n_pieces;
   g->xb_begin[XB] = (int32_t)blocks.size();
   g->n_xb_pieces = n_pieces;
   g->n_xb_long = (int32_t)(longrows.size() / 3);

@@ -83,6 +83,7 @@ grx_status_t grx::graph_is_symmetric(grx_context_t ctx, grx_graph_t g, bool* res
   if (g->sym_checked == 0) {
     const int32_t V = g->V;
     hipStream_t s = ctx->stream;
+    prep_timer tm("symmetry check", s);
     unsigned long long* h = nullptr;
     int32_t* bad = nullptr;
     GRX_HIP(hipMalloc(reinterpret_cast<void**>(&h), (2 * (size_t)V + 2) * sizeof(unsigned long long)));
@@ -108,6 +109,7 @@ grx_status_t grx::graph_build_transpose(grx_context_t ctx, grx_graph_t g) {
   const int32_t V = g->V;
   const int64_t E = g->E;
   hipStream_t s = ctx->stream;
+  prep_timer tm("transpose (expand + radix sort + offsets)", s);
   const bool weighted = g->w != nullptr;
   if (V >= (1 << 29)) return fail(GRX_ERROR_UNSUPPORTED, "transpose: more than 2^29 vertices");
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->t_ro), ((size_t)V + 2) * sizeof(int32_t)));
@@ -136,9 +138,7 @@ grx_status_t grx::graph_build_transpose(grx_context_t ctx, grx_graph_t g) {
     if (weighted) g->t_w = reinterpret_cast<float*>(sb.vals2[res]);
     sb.release(g->t_ci, g->t_w);
   }
-  std::vector<int32_t> h_ro((size_t)V + 1);
-  GRX_HIP(hipMemcpy(h_ro.data(), g->t_ro, ((size_t)V + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
-  g->h_t_ro.swap(h_ro);
+  // (the host copy of the offsets is taken by the one consumer that needs it: PageRank's static partition)
   g->has_transpose = true;
   return GRX_SUCCESS;
 }

@@ -31,12 +31,15 @@ namespace advance {
 
 namespace detail {
 // advance_direction_t::backward: the operator still sees an edge as (source, destination, edge, weight) although the walk
-// starts from the destination
+// starts from the destination.  The ends are forwarded as the MUTABLE lvalues the kernels hand in, so operators declared
+// (vertex_t&, vertex_t&, edge_t const&, weight_t const&) -- the reference's hits.hxx:137 style -- compile in this direction
+// too.  NOTE: `e` indexes the CSC arrays (the in-edge's position in its column), not the CSR arrays: an
+// operator that looks a per-edge array up by CSR edge id must not be run backward.
 template <typename operator_t>
 struct swap_ends_t {
   operator_t op;
   template <typename vertex_t, typename edge_t, typename weight_t>
-  __host__ __device__ bool operator()(vertex_t const& dst, vertex_t const& src, edge_t const& e, weight_t const& w) const {
+  __host__ __device__ bool operator()(vertex_t& dst, vertex_t& src, edge_t const& e, weight_t const& w) const {
     return op(src, dst, e, w);
   }
 };
