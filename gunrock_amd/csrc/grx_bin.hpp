@@ -71,6 +71,7 @@ struct bin_args {
   int32_t mid_v, mid_e;       // thresholds of the many-levels-per-launch body (grx_mid.hpp), 0: off (carried here for the head kernel)
   int32_t static_units;       // second scatter: units strided statically over the workgroups instead of drawn from per-XCD ticket
                               // queues (the fallback when a launch cannot be trusted to put a workgroup on every XCD)
+  int32_t pair_stores;        // second scatter: neighbouring entries of a bin leave as one store of twice the width (GRX_BIN_PAIR)
   int32_t fault_xcd;          // test aid (GRX_SC2_FAULT_XCD=k): workgroups on dense XCD index k - 1 take no units (0: off)
 };
 
@@ -1071,7 +1072,41 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     // ---- phase 7: runs leave LDS as contiguous segments (no barrier behind it: the next batch touches the sort
     // buffer and `delta` only after six more barriers).  Positions past the batch's total hold stale entries: their
     // bin field is < 256 whatever they are, so the table read stays unconditional
-    {
+    if (bn.pair_stores) {
+      // Two neighbouring sorted positions per thread: where both belong to the same bin and the first lands on an even
+      // entry, the pair leaves as ONE store of twice the width (round 4: a 2-byte store instruction costs the memory
+      // pipeline what a 4-byte one does, and every store sits in the in-order vmcnt queue the next batch's loads wait on).
+      const int btot = sm.btot;
+      uint2 p_k[ADV_ITEMS / 2];
+      int d0_k[ADV_ITEMS / 2], d1_k[ADV_ITEMS / 2];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS / 2; ++k) p_k[k] = reinterpret_cast<const uint2*>(sm.sorted)[k * SC2_BLOCK + tid];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS / 2; ++k) {
+        d0_k[k] = sm.delta[p_k[k].x >> 24];
+        d1_k[k] = sm.delta[p_k[k].y >> 24];
+      }
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS / 2; ++k) {
+        const int i0 = 2 * (k * SC2_BLOCK + tid), i1 = i0 + 1;
+        const int a0 = d0_k[k] + i0, a1 = d1_k[k] + i1;
+        const bool both = i1 < btot && a1 == a0 + 1 && (a0 & 1) == 0;
+        if constexpr (E16) {
+          unsigned short* b16 = reinterpret_cast<unsigned short*>(bn.bins);
+          if (both) reinterpret_cast<unsigned*>(bn.bins)[(size_t)(a0 >> 1)] = (p_k[k].x & 0xffffu) | (p_k[k].y << 16);
+          else {
+            if (i0 < btot) b16[(size_t)a0] = (unsigned short)(p_k[k].x & 0xffffu);
+            if (i1 < btot) b16[(size_t)a1] = (unsigned short)(p_k[k].y & 0xffffu);
+          }
+        } else {
+          if (both) reinterpret_cast<uint2*>(bn.bins)[(size_t)(a0 >> 1)] = make_uint2(p_k[k].x & 0xffffffu, p_k[k].y & 0xffffffu);
+          else {
+            if (i0 < btot) bn.bins[(size_t)a0] = (int)(p_k[k].x & 0xffffffu);
+            if (i1 < btot) bn.bins[(size_t)a1] = (int)(p_k[k].y & 0xffffffu);
+          }
+        }
+      }
+    } else {
       const int btot = sm.btot;
       unsigned s_k[ADV_ITEMS];
       int d_k[ADV_ITEMS];

@@ -377,29 +377,38 @@ __global__ __launch_bounds__(NV / 32) void blk_kernel(blk_run r, blk_dev g) {
         }
       }
     }
-    // ---- out.  First what needs no load: expansion marks and labels back (stores / fire-and-forget atomics), the
-    // smallest label left pending.  Then the edges that leave the block -- only the vertices that have any (bitmap): the
-    // first version looked the offsets of EVERY changed vertex up, a chain of dependent global round trips per thread.
+    // ---- out.  Labels back and expansion marks, COALESCED (lane <-> consecutive vertex, like the staging; the first two
+    // versions stored from the owner thread of each bitmap word -- scattered 4-byte write-through stores, the slowest
+    // kind per byte): expd is the owner's alone and is rewritten whole -- L where the vertex is expanded (or was never
+    // pending), "unreached" where it stays pending (any value above its label says so); dist only where it changed,
+    // through an atomic min on boundary vertices (a neighbour may have lowered them since they were loaded).
     {
-      const uint32_t cw = sm.chg[tid], pw = sm.pend[tid], bw = sm.bnd[tid];
+      uint32_t* dg = r.dist + base;
+      uint32_t* eg = r.expd + base;
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) {
+        const int v = k * T + tid;
+        const uint32_t L = sm.lab[v];
+        const uint32_t bit = 1u << (v & 31);
+        const uint32_t cw = sm.chg[v >> 5], pw = sm.pend[v >> 5], bw = sm.bnd[v >> 5];
+        eg[v] = (L < hi || !((cw | pw) & bit)) ? L : r.inf;
+        if (cw & bit) {
+          if (bw & bit) (void)__hip_atomic_fetch_min(&dg[v], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else dg[v] = L;
+        }
+      }
+    }
+    // what is left pending, and the edges that leave the block -- only from the vertices that have any (bitmap)
+    {
+      const uint32_t cw = sm.chg[tid], pw = sm.pend[tid];
       uint32_t m = cw | pw, xm = 0u;
       unsigned left = BLK_NONE;
       while (m) {
         const int j = __builtin_ctz(m);
         const uint32_t bit = 1u << j;
         m &= m - 1u;
-        const int v = tid * 32 + j;
-        const uint32_t L = sm.lab[v];
-        const size_t vg = base + (size_t)v;
-        if (cw & bit) {
-          if (L < hi) {
-            r.expd[vg] = L;
-            xm |= bit;
-          }
-          // a boundary vertex may have been lowered by a neighbour since it was loaded: min, not store
-          if (bw & bit) (void)__hip_atomic_fetch_min(&r.dist[vg], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else __hip_atomic_store(&r.dist[vg], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const uint32_t L = sm.lab[tid * 32 + j];
+        if ((cw & bit) && L < hi) xm |= bit;
         if (L >= hi) left = min(left, L);  // pending: it was when it came in, or its label fell in here
       }
       xm &= sm.xout[tid];

@@ -18,6 +18,8 @@
 #include "grx_common.hpp"
 #include <gunrock/hip/scan.hxx>
 
+#include <cstdlib>
+
 namespace grx {
 
 constexpr int SORT_BLOCK = 256;
@@ -26,6 +28,7 @@ constexpr int SORT_STEPS = 16;                               // 64-element steps
 constexpr int SORT_TILE = SORT_BLOCK * SORT_STEPS;           // 4096 elements per workgroup
 constexpr int SORT_MAX_BITS = 9;
 constexpr int SORT_MAX_DIGITS = 1 << SORT_MAX_BITS;
+constexpr int SORT_DEFAULT_BITS = 9;
 
 static __global__ __launch_bounds__(SORT_BLOCK) void sort_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
                                                                       int bits, int32_t* hist, int n_tiles) {
@@ -157,7 +160,10 @@ inline int radix_sort_pairs(hipStream_t s, sort_buffers& b, int key_bits) {
   const int64_t n = b.n;
   if (n <= 0) return 0;
   const int n_tiles = (int)((n + SORT_TILE - 1) / SORT_TILE);
-  const int passes = std::max(1, (key_bits + SORT_MAX_BITS - 1) / SORT_MAX_BITS);
+  // digit width: GRX_SORT_BITS (tuning knob, 4..9).  Fewer bits = more passes, but longer runs per digit in the scatter
+  int max_bits = SORT_DEFAULT_BITS;
+  if (const char* e = getenv("GRX_SORT_BITS")) { const int x = atoi(e); if (x >= 4 && x <= SORT_MAX_BITS) max_bits = x; }
+  const int passes = std::max(1, (key_bits + max_bits - 1) / max_bits);
   int cur = 0, shift = 0;
   for (int p = 0; p < passes; ++p) {
     const int bits = (key_bits - shift + (passes - p) - 1) / (passes - p);  // the remaining bits, spread evenly

@@ -47,9 +47,9 @@ for kind, weighted in (("bfs", False), ("sssp", True)):
     viol = O.check_sssp(g, src, base) if weighted else O.check_bfs(g, src, base)
     print("%s side %d level-synchronous: %.3f ms (first call %.1f ms), oracle violations %d" % (kind, side, ms0, first0, viol), flush=True)
     if weighted:
-        grid = [({"GRX_BLOCK_NV_W": str(nv), "GRX_BLOCK_DELTA_W": str(dl)}) for nv in (2048, 4096) for dl in (32, 128, 512, 4096)]
+        grid = [({"GRX_BLOCK_NV_W": str(nv), "GRX_BLOCK_DELTA_W": str(dl)}) for nv in (2048, 4096) for dl in (8, 16, 32, 64)]
     else:
-        grid = [({"GRX_BLOCK_NV": str(nv), "GRX_BLOCK_DELTA": str(dl)}) for nv in (2048, 4096, 8192) for dl in (64, 256, 1024, 1 << 30)]
+        grid = [({"GRX_BLOCK_NV": str(nv), "GRX_BLOCK_DELTA": str(dl)}) for nv in (2048, 8192) for dl in (32, 64, 256, 1024)]
     grid += [dict(grid[len(grid) // 2], GRX_BLOCK_WG_PER_CU="1")]
     for env in grid:
         got, ms, first, bs, st = run(kind, props, csr, env)
