@@ -686,6 +686,7 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   // SLOWER (1.30 / 1.76 ms): the LDS it takes costs more resident workgroups than the L2
   // requests it saves -- the kernel lives on concurrency, not on request rate.
   if (!getenv("GRX_PR_NOPERM")) {
+    prep_timer t0("  xcd layout: hub-first ranking (host)", s);
     std::vector<int32_t> h_ro((size_t)V + 1);
     GRX_HIP(hipMemcpyAsync(h_ro.data(), g->ro, ((size_t)V + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     GRX_HIP(hipStreamSynchronize(s));
@@ -721,9 +722,13 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
     (void)hipGetLastError();
     return fail(GRX_ERROR_OUT_OF_MEMORY, "pagerank: scratch for the XCD-blocked layout");
   }
-  hipLaunchKernelGGL(xb_expand_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, unit ? nullptr : g->w, V, per_block, g->xb_perm,
-                     sb.keys[0], sb.vals[0], sb.vals2[0]);
-  const int res = radix_sort_pairs(s, sb, bits_for((uint64_t)n_off));
+  int res;
+  {
+    prep_timer t1("  xcd layout: expand + radix sort", s);
+    hipLaunchKernelGGL(xb_expand_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, unit ? nullptr : g->w, V, per_block, g->xb_perm,
+                       sb.keys[0], sb.vals[0], sb.vals2[0]);
+    res = radix_sort_pairs(s, sb, bits_for((uint64_t)n_off));
+  }
   hipLaunchKernelGGL(sort_boundaries_kernel, dim3(2048), dim3(256), 0, s, sb.keys[res], E, 0, (int32_t)n_off, g->xb_ro);
   GRX_HIP(hipStreamSynchronize(s));
   GRX_HIP(hipGetLastError());
@@ -732,6 +737,7 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   sb.release(g->xb_ci, g->xb_w);
   // static partition, one list per source block (same packing rule as the plain layout), built on the device
   pr_partition pt;
+  prep_timer t2("  xcd layout: partition (device)", s);
   grx_status_t pst = build_pr_partition_device(ctx, g->xb_ro, (int64_t)V + 1, V, XB, &pt, g->xb_begin);
   if (pst != GRX_SUCCESS) return pst;
   g->xb_blocks = pt.blocks;

@@ -28,7 +28,7 @@ constexpr int SORT_STEPS = 16;                               // 64-element steps
 constexpr int SORT_TILE = SORT_BLOCK * SORT_STEPS;           // 4096 elements per workgroup
 constexpr int SORT_MAX_BITS = 9;
 constexpr int SORT_MAX_DIGITS = 1 << SORT_MAX_BITS;
-constexpr int SORT_DEFAULT_BITS = 9;
+constexpr int SORT_DEFAULT_BITS = 8;
 
 static __global__ __launch_bounds__(SORT_BLOCK) void sort_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
                                                                       int bits, int32_t* hist, int n_tiles) {
@@ -54,12 +54,16 @@ static __global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(const u
                                                                          int bits, const int32_t* __restrict__ scanned, int n_tiles,
                                                                          uint32_t* keys_out, uint32_t* vals_out,
                                                                          uint32_t* vals2_out) {
-  __shared__ int s_cnt[SORT_WAVES][SORT_MAX_DIGITS];
+  __shared__ int s_cnt[SORT_WAVES][SORT_MAX_DIGITS];   // per wave and digit: count, then first LOCAL position
+  __shared__ int s_delta[SORT_MAX_DIGITS];              // global position of local position i of digit d: s_delta[d] + i
+  __shared__ int s_wave[SORT_WAVES + 1];
+  __shared__ uint32_t s_key[SORT_TILE], s_val[SORT_TILE], s_val2[V2 ? SORT_TILE : 1];
   const int nd = 1 << bits;
   const uint32_t dmask = (uint32_t)nd - 1u;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int i = tid; i < SORT_WAVES * SORT_MAX_DIGITS; i += SORT_BLOCK) (&s_cnt[0][0])[i] = 0;
-  const int64_t base = (int64_t)blockIdx.x * SORT_TILE + (int64_t)w * (SORT_STEPS * 64) + lane;
+  const int64_t tile0 = (int64_t)blockIdx.x * SORT_TILE;
+  const int64_t base = tile0 + (int64_t)w * (SORT_STEPS * 64) + lane;
   uint32_t key[SORT_STEPS], val[SORT_STEPS], val2[V2 ? SORT_STEPS : 1];
 #pragma unroll
   for (int k = 0; k < SORT_STEPS; ++k) {
@@ -88,25 +92,54 @@ static __global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(const u
     if (valid && (m & lt) == 0ull) s_cnt[w][d] = before + __popcll(m);
   }
   __syncthreads();
-  // counts -> first output position of (wave, digit): scanned[digit][tile] + the counts of the earlier waves
-  for (int d = tid; d < nd; d += SORT_BLOCK) {
-    int at = scanned[(size_t)d * (size_t)n_tiles + blockIdx.x];
-#pragma unroll
-    for (int ww = 0; ww < SORT_WAVES; ++ww) {
-      const int c = s_cnt[ww][d];
-      s_cnt[ww][d] = at;
-      at += c;
+  // counts -> LOCAL positions (the tile sorted by digit, waves in order inside a digit) and the global offset of every digit.
+  // Thread t owns the consecutive digits [t * DPT, (t + 1) * DPT): one block scan over the threads' totals.
+  {
+    const int dpt = (nd + SORT_BLOCK - 1) / SORT_BLOCK;  // 1 or 2
+    int tot[2] = {0, 0};
+    for (int j = 0; j < dpt; ++j) {
+      const int d = tid * dpt + j;
+      if (d < nd)
+        for (int ww = 0; ww < SORT_WAVES; ++ww) tot[j] += s_cnt[ww][d];
+    }
+    int block_total;
+    int at = dev::block_exclusive_sum<SORT_BLOCK>(tot[0] + tot[1], s_wave, &block_total);
+    for (int j = 0; j < dpt; ++j) {
+      const int d = tid * dpt + j;
+      if (d < nd) {
+        s_delta[d] = scanned[(size_t)d * (size_t)n_tiles + blockIdx.x] - at;
+        for (int ww = 0; ww < SORT_WAVES; ++ww) {
+          const int c = s_cnt[ww][d];
+          s_cnt[ww][d] = at;
+          at += c;
+        }
+      }
     }
   }
   __syncthreads();
+  // the tile in sorted order through LDS: the global stores below go out in runs (consecutive threads, consecutive
+  // addresses inside a digit) instead of 16 scattered 4-byte stores per thread and array
 #pragma unroll
   for (int k = 0; k < SORT_STEPS; ++k) {
     if (base + (int64_t)k * 64 < n) {
       const uint32_t d = (key[k] >> shift) & dmask;
       const int pos = s_cnt[w][d] + rank[k];
-      keys_out[pos] = key[k];
-      vals_out[pos] = val[k];
-      if constexpr (V2) vals2_out[pos] = val2[k];
+      s_key[pos] = key[k];
+      s_val[pos] = val[k];
+      if constexpr (V2) s_val2[pos] = val2[k];
+    }
+  }
+  __syncthreads();
+  const int n_here = (int)min((int64_t)SORT_TILE, n - tile0);
+#pragma unroll
+  for (int k = 0; k < SORT_STEPS; ++k) {
+    const int i = k * SORT_BLOCK + tid;
+    if (i < n_here) {
+      const uint32_t kk = s_key[i];
+      const int pos = s_delta[(kk >> shift) & dmask] + i;
+      keys_out[pos] = kk;
+      vals_out[pos] = s_val[i];
+      if constexpr (V2) vals2_out[pos] = s_val2[i];
     }
   }
 }

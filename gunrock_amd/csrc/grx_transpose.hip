@@ -121,16 +121,26 @@ grx_status_t grx::graph_build_transpose(grx_context_t ctx, grx_graph_t g) {
     // STABLE radix sort of the edges by (destination, hub tier of the source): no atomic decides an order, so the
     // transpose -- and every fp32 sum taken over a column -- is the same on every run and every handle (grx_sort.hpp)
     sort_buffers sb;
-    if (sb.alloc(E, weighted) != hipSuccess) {
-      sb.release();
-      (void)hipGetLastError();
-      return fail(GRX_ERROR_OUT_OF_MEMORY, "transpose: scratch for the sort");
+    {
+      prep_timer t0("  transpose: scratch allocation", s);
+      if (sb.alloc(E, weighted) != hipSuccess) {
+        sb.release();
+        (void)hipGetLastError();
+        return fail(GRX_ERROR_OUT_OF_MEMORY, "transpose: scratch for the sort");
+      }
     }
     const int32_t mean = (int32_t)std::max<int64_t>(1, E / std::max(1, V));
     const bool tiers = getenv("GRX_TR_NOTIERS") == nullptr;
-    hipLaunchKernelGGL(tr_expand_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, g->w, V, tiers ? 16 * mean : INT32_MAX,
-                       tiers ? mean : INT32_MAX, sb.keys[0], sb.vals[0], sb.vals2[0]);
-    const int res = radix_sort_pairs(s, sb, bits_for((uint64_t)V) + 2);
+    {
+      prep_timer t1("  transpose: expand", s);
+      hipLaunchKernelGGL(tr_expand_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, g->w, V, tiers ? 16 * mean : INT32_MAX,
+                         tiers ? mean : INT32_MAX, sb.keys[0], sb.vals[0], sb.vals2[0]);
+    }
+    int res;
+    {
+      prep_timer t2("  transpose: radix sort", s);
+      res = radix_sort_pairs(s, sb, bits_for((uint64_t)V) + 2);
+    }
     hipLaunchKernelGGL(sort_boundaries_kernel, dim3(2048), dim3(256), 0, s, sb.keys[res], E, 2, V, g->t_ro);
     GRX_HIP(hipStreamSynchronize(s));
     GRX_HIP(hipGetLastError());

@@ -156,8 +156,10 @@ def test_reference_gpu_path_live_equal_iterations(gr, gpu_ctx, golden):
         with O.RefGpuGraph(g) as R:
             ref, k_ref, _ = R.pr(alpha, tol)
         p, it = run_pr(gr, gpu_ctx, g, alpha, tol)
-        # equal count, except where the reference's own count varies between runs (tol below its fp32 atomics noise)
-        assert it == k_ref or (tol < 1e-6 and abs(it - k_ref) <= 4), (name, it, k_ref)
+        # equal count -- except below the driver's tol, where the reference's OWN count is decided by the noise of its fp32
+        # atomics (recorded: 12, 13, 14, 16 in round 3, 21 in round 4 for 'rmat_tol8'; ours: 13 every time): there only the
+        # iterates at equal count are compared (below), the count itself against the goldens (test_reference_made_goldens)
+        assert it == k_ref or tol < 1e-6, (name, it, k_ref)
         p_k, it_k = run_pr(gr, gpu_ctx, g, alpha, 0.0, max_iterations=k_ref)
         assert it_k == k_ref
         assert np.abs(p_k.astype(np.float64) - ref).max() <= ABS_TOL, name
