@@ -767,20 +767,18 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   if (dopt) {
     // in-edges: the CSR itself when the graph is symmetric (the property is caller-supplied and
     // defaults to true, so it is verified once per graph handle), else the cached transpose
-    bool symmetric = false;
-    if (g->symmetric) {
-      st = graph_is_symmetric(ctx, g, &symmetric);
+    // Round 4: always the transpose -- built by the stable sort in a few ms, its in-lists hubs first (the likeliest
+    // parents are probed first).  GRX_BU_SYMMETRIC_CSR=1: a graph declared symmetric uses its own CSR instead (rounds 1-3),
+    // after the claim has been verified against the transpose.
+    st = graph_build_transpose(ctx, g);
+    if (st != GRX_SUCCESS) return st;
+    bool use_csr = false;
+    if (g->symmetric && env_int("GRX_BU_SYMMETRIC_CSR", 0) != 0) {
+      st = graph_is_symmetric(ctx, g, &use_csr);
       if (st != GRX_SUCCESS) return st;
     }
-    if (symmetric) {
-      d.t_ro = g->ro;
-      d.t_ci = g->ci;
-    } else {
-      st = graph_build_transpose(ctx, g);
-      if (st != GRX_SUCCESS) return st;
-      d.t_ro = g->t_ro;
-      d.t_ci = g->t_ci;
-    }
+    d.t_ro = use_csr ? g->ro : g->t_ro;
+    d.t_ci = use_csr ? g->ci : g->t_ci;
     GRX_HIP(ctx->bitmap[0].reserve(bm_words * sizeof(unsigned)));
     GRX_HIP(ctx->bitmap[1].reserve(3 * bm_words * sizeof(unsigned)));
     d.visited = ctx->bitmap[0].as<unsigned>();

@@ -420,23 +420,33 @@ __global__ __launch_bounds__(256) void pr_combine_kernel(pr_args a, int iter) {
 
 // The XCD-blocked layout is the edge list sorted by (source block, destination): key = block * (V + 1) + destination,
 // value = the (relabelled) source [, weight].  `perm` (may be null) relabels the SOURCES: in-edges are bucketed by, and
-// store, perm[u].  One wave per row, lanes on consecutive edges.
-__global__ void xb_expand_kernel(const int32_t* __restrict__ ro, const int32_t* __restrict__ ci, const float* __restrict__ w,
-                                 int32_t V, int32_t per_block, const int32_t* __restrict__ perm, uint32_t* keys, uint32_t* vals,
-                                 uint32_t* vals2) {
-  const int lane = dev::lane_id();
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t u = wave; u < V; u += nwaves) {
-    const int32_t pu = perm ? perm[u] : (int32_t)u;
-    const uint32_t kb = (uint32_t)(pu / per_block) * ((uint32_t)V + 1u);
-    const int b = ro[u], e = ro[u + 1];
-    for (int k = b + lane; k < e; k += 64) {
-      keys[k] = kb + (uint32_t)ci[k];
-      vals[k] = (uint32_t)pu;
-      if (vals2) vals2[k] = __float_as_uint(w[k]);
-    }
+// store, perm[u].  (edge_expand_kernel, grx_sort.hpp, supplies the source row of every edge.)
+struct xb_emit {
+  const float* w;
+  const int32_t* perm;
+  int32_t V, per_block;
+  uint32_t* keys;
+  uint32_t* vals;
+  uint32_t* vals2;
+  __device__ __forceinline__ void operator()(int64_t e, int row, int col) const {
+    const int32_t pu = perm ? perm[row] : row;
+    keys[e] = (uint32_t)(pu / per_block) * ((uint32_t)V + 1u) + (uint32_t)col;
+    vals[e] = (uint32_t)pu;
+    if (vals2) vals2[e] = __float_as_uint(w[e]);
   }
+};
+
+// hub-first ranking on the device: vertices sorted by out-degree, descending, ties in id order (a stable sort by the
+// complemented degree); rank r goes to block r % XB, position r / XB
+__global__ void xb_rank_keys_kernel(const int32_t* __restrict__ ro, int32_t V, uint32_t* keys, uint32_t* vals) {
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
+    keys[v] = ~(uint32_t)(ro[v + 1] - ro[v]);
+    vals[v] = (uint32_t)v;
+  }
+}
+__global__ void xb_rank_perm_kernel(const uint32_t* __restrict__ order, int32_t V, int32_t per_block, int32_t* perm) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < V; r += (int64_t)gridDim.x * blockDim.x)
+    perm[order[r]] = (int32_t)((r % XB) * per_block + r / XB);
 }
 
 __global__ void pr_init_kernel(pr_args a) {
@@ -686,31 +696,19 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   // SLOWER (1.30 / 1.76 ms): the LDS it takes costs more resident workgroups than the L2
   // requests it saves -- the kernel lives on concurrency, not on request rate.
   if (!getenv("GRX_PR_NOPERM")) {
-    prep_timer t0("  xcd layout: hub-first ranking (host)", s);
-    std::vector<int32_t> h_ro((size_t)V + 1);
-    GRX_HIP(hipMemcpyAsync(h_ro.data(), g->ro, ((size_t)V + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    GRX_HIP(hipStreamSynchronize(s));
-    // rank by out-degree, descending, ties in id order: a counting sort (O(V + max degree); the comparison sort this
-    // replaces took ~200 ms of the first call on the 2 M-vertex kron stand-in)
-    int32_t max_deg = 0;
-    for (int32_t v = 0; v < V; ++v) max_deg = std::max(max_deg, h_ro[(size_t)v + 1] - h_ro[(size_t)v]);
-    std::vector<int32_t> first((size_t)max_deg + 2, 0);  // first[d]: vertices with a degree > d ... (ranks of degree d start there)
-    for (int32_t v = 0; v < V; ++v) ++first[(size_t)(h_ro[(size_t)v + 1] - h_ro[(size_t)v])];
-    {
-      int32_t acc = 0;
-      for (int32_t d = max_deg; d >= 0; --d) {
-        const int32_t n = first[(size_t)d];
-        first[(size_t)d] = acc;
-        acc += n;
-      }
-    }
-    std::vector<int32_t> perm((size_t)V);
-    for (int32_t v = 0; v < V; ++v) {
-      const int32_t r = first[(size_t)(h_ro[(size_t)v + 1] - h_ro[(size_t)v])]++;
-      perm[(size_t)v] = (r % XB) * per_block + r / XB;
+    prep_timer t0("  xcd layout: hub-first ranking (device sort)", s);
+    sort_buffers rb;
+    if (rb.alloc(V, false) != hipSuccess) {
+      rb.release();
+      (void)hipGetLastError();
+      return fail(GRX_ERROR_OUT_OF_MEMORY, "pagerank: scratch for the hub-first ranking");
     }
     GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_perm), (size_t)V * sizeof(int32_t)));
-    GRX_HIP(hipMemcpy(g->xb_perm, perm.data(), (size_t)V * sizeof(int32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(xb_rank_keys_kernel, dim3(1024), dim3(256), 0, s, g->ro, V, rb.keys[0], rb.vals[0]);
+    const int rr = radix_sort_pairs(s, rb, 32);
+    hipLaunchKernelGGL(xb_rank_perm_kernel, dim3(1024), dim3(256), 0, s, rb.vals[rr], V, per_block, g->xb_perm);
+    GRX_HIP(hipStreamSynchronize(s));
+    rb.release();
   }
   GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ro), (n_off + 2) * sizeof(int32_t)));
   const bool unit = graph_unit_weights(g);  // no weight stream needed (graph_weight_stats ran)
@@ -725,8 +723,9 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   int res;
   {
     prep_timer t1("  xcd layout: expand + radix sort", s);
-    hipLaunchKernelGGL(xb_expand_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, unit ? nullptr : g->w, V, per_block, g->xb_perm,
-                       sb.keys[0], sb.vals[0], sb.vals2[0]);
+    const xb_emit em{unit ? nullptr : g->w, g->xb_perm, V, per_block, sb.keys[0], sb.vals[0], sb.vals2[0]};
+    hipLaunchKernelGGL((edge_expand_kernel<xb_emit>), dim3((unsigned)((E + SORT_TILE - 1) / SORT_TILE)), dim3(SORT_BLOCK), 0, s, g->ro,
+                       g->ci, V, E, em);
     res = radix_sort_pairs(s, sb, bits_for((uint64_t)n_off));
   }
   hipLaunchKernelGGL(sort_boundaries_kernel, dim3(2048), dim3(256), 0, s, sb.keys[res], E, 0, (int32_t)n_off, g->xb_ro);

@@ -268,26 +268,36 @@ def test_binned_kernels_follow_the_previous_search(gr, gpu_ctx, monkeypatch):
     assert sum(1 for l in gr.level_profile(gpu_ctx) if l["bottom_up"] == 2) >= binned[hub][1]
 
 
-def test_symmetric_property_is_verified(gr, gpu_ctx):
-    """graph_properties_t defaults to symmetric=true (inert in the reference).  Here it lets the
-    bottom-up step use the CSR as its own in-edge list -- so the engine must notice a DIRECTED CSR
-    that claims to be symmetric and fall back to a real transpose."""
+def test_symmetric_property_is_verified(gr, gpu_ctx, monkeypatch):
+    """graph_properties_t defaults to symmetric=true (inert in the reference).  Round 4: the bottom-up step always reads the
+    transpose (stable sort, hubs first); with GRX_BU_SYMMETRIC_CSR=1 a graph declared symmetric uses its own CSR as the
+    in-edge list (rounds 1-3) -- so the engine must then notice a DIRECTED CSR that claims to be symmetric (row hashes of
+    the CSR against the transpose) and keep the transpose."""
     import torch
     _, c = gr.generate("rmat", 1 << 16, 1_500_000, seed=21)  # directed
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
     src = int(np.argmax(np.diff(g.row_offsets)))
     want, _ = O.bfs(g, src)
-    G = gr.build_graph(gr.graph_properties_t(), c, gpu_ctx)  # default properties: symmetric = True
-    dist = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda:0")
-    gr.bfs(G, src, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.optimized, engine_flags=gr.FLAG_PROFILE))
-    assert np.array_equal(dist.cpu().numpy(), want)
-    assert any(l["bottom_up"] == 1 for l in gr.level_profile(gpu_ctx))
-    # and a directed cycle, whose in- and out-degrees all agree
-    n = 4096
+    _, cs = gr.generate("rmat_sym", 1 << 16, 700_000, seed=22)  # really symmetric
+    gs = O.Csr(cs.row_offsets, cs.column_indices, cs.nonzero_values)
+    src_s = int(np.argmax(np.diff(gs.row_offsets)))
+    want_s, _ = O.bfs(gs, src_s)
+    n = 4096  # a directed cycle, whose in- and out-degrees all agree
     ro = np.arange(n + 1, dtype=np.int32)
     ci = ((np.arange(n) + 1) % n).astype(np.int32)
-    d, _ = run_bfs(gr, gpu_ctx, ro, ci, 0, gr.options_t(advance_direction=gr.optimized))
-    assert np.array_equal(d, np.arange(n))
+    for env in ("0", "1"):
+        monkeypatch.setenv("GRX_BU_SYMMETRIC_CSR", env)
+        G = gr.build_graph(gr.graph_properties_t(), c, gpu_ctx)  # default properties: symmetric = True
+        dist = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda:0")
+        gr.bfs(G, src, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.optimized, engine_flags=gr.FLAG_PROFILE))
+        assert np.array_equal(dist.cpu().numpy(), want), env
+        assert any(l["bottom_up"] == 1 for l in gr.level_profile(gpu_ctx))
+        Gs = gr.build_graph(gr.graph_properties_t(), cs, gpu_ctx)
+        ds = torch.empty(gs.n_vertices, dtype=torch.int32, device="cuda:0")
+        gr.bfs(Gs, src_s, ds, None, gpu_ctx, gr.options_t(advance_direction=gr.optimized))
+        assert np.array_equal(ds.cpu().numpy(), want_s), env
+        d, _ = run_bfs(gr, gpu_ctx, ro, ci, 0, gr.options_t(advance_direction=gr.optimized))
+        assert np.array_equal(d, np.arange(n)), env
 
 
 def test_binned_scatter_unit_hand_out_safety_net(gr, monkeypatch):

@@ -10,7 +10,8 @@ kernels of interest are classified by name and by their position inside the sear
                        per LAUNCH
   topdown_fat          launches 1 and 2 of a forward search, bfs_level_bin_kernel (+ the bfs_sweep_kernel / bfs_claim_kernel of
                        the same level when the level ran binned): per LEVEL (= what bench.py's forward profile calls a launch)
-  sssp_unit_weights    all sssp_level_kernel launches of a search; per SEARCH (with many levels per launch the
+  sssp_unit_weights    all level launches of a unit-weight search (round 4: bfs_level_bin_kernel -- the search runs on the BFS
+                       engine; before: sssp_level_kernel); per SEARCH (with many levels per launch the
   sssp_weighted_1_1000 all sssp_nf_level_kernel launches           launch count is not a unit of work)
   pr_pull              pr_pull_xcd_kernel / pr_pull_kernel + pr_long* + pr_combine_kernel launches that did work
                        (launches queued past convergence exit at once and are dropped: < 10 % of the largest value);
@@ -82,6 +83,12 @@ def classify(rows):
             # a level group of a forward run: level kernel (a no-op on a binned level when the second scatter is in use),
             # scatter kernel (second version), claim / sweep kernel
             lv = [d for d, n in s["kernels"] if "bfs_level_bin_kernel" in n]
+            if len(lv) > 64:
+                # a high-diameter search (road stand-in): since round 4 the unit-weight SSSP of such a graph IS this forward
+                # BFS (grx_sssp.hip, all weights equal) -- every level launch of the search, per SEARCH
+                for d in lv:
+                    cls[d] = ("sssp_unit_weights", 0)
+                continue
             sc = [d for d, n in s["kernels"] if "bfs_scatter2_kernel" in n]
             cl = [d for d, n in s["kernels"] if "bfs_claim_kernel" in n or "bfs_sweep" in n]
             for pos in (1, 2):
