@@ -940,6 +940,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       // workgroups per XCD), a context whose coverage check failed once, or GRX_SC2_STATIC=1 -> statically strided units
       bn.static_units = (ctx->sc2_static || grid_scatter2 < 4 * ctx->n_xcd || env_int("GRX_SC2_STATIC", 0) != 0) ? 1 : 0;
       bn.fault_xcd = ctx->sc2_static ? 0 : env_int("GRX_SC2_FAULT_XCD", 0);
+      bn.sub_shift = env_int("GRX_BIN_SUB", 4) == 1 ? 0 : 2;
       bn.pair_stores = env_int("GRX_BIN_PAIR", 0);  // measured slower (round 4: LJ 0.467 vs 0.450 ms per search): off
     }
     // sweep claim: 1 = first version; 2 = second version on 512-thread workgroups, two parts per bin; 3 = second version on

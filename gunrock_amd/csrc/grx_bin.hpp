@@ -71,6 +71,7 @@ struct bin_args {
   int32_t mid_v, mid_e;       // thresholds of the many-levels-per-launch body (grx_mid.hpp), 0: off (carried here for the head kernel)
   int32_t static_units;       // second scatter: units strided statically over the workgroups instead of drawn from per-XCD ticket
                               // queues (the fallback when a launch cannot be trusted to put a workgroup on every XCD)
+  int32_t sub_shift;          // second scatter: log2 of the sub-counters per bin (2 | 0; GRX_BIN_SUB)
   int32_t pair_stores;        // second scatter: neighbouring entries of a bin leave as one store of twice the width (GRX_BIN_PAIR)
   int32_t fault_xcd;          // test aid (GRX_SC2_FAULT_XCD=k): workgroups on dense XCD index k - 1 take no units (0: off)
 };
@@ -800,15 +801,23 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
 // level kernel are written for 256-thread workgroups.
 constexpr int SC2_BLOCK = 1024;
 constexpr int SC2_Q = SC2_BLOCK / TILE;  // quarters = chunks per batch
+// SUB-COUNTERS (round 4).  With 16-bit entries the LJ stand-in has 76 bins: the 64 lanes of a wave hit a handful of hot bins
+// several times each, and a returning LDS atomic on one word serialises (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.51 in
+// profiles/r3_bench_pmc.json, class topdown_fat).  Every bin gets SC2_SUB counters in neighbouring words (= banks); a lane
+// uses counter lane % SC2_SUB.  A bin's run in the sorted buffer is the concatenation of its sub-runs, so everything behind
+// the histogram -- one reservation per bin, one `delta` per bin, the copy-out -- is unchanged.  256 bins x 4 = one counter
+// per thread of the 1024-thread workgroup.  bin_args::sub_shift = 0 switches it off (GRX_BIN_SUB=1, for the A/B).
+constexpr int SC2_SUB = 4;
+static_assert(BIN_MAX * SC2_SUB == SC2_BLOCK, "one sub-counter per thread in the offset scan");
 static_assert(SC2_Q == BIN_BATCH, "a batch is still 4 chunks");
 
 struct bin_scatter2_smem {
   alignas(16) int dlt[SC2_Q][TILE];            // per staged slot: row start - exclusive degree prefix
   alignas(16) int wtot[SC2_Q][4];              // degree sums of the four waves of a quarter (read as one int4)
   alignas(16) int cand[SC2_Q][4][4];           // [quarter][target wave][source wave]: highest slot of the source wave that begins a row before the target's first atom
-  int wave[BIN_MAX / 64 + 1];
-  int hist[BIN_MAX];
-  int off[BIN_MAX];
+  int wave[SC2_BLOCK / 64 + 1];
+  int hist[BIN_MAX * SC2_SUB];                 // per bin SC2_SUB counters: a lane counts in counter (lane % SC2_SUB) of its bin
+  int off[BIN_MAX * SC2_SUB];
   int delta[BIN_MAX];
   int btot;
   int tick[4];                                 // units of the pipeline stages (tick[3]: the stage entering next)
@@ -844,7 +853,9 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
   const unsigned gmask = (1u << gshift) - 1u;
   for (int w = tid; w < (bn.n_gran + 1) / 2; w += SC2_BLOCK)
     reinterpret_cast<unsigned*>(sm.g2b)[w] = reinterpret_cast<const unsigned*>(bn.g2b16)[w];
-  const int boff = tid < bn.nb ? bn.off[tid] : 0;  // static offset of bin `tid`
+  const int sub_shift = bn.sub_shift;                     // 2: four sub-counters per bin, 0: one
+  const int sub_mask = (1 << sub_shift) - 1;
+  const int boff = (tid >> sub_shift) < bn.nb ? bn.off[tid >> sub_shift] : 0;   // static offset of the bin of counter `tid`
   const int n_units = (total_chunks + SC2_Q - 1) / SC2_Q;
   // DYNAMIC unit hand-out, one queue per XCD.  With units strided statically over the workgroups the last workgroup of
   // a fat level finished 17-36 us after the average one (timeline of round 3, call 3: busy mean 79 / 114 us, span 96 /
@@ -915,6 +926,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     lane = tid & 63;
     wq = (tid >> 6) & 3;
     unsigned char* own = &sm.own[q][0];
+    const int my_bin = tid >> sub_shift;  // bin of counter `tid` (counters beyond nb << sub_shift stay 0)
     // ---- phase 1: degrees, wave scan; clear the owner map and the histogram
     const bool has = yA >= 0;
     const int rs = rsA;
@@ -933,7 +945,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     const int inc = dev::wave_inclusive_sum(dg);
     if (lane == 63) sm.wtot[q][wq] = inc;
     reinterpret_cast<uint2*>(own)[tq] = make_uint2(0u, 0u);
-    if (tid < BIN_MAX) sm.hist[tid] = 0;
+    sm.hist[tid] = 0;
     __syncthreads();
     const int uD = __builtin_amdgcn_readfirstlane(sm.tick[3]);  // written at the end of the previous batch (or at the start)
     tlD = S1(uD);
@@ -1027,7 +1039,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       for (int k = 0; k < ADV_ITEMS; ++k) {
         const unsigned bb = t_k[k] & 0xffu;
         e_k[k] = (bb << 24) | ((t_k[k] >> 8) << gshift) | (e_k[k] & gmask);
-        r_k[k] = atomicAdd(&sm.hist[bb], (k * TILE + tq) < n_at ? 1 : 0);
+        r_k[k] = atomicAdd(&sm.hist[(bb << sub_shift) | (unsigned)(lane & sub_mask)], (k * TILE + tq) < n_at ? 1 : 0);
       }
     }
     __syncthreads();
@@ -1037,23 +1049,28 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     // graph (LJ fat levels 136 + 168 -> 157 + 177 us): the reservation atomic below is younger than those loads, and
     // waiting for its result means waiting for them too -- vmcnt retires in order.)
     // ---- phase 5: one reservation per non-empty bin (its round trip is covered by the scan and the sort), bin offsets
-    int cnt = 0, gbase = 0, inc2 = 0;
-    if (tid < BIN_MAX) {
-      cnt = sm.hist[tid];
-      if (cnt > 0) gbase = atomicAdd(&bn.fill[(unsigned)(tid * BIN_PAD)], cnt);
-      inc2 = dev::wave_inclusive_sum(cnt);
-      if (lane == 63) sm.wave[wq] = inc2;
+    // (one counter per thread; the counters of a bin sit in neighbouring lanes: its total comes from two shuffles)
+    const int cnt = sm.hist[tid];
+    int gbase = 0;
+    {
+      int bt = cnt;
+      if (sub_shift) {
+        bt += __shfl_xor(bt, 1, 64);
+        bt += __shfl_xor(bt, 2, 64);
+      }
+      if ((tid & sub_mask) == 0 && bt > 0) gbase = atomicAdd(&bn.fill[(unsigned)(my_bin * BIN_PAD)], bt);
     }
+    const int inc2 = dev::wave_inclusive_sum(cnt);
+    if (lane == 63) sm.wave[tid >> 6] = inc2;
     __syncthreads();
-    int ex2 = 0;
-    if (tid < BIN_MAX) {
-      int b2 = 0;
-#pragma unroll
-      for (int i = 0; i < BIN_MAX / 64; ++i)
-        if (i < wq) b2 += sm.wave[i];
+    int ex2;
+    {
+      // totals of the waves before mine: lane l < 16 reads one, a wave sum adds the first (tid >> 6) of them (16 loads into
+      // 16 registers per thread spilled this kernel past its 64 VGPRs)
+      const int b2 = dev::wave_sum((lane < (tid >> 6)) ? sm.wave[lane & 15] : 0);
       ex2 = b2 + inc2 - cnt;
       sm.off[tid] = ex2;
-      if (tid == BIN_MAX - 1) sm.btot = ex2 + cnt;
+      if (tid == SC2_BLOCK - 1) sm.btot = ex2 + cnt;
     }
     __syncthreads();
     dbg_mark(5);
@@ -1061,12 +1078,12 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     {
       int o_k[ADV_ITEMS];
 #pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) o_k[k] = sm.off[e_k[k] >> 24];
+      for (int k = 0; k < ADV_ITEMS; ++k) o_k[k] = sm.off[((e_k[k] >> 24) << sub_shift) | (unsigned)(lane & sub_mask)];
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k)
         if (k * TILE + tq < n_at) sm.sorted[o_k[k] + r_k[k]] = e_k[k];
     }
-    if (tid < BIN_MAX) sm.delta[tid] = boff + gbase - ex2;  // global slot of sorted position i of this bin: delta + i
+    if ((tid & sub_mask) == 0 && my_bin < BIN_MAX) sm.delta[my_bin] = boff + gbase - ex2;  // global slot of sorted position i of this bin: delta + i
     __syncthreads();
     dbg_mark(6);
     // ---- phase 7: runs leave LDS as contiguous segments (no barrier behind it: the next batch touches the sort

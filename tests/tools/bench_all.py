@@ -66,8 +66,13 @@ for item in which:
         out["property_check_violations"] = int(O.check_bfs(g, src, mine))
         if ref:
             h = np.empty(V, np.int32)
-            for label, lb, flt in (("ref_gpu_default_block_mapped", 2, 0), ("ref_gpu_merge_path_filter", 4, 1)):
-                ts = [ref.ref_gpu_bfs(rh, src, lb, flt, 1, h) for _ in range(3)]
+            # the reference's own load-balance options without a filter (what bin/bfs_generic --advance_load_balance X runs
+            # on OUR operators: tools/bench_generic.sh) and its tuned README command (merge_path + filter)
+            for label, lb, flt in (("ref_gpu_default_block_mapped", 2, 0), ("ref_gpu_merge_path_filter", 4, 1),
+                                   ("ref_gpu_merge_path_no_filter", 4, 0), ("ref_gpu_thread_mapped_no_filter", 0, 0)):
+                if lb == 0 and name != "lj":
+                    continue
+                ts = [ref.ref_gpu_bfs(rh, src, lb, flt, 1, h) for _ in range(3 if lb else 1)]
                 out[label] = {"enact_ms": round(min(ts), 3), "mteps": round(st["edges_visited"] / (min(ts) * 1e3), 1),
                               "equal_to_ours": bool(np.array_equal(h, mine))}
     elif algo == "sssp":

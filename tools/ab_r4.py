@@ -1,4 +1,5 @@
-"""Round-4 A/B of the binned forward levels in ONE process per graph: pair stores in the scatter's copy-out (GRX_BIN_PAIR).
+"""Round-4 A/B of the binned forward levels in ONE process per graph: sub-counters per bin in the scatter's histogram
+(GRX_BIN_SUB), pair stores in its copy-out (GRX_BIN_PAIR).
     python tools/ab_r4.py [lj|kron|twitter] [reps]        -- same protocol and output as tools/ab_r3.py"""
 import os
 import sys
@@ -21,7 +22,7 @@ ctx = gr.multi_context_t(0)
 G = gr.build_graph(props, csr, ctx)
 V = G.get_number_of_vertices()
 d = torch.empty(V, dtype=torch.int32, device="cuda")
-KNOBS = ("GRX_BIN_PAIR", "GRX_BIN_E16", "GRX_SC2_STATIC")
+KNOBS = ("GRX_BIN_PAIR", "GRX_BIN_E16", "GRX_SC2_STATIC", "GRX_BIN_SUB")
 ref = None
 
 
@@ -66,10 +67,11 @@ def run(label, direction, env=None):
 
 
 print("workload", name, "V", V, "E", G.get_number_of_edges(), "src", src, flush=True)
-run("fwd single stores (round 3)", gr.forward, {"GRX_BIN_PAIR": 0})
-run("fwd pair stores", gr.forward, {"GRX_BIN_PAIR": 1})
-run("fwd single stores again", gr.forward, {"GRX_BIN_PAIR": 0})
-run("fwd pair stores again", gr.forward, {"GRX_BIN_PAIR": 1})
+run("fwd one counter per bin (round 3)", gr.forward, {"GRX_BIN_SUB": 1})
+run("fwd four sub-counters per bin", gr.forward, {"GRX_BIN_SUB": 4})
+run("fwd one counter per bin again", gr.forward, {"GRX_BIN_SUB": 1})
+run("fwd four sub-counters again", gr.forward, {"GRX_BIN_SUB": 4})
+run("fwd four sub-counters + pair stores", gr.forward, {"GRX_BIN_SUB": 4, "GRX_BIN_PAIR": 1})
 if name != "lj":
-    run("fwd pair stores, 32-bit entries", gr.forward, {"GRX_BIN_PAIR": 1, "GRX_BIN_E16": 0})
-    run("fwd single stores, 32-bit entries", gr.forward, {"GRX_BIN_PAIR": 0, "GRX_BIN_E16": 0})
+    run("fwd four sub-counters, 32-bit entries", gr.forward, {"GRX_BIN_SUB": 4, "GRX_BIN_E16": 0})
+    run("fwd one counter, 32-bit entries", gr.forward, {"GRX_BIN_SUB": 1, "GRX_BIN_E16": 0})
