@@ -21,7 +21,7 @@ from ._capi import (GrxError, grx_options_t, grx_run_stats_t, grx_level_profile_
                     merge_path_v2, work_stealing, remove, predicated, compact, bypass,
                     unique, unique_copy, forward, backward, optimized,
                     FLAG_UNFUSED, FLAG_PROFILE, FLAG_SYNC_EACH_LEVEL, FLAG_ASYNC_RETURN, FLAG_LB_STRICT,
-                    FLAG_SSSP_PLAIN, FLAG_SSSP_NEAR_FAR, FLAG_SSSP_NO_BFS, FLAG_NO_BLOCK_ASYNC)
+                    FLAG_SSSP_PLAIN, FLAG_SSSP_NEAR_FAR, FLAG_SSSP_NO_BFS, FLAG_SSSP_NO_BINS, FLAG_NO_BLOCK_ASYNC)
 
 __all__ = ["memory_space_t", "graph_properties_t", "coo_t", "csr_t", "graph_t",
            "matrix_market_t", "build_graph", "multi_context_t", "options_t",

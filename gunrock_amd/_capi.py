@@ -29,6 +29,7 @@ FLAG_LB_STRICT = 0x1000
 FLAG_SSSP_PLAIN = 0x10
 FLAG_SSSP_NEAR_FAR = 0x20
 FLAG_SSSP_NO_BFS = 0x40
+FLAG_SSSP_NO_BINS = 0x80
 FLAG_NO_BLOCK_ASYNC = 0x2000
 
 

@@ -292,6 +292,7 @@ grx_status_t grx_context_destroy(grx_context_t ctx) {
   ctx->bins.release();
   ctx->bin_fill.release();
   for (auto& b : ctx->blk_buf) b.release();
+  for (auto& b : ctx->rbins) b.release();
   if (ctx->d_ctrl) (void)hipFree(ctx->d_ctrl);
   if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
   if (ctx->h_mailbox) (void)hipHostFree((void*)ctx->h_mailbox);
@@ -331,6 +332,8 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->closed0) (void)hipFree(g->closed0);
   if (g->bu_heads) (void)hipFree(g->bu_heads);
   if (g->bin_off) (void)hipFree(g->bin_off);
+  if (g->rb_off) (void)hipFree(g->rb_off);
+  if (g->rb_g2b16) (void)hipFree(g->rb_g2b16);
   if (g->bin_tab8) (void)hipFree(g->bin_tab8);
   for (void* b : g->blk) blk_graph_free(b);
   if (g->pr_blocks) (void)hipFree(g->pr_blocks);

@@ -74,6 +74,12 @@ struct bin_args {
   int32_t sub_shift;          // second scatter: log2 of the sub-counters per bin (2 | 0; GRX_BIN_SUB)
   int32_t pair_stores;        // second scatter: neighbouring entries of a bin leave as one store of twice the width (GRX_BIN_PAIR)
   int32_t fault_xcd;          // test aid (GRX_SC2_FAULT_XCD=k): workgroups on dense XCD index k - 1 take no units (0: off)
+  // binned RELAXATION (weighted SSSP on dense graphs, grx_relax.hpp): an entry is the 16-bit offset of the target inside its
+  // bin (in `bins`) and, at the same index of rval, the tentative distance fl(dist[source] + weight) as ordered bits
+  float* rdist;               // the labels: read by the scatter (sources), read and written by the sweep (targets)
+  const float* rw;            // edge weights
+  unsigned* rval;             // E (+ padding) tentative distances, laid out like `bins`
+  int32_t* rstamp;            // per-level stamp of a vertex (parts of one bin agree on who emits an improved vertex)
 };
 
 struct bin_scatter_smem {
@@ -827,10 +833,22 @@ struct bin_scatter2_smem {
 };
 
 
+// VAL build (binned relaxation, grx_relax.hpp): every entry carries a 32-bit value through the sort, and the bin index is
+// 10 bits wide (up to BIN_MAX * SC2_SUB = 1024 bins of <= 16384 vertices, one histogram counter each: no sub-counters)
+struct bin_scatter2_val_smem : bin_scatter2_smem {
+  unsigned dsrc[SC2_Q][TILE];                  // per staged slot: label of the slot's vertex
+  int delta_v[BIN_MAX * SC2_SUB];
+  alignas(16) unsigned sortedv[SC2_Q * CHUNK]; // the values, in the order of `sorted`
+};
+
 // E16: the bins hold 16-bit offsets (half the bytes written here and streamed by the sweep)
-template <bool DBG, bool E16>
-__device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin_args& bn, bin_scatter2_smem& sm, int p,
+template <bool DBG, bool E16, bool VAL = false, class SM = bin_scatter2_smem>
+__device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin_args& bn, SM& sm, int p,
                                                    int total_chunks, const int* chunk_tile) {
+  static_assert(!VAL || E16, "values travel with 16-bit offsets");
+  constexpr int BBITS = VAL ? 10 : 8;    // bits of a bin index in the granule table
+  constexpr int BSHIFT = VAL ? 14 : 24;  // ... and where it sits in a sorted entry (above the offset inside the bin)
+  constexpr unsigned BMASK = (1u << BBITS) - 1u;
   // DBG (GRX_BIN_DEBUG, its own kernel build): wave 0's clock at the end of every phase, summed per workgroup
   long long dbg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_t = 0, dbg_t0 = 0;
   int dbg_batches = 0;
@@ -903,6 +921,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
   int2 tlC, tlD;
   int vA, vB, vC;
   int rsA, reA, rsB, reB;
+  unsigned dA = 0u, dB = 0u;  // VAL: label of the slot's vertex, staged with its row offsets
   {
     const int2 tA = S1(uA), tB = S1(uB);
     tlC = S1(uC);
@@ -913,6 +932,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     const unsigned vv = vA >= 0 ? (unsigned)vA : 0u;
     rsA = a.ro[vv];
     reA = a.ro[vv + 1u];
+    if constexpr (VAL) dA = __float_as_uint(bn.rdist[vv]);
   }
   while (uA < n_units) {
     // Everything derived from the thread index is RE-derived per batch from an opaque copy: left to itself the
@@ -937,6 +957,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       const unsigned vv = vB >= 0 ? (unsigned)vB : 0u;  // unconditional loads from a clamped index (vertex 0 exists)
       rsB = a.ro[vv];
       reB = a.ro[vv + 1u];
+      if constexpr (VAL) dB = __float_as_uint(bn.rdist[vv]);
     }
     vC = in[(unsigned)(tlC.x * TILE + tq)];
     int ticket = 0;  // drawn now, used at the end of the batch (unit of stage D of the NEXT batch)
@@ -964,6 +985,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     }
     const int ex = base + inc - dg;
     sm.dlt[q][tq] = rs - ex;
+    if constexpr (VAL) sm.dsrc[q][tq] = dA;
     const int pos = ex - a0;  // where this slot's row begins inside the chunk's window
     if (dg > 0) {
       if (pos > 0) {
@@ -1013,20 +1035,32 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     // Every LDS / global operation of the 8 atoms is issued UNCONDITIONALLY from a clamped index, phase by phase
     // (owner bytes -> row deltas -> column indices -> granule table -> histogram): under a per-lane condition each
     // one sits in its own basic block with its consumer and an s_waitcnt behind it -- 8 x 4 serialized round trips.
-    unsigned e_k[ADV_ITEMS];  // first the neighbour id, then bin << 24 | offset inside the bin
+    unsigned e_k[ADV_ITEMS];  // first the neighbour id, then bin << BSHIFT | offset inside the bin
     int r_k[ADV_ITEMS];       // rank inside the bin
+    unsigned v_k[VAL ? ADV_ITEMS : 1];  // VAL: first the source's label, then the tentative distance (ordered bits)
     const int n_at = has ? min(tot - a0, CHUNK) : 0;  // atoms of this chunk; atom k * TILE + tq is real iff < n_at
     {
       int ob[ADV_ITEMS];
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) ob[k] = own[k * TILE + tq];
+      if constexpr (VAL) {
+#pragma unroll
+        for (int k = 0; k < ADV_ITEMS; ++k) v_k[k] = sm.dsrc[q][ob[k]];
+      }
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) ob[k] = sm.dlt[q][ob[k]];
+      float w_k[VAL ? ADV_ITEMS : 1];
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) {
         const int al = k * TILE + tq;
         const int e = al < n_at ? a0 + al + ob[k] : 0;  // lanes past the end read edge 0
         e_k[k] = (unsigned)a.ci[e];
+        if constexpr (VAL) w_k[k] = bn.rw[e];
+      }
+      if constexpr (VAL) {
+        // the relaxation's arithmetic, exactly (sssp.hxx:121-123): fl(label of the source + weight)
+#pragma unroll
+        for (int k = 0; k < ADV_ITEMS; ++k) v_k[k] = __float_as_uint(__uint_as_float(v_k[k]) + w_k[k]);
       }
       if constexpr (DBG) {  // split the phase where the column indices have arrived
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1037,8 +1071,8 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       for (int k = 0; k < ADV_ITEMS; ++k) t_k[k] = sm.g2b[e_k[k] >> gshift];
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) {
-        const unsigned bb = t_k[k] & 0xffu;
-        e_k[k] = (bb << 24) | ((t_k[k] >> 8) << gshift) | (e_k[k] & gmask);
+        const unsigned bb = t_k[k] & BMASK;
+        e_k[k] = (bb << BSHIFT) | ((t_k[k] >> BBITS) << gshift) | (e_k[k] & gmask);
         r_k[k] = atomicAdd(&sm.hist[(bb << sub_shift) | (unsigned)(lane & sub_mask)], (k * TILE + tq) < n_at ? 1 : 0);
       }
     }
@@ -1078,18 +1112,47 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     {
       int o_k[ADV_ITEMS];
 #pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) o_k[k] = sm.off[((e_k[k] >> 24) << sub_shift) | (unsigned)(lane & sub_mask)];
+      for (int k = 0; k < ADV_ITEMS; ++k) o_k[k] = sm.off[((e_k[k] >> BSHIFT) << sub_shift) | (unsigned)(lane & sub_mask)];
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k)
-        if (k * TILE + tq < n_at) sm.sorted[o_k[k] + r_k[k]] = e_k[k];
+        if (k * TILE + tq < n_at) {
+          sm.sorted[o_k[k] + r_k[k]] = e_k[k];
+          if constexpr (VAL) sm.sortedv[o_k[k] + r_k[k]] = v_k[k];
+        }
     }
-    if ((tid & sub_mask) == 0 && my_bin < BIN_MAX) sm.delta[my_bin] = boff + gbase - ex2;  // global slot of sorted position i of this bin: delta + i
+    // global slot of sorted position i of this bin: delta + i
+    if constexpr (VAL) {
+      if ((tid & sub_mask) == 0) sm.delta_v[my_bin] = boff + gbase - ex2;
+    } else {
+      if ((tid & sub_mask) == 0 && my_bin < BIN_MAX) sm.delta[my_bin] = boff + gbase - ex2;
+    }
     __syncthreads();
     dbg_mark(6);
     // ---- phase 7: runs leave LDS as contiguous segments (no barrier behind it: the next batch touches the sort
     // buffer and `delta` only after six more barriers).  Positions past the batch's total hold stale entries: their
     // bin field is < 256 whatever they are, so the table read stays unconditional
-    if (bn.pair_stores) {
+    if constexpr (VAL) {
+      // offsets and values leave at the same index of their arrays.  (A stale position past the batch's total may hold any
+      // bits: its bin field is masked into the table.)
+      const int btot = sm.btot;
+      unsigned s_k[ADV_ITEMS], x_k[ADV_ITEMS];
+      int d_k[ADV_ITEMS];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) {
+        s_k[k] = sm.sorted[k * SC2_BLOCK + tid];
+        x_k[k] = sm.sortedv[k * SC2_BLOCK + tid];
+      }
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) d_k[k] = sm.delta_v[(s_k[k] >> BSHIFT) & BMASK];
+#pragma unroll
+      for (int k = 0; k < ADV_ITEMS; ++k) {
+        const int i = k * SC2_BLOCK + tid;
+        if (i < btot) {
+          reinterpret_cast<unsigned short*>(bn.bins)[(size_t)(d_k[k] + i)] = (unsigned short)(s_k[k] & 0xffffu);
+          bn.rval[(size_t)(d_k[k] + i)] = x_k[k];
+        }
+      }
+    } else if (bn.pair_stores) {
       // Two neighbouring sorted positions per thread: where both belong to the same bin and the first lands on an even
       // entry, the pair leaves as ONE store of twice the width (round 4: a 2-byte store instruction costs the memory
       // pipeline what a 4-byte one does, and every store sits in the in-order vmcnt queue the next batch's loads wait on).
@@ -1146,6 +1209,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     yA = yB; yB = tlC.y; tlC = tlD;
     vA = vB; vB = vC;
     rsA = rsB; reA = reB;
+    dA = dB;
   }
   if constexpr (DBG) {
     if (threadIdx.x == 0 && bn.debug) {
@@ -1201,9 +1265,8 @@ struct bin_sweep2_smem {
 
 // Emit list[0 .. n) as ceil(n / TILE) tiles of parity q (only the last one may be short) with their entries of the next
 // level's chunk map and their share of its counters (see sweep_emit).  Block-wide call.
-template <int NT, int LE>
-__device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q, bin_sweep2_smem<NT, LE>& sm, int n) {
-  using S = bin_sweep2_smem<NT, LE>;
+template <int NT, class S>
+__device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q, S& sm, int n) {
   static_assert(S::MAX_TILES <= 64, "one lane per tile of an emission");
   constexpr int PASSES = (S::LIST + NT - 1) / NT;
   constexpr int G = 3;  // passes whose row-offset loads travel together
@@ -1435,7 +1498,7 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
     auto emit_list = [&](bool all) {
       const int k = all ? (n_list + TILE - 1) / TILE : n_list / TILE;
       const int n_emit = all ? n_list : k * TILE;
-      sweep2_emit<NT, LE>(a, c, q, sm, n_emit);
+      sweep2_emit<NT>(a, c, q, sm, n_emit);
       const int rem = n_list - n_emit;
       int keep = 0;
       if (tid < rem) keep = sm.list[n_emit + tid];

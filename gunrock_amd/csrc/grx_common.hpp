@@ -153,6 +153,8 @@ struct grx_context {
   grx::dbuf bin_fill;      // ... its per-bin fill counters and per-XCD ticket words (per SEARCH state: lives with the context,
                            // so that two contexts may search one graph handle concurrently)
 
+  grx::dbuf rbins[3];      // binned relaxation (grx_relax.hpp): 16-bit target offsets, 32-bit tentative distances (E + 16 entries each),
+                           // fill counters + queue words
   grx::dbuf blk_buf[3];    // block-asynchronous searches (grx_block.hip): dist, expd in the block numbering; bmin + queue
   grx_block_stats_t block_stats{};  // of the last search (supersteps == 0: it did not take that path)
   bool sc2_static = false;  // the binned scatter draws its units statically (set for good once a search failed the coverage check)
@@ -186,6 +188,12 @@ struct grx_graph {
                                       // OR-ed over the searches; 0: none yet)
   int32_t bin_entry16 = 0;      // every bin spans <= 65536 vertices: offsets inside a bin fit 16-bit entries
   int32_t bin_state = 0;        // 0: not built, 1: usable, 2: not applicable to this graph, 3: a column index lies outside [0, V)
+  // binned relaxation of weighted SSSP (grx_relax.hpp), built lazily; owned
+  int32_t* rb_off = nullptr;          // off[1025], v0[1025]
+  unsigned short* rb_g2b16 = nullptr; // granule -> bin (10 bits) | index of the granule inside its bin << 10
+  int32_t rb_shift = 0, rb_ngran = 0, rb_nb = 0;
+  int32_t rb_state = 0;               // 0: not built, 1: usable, 2: not applicable to this graph
+  std::atomic<uint32_t> rb_hint{0};   // launch groups in which a weighted search on this graph met a fat level
   void* blk[2] = {nullptr, nullptr};  // block structure of the block-asynchronous searches: [0] BFS depths, [1] weighted; owned
   int32_t blk_state[2] = {0, 0};      // 0: not tried, 1: built, 2: not applicable to this graph
   double weight_sum = -1.0;  // sum of edge weights (lazy; near-far SSSP bucket width)

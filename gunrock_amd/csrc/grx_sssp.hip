@@ -25,6 +25,7 @@
 //    schedule.
 #include "grx_engine.hpp"
 #include "grx_mid.hpp"
+#include "grx_relax.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -224,6 +225,8 @@ __global__ void sssp_init_kernel(pipe_args a, float* dist, int src, float delta)
     c->nf_split = 0;
     c->nf_overflow = 0;
     c->nf_phases = 0;
+    c->map_level = -2;
+    c->bin_want = 0;
     dist[src] = 0.0f;
     a.mailbox[0] = 0;
   }
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, s
 // Head of a plain (label-correcting) level, ONE launch of one workgroup: as many tiny levels
 // as there are (tiny_levels_body), then the bookkeeping + chunk map of the next regular level.
 __global__ __launch_bounds__(PLAN_BLOCK) void sssp_head_kernel(pipe_args a, sssp_policy pol, long long n_edges,
-                                                               int mid_v, int mid_e, int allow_tiny) {
+                                                               int mid_v, int mid_e, int allow_tiny, bin_args bn, int seq) {
   __shared__ tiny_smem<sssp_policy> tsm;
   __shared__ unsigned long long s_esum[2];
   __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
@@ -478,6 +481,14 @@ __global__ __launch_bounds__(PLAN_BLOCK) void sssp_head_kernel(pipe_args a, sssp
   in.T = 0;
   in.mid_v = mid_v;  // frontiers of a few thousand vertices: many levels per launch (grx_mid.hpp)
   in.mid_e = mid_e;
+  // fat levels of a weighted search on a dense graph: binned relaxation (mode 2, grx_relax.hpp)
+  in.bin_min = bn.min_edges;
+  in.bin_fill = bn.fill;
+  in.bin_queue = bn.queue;
+  in.bin_nb = bn.nb;
+  in.bin_pad = BIN_PAD;
+  in.bin_allowed = bn.allowed;
+  in.seq = seq;
   plan_body<PLAN_BLOCK>(a, a.ctrl, 0, s_wave, s_esum, in);
 }
 
@@ -486,13 +497,30 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_level_kernel(pipe_args a, sssp
   __shared__ mid_smem<sssp_policy> sm;
   ctrl_t* c = a.ctrl;
   const level_head h = load_level_head(c);
-  if (h.done) return;
+  if (h.done || h.mode == 2) return;  // mode 2: this level is the two kernels below
   if (h.mode == 3) {
     mid_levels_run(a, c, pol, sm, h, xcc_mask);
     return;
   }
   pol.begin(c);
   advance_block<sssp_policy, false>(a, c, pol, sm.adv, h.level & 1, blockIdx.x, gridDim.x, h.total_chunks, a.chunk_tile);
+}
+
+// A fat level of the plain schedule as a binned relaxation (grx_relax.hpp): scatter, then sweep.  No-ops unless the head chose
+// mode 2.  One workgroup of 1024 threads per CU each (96 KB / 108 KB of LDS).
+__global__ __launch_bounds__(SC2_BLOCK) void sssp_rscatter_kernel(pipe_args a, bin_args bn) {
+  __shared__ __attribute__((aligned(16))) bin_scatter2_val_smem sm;
+  const level_head h = load_level_head(a.ctrl);
+  if (h.done || h.mode != 2) return;
+  bin_scatter2_block<false, true, true>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
+}
+
+__global__ __launch_bounds__(RB_BLOCK) void sssp_rsweep_kernel(pipe_args a, bin_args bn) {
+  __shared__ __attribute__((aligned(16))) relax_sweep_smem sm;
+  ctrl_t* c = a.ctrl;
+  const level_head h = load_level_head(c);
+  if (h.done || h.mode != 2) return;
+  relax_sweep_block(a, bn, c, h.level, sm, h.level & 1);
 }
 
 // out[0] = sum of weights; bits[0] / bits[1] = min / max weight as ordered uints (w >= 0)
@@ -563,6 +591,85 @@ grx_status_t grx::graph_weight_stats(grx_context_t ctx, grx_graph_t g) {
   return GRX_SUCCESS;
 }
 
+static int sssp_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+// Per-graph static part of the binned relaxation (cached in the handle): bins = runs of granules of about equal numbers of
+// in-edges, none wider than RB_WIDTH vertices, at most RB_MAX_BINS of them; capacities = the in-edges of the range (an edge is
+// relaxed at most once per level).  Not applicable (state 2) to graphs beyond RB_MAX_BINS * RB_WIDTH = 16.7 M vertices.
+static grx_status_t graph_build_relax_bins(grx_context_t ctx, grx_graph_t g) {
+  if (g->rb_state != 0) return GRX_SUCCESS;
+  g->rb_state = 2;
+  prep_timer tm("sssp: relax-bin table (granule counts + cut)", ctx->stream);
+  if (g->V <= 0 || g->E <= 0) return GRX_SUCCESS;
+  int gshift = BIN_GSHIFT_MIN;
+  while (gshift < 31 && (((long long)g->V + (1ll << gshift) - 1) >> gshift) > BIN_GRAN_MAX) ++gshift;
+  if (gshift > RB_SHIFT) return GRX_SUCCESS;
+  const int n_gran = (int)(((long long)g->V + (1ll << gshift) - 1) >> gshift);
+  const int max_width = 1 << (RB_SHIFT - gshift);  // granules per bin
+  if ((n_gran + max_width - 1) / max_width > RB_MAX_BINS) return GRX_SUCCESS;
+  hipStream_t s = ctx->stream;
+  int32_t* d_cnt = nullptr;
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt), BIN_GRAN_MAX * sizeof(int32_t)));
+  GRX_HIP(hipMemsetAsync(d_cnt, 0, BIN_GRAN_MAX * sizeof(int32_t), s));
+  hipLaunchKernelGGL(bin_count_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, g->ci, (int64_t)g->E, gshift, n_gran, d_cnt);
+  std::vector<int32_t> cnt(BIN_GRAN_MAX);
+  GRX_HIP(hipMemcpyAsync(cnt.data(), d_cnt, BIN_GRAN_MAX * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  GRX_HIP(hipStreamSynchronize(s));
+  (void)hipFree(d_cnt);
+  long long total = 0;
+  for (int i = 0; i < n_gran; ++i) total += cnt[(size_t)i];
+  if (total != (long long)g->E) return GRX_SUCCESS;  // a column index outside [0, V): the relax-per-edge path reports it as before
+  std::vector<int> first;
+  long long target = (total + 447) / 448;
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    first.clear();
+    long long acc = 0;
+    int width = 0;
+    for (int i = 0; i < n_gran; ++i) {
+      if (width == 0) first.push_back(i);
+      acc += cnt[(size_t)i];
+      ++width;
+      if (acc >= target || width == max_width) { acc = 0; width = 0; }
+    }
+    if ((int)first.size() <= RB_MAX_BINS) break;
+    target += target / 4 + 1;
+  }
+  const int nb = (int)first.size();
+  if (nb < 1 || nb > RB_MAX_BINS) return GRX_SUCCESS;
+  first.push_back(n_gran);
+  std::vector<int32_t> offv0(2 * ((size_t)RB_MAX_BINS + 1), 0);
+  int32_t* off = offv0.data();
+  int32_t* v0 = offv0.data() + RB_MAX_BINS + 1;
+  std::vector<unsigned short> g2b16((size_t)BIN_GRAN_MAX, 0);
+  long long acc = 0;
+  for (int b = 0; b <= RB_MAX_BINS; ++b) {
+    off[b] = (int32_t)acc;
+    if (b < nb) {
+      for (int i = first[(size_t)b]; i < first[(size_t)b + 1]; ++i) {
+        acc += cnt[(size_t)i];
+        g2b16[(size_t)i] = (unsigned short)(b | ((i - first[(size_t)b]) << 10));
+      }
+      v0[b] = (int32_t)((long long)first[(size_t)b] << gshift);
+    } else {
+      v0[b] = (int32_t)((long long)n_gran << gshift);
+    }
+  }
+  static_assert(RB_MAX_BINS <= 1024 && (1 << (RB_SHIFT - BIN_GSHIFT_MIN)) <= 64, "bin | granule index fit 16 bits");
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->rb_off), offv0.size() * sizeof(int32_t)));
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->rb_g2b16), (size_t)BIN_GRAN_MAX * sizeof(unsigned short)));
+  GRX_HIP(hipMemcpyAsync(g->rb_off, offv0.data(), offv0.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  GRX_HIP(hipMemcpyAsync(g->rb_g2b16, g2b16.data(), (size_t)BIN_GRAN_MAX * sizeof(unsigned short), hipMemcpyHostToDevice, s));
+  GRX_HIP(hipStreamSynchronize(s));
+  g->rb_shift = gshift;
+  g->rb_ngran = n_gran;
+  g->rb_nb = nb;
+  g->rb_state = 1;
+  return GRX_SUCCESS;
+}
+
 static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, const grx_options_t& opt,
                              float* d_dist, bool near_far, float delta, float* elapsed_ms, bool* overflow) {
   pipe_args a;
@@ -600,6 +707,51 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
   const char* me = getenv("GRX_MID_E");
   const int mid_v = mid_on ? ((mv && atoi(mv) > 0) ? atoi(mv) : MID_ENTER_V) : 0;
   const int mid_e = mid_on ? ((me && atoi(me) > 0) ? atoi(me) : MID_ENTER_E) : 0;
+  // Binned relaxation of the fat levels (grx_relax.hpp): plain schedule, non-negative weights, dense graphs
+  bin_args rb{};
+  rb.xcc_mask = ctx->xcc_mask;
+  rb.n_xcd = ctx->n_xcd;
+  int grid_rscatter = 0, grid_rsweep = 0;
+  const bool want_bins = !near_far && w_eff && g->weight_min > 0.0f && !strict_mp && opt.max_iterations == 0 &&
+                         !(opt.engine_flags & (GRX_FLAG_SSSP_NO_BINS | GRX_FLAG_UNFUSED | GRX_FLAG_SYNC_EACH_LEVEL)) &&
+                         sssp_env_int("GRX_SSSP_BINS", 1) != 0 &&
+                         (long long)g->E >= (long long)sssp_env_int("GRX_RBIN_MIN_GRAPH_EDGES", 1 << 22);
+  if (want_bins) {
+    st = graph_build_relax_bins(ctx, g);
+    if (st != GRX_SUCCESS) return st;
+  }
+  const bool use_rbins = want_bins && g->rb_state == 1;
+  if (use_rbins) {
+    const size_t fill_bytes = ((size_t)RB_MAX_BINS + 16) * BIN_PAD * sizeof(int32_t);
+    GRX_HIP(ctx->rbins[0].reserve(((size_t)g->E + 16) * sizeof(unsigned short)));
+    GRX_HIP(ctx->rbins[1].reserve(((size_t)g->E + 16) * sizeof(unsigned)));
+    GRX_HIP(ctx->rbins[2].reserve(fill_bytes));
+    rb.bins = ctx->rbins[0].as<int32_t>();
+    rb.rval = ctx->rbins[1].as<unsigned>();
+    rb.fill = ctx->rbins[2].as<int32_t>();
+    rb.queue = rb.fill + (size_t)RB_MAX_BINS * BIN_PAD;
+    rb.off = g->rb_off;
+    rb.v0 = g->rb_off + RB_MAX_BINS + 1;
+    rb.g2b16 = g->rb_g2b16;
+    rb.gshift = g->rb_shift;
+    rb.n_gran = g->rb_ngran;
+    rb.nb = g->rb_nb;
+    rb.local_ids = 1;
+    rb.entry16 = 1;
+    rb.sub_shift = 0;  // a counter per bin: up to 1024 bins
+    rb.rdist = d_dist;
+    rb.rw = w_eff;
+    rb.rstamp = stamp;
+    rb.min_edges = (long long)sssp_env_int("GRX_RBIN_MIN_EDGES", 1 << 22);
+    if (rb.min_edges < 1) rb.min_edges = 1;
+    grid_rscatter = ctx->num_cus;
+    grid_rsweep = ctx->num_cus * sssp_env_int("GRX_RBIN_SWEEP_WG_PER_CU", 1);
+    rb.static_units = (ctx->sc2_static || grid_rscatter < 4 * ctx->n_xcd || sssp_env_int("GRX_SC2_STATIC", 0) != 0) ? 1 : 0;
+    rb.fault_xcd = ctx->sc2_static ? 0 : sssp_env_int("GRX_SC2_FAULT_XCD", 0);
+    rb.sweep_items = rb.nb + sssp_env_int("GRX_RBIN_PARTS", 2 * ctx->num_cus);
+  }
+  const uint32_t rhint0 = (use_rbins && sssp_env_int("GRX_BIN_HINT", 1) != 0) ? g->rb_hint.load(std::memory_order_relaxed) : 0u;
+  const uint32_t rbin_groups = rhint0 ? (rhint0 | (rhint0 << 1) | (rhint0 >> 1)) : ~0u;
   ctx->levels.clear();
   hipError_t launch_err = hipSuccess;
   // GRX_FLAG_PROFILE: one record per iteration -- head / level kernel times from events on this
@@ -630,7 +782,9 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     level_rec& r = ctx->levels.back();
     r.frontier_size = h.vertices_visited - prof_v;
     r.edges = h.edges_visited - prof_e;
-    r.bottom_up = near_far ? 2 * h.nf_split : 0;  // 2: this iteration only pulled a bucket out of the far pile
+    // near-far: 2 = this iteration only pulled a bucket out of the far pile; plain: the level's mode (2 = binned relaxation,
+    // 3 = many levels in this launch)
+    r.bottom_up = near_far ? 2 * h.nf_split : h.mode;
     prof_v = h.vertices_visited;
     prof_e = h.edges_visited;
     // the group that only detected the end carries no work; one that ran the last iterations itself (many per
@@ -646,19 +800,42 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     }, after);
   } else {
     sssp_policy pol{d_dist, stamp, w_eff, 0, 0, (!g->w || g->uniform_weights) ? 1 : 0};
-    st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
+    st = run_levels(ctx, opt, [&](hipStream_t stream, int seq) {
+      // (as for the BFS: the two kernels of a binned level ride only in the groups where the previous search on the graph
+      // met a fat level, one group of slack either side; a fat level elsewhere runs on the relax-per-edge advance)
+      const bool bins_here = use_rbins && (seq >= 32 || ((rbin_groups >> seq) & 1u) != 0u);
+      rb.allowed = bins_here ? 1 : 0;
       group(stream,
-            [&] { hipLaunchKernelGGL(sssp_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, pol, (long long)g->E, mid_v, mid_e, strict_mp ? 0 : 1); },
-            [&] { hipLaunchKernelGGL(sssp_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol, ctx->xcc_mask); });
+            [&] { hipLaunchKernelGGL(sssp_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, pol, (long long)g->E, mid_v, mid_e, strict_mp ? 0 : 1, rb, seq); },
+            [&] {
+              hipLaunchKernelGGL(sssp_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol, ctx->xcc_mask);
+              if (bins_here) {
+                hipLaunchKernelGGL(sssp_rscatter_kernel, dim3(grid_rscatter), dim3(SC2_BLOCK), 0, stream, a, rb);
+                hipLaunchKernelGGL(sssp_rsweep_kernel, dim3(grid_rsweep), dim3(RB_BLOCK), 0, stream, a, rb);
+              }
+            });
     }, after);
   }
   if (profile) for (auto& e : pe) (void)hipEventDestroy(e);
   if (st != GRX_SUCCESS) return st;
   if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));
   if (ctx->h_ctrl->mid_err != 0 || ctx->h_mailbox[10] != 0) {
+    const int code = ctx->h_mailbox[10] != 0 ? (int)ctx->h_mailbox[10] : (int)ctx->h_ctrl->mid_err;
     ctx->h_mailbox[10] = 0;
+    if (code == 2) {
+      // the bins of a level did not receive exactly its out-edges (grx_bin.hpp, safety net of the scatter's per-XCD queues):
+      // nothing wrong was returned -- the search stopped there.  Repeat it with statically strided units, and keep that mode.
+      GRX_HIP(hipStreamSynchronize(s));
+      GRX_HIP(hipMemsetAsync(&ctx->d_ctrl->mid_err, 0, sizeof(int32_t), s));
+      if (!ctx->sc2_static) {
+        ctx->sc2_static = true;
+        return run_sssp(ctx, g, src, opt, d_dist, near_far, delta, elapsed_ms, overflow);
+      }
+      return fail(GRX_ERROR_HIP, "grx_sssp: the binned scatter did not cover the level's edges (grx_bin.hpp)");
+    }
     return fail(GRX_ERROR_HIP, "grx_sssp: a device-side barrier timed out (grx_mid.hpp)");
   }
+  if (use_rbins) g->rb_hint.fetch_or((uint32_t)ctx->h_ctrl->bin_want, std::memory_order_relaxed);
 
   GRX_HIP(hipEventRecord(ctx->ev_end, s));
   GRX_HIP(hipEventSynchronize(ctx->ev_end));

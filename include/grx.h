@@ -114,6 +114,9 @@ typedef struct grx_options {
 #define GRX_FLAG_SSSP_NO_BFS 0x40    /* grx_sssp: relax with the SSSP kernels even when all weights are equal.  By default
                                         such a graph (every pattern .mtx: the reference loader stores 1.0, io/matrix_market.hxx:
                                         170-171) is searched by the BFS engine and the depths become k-fold fp32 sums of w */
+#define GRX_FLAG_SSSP_NO_BINS 0x80   /* grx_sssp: every level on the relax-per-edge advance.  By default the fat levels of a
+                                        weighted search on a dense graph run as a binned relaxation: (target, tentative distance)
+                                        pairs scattered to bins by target range, minimum taken in LDS (grx_relax.hpp) */
 
 typedef struct grx_context* grx_context_t;
 typedef struct grx_graph* grx_graph_t;
