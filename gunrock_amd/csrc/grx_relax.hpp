@@ -141,7 +141,19 @@ __device__ __forceinline__ void relax_sweep_block(const pipe_args& a, const bin_
       }
     };
     LOAD(0, nx_o, nx_v);  // the first entries are on their way while the labels are copied
-    for (int i = tid; i < nv; i += NT) sm.d[i] = (vbase + i) < a.V ? dist_u[vbase + i] : 0u;
+    {
+      // (all loads of the slice issued before the first LDS store: a loop of load -> store pairs is one memory round trip
+      // per iteration, 16 of them per item -- measured: ~125 us of every sweep, whatever the level's size)
+      unsigned g16[RB_WIDTH / NT];
+#pragma unroll
+      for (int k = 0; k < RB_WIDTH / NT; ++k) {
+        const int i = k * NT + tid;
+        g16[k] = (i < nv && (vbase + i) < a.V) ? dist_u[vbase + i] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < RB_WIDTH / NT; ++k)
+        if (k * NT < nv) sm.d[k * NT + tid] = g16[k];
+    }
     __syncthreads();
     // A. entries -> minimum in LDS (loads one round ahead)
     const int rounds = (i4_last - i4_first + RB_U * NT) / (RB_U * NT);
@@ -182,25 +194,48 @@ __device__ __forceinline__ void relax_sweep_block(const pipe_args& a, const bin_
       }
     }
     __syncthreads();
-    // B. what changed goes back (vertex order, lanes on consecutive labels); the ballots are the changed bitmap
-    for (int r0 = 0; r0 < nv; r0 += NT) {
-      const int i = r0 + tid;
-      const int v = vbase + i;
-      const unsigned l = sm.d[i];
-      const unsigned g = v < a.V ? dist_u[v] : 0u;
-      bool mine = l < g;
-      if (mine) {
-        if (single) dist_u[v] = l;
-        else {
-          // parts of one bin race here, and only here
-          const unsigned old = atomicMin(&dist_u[v], l);
-          mine = l < old && atomicExch(&bn.rstamp[v], level) != level;
-        }
+    // B. what changed goes back (vertex order, lanes on consecutive labels); the ballots are the changed bitmap.  The current
+    // labels are re-read in one batch (a part of a bin may have been overtaken by another part meanwhile).
+    {
+      constexpr int K = RB_WIDTH / NT;
+      unsigned g16[K], l16[K];
+      bool mine[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int i = k * NT + tid;
+        g16[k] = (i < nv && (vbase + i) < a.V) ? dist_u[vbase + i] : 0u;
       }
-      const unsigned long long m = dev::ballot(mine);
-      if ((tid & 63) == 0) {
-        sm.chg[i >> 5] = (unsigned)m;
-        sm.chg[(i >> 5) + 1] = (unsigned)(m >> 32);
+#pragma unroll
+      for (int k = 0; k < K; ++k) l16[k] = sm.d[k * NT + tid];
+#pragma unroll
+      for (int k = 0; k < K; ++k) mine[k] = k * NT < nv && l16[k] < g16[k];
+      if (single) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if (mine[k]) dist_u[vbase + k * NT + tid] = l16[k];
+      } else {
+        // parts of one bin race here, and only here: one device-scope atomic per changed vertex and part, then the stamp
+        // of the level decides which part emits the vertex
+#pragma unroll
+        for (int k = 0; k < K; ++k) g16[k] = mine[k] ? atomicMin(&dist_u[vbase + k * NT + tid], l16[k]) : 0u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) mine[k] = mine[k] && l16[k] < g16[k];
+        int st[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) st[k] = mine[k] ? atomicExch(&bn.rstamp[vbase + k * NT + tid], level) : level;
+#pragma unroll
+        for (int k = 0; k < K; ++k) mine[k] = mine[k] && st[k] != level;
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (k * NT < nv) {  // uniform
+          const unsigned long long m = dev::ballot(mine[k]);
+          if ((tid & 63) == 0) {
+            const int i = k * NT + tid;
+            sm.chg[i >> 5] = (unsigned)m;
+            sm.chg[(i >> 5) + 1] = (unsigned)(m >> 32);
+          }
+        }
       }
     }
     __syncthreads();

@@ -623,7 +623,8 @@ static grx_status_t graph_build_relax_bins(grx_context_t ctx, grx_graph_t g) {
   for (int i = 0; i < n_gran; ++i) total += cnt[(size_t)i];
   if (total != (long long)g->E) return GRX_SUCCESS;  // a column index outside [0, V): the relax-per-edge path reports it as before
   std::vector<int> first;
-  long long target = (total + 447) / 448;
+  const int want_bins = std::max(1, std::min(RB_MAX_BINS, sssp_env_int("GRX_RBIN_BINS", 448)));  // (tuning aid; read when the table is built)
+  long long target = (total + want_bins - 1) / want_bins;
   for (int attempt = 0; attempt < 64; ++attempt) {
     first.clear();
     long long acc = 0;
@@ -742,13 +743,16 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     rb.rdist = d_dist;
     rb.rw = w_eff;
     rb.rstamp = stamp;
-    rb.min_edges = (long long)sssp_env_int("GRX_RBIN_MIN_EDGES", 1 << 22);
+    rb.min_edges = (long long)sssp_env_int("GRX_RBIN_MIN_EDGES", 1 << 20);
     if (rb.min_edges < 1) rb.min_edges = 1;
     grid_rscatter = ctx->num_cus;
     grid_rsweep = ctx->num_cus * sssp_env_int("GRX_RBIN_SWEEP_WG_PER_CU", 1);
     rb.static_units = (ctx->sc2_static || grid_rscatter < 4 * ctx->n_xcd || sssp_env_int("GRX_SC2_STATIC", 0) != 0) ? 1 : 0;
     rb.fault_xcd = ctx->sc2_static ? 0 : sssp_env_int("GRX_SC2_FAULT_XCD", 0);
-    rb.sweep_items = rb.nb + sssp_env_int("GRX_RBIN_PARTS", 2 * ctx->num_cus);
+    // parts: a bin is cut when it holds more than 1 / GRX_RBIN_PARTS of the level's entries.  Few parts: the parts of a bin pay
+    // two device-scope atomics per changed vertex each (a level of 16.7 M entries on the LJ stand-in: 122 us with most bins in two
+    // parts, ~60 us with one), many: the one workgroup of a hub range is the tail of the launch
+    rb.sweep_items = rb.nb + sssp_env_int("GRX_RBIN_PARTS", ctx->num_cus);
   }
   const uint32_t rhint0 = (use_rbins && sssp_env_int("GRX_BIN_HINT", 1) != 0) ? g->rb_hint.load(std::memory_order_relaxed) : 0u;
   const uint32_t rbin_groups = rhint0 ? (rhint0 | (rhint0 << 1) | (rhint0 >> 1)) : ~0u;

@@ -82,6 +82,14 @@ def sweep(budget_s, seed=1234, log=print, max_vertices=600_000):
                             % (kind, V, nnz, gseed, s, direction, flags, force_bins, len(w),
                                [(int(i), int(got[i]), int(want_b[i])) for i in w[:6]]))
                 want_s, _ = O.sssp(g, s)
+                # weighted dense graphs: the binned relaxation (grx_relax.hpp) on every level the head kernel plans, or on the
+                # fat ones only; every other time with so many parts that the bins of a level are relaxed by racing workgroups
+                os.environ["GRX_RBIN_MIN_GRAPH_EDGES"] = "0"
+                os.environ["GRX_RBIN_MIN_EDGES"] = "1" if force_bins else "50000"
+                if int(rng.integers(0, 2)):
+                    os.environ["GRX_RBIN_PARTS"] = "4096"
+                else:
+                    os.environ.pop("GRX_RBIN_PARTS", None)
                 gr.sssp(G, s, d_f, None, ctx, gr.options_t())
                 n_checks += 1
                 if not np.array_equal(d_f.cpu().numpy(), want_s):
@@ -95,6 +103,8 @@ def sweep(budget_s, seed=1234, log=print, max_vertices=600_000):
         os.environ.pop("GRX_BLOCK_MIN_V", None)
         os.environ.pop("GRX_BLOCK", None)
         os.environ.pop("GRX_BIN_MAX_DEGREE", None)
+        for k in ("GRX_RBIN_MIN_GRAPH_EDGES", "GRX_RBIN_MIN_EDGES", "GRX_RBIN_PARTS"):
+            os.environ.pop(k, None)
         if saved_env is None:
             os.environ.pop("GRX_BIN_MIN_EDGES", None)
         else:

@@ -1,6 +1,6 @@
 """Weighted SSSP on the dense stand-ins (LJ / kron, U{1..1000} per-pair weights): the relax-per-edge levels (round 3,
 GRX_FLAG_SSSP_NO_BINS) against the binned relaxation of the fat levels (grx_relax.hpp), with the per-level profile.
-    python tools/ab_relax.py lj|kron [GRX_RBIN_MIN_EDGES ...]"""
+    python tools/ab_relax.py lj|kron [VAR=value,VAR=value ...]"""
 import os
 import sys
 
@@ -24,7 +24,7 @@ d = torch.empty(V, dtype=torch.float32, device="cuda")
 
 
 def run(label, flags, env):
-    for k in ("GRX_RBIN_MIN_EDGES", "GRX_RBIN_PARTS", "GRX_RBIN_SWEEP_WG_PER_CU"):
+    for k in [k for k in os.environ if k.startswith("GRX_RBIN_")]:
         os.environ.pop(k, None)
     os.environ.update(env)
     o = gr.options_t(advance_load_balance=gr.merge_path, engine_flags=flags)
@@ -38,15 +38,13 @@ def run(label, flags, env):
     prof = gr.level_profile(ctx)
     lv = " ".join("%d/%d:%s%.0f+h%.0f" % (r["frontier_size"], r["edges"], {0: "T", 2: "R", 3: "M"}.get(r["bottom_up"], "?"),
                                           r["advance_ms"] * 1e3, r["other_ms"] * 1e3) for r in prof)
-    print("%-34s %.3f ms (first %.2f)  levels %d  relaxed %d | %s" % (label, ts[3], first, st["search_depth"], st["edges_visited"], lv), flush=True)
+    print("%-58s %.3f ms (first %.2f)  levels %d  relaxed %d | %s" % (label, ts[3], first, st["search_depth"], st["edges_visited"], lv), flush=True)
     return out
 
 
 ref = run("relax per edge (round 3)", gr.FLAG_SSSP_NO_BINS, {})
-for me in (sys.argv[2:] or ["4194304", "1048576", "16777216"]):
-    r = run("binned, levels >= %s edges" % me, 0, {"GRX_RBIN_MIN_EDGES": me})
+# variants: comma-separated environment settings, e.g.  GRX_RBIN_MIN_EDGES=1048576,GRX_RBIN_PARTS=256
+for spec in (sys.argv[2:] or ["", "GRX_RBIN_MIN_EDGES=1048576", "GRX_RBIN_PARTS=256", "GRX_RBIN_MIN_EDGES=1048576,GRX_RBIN_PARTS=256"]):
+    env = dict(kv.split("=") for kv in spec.split(",") if kv)
+    r = run("binned %s" % (spec or "(defaults)"), 0, env)
     print("   same as relax-per-edge: %s" % bool(np.array_equal(r, ref)), flush=True)
-r = run("binned, 1024 parts", 0, {"GRX_RBIN_PARTS": "1024"})
-print("   same: %s" % bool(np.array_equal(r, ref)), flush=True)
-r = run("binned, 256 parts", 0, {"GRX_RBIN_PARTS": "256"})
-print("   same: %s" % bool(np.array_equal(r, ref)), flush=True)
