@@ -584,25 +584,35 @@ def bench_sssp_on(env, tag, props, csr, src, info, G_unit=None):
         prof = best_profile(lambda: gr.sssp(G, src_v, d, None, ctx, po), lambda: gr.level_profile(ctx), tries=1 if road else 2)
         # near-far: records with bottom_up == 2 only pull a bucket out of the far pile; unit weights run on the BFS engine,
         # whose records carry the body (2 = binned there) -- all of them are advance launches
-        adv = [l for l in prof if not (weighted and l["bottom_up"] == 2)]
+        mean_deg = E / max(1, V)
+        near_far = weighted and mean_deg < 6  # (grx_sssp.hip: dense graphs run the plain label-correcting schedule)
+        adv = [l for l in prof if not (near_far and l["bottom_up"] == 2)]
         per_edge = 16 if weighted else 12  # weighted: + 4 B weight; all-equal weights are never read
         r = roof(adv, lambda l: 12 * l["frontier_size"] + per_edge * l["edges"],
-                 "SSSP relaxation kernels (advance_block<sssp policies>, near-far on road-like graphs)" if weighted else
+                 ("SSSP relaxation kernels (near-far schedule, advance_block<sssp_nf_policy>)" if near_far else
+                  "SSSP relaxation kernels: fat levels as binned relaxation (sssp_rscatter_kernel + sssp_rsweep_kernel, "
+                  "grx_relax.hpp), the others advance_block<sssp_policy>") if weighted else
                  "BFS engine level kernels (all weights equal: depths -> k-fold sums of w)",
                  "12 B per frontier slot + %d B per relaxed edge (SURVEY 8d)" % per_edge)
+        if weighted and not near_far:
+            fat = [l for l in prof if l["bottom_up"] == 2]
+            r["binned_levels"] = len(fat)
+            if fat:
+                r["binned_levels_frac"] = round(sum(12 * l["frontier_size"] + per_edge * l["edges"] for l in fat) /
+                                                (sum(l["advance_ms"] for l in fat) * 1e-3) / 8.0e12, 4)
+                r["binned_levels_edges_relaxed"] = int(sum(l["edges"] for l in fat))
         if road:
             attach_traffic(r, pmc, "sssp_" + label, per_step=True)
         r["head_kernel_ms_per_step"] = round(sum(l["other_ms"] for l in prof), 3)
-        if weighted:
+        if near_far:
             r["bucket_pull_launches"] = len(prof) - len(adv)
             r["bucket_pull_ms_per_step"] = round(sum(l["advance_ms"] for l in prof if l["bottom_up"] == 2), 3)
         if not road:
             r["levels"] = [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
                             round(l["other_ms"], 4)] for l in prof]
-        mean_deg = E / max(1, V)
         blocky = bs["supersteps"] > 0
         item = {"schedule": (("all weights equal: BFS engine + one pass depths -> distances (grx_sssp.hip)" if not weighted
-                              else ("near-far (delta-stepping)" if mean_deg < 6 else "label-correcting levels (frontier "
+                              else ("near-far (delta-stepping)" if mean_deg < 6 else "label-correcting levels, the fat ones as binned relaxation (frontier "
                                     "Bellman-Ford, the reference's schedule)")) +
                              ("; road-like graph: block-asynchronous relaxation (grx_block.hip), supersteps between blocks "
                               "of %d vertices inside global label buckets" % bs["block_vertices"] if blocky else "")),
