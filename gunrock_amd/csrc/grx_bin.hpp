@@ -71,7 +71,7 @@ struct bin_args {
   int32_t mid_v, mid_e;       // thresholds of the many-levels-per-launch body (grx_mid.hpp), 0: off (carried here for the head kernel)
   int32_t static_units;       // second scatter: units strided statically over the workgroups instead of drawn from per-XCD ticket
                               // queues (the fallback when a launch cannot be trusted to put a workgroup on every XCD)
-  int32_t sub_shift;          // second scatter: log2 of the sub-counters per bin (2 | 0; GRX_BIN_SUB)
+  int32_t sub_shift;          // second scatter: log2 of the sub-counters per bin (2 | 1 | 0; GRX_BIN_SUB; nb << sub_shift <= 1024)
   int32_t pair_stores;        // second scatter: neighbouring entries of a bin leave as one store of twice the width (GRX_BIN_PAIR)
   int32_t fault_xcd;          // test aid (GRX_SC2_FAULT_XCD=k): workgroups on dense XCD index k - 1 take no units (0: off)
   // binned RELAXATION (weighted SSSP on dense graphs, grx_relax.hpp): an entry is the 16-bit offset of the target inside its
@@ -1088,10 +1088,8 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     int gbase = 0;
     {
       int bt = cnt;
-      if (sub_shift) {
-        bt += __shfl_xor(bt, 1, 64);
-        bt += __shfl_xor(bt, 2, 64);
-      }
+      if (sub_shift >= 1) bt += __shfl_xor(bt, 1, 64);  // (uniform)
+      if (sub_shift >= 2) bt += __shfl_xor(bt, 2, 64);
       if ((tid & sub_mask) == 0 && bt > 0) gbase = atomicAdd(&bn.fill[(unsigned)(my_bin * BIN_PAD)], bt);
     }
     const int inc2 = dev::wave_inclusive_sum(cnt);

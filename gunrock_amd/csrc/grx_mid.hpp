@@ -37,8 +37,10 @@
 // The multi-level bodies and the l2_local claims rely on two gfx950 (CDNA3/4 multi-XCD) facts: s_getreg_b32 0x1814 is
 // HW_REG_XCC_ID, and workgroup-scope atomics / sc1 loads are coherent inside ONE XCD's L2.  Any other target would turn
 // claims silently wrong, so the device pass refuses to compile for it.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
-#error "grx_mid.hpp is written for gfx950 (XCC id register, XCD-local L2 coherence); build with --offload-arch=gfx950"
+// (gfx950 ONLY: the sweep / relax kernels keep 82-111 KB of static LDS per workgroup -- gfx942 has 64 KB -- and the DPP scans of
+// include/gunrock/hip/wave.hxx use gfx950 row controls.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "grx_mid.hpp is written for gfx950 (XCC id register, XCD-local L2 coherence, 160 KB of LDS); build with --offload-arch=gfx950"
 #endif
 
 

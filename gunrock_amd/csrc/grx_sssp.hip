@@ -721,12 +721,20 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     st = graph_build_relax_bins(ctx, g);
     if (st != GRX_SUCCESS) return st;
   }
-  const bool use_rbins = want_bins && g->rb_state == 1;
+  bool use_rbins = want_bins && g->rb_state == 1;
   if (use_rbins) {
+    // per-SEARCH scratch, owned by the context: 6 bytes per edge.  When it cannot be had the search runs on the relax-per-edge
+    // levels -- slower, same result -- instead of failing.
     const size_t fill_bytes = ((size_t)RB_MAX_BINS + 16) * BIN_PAD * sizeof(int32_t);
-    GRX_HIP(ctx->rbins[0].reserve(((size_t)g->E + 16) * sizeof(unsigned short)));
-    GRX_HIP(ctx->rbins[1].reserve(((size_t)g->E + 16) * sizeof(unsigned)));
-    GRX_HIP(ctx->rbins[2].reserve(fill_bytes));
+    if (ctx->rbins[0].reserve(((size_t)g->E + 16) * sizeof(unsigned short)) != hipSuccess ||
+        ctx->rbins[1].reserve(((size_t)g->E + 16) * sizeof(unsigned)) != hipSuccess ||
+        ctx->rbins[2].reserve(fill_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      for (auto& b : ctx->rbins) b.release();
+      use_rbins = false;
+    }
+  }
+  if (use_rbins) {
     rb.bins = ctx->rbins[0].as<int32_t>();
     rb.rval = ctx->rbins[1].as<unsigned>();
     rb.fill = ctx->rbins[2].as<int32_t>();
@@ -739,7 +747,9 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     rb.nb = g->rb_nb;
     rb.local_ids = 1;
     rb.entry16 = 1;
-    rb.sub_shift = 0;  // a counter per bin: up to 1024 bins
+    // sub-counters per bin in the scatter's LDS histogram (grx_bin.hpp: a hot bin's ranking atomics serialise on one word): as
+    // many as the 1024 counters allow
+    rb.sub_shift = sssp_env_int("GRX_RBIN_SUB", 1) == 0 ? 0 : (rb.nb <= RB_MAX_BINS / 4 ? 2 : (rb.nb <= RB_MAX_BINS / 2 ? 1 : 0));
     rb.rdist = d_dist;
     rb.rw = w_eff;
     rb.rstamp = stamp;
