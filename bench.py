@@ -603,6 +603,8 @@ def bench_sssp_on(env, tag, props, csr, src, info, G_unit=None):
                 r["binned_levels_edges_relaxed"] = int(sum(l["edges"] for l in fat))
         if road:
             attach_traffic(r, pmc, "sssp_" + label, per_step=True)
+        elif weighted and tag == "lj":  # (tools/profile_r4.sh ssspd: the same graph, weights and source)
+            attach_traffic(r, pmc, "sssp_weighted_dense", per_step=True)
         r["head_kernel_ms_per_step"] = round(sum(l["other_ms"] for l in prof), 3)
         if near_far:
             r["bucket_pull_launches"] = len(prof) - len(adv)

@@ -9,9 +9,11 @@ cp $G/r4_bench_pmc.json $P/r4_bench_pmc.json
 cp $G/r4_bfs_rocprofv3_summary.md $P/r4_bfs_rocprofv3_summary.md;   cp $G/r4_bfs_kernel_stats.csv $P/r4_bfs_kernel_stats.csv
 cp $G/r4_ssspu_rocprofv3_summary.md $P/r4_sssp_unit_rocprofv3_summary.md; cp $G/r4_ssspu_kernel_stats.csv $P/r4_sssp_unit_kernel_stats.csv
 cp $G/r4_sssp_rocprofv3_summary.md $P/r4_sssp_weighted_rocprofv3_summary.md; cp $G/r4_sssp_kernel_stats.csv $P/r4_sssp_weighted_kernel_stats.csv
+cp $G/r4_ssspd_rocprofv3_summary.md $P/r4_sssp_weighted_dense_rocprofv3_summary.md; cp $G/r4_ssspd_kernel_stats.csv $P/r4_sssp_weighted_dense_kernel_stats.csv
 cp $G/r4_pr_rocprofv3_summary.md $P/r4_pr_rocprofv3_summary.md;     cp $G/r4_pr_kernel_stats.csv $P/r4_pr_kernel_stats.csv
 grep -h '^{' $G/final_bench_all.log > $P/r4_all_configs.jsonl
 cp $G/final_prep_timing.log $P/r4_prep_timing_final.txt
+{ echo "# tools/ab_relax.py on the final sources"; grep -hv amdgpu.ids $G/final_ab_relax_lj.log $G/final_ab_relax_kron.log | cut -c1-700; } > $P/r4_ab_relax_final_sources.txt
 { echo "# tools/ab_r4.py lj on the final sources"; grep -hv amdgpu.ids $G/final_ab_lj.log | cut -c1-420; } > $P/r4_ab_final_sources.txt
 { echo "== level 1 (89 k vertices, 31 M edges)"; grep -v amdgpu.ids $G/final_bin_debug_l1.log; echo "== level 2 (2.0 M vertices, 36 M edges)"; grep -v amdgpu.ids $G/final_bin_debug_l2.log; } | cut -c1-420 > $P/r4_binned_levels_timeline_lj.txt
 cp $G/generic_bfs.log $P/r4_generic_operators_bfs_lj.txt; cp $G/generic_kernel_stats.md $P/r4_generic_operators_kernel_stats.md

@@ -16,6 +16,8 @@ if [ "${FINAL_SHORT:-0}" != 1 ]; then
   timeout 1200 python tests/tools/bench_all.py bfs_lj ssspu_lj sssp_lj pr_lj bfs_kron ssspu_kron sssp_kron pr_kron bfs_road ssspu_road sssp_road bfs_twitter > gpurun_out/final_bench_all.log 2>&1
   timeout 300 python tools/prep_timing.py lj kron 2>&1 | grep -v amdgpu.ids > gpurun_out/final_prep_timing.log
   timeout 300 python tools/ab_r4.py lj 20 > gpurun_out/final_ab_lj.log 2>&1
+  timeout 300 python tools/ab_relax.py lj "" > gpurun_out/final_ab_relax_lj.log 2>&1
+  timeout 300 python tools/ab_relax.py kron "" > gpurun_out/final_ab_relax_kron.log 2>&1
   GRX_BIN_DEBUG=1 timeout 200 python tools/bin_debug.py lj > gpurun_out/final_bin_debug_l1.log 2>&1
   GRX_BIN_DEBUG=2 timeout 200 python tools/bin_debug.py lj > gpurun_out/final_bin_debug_l2.log 2>&1
   bash tools/bench_generic.sh > gpurun_out/final_generic.log 2>&1

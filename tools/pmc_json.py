@@ -13,6 +13,8 @@ kernels of interest are classified by name and by their position inside the sear
   sssp_unit_weights    all level launches of a unit-weight search (round 4: bfs_level_bin_kernel -- the search runs on the BFS
                        engine; before: sssp_level_kernel); per SEARCH (with many levels per launch the
   sssp_weighted_1_1000 all sssp_nf_level_kernel launches           launch count is not a unit of work)
+  sssp_weighted_dense  round 4: weighted search on a dense graph -- sssp_level_kernel + sssp_rscatter_kernel + sssp_rsweep_kernel
+                       launches (binned relaxation of the fat levels); per SEARCH
   pr_pull              pr_pull_xcd_kernel / pr_pull_kernel + pr_long* + pr_combine_kernel launches that did work
                        (launches queued past convergence exit at once and are dropped: < 10 % of the largest value);
                        per ITERATION
@@ -71,9 +73,10 @@ def classify(rows):
     ss = searches_of(rows)
     last = {}
     for s in ss:
-        key = (s["kind"], s["do"], any("sssp_nf_level" in n for _, n in s["kernels"]))
+        key = (s["kind"], s["do"], any("sssp_nf_level" in n for _, n in s["kernels"]),
+               any("sssp_rscatter" in n for _, n in s["kernels"]))
         last[key] = s
-    for (kind, do, nf), s in last.items():
+    for (kind, do, nf, rb), s in last.items():
         if kind == "bfs" and do:
             lv = [d for d, n in s["kernels"] if "bfs_level_kernel" in n]
             for pos, d in enumerate(lv):
@@ -96,9 +99,11 @@ def classify(rows):
                     if pos < len(group):
                         cls[group[pos]] = ("topdown_fat", pos)
         elif kind == "sssp":
-            name = "sssp_weighted_1_1000" if nf else "sssp_unit_weights"
+            # rb: a weighted search on a dense graph, fat levels as binned relaxation (grx_relax.hpp): scatter + sweep kernels
+            name = "sssp_weighted_1_1000" if nf else ("sssp_weighted_dense" if rb else "sssp_unit_weights")
             for d, n in s["kernels"]:
-                if "sssp_nf_level_kernel" in n or "sssp_level_kernel" in n or "advance_kernel" in n:
+                if any(k in n for k in ("sssp_nf_level_kernel", "sssp_level_kernel", "advance_kernel", "sssp_rscatter_kernel",
+                                        "sssp_rsweep_kernel")):
                     cls[d] = (name, 0)
         elif kind == "pr":
             it = -1

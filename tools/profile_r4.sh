@@ -1,16 +1,17 @@
 #!/bin/bash
 # Round-4 rocprofv3 evidence: kernel-trace stats + separate PMC passes for the bench workloads, then
 # profiles/r4_bench_pmc.json (tools/pmc_json.py) and the per-target summaries.
-#   tools/profile_r4.sh [bfs] [ssspu] [sssp] [pr]
+#   tools/profile_r4.sh [bfs] [ssspu] [sssp] [ssspd] [pr]      (ssspd: weighted SSSP on the LJ stand-in = binned relaxation)
 set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-T=${*:-bfs ssspu sssp pr}
+T=${*:-bfs ssspu sssp ssspd pr}
 DIRS=""
 for t in $T; do
   case $t in
     bfs)   CMD="python bench.py --only bfs,bfs_do --no-cpu-baseline --steps 5 --warmup 2" ;;
     ssspu) CMD="python tools/run_algo.py ssspu road 2" ;;
     sssp)  CMD="python tools/run_algo.py sssp road 2" ;;
+    ssspd) CMD="python tools/run_algo.py sssp lj 3" ;;
     pr)    CMD="python tools/run_algo.py pr kron 2" ;;
   esac
   PROF_SHORT=1 bash tools/profile.sh r4_$t $CMD > gpurun_out/prof_r4_$t.log 2>&1

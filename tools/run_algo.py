@@ -20,9 +20,10 @@ props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], w
 if algo == "sssp" and sys.argv[2] == "road":
     props, csr = gr.generate("road", wl["V"], 0, wl["a"], 0.0, 1.0, seed=42)  # the weighted road variant of bench.py
 elif algo == "sssp" and not props.weighted:
-    rng = np.random.default_rng(1)
-    csr.nonzero_values = rng.integers(1, 1001, csr.number_of_nonzeros).astype(np.float32)
+    from bench import pair_hash_weights  # the weights of bench.py's sssp_{lj,kron}_w sections: same workload
+    csr.nonzero_values = pair_hash_weights(csr)
     csr._device = None
+    props.weighted = True
 src = int(np.argmax(np.diff(csr.row_offsets)))
 if sys.argv[2] == "road":
     src = (4894 // 2) * 4894 + 4894 // 2
