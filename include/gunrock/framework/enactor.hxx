@@ -66,9 +66,16 @@ struct enactor_t {
         iteration(0) {
     if (!properties.self_manage_frontiers) {
       auto g = problem->get_graph();
+      // as upstream (enactor.hxx:183-190): room for max(E, V) x frontier_sizing_factor elements per buffer, allocated HERE --
+      // an advance without a filter writes one slot per out-edge of its input, and growing a buffer inside enact() is a device
+      // synchronisation + hipMalloc + copy + hipFree per level (round 4: 8 of the 9.6 ms of `merge_path` without a filter on the
+      // LJ stand-in were that)
+      const std::size_t initial_size = (std::size_t)g.get_number_of_edges() > (std::size_t)g.get_number_of_vertices()
+                                           ? (std::size_t)g.get_number_of_edges()
+                                           : (std::size_t)g.get_number_of_vertices();
       for (auto& f : frontiers) {
         f.set_resizing_factor(properties.frontier_sizing_factor);
-        f.reserve((std::size_t)g.get_number_of_vertices());
+        f.reserve(initial_size);
       }
     }
   }
