@@ -1,13 +1,13 @@
-// merge_path.hxx -- every workgroup gets the same number of edges (2048),
-// whatever the degree distribution: hubs are split across workgroups, runs of
-// tiny rows are fused.
+// merge_path.hxx -- every workgroup gets the same number of input slots + edges
+// (2048), whatever the degree distribution: hubs are split across workgroups,
+// runs of tiny rows are fused, runs of invalid / empty slots are shared out.
 // API parity: include/gunrock/framework/operators/advance/merge_path.hxx:78-362
 // (reference): output = concatenation of neighbour lists in input order
 // (output[global_atom]).  Differences: the reference gives each THREAD 11
 // consecutive atoms (a wave then touches 64 addresses 44 bytes apart); here lanes
 // take consecutive atoms so the column-index stream is coalesced.  The partition
-// is on atoms only; slots are swept in LDS windows of 256, so runs of zero-degree
-// slots cost extra windows instead of a second merge dimension.  Sizes are
+// is on the merge path of slots and atoms (found per workgroup by a k-ary search
+// over the scanned degrees); inside a workgroup slots are swept in LDS windows of 256.  Sizes are
 // 64-bit on the host side; 32-bit atom ids inside a launch (E < 2^31).
 #pragma once
 
@@ -29,18 +29,27 @@ __global__ __launch_bounds__(detail::BLOCK) void kernel(graph_t G, operator_t op
   __shared__ int s_start[detail::BLOCK];
   __shared__ type_t s_src[detail::BLOCK];
   __shared__ int s_first;
-  const edge_t a0 = (edge_t)blockIdx.x * detail::ATOMS_PER_BLOCK;
-  const edge_t a1 = min(total_atoms, a0 + detail::ATOMS_PER_BLOCK);
-  if (a0 >= a1) return;
-  // first slot whose range contains atom a0: largest i with segments[i] <= a0.
-  // 64 lanes probe 64 evenly spaced positions per round (k-ary search).
-  if (threadIdx.x < 64) {
-    std::size_t lo = 0, hi = n;  // invariant: segments[lo] <= a0 < segments[hi]
+  __shared__ long long s_a[2];
+  // Partition on the MERGE PATH of slots and atoms (round 4): workgroup b owns the stretch [b, b + 1) x ITEMS of the diagonal
+  // d = slots passed + atoms consumed; a state of the path is (i, d - i) with i the largest slot index for which
+  // i + segments[i] <= d (the sum is strictly increasing in i).  Before, the partition was on atoms alone and a workgroup swept
+  // however many slots its 2048 atoms were spread over: on the input of a BFS level WITHOUT a filter -- 36 M slots, 0.5 M of them
+  // valid, 0.7 M atoms on the LJ stand-in -- that was 390 windows of 256 slots per workgroup, 3 ms for the level (upstream's
+  // merge path splits both dimensions, merge_path.hxx:112-362).  Now a workgroup sweeps at most ITEMS slots.
+  // Waves 0 and 1 find the two ends: 64 lanes probe 64 evenly spaced positions per round (k-ary search).
+  const unsigned long long d_total = (unsigned long long)n + (unsigned long long)total_atoms;
+  const unsigned long long d_lo = (unsigned long long)blockIdx.x * detail::ATOMS_PER_BLOCK;
+  if (d_lo >= d_total) return;
+  const unsigned long long d_hi = d_lo + detail::ATOMS_PER_BLOCK < d_total ? d_lo + detail::ATOMS_PER_BLOCK : d_total;
+  if (threadIdx.x < 128) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long d = threadIdx.x < 64 ? d_lo : d_hi;
+    std::size_t lo = 0, hi = n + 1;  // invariant: lo + segments[lo] <= d; hi == n + 1 or hi + segments[hi] > d
     while (hi - lo > 1) {
       const std::size_t span = hi - lo;
       const std::size_t step = (span + 63) / 64;
-      const std::size_t pos = lo + (std::size_t)(threadIdx.x + 1) * step;
-      const bool le = pos < hi && segments[pos] <= a0;
+      const std::size_t pos = lo + (std::size_t)(lane + 1) * step;
+      const bool le = pos < hi && (unsigned long long)pos + (unsigned long long)segments[pos] <= d;
       const unsigned long long m = grx::dev::ballot(le);
       const int cnt = __popcll(m);  // positions are monotone => prefix of lanes
       const std::size_t nlo = lo + (std::size_t)cnt * step;
@@ -48,9 +57,15 @@ __global__ __launch_bounds__(detail::BLOCK) void kernel(graph_t G, operator_t op
       lo = nlo;
       hi = nhi;
     }
-    if (threadIdx.x == 0) s_first = (int)lo;
+    if (lane == 0) {
+      if (threadIdx.x == 0) { s_first = (int)lo; s_a[0] = (long long)(d - lo); }
+      else s_a[1] = (long long)(d - lo);
+    }
   }
   __syncthreads();
+  const edge_t a0 = (edge_t)min((long long)total_atoms, s_a[0]);
+  const edge_t a1 = (edge_t)min((long long)total_atoms, s_a[1]);
+  if (a0 >= a1) return;  // a stretch of empty slots
   for (std::size_t ws = (std::size_t)s_first; ws < n; ws += detail::BLOCK) {
     const std::size_t i = ws + threadIdx.x;
     const edge_t base = segments[ws];
@@ -88,7 +103,7 @@ template <advance_io_type_t output_type, typename graph_t, typename operator_t, 
 void launch(graph_t& G, operator_t op, const type_t* input, std::size_t n, type_t* output, const edge_t* segments,
             std::size_t total_atoms, gcuda::standard_context_t& context) {
   if (n == 0 || total_atoms == 0) return;
-  const std::size_t blocks = (total_atoms + detail::ATOMS_PER_BLOCK - 1) / detail::ATOMS_PER_BLOCK;
+  const std::size_t blocks = (n + total_atoms + detail::ATOMS_PER_BLOCK - 1) / detail::ATOMS_PER_BLOCK;
   hipLaunchKernelGGL((kernel<output_type, false, graph_t, operator_t, type_t, edge_t>), dim3((unsigned)blocks),
                      dim3(detail::BLOCK), 0, context.stream(), G, op, input, n, output, segments, (edge_t)total_atoms,
                      (int32_t*)nullptr);
@@ -99,7 +114,7 @@ template <advance_io_type_t output_type, typename graph_t, typename operator_t, 
 void launch_compact(graph_t& G, operator_t op, const type_t* input, std::size_t n, type_t* output, const edge_t* segments,
                     std::size_t total_atoms, int32_t* counter, gcuda::standard_context_t& context) {
   if (n == 0 || total_atoms == 0) return;
-  const std::size_t blocks = (total_atoms + detail::ATOMS_PER_BLOCK - 1) / detail::ATOMS_PER_BLOCK;
+  const std::size_t blocks = (n + total_atoms + detail::ATOMS_PER_BLOCK - 1) / detail::ATOMS_PER_BLOCK;
   hipLaunchKernelGGL((kernel<output_type, true, graph_t, operator_t, type_t, edge_t>), dim3((unsigned)blocks),
                      dim3(detail::BLOCK), 0, context.stream(), G, op, input, n, output, segments, (edge_t)total_atoms,
                      counter);
