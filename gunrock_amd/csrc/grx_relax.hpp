@@ -39,292 +39,10 @@ constexpr int RB_PART_MIN = 1 << 15;            // a bin is cut into parts of at
 constexpr int RB_U = 2;                         // 16-byte offset loads (8 entries each) per thread and round
 constexpr int RB_QUEUE_SLOT = 15;               // bin_args::queue word (x BIN_PAD) the sweep draws its items from
 
-// ---------------------------------------------------------------------------------------------------------------
-// SCATTER with values, software-pipelined across batches.
-//
-// bin_scatter2_block<.., VAL = true> (grx_bin.hpp) is the BFS scatter with a value riding along: a chain of seven
-// barrier-separated phases per batch of 8192 edges, ~11.7 us.  The BFS build hides that chain behind a second workgroup on the
-// CU; this one has LDS for ONE (the values double the sort buffer: 104 KB), so every round trip of the chain is exposed -- 190 G
-// edges/s against 330.  The longest exposed wait is for the column indices and weights of the batch, which can only be
-// requested once the batch's owner map exists (phases 1-3).  Here the owner map of batch i + 1 is built, and its column / weight
-// loads are issued, BEFORE the reservation, sort and copy-out of batch i (phases 5-7): the loads travel while those run.
-//   iteration i:  [4b] consume the loads of batch i (tentative distances, granule table, histogram)    | barrier
-//                 [1-3 of batch i + 1] degrees, owner map                                               | 3 barriers
-//                 [4a of batch i + 1] edge index of every atom, column + weight loads ISSUED
-//                 [5] reservation + offsets of batch i  | 2 barriers   [6] sort in LDS | barrier   [7] copy-out
-// Same phases, same barriers, same LDS; +16 VGPRs (the loads in flight).  What makes the order legal: the owner map, row
-// deltas and labels of batch i are last read in [4b] (barrier behind it) before [1-3] of batch i + 1 overwrite them; the
-// histogram of batch i is read into a register before [1] clears it; [5-7] touch only the scan words, offsets and the
-// sort buffers, which [1-4a] never do.  The front of the pipeline (descriptor -> slot -> row offsets + label, one stage per
-// batch) is the one of bin_scatter2_block.
-__device__ __forceinline__ void relax_scatter_block(const pipe_args& a, const bin_args& bn, bin_scatter2_val_smem& sm, int p,
-                                                    int total_chunks, const int* chunk_tile) {
-  constexpr int BBITS = 10, BSHIFT = 14;
-  constexpr unsigned BMASK = (1u << BBITS) - 1u;
-  const int tid0 = threadIdx.x;
-  int tid = tid0;
-  int q = tid >> 8;          // quarter of the workgroup = chunk of the batch
-  int tq = tid & (TILE - 1); // slot of the staged tile
-  int lane = tid & 63;
-  int wq = (tid >> 6) & 3;   // wave inside the quarter
-  const int32_t* in = a.frontier[p];
-  const int gshift = bn.gshift;
-  const unsigned gmask = (1u << gshift) - 1u;
-  for (int w = tid; w < (bn.n_gran + 1) / 2; w += SC2_BLOCK)
-    reinterpret_cast<unsigned*>(sm.g2b)[w] = reinterpret_cast<const unsigned*>(bn.g2b16)[w];
-  const int sub_shift = bn.sub_shift;
-  const int sub_mask = (1 << sub_shift) - 1;
-  const int boff = (tid >> sub_shift) < bn.nb ? bn.off[tid >> sub_shift] : 0;
-  const int n_units = (total_chunks + SC2_Q - 1) / SC2_Q;
-  // units: one ticket queue per XCD, or statically strided (bin_scatter2_block; the sweep checks the coverage)
-  const int xcd = xcd_index(bn.xcc_mask, bn.n_xcd);
-  if (bn.fault_xcd == xcd + 1) return;
-  const bool stat = bn.static_units != 0;
-  const int n_xcd = stat ? (int)gridDim.x : bn.n_xcd;
-  const int first_unit = stat ? (int)blockIdx.x : xcd;
-  int next_static = 4;
-  int* qhead = &bn.queue[(unsigned)(xcd * BIN_PAD)];
-  if (tid0 == 0) {
-    int t[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = stat ? i : __hip_atomic_fetch_add(qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sm.tick[i] = first_unit + n_xcd * t[i];
-  }
-  __syncthreads();
-  int vzero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-  const int2* map = reinterpret_cast<const int2*>(chunk_tile);
-  auto S1 = [&](int u) -> int2 {
-    const long long cidx = (long long)u * SC2_Q + q;
-    const bool ok = u < n_units && cidx < total_chunks;
-    int2 t = map[(unsigned)((ok ? (int)cidx : 0) + vzero)];
-    if (!ok) t.y = -1;
-    return t;
-  };
-  int uA = __builtin_amdgcn_readfirstlane(sm.tick[0]), uB = __builtin_amdgcn_readfirstlane(sm.tick[1]),
-      uC = __builtin_amdgcn_readfirstlane(sm.tick[2]);
-  int yA, yB;
-  int2 tlC, tlD;
-  int vA, vB, vC;
-  int rsA, reA, rsB, reB;
-  unsigned dA, dB = 0u;
-  {
-    const int2 tA = S1(uA), tB = S1(uB);
-    tlC = S1(uC);
-    yA = tA.y;
-    yB = tB.y;
-    vA = in[(unsigned)(tA.x * TILE + tq)];
-    vB = in[(unsigned)(tB.x * TILE + tq)];
-    const unsigned vv = vA >= 0 ? (unsigned)vA : 0u;
-    rsA = a.ro[vv];
-    reA = a.ro[vv + 1u];
-    dA = __float_as_uint(bn.rdist[vv]);
-  }
-  // BUILD: phases 1-3 of the batch in stage A and the issue of its column / weight loads; rotates the front stages.
-  // Leaves: ci_k / w_k (in flight), n_at (atoms of this thread's chunk), and returns the unit it worked on.
-  unsigned ci_n[ADV_ITEMS];
-  float w_n[ADV_ITEMS];
-  int n_at_n = 0;
-  auto build = [&]() -> int {
-    tid = tid0;
-    asm volatile("" : "+v"(tid));  // (per-thread constants are re-derived per batch: see bin_scatter2_block)
-    q = tid >> 8;
-    tq = tid & (TILE - 1);
-    lane = tid & 63;
-    wq = (tid >> 6) & 3;
-    unsigned char* own = &sm.own[q][0];
-    // ---- phase 1
-    const bool has = yA >= 0;
-    const int rs = rsA;
-    const int dg = (has && vA >= 0) ? reA - rsA : 0;
-    const int a0 = has ? yA * CHUNK : 0;
-    {
-      const unsigned vv = vB >= 0 ? (unsigned)vB : 0u;
-      rsB = a.ro[vv];
-      reB = a.ro[vv + 1u];
-      dB = __float_as_uint(bn.rdist[vv]);
-    }
-    vC = in[(unsigned)(tlC.x * TILE + tq)];
-    int ticket = 0;
-    if (stat) ticket = next_static++;
-    else if (tid == 0) ticket = __hip_atomic_fetch_add(qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const int inc = dev::wave_inclusive_sum(dg);
-    if (lane == 63) sm.wtot[q][wq] = inc;
-    reinterpret_cast<uint2*>(own)[tq] = make_uint2(0u, 0u);
-    sm.hist[tid] = 0;  // (the previous batch's count is in a register by now)
-    __syncthreads();
-    const int uD = __builtin_amdgcn_readfirstlane(sm.tick[3]);
-    tlD = S1(uD);
-    // ---- phase 2
-    int base = 0, tot = 0;
-    {
-      const int4 wt = *reinterpret_cast<const int4*>(&sm.wtot[q][0]);
-      const int x[4] = {wt.x, wt.y, wt.z, wt.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (i < wq) base += x[i];
-        tot += x[i];
-      }
-    }
-    const int ex = base + inc - dg;
-    sm.dlt[q][tq] = rs - ex;
-    sm.dsrc[q][tq] = dA;
-    const int pos = ex - a0;
-    if (dg > 0) {
-      if (pos > 0) {
-        if (pos < CHUNK) own[pos] = (unsigned char)tq;
-      } else if (pos + dg > 0) {
-        own[0] = (unsigned char)tq;
-      }
-    }
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const unsigned long long m = dev::ballot(dg > 0 && pos < w * (CHUNK / 4));
-      if (lane == 0) sm.cand[q][w][wq] = m ? (wq * 64 + 63 - __builtin_clzll(m)) : 0;
-    }
-    __syncthreads();
-    // ---- phase 3
-    {
-      const uint2 w8 = reinterpret_cast<const uint2*>(own)[tq];
-      unsigned m_k[8];
-      unsigned run = 0u;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const unsigned b = ((i < 4 ? w8.x : w8.y) >> ((i & 3) * 8)) & 0xffu;
-        run = b > run ? b : run;
-        m_k[i] = run;
-      }
-      const int incm = dev::wave_inclusive_max_nonneg((int)run);
-      unsigned carry = (unsigned)dev::wave_shift_up1(incm);
-      if (wq > 0) {
-        const int4 cd = *reinterpret_cast<const int4*>(&sm.cand[q][wq][0]);
-        const int c4 = max(max(cd.x, cd.y), max(cd.z, cd.w));
-        carry = (unsigned)c4 > carry ? (unsigned)c4 : carry;
-      }
-      uint2 r8 = make_uint2(0u, 0u);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const unsigned v = m_k[i] > carry ? m_k[i] : carry;
-        if (i < 4) r8.x |= v << (i * 8);
-        else r8.y |= v << ((i - 4) * 8);
-      }
-      reinterpret_cast<uint2*>(own)[tq] = r8;
-    }
-    __syncthreads();
-    // ---- phase 4a: edge index of every atom; column index and weight requested, not waited for
-    n_at_n = has ? min(tot - a0, CHUNK) : 0;
-    {
-      int ob[ADV_ITEMS];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) ob[k] = own[k * TILE + tq];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) ob[k] = sm.dlt[q][ob[k]];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) {
-        const int al = k * TILE + tq;
-        const int e = al < n_at_n ? a0 + al + ob[k] : 0;  // lanes past the end read edge 0
-        ci_n[k] = (unsigned)a.ci[e];
-        w_n[k] = bn.rw[e];
-      }
-    }
-    if (tid == 0) sm.tick[3] = first_unit + n_xcd * ticket;  // read behind the first barrier of the next build
-    const int unit = uA;
-    uA = uB; uB = uC; uC = uD;
-    yA = yB; yB = tlC.y; tlC = tlD;
-    vA = vB; vB = vC;
-    rsA = rsB; reA = reB;
-    dA = dB;
-    return unit;
-  };
-  int cur = build();
-  while (cur < n_units) {
-    // ---- phase 4b of the current batch: its loads have had phases 5-7 of the previous batch to arrive
-    unsigned e_k[ADV_ITEMS], v_k[ADV_ITEMS];
-    int r_k[ADV_ITEMS];
-    const int n_at = n_at_n;
-    {
-      unsigned char* own = &sm.own[q][0];
-      int ob[ADV_ITEMS];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) ob[k] = own[k * TILE + tq];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) v_k[k] = sm.dsrc[q][ob[k]];
-      // the relaxation's arithmetic, exactly (sssp.hxx:121-123): fl(label of the source + weight)
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) v_k[k] = __float_as_uint(__uint_as_float(v_k[k]) + w_n[k]);
-      unsigned t_k[ADV_ITEMS];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) t_k[k] = sm.g2b[ci_n[k] >> gshift];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) {
-        const unsigned bb = t_k[k] & BMASK;
-        e_k[k] = (bb << BSHIFT) | ((t_k[k] >> BBITS) << gshift) | (ci_n[k] & gmask);
-        r_k[k] = atomicAdd(&sm.hist[(bb << sub_shift) | (unsigned)(lane & sub_mask)], (k * TILE + tq) < n_at ? 1 : 0);
-      }
-    }
-    __syncthreads();
-    const int cnt = sm.hist[tid];
-    const int my_bin = tid >> sub_shift;
-    // ---- phases 1-4a of the next batch
-    const int nxt = build();
-    // ---- phase 5 of the current batch
-    int gbase = 0;
-    {
-      int bt = cnt;
-      if (sub_shift >= 1) bt += __shfl_xor(bt, 1, 64);
-      if (sub_shift >= 2) bt += __shfl_xor(bt, 2, 64);
-      if ((tid & sub_mask) == 0 && bt > 0) gbase = atomicAdd(&bn.fill[(unsigned)(my_bin * BIN_PAD)], bt);
-    }
-    const int inc2 = dev::wave_inclusive_sum(cnt);
-    if (lane == 63) sm.wave[tid >> 6] = inc2;
-    __syncthreads();
-    int ex2;
-    {
-      const int b2 = dev::wave_sum((lane < (tid >> 6)) ? sm.wave[lane & 15] : 0);
-      ex2 = b2 + inc2 - cnt;
-      sm.off[tid] = ex2;
-      if (tid == SC2_BLOCK - 1) sm.btot = ex2 + cnt;
-    }
-    __syncthreads();
-    // ---- phase 6
-    {
-      int o_k[ADV_ITEMS];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) o_k[k] = sm.off[((e_k[k] >> BSHIFT) << sub_shift) | (unsigned)(lane & sub_mask)];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k)
-        if (k * TILE + tq < n_at) {
-          sm.sorted[o_k[k] + r_k[k]] = e_k[k];
-          sm.sortedv[o_k[k] + r_k[k]] = v_k[k];
-        }
-    }
-    if ((tid & sub_mask) == 0) sm.delta_v[my_bin] = boff + gbase - ex2;
-    __syncthreads();
-    // ---- phase 7 (no barrier behind it: the sort buffers and `delta_v` are next written six barriers on)
-    {
-      const int btot = sm.btot;
-      unsigned s_k[ADV_ITEMS], x_k[ADV_ITEMS];
-      int d_k[ADV_ITEMS];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) {
-        s_k[k] = sm.sorted[k * SC2_BLOCK + tid];
-        x_k[k] = sm.sortedv[k * SC2_BLOCK + tid];
-      }
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) d_k[k] = sm.delta_v[(s_k[k] >> BSHIFT) & BMASK];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) {
-        const int i = k * SC2_BLOCK + tid;
-        if (i < btot) {
-          reinterpret_cast<unsigned short*>(bn.bins)[(size_t)(d_k[k] + i)] = (unsigned short)(s_k[k] & 0xffffu);
-          bn.rval[(size_t)(d_k[k] + i)] = x_k[k];
-        }
-      }
-    }
-    cur = nxt;
-  }
-}
+// (Measured and removed, round 4 call 17: a software-pipelined build of the scatter -- owner map and column / weight loads of batch
+// i + 1 issued ahead of the reservation, sort and copy-out of batch i, same phases and barriers, +25 VGPRs -- was correct and 2-3 %
+// SLOWER on the LJ and kron stand-ins: profiles/r4_ab_relax_scatter_pipelined_rejected.txt.  The scatter is
+// bin_scatter2_block<.., VAL = true> of grx_bin.hpp.)
 
 struct relax_sweep_smem {
   static constexpr int LIST = RB_SEG_WORDS * 32 + TILE;

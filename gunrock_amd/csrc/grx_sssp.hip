@@ -508,15 +508,11 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_level_kernel(pipe_args a, sssp
 
 // A fat level of the plain schedule as a binned relaxation (grx_relax.hpp): scatter, then sweep.  No-ops unless the head chose
 // mode 2.  One workgroup of 1024 threads per CU each (96 KB / 108 KB of LDS).
-// PIPE: the owner map and the column / weight loads of batch i + 1 ahead of the sort and copy-out of batch i (relax_scatter_block);
-// else the BFS scatter with a value riding along (GRX_RBIN_PIPE=0, for the A/B)
-template <bool PIPE>
 __global__ __launch_bounds__(SC2_BLOCK) void sssp_rscatter_kernel(pipe_args a, bin_args bn) {
   __shared__ __attribute__((aligned(16))) bin_scatter2_val_smem sm;
   const level_head h = load_level_head(a.ctrl);
   if (h.done || h.mode != 2) return;
-  if constexpr (PIPE) relax_scatter_block(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
-  else bin_scatter2_block<false, true, true>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
+  bin_scatter2_block<false, true, true>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
 }
 
 __global__ __launch_bounds__(RB_BLOCK) void sssp_rsweep_kernel(pipe_args a, bin_args bn) {
@@ -768,7 +764,6 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     // parts, ~60 us with one), many: the one workgroup of a hub range is the tail of the launch
     rb.sweep_items = rb.nb + sssp_env_int("GRX_RBIN_PARTS", ctx->num_cus);
   }
-  const bool rpipe = sssp_env_int("GRX_RBIN_PIPE", 1) != 0;
   const uint32_t rhint0 = (use_rbins && sssp_env_int("GRX_BIN_HINT", 1) != 0) ? g->rb_hint.load(std::memory_order_relaxed) : 0u;
   const uint32_t rbin_groups = rhint0 ? (rhint0 | (rhint0 << 1) | (rhint0 >> 1)) : ~0u;
   ctx->levels.clear();
@@ -829,8 +824,7 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
             [&] {
               hipLaunchKernelGGL(sssp_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol, ctx->xcc_mask);
               if (bins_here) {
-                if (rpipe) hipLaunchKernelGGL(sssp_rscatter_kernel<true>, dim3(grid_rscatter), dim3(SC2_BLOCK), 0, stream, a, rb);
-                else hipLaunchKernelGGL(sssp_rscatter_kernel<false>, dim3(grid_rscatter), dim3(SC2_BLOCK), 0, stream, a, rb);
+                hipLaunchKernelGGL(sssp_rscatter_kernel, dim3(grid_rscatter), dim3(SC2_BLOCK), 0, stream, a, rb);
                 hipLaunchKernelGGL(sssp_rsweep_kernel, dim3(grid_rsweep), dim3(RB_BLOCK), 0, stream, a, rb);
               }
             });
