@@ -1267,7 +1267,7 @@ template <int NT, class S>
 __device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q, S& sm, int n) {
   static_assert(S::MAX_TILES <= 64, "one lane per tile of an emission");
   constexpr int PASSES = (S::LIST + NT - 1) / NT;
-  constexpr int G = 3;  // passes whose row-offset loads travel together
+  constexpr int G = 3;  // passes whose row-offset loads travel together (6 measured equal: round 4, call 18)
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));  // (re-derive per call what depends on the thread index: see bin_scatter2_block)
   const int lane = tid & 63;
