@@ -969,6 +969,10 @@ def bench_multi_gpu(args, gr, torch, rank, local_rank, world):
                        "rccl_ranks_seen": int(dist.get_world_size()),
                        "n1_path": "python bench.py --gpus 1 runs the single-GPU engine (no partition, no collective); "
                                   "this line is the partitioned path",
+                       "like_for_like_n1": "the N = 1 line's TOP LEVEL is the forward search (BASELINE configs[1] as written); "
+                                           "this line's search is direction-optimising unless --topdown-only: its single-GPU "
+                                           "counterpart is config.sections.bfs_do of the N = 1 line (C2' stand-in) and "
+                                           "c5_1gpu.do_mteps (C5' stand-in) -- take scaling efficiency against those",
                        "level_group_captured_as_hip_graph_on_all_ranks": bool(cap_t.item()),
                        "per_level_breakdown": levels_breakdown, "parity_check": check},
             "roofline": None, "cpu_baseline": None}))
