@@ -86,9 +86,10 @@ def classify(rows):
             # a level group of a forward run: level kernel (a no-op on a binned level when the second scatter is in use),
             # scatter kernel (second version), claim / sweep kernel
             lv = [d for d, n in s["kernels"] if "bfs_level_bin_kernel" in n]
-            if len(lv) > 64:
-                # a high-diameter search (road stand-in): since round 4 the unit-weight SSSP of such a graph IS this forward
-                # BFS (grx_sssp.hip, all weights equal) -- every level launch of the search, per SEARCH
+            if len(lv) > 64 or any("sssp_depth_to_dist" in n for _, n in s["kernels"]):
+                # a unit-weight SSSP: since round 4 it IS this forward BFS (grx_sssp.hip, all weights equal; the pass that turns
+                # depths into distances follows the search) -- or a high-diameter BFS (road stand-in), the same kernels: every
+                # level launch of the search (many levels per launch on such graphs), per SEARCH
                 for d in lv:
                     cls[d] = ("sssp_unit_weights", 0)
                 continue
