@@ -126,6 +126,26 @@ class csr_t:
             L.grx_host_csr_destroy(h)
         return self._set(ro, ci, x, coo.number_of_columns)
 
+    @staticmethod
+    def from_coo_device(row_indices, column_indices, values, number_of_rows, context):
+        """csr_t::from_coo (formats/csr.hxx:81-140) on the DEVICE: torch tensors in (int32 rows / columns, float32 values or
+        None, on the context's device), torch tensors out (row_offsets, column_indices, values or None) -- the same stable
+        order as the host builder (entries of a row keep their input order), byte-identical to `from_coo`."""
+        import torch
+        nnz = int(row_indices.numel())
+        dev = row_indices.device
+        ro = torch.empty(int(number_of_rows) + 1, dtype=torch.int32, device=dev)
+        ci = torch.empty(nnz, dtype=torch.int32, device=dev)
+        x = None if values is None else torch.empty(nnz, dtype=torch.float32, device=dev)
+        assert row_indices.dtype == torch.int32 and column_indices.dtype == torch.int32 and row_indices.is_contiguous() \
+            and column_indices.is_contiguous() and (values is None or (values.dtype == torch.float32 and values.is_contiguous()))
+        torch.cuda.current_stream(dev).synchronize()  # the inputs may come from torch's stream; the library uses its own
+        _capi.check(_capi.lib().grx_csr_from_coo_device(
+            context._h, int(number_of_rows), nnz, row_indices.data_ptr() if nnz else None,
+            column_indices.data_ptr() if nnz else None, None if values is None else values.data_ptr(),
+            ro.data_ptr(), ci.data_ptr() if nnz else None, None if x is None else x.data_ptr()))
+        return ro, ci, x
+
     def read_binary(self, filename):
         """csr_t::read_binary (formats/csr.hxx:142-192)."""
         L = _capi.lib()

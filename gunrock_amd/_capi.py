@@ -126,6 +126,7 @@ def lib():
         "grx_host_csr_read_binary": (i32, [C.c_char_p, P(vp)]),
         "grx_host_csr_write_binary": (i32, [vp, C.c_char_p]),
         "grx_host_csr_from_coo": (i32, [i32, i32, i64, vp, vp, vp, P(vp)]),
+        "grx_csr_from_coo_device": (i32, [vp, i32, i64, vp, vp, vp, vp, vp, vp]),
         "grx_host_csr_info": (i32, [vp, P(i32), P(i32), P(i32), P(i32), P(i32)]),
         "grx_host_csr_row_offsets": (P(i32), [vp]),
         "grx_host_csr_column_indices": (P(i32), [vp]),

@@ -174,3 +174,46 @@ extern "C" grx_status_t grx_debug_radix_sort(grx_context_t ctx, uint32_t* d_keys
   GRX_HIP(hipGetLastError());
   return GRX_SUCCESS;
 }
+
+// format::csr_t::from_coo on the DEVICE.  Upstream builds a CSR from COO triples with a host counting sort by row
+// (formats/csr.hxx:81-140): stable, so the entries of a row keep their input order -- duplicates and self loops included; that
+// order is part of the contract (it decides the order of a frontier).  Here: the stable radix sort of grx_sort.hpp by the row
+// index, columns and values riding along, then the offsets from the sorted keys.  The result is byte-identical to the host
+// builder's (grx_host_csr_from_coo) on the same triples.
+extern "C" grx_status_t grx_csr_from_coo_device(grx_context_t ctx, int32_t n_rows, int64_t nnz, const int32_t* d_row_indices,
+                                                const int32_t* d_column_indices, const float* d_values, int32_t* d_row_offsets,
+                                                int32_t* d_out_columns, float* d_out_values) {
+  if (!ctx || n_rows < 0 || nnz < 0 || nnz > 0x7fffffffll || !d_row_offsets ||
+      (nnz > 0 && (!d_row_indices || !d_column_indices || !d_out_columns)) || ((d_values == nullptr) != (d_out_values == nullptr)))
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_csr_from_coo_device: bad argument");
+  GRX_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  if (nnz == 0) {
+    GRX_HIP(hipMemsetAsync(d_row_offsets, 0, ((size_t)n_rows + 1) * sizeof(int32_t), s));
+    GRX_HIP(hipStreamSynchronize(s));
+    return GRX_SUCCESS;
+  }
+  if (n_rows == 0) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_csr_from_coo_device: entries without rows");
+  sort_buffers sb;
+  if (sb.alloc(nnz, d_values != nullptr) != hipSuccess) {
+    sb.release();
+    (void)hipGetLastError();
+    return fail(GRX_ERROR_OUT_OF_MEMORY, "grx_csr_from_coo_device: scratch");
+  }
+  const size_t bytes = (size_t)nnz * sizeof(uint32_t);
+  GRX_HIP(hipMemcpyAsync(sb.keys[0], d_row_indices, bytes, hipMemcpyDeviceToDevice, s));
+  GRX_HIP(hipMemcpyAsync(sb.vals[0], d_column_indices, bytes, hipMemcpyDeviceToDevice, s));
+  if (d_values) GRX_HIP(hipMemcpyAsync(sb.vals2[0], d_values, bytes, hipMemcpyDeviceToDevice, s));
+  // all 32 key bits when a row index may lie outside [0, n_rows): such a key then sorts to the end, where it is seen
+  const int res = radix_sort_pairs(s, sb, 32);
+  uint32_t last = 0u;
+  GRX_HIP(hipMemcpyAsync(&last, sb.keys[res] + (nnz - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(sort_boundaries_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, sb.keys[res], nnz, 0, n_rows, d_row_offsets);
+  GRX_HIP(hipMemcpyAsync(d_out_columns, sb.vals[res], bytes, hipMemcpyDeviceToDevice, s));
+  if (d_values) GRX_HIP(hipMemcpyAsync(d_out_values, sb.vals2[res], bytes, hipMemcpyDeviceToDevice, s));
+  GRX_HIP(hipStreamSynchronize(s));
+  sb.release();
+  GRX_HIP(hipGetLastError());
+  if (last >= (uint32_t)n_rows) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_csr_from_coo_device: a row index lies outside [0, n_rows)");
+  return GRX_SUCCESS;
+}

@@ -412,6 +412,15 @@ grx_status_t grx_host_csr_from_coo(int32_t n_rows, int32_t n_cols, int64_t nnz,
                                    const int32_t* column_indices,
                                    const float* values, /* NULL = 1.0 */
                                    grx_host_csr_t* out);
+/* The same conversion on the DEVICE (device arrays, caller-owned, on the context's device): stable by row -- the entries of a
+ * row keep their input order, duplicates and self loops included, exactly as the host counting sort leaves them
+ * (formats/csr.hxx:81-140) -- so the result is byte-identical to grx_host_csr_from_coo on the same triples.
+ * d_row_offsets: n_rows + 1 ints; d_out_columns / d_out_values: nnz entries; d_values and d_out_values both NULL for a
+ * pattern.  Synchronous; a row index outside [0, n_rows) is an error. */
+grx_status_t grx_csr_from_coo_device(grx_context_t ctx, int32_t n_rows, int64_t nnz,
+                                     const int32_t* d_row_indices, const int32_t* d_column_indices,
+                                     const float* d_values, int32_t* d_row_offsets,
+                                     int32_t* d_out_columns, float* d_out_values);
 grx_status_t grx_host_csr_info(grx_host_csr_t csr, int32_t* n_vertices, int32_t* n_edges,
                                int32_t* directed, int32_t* weighted, int32_t* symmetric);
 const int32_t* grx_host_csr_row_offsets(grx_host_csr_t csr);

@@ -7,11 +7,15 @@
 
 #include <cstdio>
 #include <string>
+#include <type_traits>
 #include <vector>
+
+#include <grx.h>
 
 #include <gunrock/container/vector.hxx>
 #include <gunrock/error.hxx>
 #include <gunrock/formats/coo.hxx>
+#include <gunrock/memory.hxx>
 
 namespace gunrock {
 namespace format {
@@ -62,6 +66,39 @@ struct csr_t {
     row_offsets = thrust::host_vector<offset_t>(offsets.begin(), offsets.end());
     column_indices = thrust::host_vector<index_t>(cols.begin(), cols.end());
     nonzero_values = thrust::host_vector<value_t>(vals.begin(), vals.end());
+    return *this;
+  }
+
+  // from_coo on the DEVICE (an extension: upstream converts on the host, formats/csr.hxx:81-140, and copies).  Device COO in,
+  // this device CSR out, in the SAME order as the host builder -- stable by row: the entries of a row keep their input order,
+  // duplicates and self loops included -- through the library's stable radix sort (grx_csr_from_coo_device, include/grx.h).
+  template <memory_space_t s = space, typename std::enable_if<s == memory_space_t::device, int>::type = 0>
+  csr_t<space, index_t, offset_t, value_t> from_coo(
+      const coo_t<memory_space_t::device, index_t, offset_t, value_t>& coo) {
+    static_assert(sizeof(index_t) == 4 && sizeof(offset_t) == 4 && std::is_same<value_t, float>::value,
+                  "the device conversion handles 32-bit indices / offsets and float values");
+    number_of_rows = coo.number_of_rows;
+    number_of_columns = coo.number_of_columns;
+    number_of_nonzeros = coo.number_of_nonzeros;
+    row_offsets.resize((std::size_t)number_of_rows + 1);
+    column_indices.resize((std::size_t)number_of_nonzeros);
+    nonzero_values.resize((std::size_t)number_of_nonzeros);
+    int device = 0;
+    error::throw_if_exception(hipGetDevice(&device), "from_coo: hipGetDevice");
+    error::throw_if_exception(hipDeviceSynchronize(), "from_coo: inputs pending");  // the triples may be in flight on any stream
+    grx_context_t ctx = nullptr;
+    error::throw_if_exception(grx_context_create(device, nullptr, &ctx) != GRX_SUCCESS, "from_coo: context");
+    const grx_status_t st = grx_csr_from_coo_device(
+        ctx, (int32_t)number_of_rows, (int64_t)number_of_nonzeros,
+        reinterpret_cast<const int32_t*>(memory::raw_pointer_cast(coo.row_indices.data())),
+        reinterpret_cast<const int32_t*>(memory::raw_pointer_cast(coo.column_indices.data())),
+        memory::raw_pointer_cast(coo.nonzero_values.data()),
+        reinterpret_cast<int32_t*>(memory::raw_pointer_cast(row_offsets.data())),
+        reinterpret_cast<int32_t*>(memory::raw_pointer_cast(column_indices.data())),
+        memory::raw_pointer_cast(nonzero_values.data()));
+    const std::string why = st == GRX_SUCCESS ? std::string() : std::string(grx_last_error_string());
+    (void)grx_context_destroy(ctx);
+    error::throw_if_exception(st != GRX_SUCCESS, "from_coo (device): " + why);
     return *this;
   }
 

@@ -115,6 +115,35 @@ int main() {
     hipMemcpy(b.data(), p.data().get(), V * sizeof(float), hipMemcpyDeviceToHost);
     check("engine.full.pr_sees_weight_edit", ro[6] - ro[5] < 2 || a != b);
   }
+  // ---- csr_t<device>::from_coo(coo_t<device>): the device conversion (libgrx's stable radix sort) equals the host one --------
+  {
+    using namespace gunrock;
+    std::mt19937 rng(99);
+    const int R = 5000, NZ = 200003;
+    format::coo_t<memory_space_t::host, int, int, float> hc(R, R, NZ);
+    for (int k = 0; k < NZ; ++k) {
+      hc.row_indices[k] = (int)(rng() % R);
+      hc.column_indices[k] = (int)(rng() % R);
+      hc.nonzero_values[k] = (float)(1 + rng() % 1000) * 0.25f;
+    }
+    for (int k = 0; k < 50; ++k) {  // duplicates and self loops
+      hc.row_indices[k] = hc.row_indices[k + 50];
+      hc.column_indices[k] = hc.column_indices[k + 50];
+      hc.column_indices[k + 100] = hc.row_indices[k + 100];
+    }
+    format::csr_t<memory_space_t::host, int, int, float> want_csr;
+    want_csr.from_coo(hc);
+    format::coo_t<memory_space_t::device, int, int, float> dc(hc);
+    format::csr_t<memory_space_t::device, int, int, float> got;
+    got.from_coo(dc);
+    thrust::host_vector<int> gro = got.row_offsets, gci = got.column_indices;
+    thrust::host_vector<float> gnz = got.nonzero_values;
+    bool ok = gro.size() == want_csr.row_offsets.size() && gci.size() == want_csr.column_indices.size();
+    for (std::size_t i = 0; ok && i < gro.size(); ++i) ok = gro[i] == want_csr.row_offsets[i];
+    for (std::size_t i = 0; ok && i < gci.size(); ++i)
+      ok = gci[i] == want_csr.column_indices[i] && gnz[i] == want_csr.nonzero_values[i];
+    check("formats.csr_from_coo_on_the_device", ok);
+  }
   printf(failures ? "FAILED\n" : "ALL CHECKS PASSED\n");
   return failures ? 1 : 0;
 }

@@ -70,3 +70,35 @@ def test_transpose_and_pagerank_are_reproducible_across_handles(gr, gpu_ctx):
         for other in same[1:]:
             assert other[2] == same[0][2] and np.array_equal(other[1], same[0][1]), flags
     assert all(np.array_equal(depths[0], x) for x in depths[1:])
+
+
+def test_device_coo_to_csr_is_byte_identical_to_the_host_builder(gr, gpu_ctx):
+    """grx_csr_from_coo_device against grx_host_csr_from_coo (the reference's stable row bucket sort, formats/csr.hxx:81-140):
+    unsorted triples with duplicates and self loops, empty rows, a pattern (no values), sizes around the sort's tile, nnz = 0;
+    a row index outside [0, n_rows) is refused."""
+    import torch
+    rng = np.random.default_rng(7)
+    for n_rows, nnz in ((1, 1), (5, 0), (7, 40), (1000, 4096), (1000, 4097), (300_000, 2_000_003), (17, 100_000)):
+        I = rng.integers(0, n_rows, nnz).astype(np.int32)
+        J = rng.integers(0, n_rows, nnz).astype(np.int32)
+        if nnz > 10:
+            I[:5] = I[5:10]          # duplicates
+            J[:5] = J[5:10]
+            J[10:13] = I[10:13]      # self loops
+            I[I == (n_rows // 2)] = 0  # an empty row
+        X = (rng.random(nnz, dtype=np.float32) * 9 + 1).astype(np.float32)
+        coo = gr.coo_t()
+        coo.number_of_rows = coo.number_of_columns = n_rows
+        coo.number_of_nonzeros = nnz
+        coo.row_indices, coo.column_indices, coo.nonzero_values = I, J, X
+        want = gr.csr_t().from_coo(coo)
+        for vals in (X, None):
+            ro, ci, x = gr.csr_t.from_coo_device(torch.from_numpy(I).cuda(), torch.from_numpy(J).cuda(),
+                                                 None if vals is None else torch.from_numpy(vals).cuda(), n_rows, gpu_ctx)
+            assert np.array_equal(ro.cpu().numpy(), want.row_offsets), (n_rows, nnz)
+            assert np.array_equal(ci.cpu().numpy(), want.column_indices), (n_rows, nnz)
+            if vals is not None:
+                assert np.array_equal(x.cpu().numpy(), want.nonzero_values), (n_rows, nnz)
+    bad = torch.tensor([0, 3, 9], dtype=torch.int32, device="cuda")
+    with pytest.raises(gr.GrxError):
+        gr.csr_t.from_coo_device(bad, bad.clone(), None, 5, gpu_ctx)
