@@ -402,6 +402,9 @@ def main():
                          "parallelism": "single GPU (the single-GPU engine; the partitioned path is used for N > 1 only)",
                          "edges_visited_per_step": edges_rank, "search_depth": st["search_depth"],
                          "enact_ms_last": round(st["elapsed_ms"], 4), "ms_per_step_repeated": rep_ms,
+                         "launch_groups_last": int(st.get("aux", 0)),
+                         "schedule": "launch groups and binned-level kernels follow the previous search on the handle (one "
+                                     "repeated source, like the reference's driver); multi_source: other sources + cold",
                          "first_call_ms": round(first_call_ms[gr.forward], 3),
                          "one_shot_ms": round(first_call_ms[gr.forward], 3),
                          "one_shot_note": "fresh graph handle: per-graph preprocessing + one search",

@@ -140,6 +140,9 @@ __device__ __forceinline__ void bfs_seed_body(const pipe_args& a, int32_t* dist,
       c->total_chunks = (deg + CHUNK - 1) / CHUNK;
       a.mailbox[1] = 0;
       a.mailbox[2] = 1;
+      // source_level == 2: bfs_source_kernel also writes the chunk map and the counters of level 1 (map_chunks, n_items[1] and
+      // q_edges[1] start at 0 above), as the sweep of a binned level does for the level behind it
+      if (source_level == 2) c->map_level = 1;
     }
     if (!labels) return;
     dist[src] = 0;
@@ -165,6 +168,38 @@ __global__ void bfs_reset_seed_kernel(int32_t* dist, int64_t V, dobfs_args d, co
   bfs_reset_body(dist, V, d, closed0, src);
 }
 
+// The same for a forward-only search that keeps a visited bitmap: labels = INT_MAX (16-byte stores), visited = 0, the source's
+// label and bit written by the fill, the seed in workgroup 0 -- one launch where fill_i32 + hipMemsetAsync + bfs_init_kernel
+// were three (9 + 4 + 4 us on the LJ stand-in).  dist: 16-byte aligned (the host checks); n_words: a multiple of 4.
+// <<<any, TILE>>>
+__global__ void bfs_fwd_reset_seed_kernel(int32_t* dist, int64_t V, unsigned* visited, int n_words, pipe_args a, int src,
+                                          dobfs_args d, int source_level) {
+  if (blockIdx.x == 0) bfs_seed_body(a, dist, nullptr, src, d, source_level, false);
+  const int64_t gsz = (int64_t)gridDim.x * blockDim.x, gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n4 = V >> 2, s4 = (int64_t)src >> 2;
+  int4* d4 = reinterpret_cast<int4*>(dist);
+  for (int64_t i = gid; i < n4; i += gsz) {
+    int4 v = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX);
+    if (i == s4) {
+      const int k = src & 3;
+      if (k == 0) v.x = 0; else if (k == 1) v.y = 0; else if (k == 2) v.z = 0; else v.w = 0;
+    }
+    d4[i] = v;
+  }
+  for (int64_t i = (n4 << 2) + gid; i < V; i += gsz) dist[i] = i == (int64_t)src ? 0 : INT_MAX;
+  uint4* b4 = reinterpret_cast<uint4*>(visited);
+  const int64_t w4 = (int64_t)(src >> 5) >> 2;
+  for (int64_t i = gid; i < (int64_t)(n_words >> 2); i += gsz) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (i == w4) {
+      const unsigned bit = 1u << (src & 31);
+      const int k = (src >> 5) & 3;
+      if (k == 0) v.x = bit; else if (k == 1) v.y = bit; else if (k == 2) v.z = bit; else v.w = bit;
+    }
+    b4[i] = v;
+  }
+}
+
 // LEVEL 0 WITHOUT A LAUNCH PAIR.  Every search starts from one vertex; when that vertex is a hub (the benchmark sources
 // are: 125 k out-edges on the LJ stand-in) level 0 used to cost a head kernel (12 us: bookkeeping and a chunk map for ONE
 // tile) plus a level kernel (27 us: the general advance body, staging a 256-slot tile of which one slot is used).  Here
@@ -177,8 +212,57 @@ struct source_smem {
   int cnt;
   int res[3];
   emit_smem emit;
+  int cpre[MAX_EMIT + 1];  // write_map: chunks before tile j of the emission
+  int map_n, map_base;
 };
-__global__ __launch_bounds__(ADV_BLOCK) void bfs_source_kernel(pipe_args a, dobfs_args d, bfs_policy pol, int src) {
+// write_map (forward runs with binned levels): the chunk map entries and the counters of the tiles just emitted -- sm.emit.tix /
+// sm.emit.sum of k full tiles (k > 0), or the one short tile sm.res[2] / sm.wave (k == 0, n vertices) -- are appended by
+// the producers (one reservation atomic on ctrl.map_chunks per call), so the head of level 1 has nothing to walk (it took
+// 18 us to plan the 349 tiles / 15 k chunks behind the LJ stand-in's source, 35 / 45 us on the kron / twitter stand-ins).
+// Block-wide call right behind the emission.
+static_assert(MAX_EMIT + 1 <= 64, "one lane per tile of an emission");
+__device__ __forceinline__ void source_append_map(const pipe_args& a, ctrl_t* c, source_smem& sm, int k, int n) {
+  const int tid = threadIdx.x, lane = dev::lane_id();
+  const int nt = k > 0 ? k : 1;
+  if (tid < 64) {
+    int tot = 0;
+    if (lane < nt) {
+      if (k > 0) {
+#pragma unroll
+        for (int i = 0; i < ADV_BLOCK / 64; ++i) tot += sm.emit.sum[lane][i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < ADV_BLOCK / 64; ++i) tot += sm.wave[i];
+      }
+    }
+    const int ch = (tot + CHUNK - 1) / CHUNK;
+    const int inc = dev::wave_inclusive_sum(ch);
+    long long es = (long long)tot;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) es += __shfl_xor(es, o, 64);
+    if (lane <= MAX_EMIT) sm.cpre[lane] = inc - ch;
+    if (lane == 63) {
+      sm.map_n = inc;
+      sm.map_base = inc > 0 ? atomicAdd(&c->map_chunks, inc) : 0;
+    }
+    if (lane == 0) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(&c->q_edges[1]), (unsigned long long)es);
+      atomicAdd(&c->n_items[1], k > 0 ? k * TILE : n);
+    }
+  }
+  __syncthreads();
+  int2* map = reinterpret_cast<int2*>(a.chunk_tile) + sm.map_base;
+  const int nc = sm.map_n;
+  for (int ci = tid; ci < nc; ci += ADV_BLOCK) {
+    int t = 0;  // largest t < nt with cpre[t] <= ci (tiles without chunks are skipped over)
+#pragma unroll
+    for (int step = 8; step >= 1; step >>= 1)
+      if (t + step < nt && sm.cpre[t + step] <= ci) t += step;
+    map[ci] = make_int2(k > 0 ? sm.emit.tix[t] : sm.res[2], ci - sm.cpre[t]);
+  }
+  __syncthreads();
+}
+__global__ __launch_bounds__(ADV_BLOCK) void bfs_source_kernel(pipe_args a, dobfs_args d, bfs_policy pol, int src, int write_map) {
   __shared__ source_smem sm;
   const int tid = threadIdx.x;
   const int lane = dev::lane_id();
@@ -240,13 +324,18 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_source_kernel(pipe_args a, dobf
     if (cnt >= TILE) {
       const int k = cnt / TILE;
       emit_full_tiles(a, c, 1, sm.out, cnt - k * TILE, k, sm.emit, sm.res);
+      if (write_map) source_append_map(a, c, sm, k, 0);
       cnt -= k * TILE;
     }
     if (tid == 0) sm.cnt = cnt;
     __syncthreads();
   }
   const int rem = sm.cnt;
-  if (rem > 0) emit_tile(a, c, 1, sm.out, 0, rem, sm.wave, sm.res);
+  if (rem > 0) {
+    emit_tile(a, c, 1, sm.out, 0, rem, sm.wave, sm.res);
+    __syncthreads();
+    if (write_map) source_append_map(a, c, sm, 0, rem);
+  }
   __syncthreads();
   release_tiles(a, sm.res);
 }
@@ -833,7 +922,11 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   // problem.reset() -- outside the timed region, as in the reference; direction-optimising runs: one launch with the seed
   // (bfs_reset_seed_kernel, below: inside the timed region then).  GRX_SEED_IN_RESET=0: two launches
   const bool seed_in_reset = dopt && variant == 0 && env_int("GRX_SEED_IN_RESET", 1) != 0;
-  if (seed_in_reset) {
+  // forward-only runs with a visited bitmap: reset + seed in one launch too (bfs_fwd_reset_seed_kernel); GRX_FWD_SEED_IN_RESET=0:
+  // fill + memset + seed kernel
+  const bool fwd_seed_in_reset = !dopt && variant == 0 && fwd_bm && visited != nullptr && (bm_words & 3) == 0 &&
+                                 (reinterpret_cast<uintptr_t>(d_dist) & 15) == 0 && env_int("GRX_FWD_SEED_IN_RESET", 1) != 0;
+  if (seed_in_reset || fwd_seed_in_reset) {
   } else if (dopt) {
     hipLaunchKernelGGL(bfs_reset_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, s, d_dist, (int64_t)g->V, d, g->closed0);
   } else {
@@ -869,15 +962,22 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   }
   // seed; then level 0 itself when the source is a hub (bfs_source_kernel: a no-op otherwise).  Profiled and
   // strict-merge-path runs keep one launch pair per level, level 0 included.
-  const int source_level = (variant == 0 && !profile && !strict_mp && env_int("GRX_SOURCE_LEVEL", 1) != 0) ? 1 : 0;
+  // (2: the source kernel also writes level 1's chunk map and counters -- forward runs with binned levels, whose head takes
+  // them from the producers; GRX_SOURCE_MAP=0: the head of level 1 walks the tiles)
+  const int source_level = (variant == 0 && !profile && !strict_mp && env_int("GRX_SOURCE_LEVEL", 1) != 0)
+                               ? ((use_bins && !dopt && env_int("GRX_SOURCE_MAP", 1) != 0) ? 2 : 1) : 0;
   static_assert(TILE == 256, "the seed runs in a workgroup of the reset kernel");
   if (seed_in_reset)
     hipLaunchKernelGGL(bfs_reset_seed_kernel, dim3(ctx->num_cus * 8), dim3(TILE), 0, s, d_dist, (int64_t)g->V, d, g->closed0, a, src,
                        source_level);
+  else if (fwd_seed_in_reset)
+    hipLaunchKernelGGL(bfs_fwd_reset_seed_kernel, dim3(ctx->num_cus * 8), dim3(TILE), 0, s, d_dist, (int64_t)g->V, visited,
+                       (int)bm_words, a, src, d, source_level);
   else
     hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, visited, src, d, source_level);
   if (source_level)
-    hipLaunchKernelGGL(bfs_source_kernel, dim3(ctx->num_cus * env_int("GRX_SOURCE_WG_PER_CU", 4)), dim3(ADV_BLOCK), 0, s, a, d, lp, src);
+    hipLaunchKernelGGL(bfs_source_kernel, dim3(ctx->num_cus * env_int("GRX_SOURCE_WG_PER_CU", 4)), dim3(ADV_BLOCK), 0, s, a, d, lp, src,
+                       source_level == 2 ? 1 : 0);
   bin_args bn{};
   bn.xcc_mask = ctx->xcc_mask;
   bn.n_xcd = ctx->n_xcd;
@@ -987,6 +1087,10 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   // search.  GRX_BIN_HINT=0: every group carries them.
   const uint32_t hint0 = (use_bins && env_int("GRX_BIN_HINT", 1) != 0) ? g->bin_hint.load(std::memory_order_relaxed) : 0u;
   const uint32_t bin_groups = hint0 ? (hint0 | (hint0 << 1) | (hint0 >> 1)) : ~0u;
+  // Paced searches: enqueue as many groups as the previous search on this graph (same direction rule) needed, then wait
+  // for the end instead of queueing two more behind it (run_levels: hold_after).  GRX_GROUP_HINT=0: off
+  const int hold_after = (pace > 0 && env_int("GRX_GROUP_HINT", 1) != 0) ? g->group_hint[dopt ? 1 : 0].load(std::memory_order_relaxed) : 0;
+  int groups_used = 0;
   st = run_levels(ctx, opt, [&](hipStream_t stream, int seq) {
     if (profile) (void)hipEventRecord(pe[0], stream);
     const bool bins_here = use_bins && (seq >= 32 || ((bin_groups >> seq) & 1u) != 0u);
@@ -1071,8 +1175,9 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     // (many levels per launch, grx_mid.hpp) and found the end is a record like any other
     if (h.done && r.frontier_size == 0 && r.edges == 0) ctx->levels.pop_back();
   }, /*first_batch=*/dense ? 8 : 4, /*pace_depth=*/pace, /*fast_return=*/pace > 0 && ((opt.engine_flags & GRX_FLAG_ASYNC_RETURN) != 0 || env_int("GRX_FAST_RETURN", 0) != 0),
-     &returned_fast);
+     &returned_fast, hold_after, &groups_used);
   if (st != GRX_SUCCESS) return st;
+  if (pace > 0 && groups_used > 0) g->group_hint[dopt ? 1 : 0].store(groups_used, std::memory_order_relaxed);
   if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));
   if (ctx->h_mailbox[10] != 0 || (!returned_fast && ctx->h_ctrl->mid_err != 0)) {
     const int code = ctx->h_mailbox[10] != 0 ? (int)ctx->h_mailbox[10] : (int)ctx->h_ctrl->mid_err;

@@ -186,6 +186,12 @@ struct grx_graph {
   int32_t bin_shift = 0, bin_ngran = 0, bin_nb = 0;
   std::atomic<uint32_t> bin_hint{0};  // launch groups in which forward searches on this graph met a fat level (ctrl_t::bin_want,
                                       // OR-ed over the searches; 0: none yet)
+  // launch groups the previous search on this graph needed (0: none yet) -- [0] forward BFS, [1] direction-optimising BFS
+  // (paced: the host enqueues that many groups and then waits for the end of the search, or for the stream to drain without
+  // it, instead of queueing two more behind the running one), [2] weighted SSSP on a dense graph (blind batches: the first
+  // batch is that many groups instead of 4, 8, 16, ... with a host round trip between them).  run_levels, grx_engine.hpp
+  std::atomic<int32_t> group_hint[3] = {{0}, {0}, {0}};
+  std::atomic<int32_t> pr_iter_hint{0};  // iterations of the previous PageRank run on this handle: its first blind batch (grx_pr.hip)
   int32_t bin_entry16 = 0;      // every bin spans <= 65536 vertices: offsets inside a bin fit 16-bit entries
   int32_t bin_state = 0;        // 0: not built, 1: usable, 2: not applicable to this graph, 3: a column index lies outside [0, V)
   // binned relaxation of weighted SSSP (grx_relax.hpp), built lazily; owned

@@ -92,11 +92,21 @@ inline int advance_grid_for(grx_context_t ctx, grx_graph_t g) {
 //    pace_depth) groups still queued exit on `done` behind the caller's back, and anything the
 //    caller enqueues next on this stream is ordered after them.  *returned_fast tells the caller
 //    that ctx->h_ctrl was filled from the mailbox.
+//    hold_after (paced mode only, 0: off): the number of groups the PREVIOUS search on the graph needed.  The no-op
+//    groups queued behind the end of a search are what a back-to-back sequence of searches pays for pacing (two
+//    groups = four full-grid launches, ~18 us of a 160 us search): with a prediction the host enqueues exactly
+//    hold_after groups and then waits -- for `done`, or for the stream to drain without it (the search is longer than
+//    the last one: a bubble of one host round trip, once, then the usual pacing).  *groups_used receives the number
+//    of groups that started before the end was published (the next search's hold_after).
+//    batch_after_first (batch mode, 0: off): first_batch is a prediction (the groups the previous search needed); when it
+//    falls short the batches restart from this size instead of doubling the prediction.
 template <class LaunchLevel, class AfterSync>
 grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel launch_level,
                         AfterSync after_sync, int first_batch = 4, int pace_depth = 0, bool fast_return = false,
-                        bool* returned_fast = nullptr) {
+                        bool* returned_fast = nullptr, int hold_after = 0, int* groups_used = nullptr,
+                        int batch_after_first = 0) {
   if (returned_fast) *returned_fast = false;
+  if (groups_used) *groups_used = 0;
   const bool sync_each = (opt.engine_flags & (GRX_FLAG_SYNC_EACH_LEVEL | GRX_FLAG_PROFILE)) != 0;
   int batch = sync_each ? 1 : first_batch;
   int launched = 0;
@@ -115,6 +125,7 @@ grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel
       unsigned spins = 0;
       for (;;) {
         if (mb[0] != 0) {  // done
+          if (groups_used) *groups_used = mb[3] + 1;
           if (fast_return) {
             const volatile long long* mb64 = reinterpret_cast<const volatile long long*>(mb + 4);
             ctx->h_ctrl->done = 1;
@@ -129,7 +140,8 @@ grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel
           break;
         }
         const int started = mb[3] + 1;
-        if (launched < max_levels && launched - started < pace_depth) {
+        const bool hold = hold_after > 0 && launched == hold_after;  // every predicted group is queued
+        if (launched < max_levels && launched - started < pace_depth && !hold) {
           launch_level(ctx->stream, launched);
           ++launched;
           spins = 0;
@@ -137,7 +149,19 @@ grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel
         }
         if (launched >= max_levels && started >= launched) break;
         __builtin_ia32_pause();
-        if ((++spins & 0xfffff) == 0) {
+        ++spins;
+        if (hold && started >= launched && (spins & 0x3f) == 0) {
+          // the last predicted group has started and the end has not been published yet: still running, or is this
+          // search longer than the previous one?  (A drained stream has made its mailbox writes visible.)
+          const hipError_t q = hipStreamQuery(ctx->stream);
+          if (q == hipSuccess) {
+            if (mb[0] == 0) { hold_after = 0; spins = 0; }
+            continue;
+          }
+          if (q != hipErrorNotReady) GRX_HIP(q);
+          (void)hipGetLastError();
+        }
+        if ((spins & 0xfffff) == 0) {
           // no progress for a long time: if the stream drained without `done` (mailbox writes
           // not visible to this host?), fall back to blind enqueueing
           hipError_t q = hipStreamQuery(ctx->stream);
@@ -191,7 +215,12 @@ grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel
     after_sync(*ctx->h_ctrl);
     if (ctx->h_ctrl->done) break;
     if (launched >= max_levels) break;
-    if (!sync_each && batch < (graph_exec ? 1024 : 64)) batch *= 2;
+    if (!sync_each && batch_after_first > 0) {
+      batch = batch_after_first;
+      batch_after_first = 0;
+    } else if (!sync_each && batch < (graph_exec ? 1024 : 64)) {
+      batch *= 2;
+    }
   }
   return GRX_SUCCESS;
 }

@@ -838,7 +838,14 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
   if (profile) for (auto& e : pe) GRX_HIP(hipEventCreate(&e));
   ctx->levels.clear();
-  int launched = 0, batch = profile ? 1 : 4;
+  // First blind batch: as many iterations as the previous run on this graph handle needed + the one that finds the norm below
+  // the tolerance (the count is a function of graph, alpha and tol: a repeated run is predicted exactly), instead of 4 + 8
+  // with a host round trip in between and the rest of the second batch exiting at once.  GRX_GROUP_HINT=0: off
+  const char* hint_env = getenv("GRX_GROUP_HINT");
+  const bool use_hint = !(hint_env && *hint_env == '0');
+  const int hinted = (use_hint && !profile) ? g->pr_iter_hint.load(std::memory_order_relaxed) : 0;
+  int launched = 0, batch = profile ? 1 : (hinted > 0 ? std::min(std::max(hinted + 1, 4), 128) : 4);
+  bool first_is_hint = hinted > 0;
   for (;;) {
     for (int i = 0; i < batch && launched < max_iter; ++i, ++launched) {
       if (profile) (void)hipEventRecord(pe[0], s);
@@ -873,8 +880,10 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
     if (profile && ctx->h_ctrl->done && !ctx->levels.empty() && (int)ctx->levels.size() > ctx->h_ctrl->pr_iter)
       ctx->levels.pop_back();  // the group that only detected convergence
     if (ctx->h_ctrl->done || launched >= max_iter) break;
-    if (!profile && batch < 16) batch *= 2;
+    if (first_is_hint) { batch = 4; first_is_hint = false; }
+    else if (!profile && batch < 16) batch *= 2;
   }
+  if (ctx->h_ctrl->done && opt.max_iterations <= 0) g->pr_iter_hint.store(ctx->h_ctrl->pr_iter, std::memory_order_relaxed);
   if (profile) for (auto& e : pe) (void)hipEventDestroy(e);
   GRX_HIP(hipGetLastError());
   GRX_HIP(hipEventRecord(ctx->ev_end, s));

@@ -814,6 +814,13 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     }, after);
   } else {
     sssp_policy pol{d_dist, stamp, w_eff, 0, 0, (!g->w || g->uniform_weights) ? 1 : 0};
+    // Dense graphs (a few dozen fat levels, one per group): the first blind batch is as many groups as the previous search on
+    // the graph ran levels (+ the one that finds the frontier empty), instead of 4 + 8 + 16 with a host round trip after each
+    // and up to half of the last batch wasted (LJ stand-in, U{1..1000}: 18 levels -> 28 groups, 3 round trips).
+    // GRX_GROUP_HINT=0: off
+    const bool dense_plain = g->V > 0 && (long long)g->E >= 8ll * g->V && opt.max_iterations == 0;
+    const int hinted = (dense_plain && sssp_env_int("GRX_GROUP_HINT", 1) != 0) ? g->group_hint[2].load(std::memory_order_relaxed) : 0;
+    const int first_batch = hinted > 0 ? std::min(std::max(hinted, 4), 64) : 4;
     st = run_levels(ctx, opt, [&](hipStream_t stream, int seq) {
       // (as for the BFS: the two kernels of a binned level ride only in the groups where the previous search on the graph
       // met a fat level, one group of slack either side; a fat level elsewhere runs on the relax-per-edge advance)
@@ -828,7 +835,9 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
                 hipLaunchKernelGGL(sssp_rsweep_kernel, dim3(grid_rsweep), dim3(RB_BLOCK), 0, stream, a, rb);
               }
             });
-    }, after);
+    }, after, first_batch, /*pace_depth=*/0, /*fast_return=*/false, nullptr, 0, nullptr, /*batch_after_first=*/hinted > 0 ? 4 : 0);
+    if (st == GRX_SUCCESS && dense_plain && ctx->h_ctrl->done && ctx->h_ctrl->mid_err == 0)
+      g->group_hint[2].store(ctx->h_ctrl->level + 1, std::memory_order_relaxed);
   }
   if (profile) for (auto& e : pe) (void)hipEventDestroy(e);
   if (st != GRX_SUCCESS) return st;

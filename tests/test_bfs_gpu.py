@@ -368,3 +368,66 @@ def test_two_contexts_search_one_graph_handle_concurrently(gr, gpu_ctx):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def _with_tail(g, anchor, length):
+    """the graph plus a path of `length` new vertices hung onto `anchor` (edges both ways): a source at its end is `length`
+    levels deeper than anything else"""
+    V = g.n_vertices
+    src_e = np.repeat(np.arange(V, dtype=np.int64), np.diff(g.row_offsets))
+    dst_e = g.column_indices.astype(np.int64)
+    a = np.concatenate([[anchor], V + np.arange(length - 1)])
+    b = V + np.arange(length)
+    s2 = np.concatenate([src_e, a, b])
+    d2 = np.concatenate([dst_e, b, a])
+    order = np.argsort(s2, kind="stable")
+    ro = np.zeros(V + length + 1, np.int64)
+    np.cumsum(np.bincount(s2, minlength=V + length), out=ro[1:])
+    ci = d2[order].astype(np.int32)
+    return O.Csr(ro.astype(np.int32), ci, np.ones(len(ci), np.float32))
+
+
+def test_launch_groups_follow_the_previous_search(gr, gpu_ctx, monkeypatch):
+    """Paced searches enqueue as many launch groups as the previous search on the graph handle needed and then WAIT for the
+    end (run_levels: hold_after) -- a search that is longer than the prediction (the stream drains without `done`), shorter,
+    or equal must give the oracle's depths, blocking and with GRX_FLAG_ASYNC_RETURN, forward and direction-optimising; so
+    must the one-launch reset + seed of a forward search and the source kernel that writes level 1's chunk map
+    (GRX_FWD_SEED_IN_RESET, GRX_SOURCE_MAP: on / off)."""
+    import torch
+    _, c = gr.generate("rmat_sym", 1 << 18, 6_000_000, seed=21)
+    g0 = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    deg = np.diff(g0.row_offsets)
+    hub = int(np.argmax(deg))
+    anchor = int(np.nonzero(deg == 1)[0][0])
+    g = _with_tail(g0, anchor, 9)
+    far = g.n_vertices - 1
+    assert g.n_edges >= 8 * g.n_vertices  # paced enqueueing
+    G = gr.build_graph(gr.graph_properties_t(directed=True, weighted=False, symmetric=True),
+                       gr.csr_t.from_arrays(g.row_offsets, g.column_indices, None), gpu_ctx)
+    monkeypatch.setenv("GRX_BIN_MIN_EDGES", "100000")
+    want = {s: O.bfs_queue(g, s) for s in (hub, far, anchor)}
+    dist = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda:0")
+    groups = {}  # launch groups of the LAST of the repeated hub searches, per (hint on?, direction)
+    for env in ({}, {"GRX_GROUP_HINT": "0"}, {"GRX_FWD_SEED_IN_RESET": "0"}, {"GRX_SOURCE_MAP": "0"},
+                {"GRX_FWD_SEED_IN_RESET": "0", "GRX_SOURCE_MAP": "0", "GRX_GROUP_HINT": "0"}):
+        for k in ("GRX_GROUP_HINT", "GRX_FWD_SEED_IN_RESET", "GRX_SOURCE_MAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for direction in (gr.forward, gr.optimized):
+            for flags in (0, gr.FLAG_ASYNC_RETURN):
+                # short, long (prediction too short), long (exact), short (prediction too long), a third depth, short
+                for src in (hub, far, far, hub, anchor, hub, hub):
+                    dist.fill_(-5)
+                    gr.bfs(G, src, dist, None, gpu_ctx, gr.options_t(advance_direction=direction, engine_flags=flags))
+                    gpu_ctx.synchronize()
+                    got = dist.cpu().numpy()
+                    assert np.array_equal(got, want[src][0]), (env, direction, flags, src)
+                    if not flags:
+                        st = gr.run_stats(gpu_ctx)
+                        assert st["edges_visited"] == want[src][2]
+                        if len(env) <= 1 and "GRX_FWD_SEED_IN_RESET" not in env and "GRX_SOURCE_MAP" not in env:
+                            groups[(env.get("GRX_GROUP_HINT", "1"), direction)] = int(st["aux"])
+    # a repeated search launches exactly the groups it needs with the prediction, and never fewer without it
+    for direction in (gr.forward, gr.optimized):
+        assert 1 <= groups[("1", direction)] <= groups[("0", direction)], groups
