@@ -181,7 +181,7 @@ grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel
       // replays (one host call per 64 levels).  Capture + instantiate costs about what launching
       // the same groups costs, so short searches never pay for it.
       constexpr int GRAPH_GROUPS = 64;
-      if (!sync_each && use_graph && !graph_exec && !graph_failed && launched >= 64 &&
+      if (!sync_each && use_graph && !graph_exec && !graph_failed && launched >= 64 && batch >= GRAPH_GROUPS &&
           launched + GRAPH_GROUPS <= max_levels) {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -204,8 +204,9 @@ grx_status_t run_levels(grx_context_t ctx, const grx_options_t& opt, LaunchLevel
           launched += GRAPH_GROUPS;
           left -= GRAPH_GROUPS;
         }
-        for (; left > 0 && launched < max_levels && launched + GRAPH_GROUPS > max_levels; --left, ++launched)
-          launch_level(ctx->stream, launched);
+        // (what is left of a batch that is not a multiple of the graph -- a batch restarted after a predicted first batch
+        // fell short, or the last groups before max_levels -- is launched directly)
+        for (; left > 0 && launched < max_levels; --left, ++launched) launch_level(ctx->stream, launched);
       } else {
         for (int i = 0; i < batch && launched < max_levels; ++i, ++launched) launch_level(ctx->stream, launched);
       }

@@ -236,3 +236,27 @@ def test_kron_c4_full_size_and_reference_gpu_path(gr, gpu_ctx):
     with open(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "pr_parity_c4.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
+
+
+def test_first_batch_follows_the_previous_run(gr, gpu_ctx, golden, monkeypatch):
+    """The first blind batch of a run is the previous run's iteration count + 1 on the same graph handle (grx_pr.hip): a
+    repeated run, a run that needs MORE iterations than predicted (smaller tol) and one that needs fewer must give the bits
+    and the count of a run on a fresh handle; so must GRX_GROUP_HINT=0."""
+    import torch
+    _, c = gr.generate("rmat_sym", 1 << 15, 600_000, seed=13)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    csr = gr.csr_t.from_arrays(g.row_offsets, g.column_indices, g.values)
+    fresh = {}
+    for tol in (1e-6, 1e-9, 1e-3):
+        fresh[tol] = run_pr(gr, gpu_ctx, g, tol=tol)
+    assert fresh[1e-9][1] > fresh[1e-6][1] > fresh[1e-3][1]
+    G = gr.build_graph(gr.graph_properties_t(True, True, False), csr, gpu_ctx)
+    p = torch.zeros(g.n_vertices, dtype=torch.float32, device="cuda:0")
+    res = gr.pr_result_t(p)
+    for hint in ("1", "0"):
+        monkeypatch.setenv("GRX_GROUP_HINT", hint)
+        for tol in (1e-6, 1e-6, 1e-9, 1e-9, 1e-3, 1e-6, 1e-3):
+            p.zero_()
+            gr.pr_run(G, gr.pr_param_t(0.85, tol), res, gpu_ctx)
+            assert res.iterations == fresh[tol][1], (hint, tol)
+            assert np.array_equal(p.cpu().numpy(), fresh[tol][0]), (hint, tol)

@@ -83,3 +83,41 @@ def test_scatter_safety_net(gr, monkeypatch):
     src = int(np.argmax(np.diff(g.row_offsets)))
     d, st, prof = _run(gr, ctx, c, w, src)
     assert np.array_equal(d, O.sssp(g, src)[0])
+
+
+def test_first_batch_follows_the_previous_search(gr, gpu_ctx, monkeypatch):
+    """Weighted SSSP on a dense graph: the first blind batch of launch groups is the previous search's level count + 1
+    (grx_sssp.hip) -- alternating sources whose searches need different numbers of levels (a tail hung onto the graph makes one
+    much deeper), with and without the prediction, must give the oracle's distances."""
+    import torch
+    monkeypatch.setenv("GRX_RBIN_MIN_GRAPH_EDGES", "0")
+    monkeypatch.setenv("GRX_RBIN_MIN_EDGES", "20000")
+    rng = np.random.default_rng(19)
+    _, c = gr.generate("rmat", 1 << 16, 1_500_000, seed=41)
+    V, L = c.number_of_rows, 40
+    deg = np.diff(c.row_offsets)
+    hub = int(np.argmax(deg))
+    # tail: V -> V+1 -> ... -> V+L-1 -> hub (directed towards the graph); the graph stays dense enough (E >= 8 V) for the
+    # prediction to apply
+    src_e = np.concatenate([np.repeat(np.arange(V, dtype=np.int64), deg), V + np.arange(L)])
+    dst_e = np.concatenate([c.column_indices.astype(np.int64), np.concatenate([V + 1 + np.arange(L - 1), [hub]])])
+    order = np.argsort(src_e, kind="stable")
+    ro = np.zeros(V + L + 1, np.int64)
+    np.cumsum(np.bincount(src_e, minlength=V + L), out=ro[1:])
+    ci = dst_e[order].astype(np.int32)
+    w = _weights("int", len(ci), rng)
+    g = O.Csr(ro.astype(np.int32), ci, w)
+    assert g.n_edges >= 8 * g.n_vertices
+    G = gr.build_graph(gr.graph_properties_t(directed=True, weighted=True, symmetric=False),
+                       gr.csr_t.from_arrays(g.row_offsets, g.column_indices, w), gpu_ctx)
+    want = {s: O.sssp(g, s)[0] for s in (hub, V)}
+    d = torch.empty(g.n_vertices, dtype=torch.float32, device="cuda:0")
+    depths = {}
+    for hint in ("1", "0"):
+        monkeypatch.setenv("GRX_GROUP_HINT", hint)
+        for s in (hub, hub, V, V, hub, V, hub):
+            d.fill_(-1.0)
+            gr.sssp(G, s, d, None, gpu_ctx, gr.options_t())
+            assert np.array_equal(d.cpu().numpy(), want[s]), (hint, s)
+            depths[s] = gr.run_stats(gpu_ctx)["search_depth"]
+    assert depths[V] >= depths[hub] + L - 2, depths  # the tail source IS deeper: its prediction from the hub falls short

@@ -25,7 +25,7 @@ wl = WORKLOADS[name]
 props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], wl["c"], seed=42)
 src = int(np.argmax(np.diff(csr.row_offsets)))
 ctx = gr.multi_context_t(0)
-KNOBS = ("GRX_GROUP_HINT", "GRX_FWD_SEED_IN_RESET", "GRX_SOURCE_MAP")
+KNOBS = ("GRX_GROUP_HINT", "GRX_FWD_SEED_IN_RESET", "GRX_SOURCE_MAP", "GRX_BIN_MIN_EDGES", "GRX_SOURCE_WG_PER_CU", "GRX_PACE_DEPTH")
 
 
 def set_env(env):
@@ -65,7 +65,16 @@ if "bfs" in what:
                            ("no fused reset+seed", {"GRX_FWD_SEED_IN_RESET": 0}),
                            ("no source chunk map", {"GRX_SOURCE_MAP": 0}),
                            ("all off (previous sources' schedule)", {"GRX_GROUP_HINT": 0, "GRX_FWD_SEED_IN_RESET": 0, "GRX_SOURCE_MAP": 0}),
-                           ("default again", {})):
+                           ("default again", {}),
+                           # existing knobs, measured here because they are free to try
+                           ("binned from 2^19 out-edges (default 2^20)", {"GRX_BIN_MIN_EDGES": 1 << 19}),
+                           ("source level: 1 workgroup per CU (default 4)", {"GRX_SOURCE_WG_PER_CU": 1}),
+                           ("source level: 8 workgroups per CU", {"GRX_SOURCE_WG_PER_CU": 8}),
+                           ("pace depth 1 (default 2)", {"GRX_PACE_DEPTH": 1}),
+                           ("pace depth 3", {"GRX_PACE_DEPTH": 3}),
+                           ("default, third time", {})):
+            if dname == "DO " and "BIN_MIN" in "".join(env):
+                continue
             if dname == "DO " and ("FWD_SEED" in "".join(env) or "SOURCE_MAP" in "".join(env)) and len(env) == 1:
                 continue  # forward-only knobs
             set_env(env)
