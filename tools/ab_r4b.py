@@ -25,7 +25,10 @@ wl = WORKLOADS[name]
 props, csr = gr.generate(wl["kind"], wl["V"], wl["entries"], wl["a"], wl["b"], wl["c"], seed=42)
 src = int(np.argmax(np.diff(csr.row_offsets)))
 ctx = gr.multi_context_t(0)
-KNOBS = ("GRX_GROUP_HINT", "GRX_FWD_SEED_IN_RESET", "GRX_SOURCE_MAP", "GRX_BIN_MIN_EDGES", "GRX_SOURCE_WG_PER_CU", "GRX_PACE_DEPTH")
+KNOBS = ("GRX_GROUP_HINT", "GRX_FWD_SEED_IN_RESET", "GRX_SOURCE_MAP", "GRX_BIN_MIN_EDGES", "GRX_SOURCE_WG_PER_CU", "GRX_PACE_DEPTH",
+         "GRX_BIN_SWEEP", "GRX_SW2_WG_PER_CU", "GRX_SW2_PARTS_PER_BIN", "GRX_SW2_ITEMS", "GRX_RBIN_MIN_EDGES", "GRX_RBIN_PARTS", "GRX_SSSP_BFS_ASYNC")
+# argv[3] may also name "knobs": sweeps of EXISTING tuning knobs on the final sources (sweep geometry of the binned BFS levels,
+# threshold / parts of the binned relaxation) instead of the session's own switches
 
 
 def set_env(env):
@@ -86,6 +89,68 @@ if "bfs" in what:
                   % (dname, label, step, st["elapsed_ms"], st["edges_visited"] / (step * 1e6), int(st["aux"]),
                      bool(np.array_equal(h, ref["bfs"]))), flush=True)
     del G, d
+if "knobs" in what:
+    G = gr.build_graph(props, csr, ctx)
+    V = G.get_number_of_vertices()
+    d = torch.empty(V, dtype=torch.int32, device="cuda")
+    o = gr.options_t(advance_load_balance=gr.merge_path, enable_filter=True, filter_algorithm=gr.compact,
+                     advance_direction=gr.forward, engine_flags=gr.FLAG_ASYNC_RETURN)
+    refk = None
+    for label, env in (("default (sweep 3: 1024 threads, 1 per CU, nb + 160 items)", {}),
+                       ("sweep 3, 300 items", {"GRX_SW2_ITEMS": 300}),
+                       ("sweep 3, 400 items", {"GRX_SW2_ITEMS": 400}),
+                       ("sweep 3, 512 items", {"GRX_SW2_ITEMS": 512}),
+                       ("sweep 2 (512 threads, 2 per CU, 2 parts per bin)", {"GRX_BIN_SWEEP": 2}),
+                       ("sweep 2, 3 per CU, 5 parts per bin", {"GRX_BIN_SWEEP": 2, "GRX_SW2_WG_PER_CU": 3, "GRX_SW2_PARTS_PER_BIN": 5}),
+                       ("sweep 2, 3 per CU, 8 parts per bin", {"GRX_BIN_SWEEP": 2, "GRX_SW2_WG_PER_CU": 3, "GRX_SW2_PARTS_PER_BIN": 8}),
+                       ("sweep 2, 4 per CU, 12 parts per bin", {"GRX_BIN_SWEEP": 2, "GRX_SW2_WG_PER_CU": 4, "GRX_SW2_PARTS_PER_BIN": 12}),
+                       ("default again", {})):
+        set_env(env)
+        step = timed(lambda: gr.bfs(G, src, d, None, ctx, o), reps)
+        st = gr.run_stats(ctx)
+        h = d.cpu().numpy()
+        refk = h.copy() if refk is None else refk
+        print("fwd %-56s step %.4f ms | enact %.4f | GTEPS %.1f | same %s"
+              % (label, step, st["elapsed_ms"], st["edges_visited"] / (step * 1e6), bool(np.array_equal(h, refk))), flush=True)
+    del G, d
+    w = pair_hash_weights(csr)
+    csr_w = gr.csr_t.from_arrays(csr.row_offsets, csr.column_indices, w)
+    dd = torch.empty(csr.number_of_rows, dtype=torch.float32, device="cuda")
+    refw = None
+    for label, env in (("default (binned from 2^20 relaxed edges, parts = CUs)", {}),
+                       ("binned from 2^19", {"GRX_RBIN_MIN_EDGES": 1 << 19}),
+                       ("binned from 2^21", {"GRX_RBIN_MIN_EDGES": 1 << 21}),
+                       ("binned from 2^22", {"GRX_RBIN_MIN_EDGES": 1 << 22}),
+                       ("binned from 2^23", {"GRX_RBIN_MIN_EDGES": 1 << 23}),
+                       ("parts 128", {"GRX_RBIN_PARTS": 128}),
+                       ("parts 512", {"GRX_RBIN_PARTS": 512}),
+                       ("default again", {})):
+        set_env(env)
+        # a fresh handle per line: the launch groups that carry the scatter / sweep kernels are OR-ed over a handle's searches
+        Gw = gr.build_graph(gr.graph_properties_t(directed=True, weighted=True, symmetric=False), csr_w, ctx)
+        step = timed(lambda: gr.sssp(Gw, src, dd, None, ctx, gr.options_t()), max(3, reps // 4))
+        st = gr.run_stats(ctx)
+        h = dd.cpu().numpy()
+        refw = h.copy() if refw is None else refw
+        print("sssp U{1..1000} %-44s step %.4f ms | iterations %d | relaxed %d | same %s"
+              % (label, step, st["search_depth"], st["edges_visited"], bool(np.array_equal(h, refw))), flush=True)
+        del Gw
+    del dd
+if "unit" in what:
+    # SSSP with the weights the reference's loader gives a pattern file (all 1.0): the BFS engine + one conversion pass
+    Gu = gr.build_graph(props, csr, ctx)
+    du = torch.empty(csr.number_of_rows, dtype=torch.float32, device="cuda")
+    refu = None
+    for label, env in (("default (inner search returns on the published end)", {}), ("inner search blocks (before)", {"GRX_SSSP_BFS_ASYNC": 0}),
+                       ("default again", {})):
+        set_env(env)
+        step = timed(lambda: gr.sssp(Gu, src, du, None, ctx, gr.options_t()), reps)
+        st = gr.run_stats(ctx)
+        h = du.cpu().numpy()
+        refu = h.copy() if refu is None else refu
+        print("sssp all 1.0 %-52s step %.4f ms | enact %.4f | depth %d | same %s"
+              % (label, step, st["elapsed_ms"], st["search_depth"], bool(np.array_equal(h, refu))), flush=True)
+    del Gu, du
 if "sssp" in what:
     w = pair_hash_weights(csr)
     Gw = gr.build_graph(gr.graph_properties_t(directed=True, weighted=True, symmetric=False),
