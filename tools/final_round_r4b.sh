@@ -16,9 +16,11 @@ el "profile: $(head -c 300 gpurun_out/r4b_bench_pmc.json | tr '\n' ' ')"
 timeout 280 python bench.py > gpurun_out/r4b_bench.log 2> gpurun_out/r4b_bench.err; echo "rc $?" >> gpurun_out/r4b_bench.log
 cp gpurun_out/bench_detail.json gpurun_out/r4b_bench_detail.json 2>/dev/null; el "bench"
 (timeout 60 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r4b_smoke.log 2>&1; echo "smoke rc $?" >> gpurun_out/r4b_smoke.log); el "smoke"
-(timeout 240 python -m pytest tests -m gpu -q --durations=15 \
+# FINAL_TESTS: a test selection instead of the whole suite (the last pass of the session re-ran what the last change touched;
+# the whole suite ran one commit earlier: profiles/r4b_pytest_gpu.log)
+(timeout 240 python -m pytest ${FINAL_TESTS:-tests} -m gpu -q --durations=15 \
    --deselect tests/test_bfs_gpu.py::test_full_size_twitter_standin_properties \
    --deselect tests/test_distributed.py::test_c5_twitter_standin_two_ranks_one_gpu \
    --deselect tests/test_distributed.py::test_c5_twitter_standin_eight_ranks_one_gpu \
-   > gpurun_out/r4b_pytest_gpu.log 2>&1; echo "pytest rc $?" >> gpurun_out/r4b_pytest_gpu.log); el "pytest"
-tail -4 gpurun_out/r4b_pytest_gpu.log; tail -1 gpurun_out/r4b_smoke.log; head -c 600 gpurun_out/r4b_bench.log; echo; tail -c 300 gpurun_out/r4b_bench.log
+   > gpurun_out/r4b_pytest_gpu_${FINAL_TAG:-all}.log 2>&1; echo "pytest rc $?" >> gpurun_out/r4b_pytest_gpu_${FINAL_TAG:-all}.log); el "pytest"
+tail -4 gpurun_out/r4b_pytest_gpu_${FINAL_TAG:-all}.log; tail -1 gpurun_out/r4b_smoke.log; head -c 600 gpurun_out/r4b_bench.log; echo; tail -c 300 gpurun_out/r4b_bench.log
