@@ -266,7 +266,7 @@ def _run(world, use_gpu, tmp_path):
         assert bottom_up_seen  # the direction switch is part of what this test covers
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_protocol_on_cpu_with_gloo(world, tmp_path):
     _run(world, False, tmp_path)
 

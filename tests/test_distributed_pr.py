@@ -182,7 +182,7 @@ def _run(world, use_gpu, tmp_path):
     _check(gr, per_rank, world)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_pagerank_protocol_on_cpu_with_gloo(world, tmp_path):
     _run(world, False, tmp_path)
 

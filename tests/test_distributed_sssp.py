@@ -170,7 +170,7 @@ def _run(world, use_gpu, tmp_path):
                 assert len(depths) == 1  # every rank stopped in the same iteration
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_sssp_protocol_on_cpu_with_gloo(world, tmp_path):
     _run(world, False, tmp_path)
 
