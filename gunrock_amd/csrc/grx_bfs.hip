@@ -459,6 +459,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
     in.bin_nb = bn.nb;
     in.bin_pad = BIN_PAD;
     in.bin_allowed = bn.allowed;
+    in.bin_forced = bn.no_level;
     in.seq = seq;
     plan_body<PLAN_BLOCK>(a, c, 0, s_wave, &s_red[0], in);
     return;
@@ -1102,7 +1103,24 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   // without them runs on the claim-per-edge advance (the head is told: bin_args::allowed) and is recorded for the next
   // search.  GRX_BIN_HINT=0: every group carries them.
   const uint32_t hint0 = (use_bins && env_int("GRX_BIN_HINT", 1) != 0) ? g->bin_hint.load(std::memory_order_relaxed) : 0u;
-  const uint32_t bin_groups = hint0 ? (hint0 | (hint0 << 1) | (hint0 >> 1)) : ~0u;
+  uint32_t bin_groups = hint0 ? (hint0 | (hint0 << 1) | (hint0 >> 1)) : ~0u;
+  // The same source as the last forward search on this handle: the groups with a fat level are known EXACTLY (grx_graph::
+  // bin_exact).  Those groups carry head + scatter + sweep, the others head + level kernel: a forward search on the LJ
+  // stand-in spent ~25 us on six no-op launches (the level kernel in front of either fat level, scatter + sweep of the slack
+  // group behind them).  A wrong prediction is only slow: a fat level in a group without the two kernels runs on the
+  // claim-per-edge advance (bin_args::allowed), a thin one in a group without a level kernel is binned (bin_args::no_level).
+  // GRX_BIN_EXACT=0: off.  Profiled runs keep every kernel (their records are per launch group).
+  uint32_t exact_groups = 0u;
+  bool exact = false;
+  {
+    const uint64_t ex = g->bin_exact.load(std::memory_order_relaxed);
+    if (use_bins && hint0 && !(opt.engine_flags & GRX_FLAG_PROFILE) && (uint32_t)(ex >> 32) == (uint32_t)src + 1u &&
+        env_int("GRX_BIN_EXACT", 1) != 0) {
+      exact = true;
+      exact_groups = (uint32_t)ex;
+      bin_groups = exact_groups;
+    }
+  }
   // Paced searches: enqueue as many groups as the previous search on this graph (same direction rule) needed, then wait
   // for the end instead of queueing two more behind it (run_levels: hold_after).  GRX_GROUP_HINT=0: off
   const int hold_after = (pace > 0 && env_int("GRX_GROUP_HINT", 1) != 0) ? g->group_hint[dopt ? 1 : 0].load(std::memory_order_relaxed) : 0;
@@ -1110,7 +1128,10 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   st = run_levels(ctx, opt, [&](hipStream_t stream, int seq) {
     if (profile) (void)hipEventRecord(pe[0], stream);
     const bool bins_here = use_bins && (seq >= 32 || ((bin_groups >> seq) & 1u) != 0u);
+    // (the second scatter + a sweep: the first versions of the two kernels share the level kernel's launch)
+    const bool level_here = !(exact && bins_here && seq < 32 && grid_scatter2 > 0 && claim_version == 3);
     bn.allowed = bins_here ? 1 : 0;
+    bn.no_level = level_here ? 0 : 1;
     if (variant == 0) {
       // head (tiny levels + decide + plan) -> level
       hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, lp, (profile || strict_mp) ? 0 : 1, seq, bn);
@@ -1118,7 +1139,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       if (!dopt) {
         // forward-only run.  level = claim-per-edge advance, many mid-size levels (grx_mid.hpp), or the SCATTER phase of
         // a binned level; the CLAIM phase is launched only when levels can be binned (a no-op unless the head did)
-        hipLaunchKernelGGL(bfs_level_bin_kernel, dim3(grid_scatter), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
+        if (level_here) hipLaunchKernelGGL(bfs_level_bin_kernel, dim3(grid_scatter), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
         // (four builds of each: tuning clocks on / off x 16-bit / 32-bit bin entries)
         auto launch2 = [&](auto dbg_c, auto e16_c) {
           constexpr bool DBG = decltype(dbg_c)::value, E16 = decltype(e16_c)::value;
@@ -1221,6 +1242,8 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     const uint32_t want = returned_fast ? (uint32_t)ctx->h_mailbox[11] : (uint32_t)ctx->h_ctrl->bin_want;
     if (env_int("GRX_BIN_HINT_REPLACE", 0) != 0) g->bin_hint.store(want, std::memory_order_relaxed);
     else g->bin_hint.fetch_or(want, std::memory_order_relaxed);
+    if (!dopt && variant == 0 && opt.max_iterations == 0 && !profile)
+      g->bin_exact.store(((uint64_t)((uint32_t)src + 1u) << 32) | (uint64_t)want, std::memory_order_relaxed);
   }
   float ms = 0;
   if (returned_fast) {

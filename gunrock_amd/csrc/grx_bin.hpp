@@ -67,6 +67,7 @@ struct bin_args {
   long long* debug;           // tuning aid (GRX_BIN_DEBUG=<level>): 8 words per workgroup and phase for that level, else null
   int32_t debug_level;
   int32_t allowed;            // this launch group carries the scatter / sweep kernels
+  int32_t no_level;           // ... and NO level kernel (exact schedule of a repeated search): a level that is not over plans mode 2
   int32_t max_degree;         // ... and whose frontier averages at most this many out-edges per vertex
   int32_t mid_v, mid_e;       // thresholds of the many-levels-per-launch body (grx_mid.hpp), 0: off (carried here for the head kernel)
   int32_t static_units;       // second scatter: units strided statically over the workgroups instead of drawn from per-XCD ticket
@@ -934,6 +935,13 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     reA = a.ro[vv + 1u];
     if constexpr (VAL) dA = __float_as_uint(bn.rdist[vv]);
   }
+  // DRAIN THE PROLOGUE (round 5, from the ISA).  The waitcnt pass merges what is pending on the two ways into the loop
+  // header: entering from here the loads above were the YOUNGEST operations in flight, so the header got
+  // `s_waitcnt vmcnt(0)` -- which on the back edge means "wait for the eight copy-out stores this wave has just
+  // issued" at the top of every batch.  Consuming the values here (an empty asm that reads them) puts the wait in
+  // front of the loop; on the back edge everything the header reads is a batch old and needs no wait at all.
+  if constexpr (VAL) asm volatile("" ::"v"(dA));
+  asm volatile("" ::"v"(vA), "v"(vB), "v"(rsA), "v"(reA), "v"(tlC.x), "v"(tlC.y), "v"(yA), "v"(yB));
   while (uA < n_units) {
     // Everything derived from the thread index is RE-derived per batch from an opaque copy: left to itself the
     // compiler hoists two dozen per-thread constants (k * 256 + tq, LDS addresses, ...) out of the loop, runs out
@@ -960,9 +968,14 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       if constexpr (VAL) dB = __float_as_uint(bn.rdist[vv]);
     }
     vC = in[(unsigned)(tlC.x * TILE + tq)];
-    int ticket = 0;  // drawn now, used at the end of the batch (unit of stage D of the NEXT batch)
+    // drawn now, used behind the sort (unit of stage D of the NEXT batch).  Round 5, from the ISA: the compiler's atomic
+    // optimizer turns a one-lane atomic on a UNIFORM address into mbcnt + atomic + readfirstlane and waits for the result on
+    // the spot -- `s_waitcnt vmcnt(0)` behind the three front loads just issued: wave 0 sat out a whole memory round trip at
+    // the top of every batch and the other fifteen waves waited for it at the first barrier.  An address the compiler cannot
+    // prove uniform (the opaque zero below) keeps it a plain per-lane atomic whose result is waited for where it is used.
+    int ticket = 0;
     if (stat) ticket = next_static++;
-    else if (tid == 0) ticket = __hip_atomic_fetch_add(qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if (tid == 0) ticket = __hip_atomic_fetch_add(qhead + vzero, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const int inc = dev::wave_inclusive_sum(dg);
     if (lane == 63) sm.wtot[q][wq] = inc;
     reinterpret_cast<uint2*>(own)[tq] = make_uint2(0u, 0u);
@@ -1124,6 +1137,10 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     } else {
       if ((tid & sub_mask) == 0 && my_bin < BIN_MAX) sm.delta[my_bin] = boff + gbase - ex2;
     }
+    // the next batch's stage D: the ticket arrived long ago (it is older than the column-index loads), nothing else of this
+    // wave is in flight here, so the wait is free -- and it must not sit behind the copy-out stores below.  Read after the
+    // next batch's first barrier.
+    if (tid == 0) sm.tick[3] = first_unit + n_xcd * ticket;
     __syncthreads();
     dbg_mark(6);
     // ---- phase 7: runs leave LDS as contiguous segments (no barrier behind it: the next batch touches the sort
@@ -1202,7 +1219,6 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       }
     }
     dbg_mark(7);
-    if (tid == 0) sm.tick[3] = first_unit + n_xcd * ticket;  // read after the next batch's first barrier
     uA = uB; uB = uC; uC = uD;
     yA = yB; yB = tlC.y; tlC = tlD;
     vA = vB; vB = vC;
@@ -1241,6 +1257,10 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
 //     chunk-map reservation as soon as the degree sums are known, behind the stores of the frontier slots.
 constexpr int SW2_PART_MIN = 1 << 15;
 constexpr int SW2_U = 2;          // 16-byte candidate loads per thread and round
+#ifndef GRX_SW_RING
+#define GRX_SW_RING 2
+#endif
+constexpr int SW2_RING = GRX_SW_RING;  // rounds of candidate loads in flight per thread (bin_sweep2_block)
 
 template <int NT, int LIST_ENTRIES>
 struct bin_sweep2_smem {
@@ -1411,7 +1431,15 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
     const int gw0 = vbase >> 5;
     // first candidates on their way while the bitmap slice is copied
     const int i4_first = lo / EPL, i4_last = (hi - 1) / EPL;
-    int4 nx[SW2_U];
+    // A RING of SW2_RING rounds of candidate loads in flight (round 5, from the ISA).  The round-3 loop read `cur = nx;
+    // LOAD(r + 1, nx); process(cur)`: the compiler put the copy nx -> cur at the END of the body, behind `s_waitcnt vmcnt(0)`
+    // -- every round waited out the full latency of the loads it had just issued (2 x 16 B per thread = 32 KB per CU in flight:
+    // 17 us for the 300 KB of an item, 3.6 TB/s over the device), and the deeper variant of round 3 (profiles/
+    // r3_ab_sweep_deeper_prefetch_rejected.txt) serialised the same way with more registers.  Here the buffers are indexed
+    // by compile-time constants of a fully unrolled group of SW2_RING rounds -- no register copies -- so a round waits with
+    // vmcnt((SW2_RING - 1) * SW2_U) for loads issued SW2_RING - 1 rounds ago.  Rounds past the end load a clamped index and
+    // find every entry out of range.
+    int4 buf[SW2_RING][SW2_U];
     auto LOAD = [&](int r, int4(&v)[SW2_U]) {
 #pragma unroll
       for (int u = 0; u < SW2_U; ++u) {
@@ -1419,16 +1447,13 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
         v[u] = src4[idx < i4_last ? idx : i4_last];
       }
     };
-    LOAD(0, nx);
-    for (int w = tid; w < words; w += NT) sm.bm[w] = (gw0 + w) < bn.visited_words ? bn.visited[gw0 + w] : ~0u;
-    __syncthreads();
-    // A. candidates -> LDS bitmap (loads one round ahead)
-    const int rounds = (i4_last - i4_first + SW2_U * NT) / (SW2_U * NT);
-    for (int r = 0; r < rounds; ++r) {
-      int4 cur[SW2_U];
 #pragma unroll
-      for (int u = 0; u < SW2_U; ++u) cur[u] = nx[u];
-      LOAD(r + 1, nx);
+    for (int k = 0; k < SW2_RING; ++k) LOAD(k, buf[k]);
+    for (int w = tid; w < words; w += NT) sm.bm[w] = (gw0 + w) < bn.visited_words ? bn.visited[gw0 + w] : ~0u;
+    // (the slice's loads are consumed here: what the stream loop below finds in flight is the ring alone)
+    __syncthreads();
+    // A. candidates -> LDS bitmap
+    auto PROCESS = [&](int r, const int4(&cur)[SW2_U]) {
 #pragma unroll
       for (int u = 0; u < SW2_U; ++u) {
         const int idx = i4_first + (r * SW2_U + u) * NT + tid;
@@ -1461,6 +1486,54 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
           // one word serialises
           if (!(wv[j] & bit)) atomicOr(&sm.bm[local >> 5], bit);
         }
+      }
+    };
+    // The LEAN body (round 5; 16-bit entries, every entry of every lane inside [lo, hi)).  The general body above spends ~20
+    // instructions on an entry -- three range compares, two mask operations, the unpacking, an exec-masked read, a branch around
+    // the atomic -- and the per-item clocks of round 4 (17 us for 154 k entries on ONE CU: 64 entries per ~17 clocks) are what
+    // that many VALU / SALU instructions cost four waves per SIMD, not what the loads cost (more loads in flight changed
+    // nothing).  All but the first and the last 16-byte load of an item are interior: there the word is read at the byte address
+    // (x >> 3) & 0x1ffc straight from the packed pair, the bit tested with one v_bfe, and ONE branch per load skips the eight
+    // atomics when every bit is already set (98 % of the candidates of the second fat level are visited).
+    auto PROCESS_LEAN = [&](const int4(&cur)[SW2_U]) {
+      const char* bmb = reinterpret_cast<const char*>(sm.bm);
+#pragma unroll
+      for (int u = 0; u < SW2_U; ++u) {
+        const unsigned q4[4] = {(unsigned)cur[u].x, (unsigned)cur[u].y, (unsigned)cur[u].z, (unsigned)cur[u].w};
+        unsigned wv[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          wv[2 * j] = *reinterpret_cast<const unsigned*>(bmb + ((q4[j] >> 3) & 0x1ffcu));
+          wv[2 * j + 1] = *reinterpret_cast<const unsigned*>(bmb + ((q4[j] >> 19) & 0x1ffcu));
+          sh[2 * j] = q4[j];            // (a shift uses the low five bits of its amount)
+          sh[2 * j + 1] = q4[j] >> 16;
+        }
+        unsigned all = 1u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          wv[j] = (wv[j] >> (sh[j] & 31u)) & 1u;
+          all &= wv[j];
+        }
+        if (!all) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned local = (j & 1) ? (q4[j >> 1] >> 16) : (q4[j >> 1] & 0xffffu);
+            if (!wv[j]) atomicOr(&sm.bm[local >> 5], 1u << (local & 31u));
+          }
+        }
+      }
+    };
+    const int rounds = (i4_last - i4_first + SW2_U * NT) / (SW2_U * NT);
+    for (int r0 = 0; r0 < rounds; r0 += SW2_RING) {
+#pragma unroll
+      for (int k = 0; k < SW2_RING; ++k) {
+        const int r = r0 + k;
+        // uniform: the 16-byte loads of this round lie strictly inside the item for every thread (the first load of an item
+        // may begin before `lo`, its last one end behind `hi`; rounds past the end are not interior either)
+        const int f = i4_first + r * SW2_U * NT;
+        if (E16 && vsub == 0 && f > i4_first && f + SW2_U * NT - 1 < i4_last) PROCESS_LEAN(buf[k]);
+        else PROCESS(r, buf[k]);
+        LOAD(r + SW2_RING, buf[k]);
       }
     }
     __syncthreads();

@@ -191,6 +191,12 @@ struct grx_graph {
   // it, instead of queueing two more behind the running one), [2] weighted SSSP on a dense graph (blind batches: the first
   // batch is that many groups instead of 4, 8, 16, ... with a host round trip between them).  run_levels, grx_engine.hpp
   std::atomic<int32_t> group_hint[3] = {{0}, {0}, {0}};
+  // EXACT schedule of a repeated forward search (round 5): {source + 1 (0: none), launch groups in which THAT search met a fat
+  // level} of the last forward search with binned levels.  A search from the same source on the same handle visits the same
+  // levels in the same groups, so its fat groups carry head + scatter + sweep (no level kernel: the head is told and plans
+  // the binned body whatever it finds) and the other groups head + level kernel only -- no no-op launches at all.  Any other
+  // source falls back to the OR-ed hint above with its slack.  Packed into one word so that concurrent searches read a pair.
+  std::atomic<uint64_t> bin_exact{0};
   std::atomic<int32_t> pr_iter_hint{0};  // iterations of the previous PageRank run on this handle: its first blind batch (grx_pr.hip)
   int32_t bin_entry16 = 0;      // every bin spans <= 65536 vertices: offsets inside a bin fit 16-bit entries
   int32_t bin_state = 0;        // 0: not built, 1: usable, 2: not applicable to this graph, 3: a column index lies outside [0, V)

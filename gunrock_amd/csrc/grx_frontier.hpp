@@ -152,6 +152,7 @@ struct plan_in {
   // the launch group of this level carries the scatter / sweep kernels (the host leaves them out of groups where the
   // previous search on the graph had no fat level); seq: index of the group
   int bin_allowed = 1, seq = 0;
+  int bin_forced = 0;            // the group has no level kernel (exact schedule, grx_graph::bin_exact): mode 2 whatever the size
   int32_t* bin_fill = nullptr;
   int32_t* bin_queue = nullptr;  // per-XCD claim queue heads (16 slots, bin_pad apart), zeroed with the fill counters
   int bin_nb = 0, bin_pad = 0;
@@ -294,12 +295,12 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
         const bool fat = in.bin_min > 0 && edges >= in.bin_min &&
                          (in.bin_max_degree <= 0 || edges <= (long long)in.bin_max_degree * nitems);
         if (fat && in.seq < 32) c->bin_want |= 1 << in.seq;
-        if (fat && in.bin_allowed)
+        if ((fat || in.bin_forced) && in.bin_allowed)
           mode = 2;
         // (the tile queue must be reasonably dense too: the few workgroups of that body walk it themselves, and a
         // level of the regular kernels on a wide grid leaves thousands of nearly empty tiles behind -- such a level
         // is expanded by the regular kernels once more, which compacts it)
-        else if (!fat && in.mid_v > 0 && nitems > 0 && nitems <= in.mid_v && edges <= (long long)in.mid_e &&
+        else if (!fat && !in.bin_forced && in.mid_v > 0 && nitems > 0 && nitems <= in.mid_v && edges <= (long long)in.mid_e &&
                  nt <= 4 * ((nitems + TILE - 1) / TILE) + 256)
           mode = 3;
         c->mode = mode;

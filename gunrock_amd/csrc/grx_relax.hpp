@@ -37,6 +37,10 @@ constexpr int RB_MAX_BINS = BIN_MAX * SC2_SUB;  // 1024: one histogram counter p
 constexpr int RB_SEG_WORDS = RB_BLOCK / 4;      // words of the changed bitmap per expansion round (a thread expands one byte)
 constexpr int RB_PART_MIN = 1 << 15;            // a bin is cut into parts of at least this many entries
 constexpr int RB_U = 2;                         // 16-byte offset loads (8 entries each) per thread and round
+#ifndef GRX_RB_RING
+#define GRX_RB_RING 2
+#endif
+constexpr int RB_RING = GRX_RB_RING;            // rounds of entry loads in flight per thread (3 x RB_U 16-byte loads each)
 constexpr int RB_QUEUE_SLOT = 15;               // bin_args::queue word (x BIN_PAD) the sweep draws its items from
 
 // (Measured and removed, round 4 call 17: a software-pipelined build of the scatter -- owner map and column / weight loads of batch
@@ -120,8 +124,15 @@ __device__ __forceinline__ void relax_sweep_block(const pipe_args& a, const bin_
     __syncthreads();  // everybody has read the item
     tid = tid0;
     asm volatile("" : "+v"(tid));  // (per-thread constants are re-derived per item instead of living in VGPRs)
+    // the next item's ticket: its round trip overlaps this item.  The address is made opaque (see bin_scatter2_block): on a
+    // uniform address the compiler's lowering of a one-lane atomic waits for the result on the spot, in front of this item's
+    // first loads.
     int next_item = 0;
-    if (tid == 0) next_item = atomicAdd(qhead, 1);  // its round trip overlaps this item
+    {
+      int vz;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+      if (tid == 0) next_item = atomicAdd(qhead + vz, 1);
+    }
     int b = 0;  // largest b with pre[b] <= item (bins without items are skipped over)
 #pragma unroll
     for (int step = RB_MAX_BINS / 2; step >= 1; step >>= 1)
@@ -134,7 +145,9 @@ __device__ __forceinline__ void relax_sweep_block(const pipe_args& a, const bin_
     const int vbase = bn.v0[b];
     const int nv = bn.v0[b + 1] - vbase;  // a multiple of the granule (>= 1024 vertices); the last bin may reach past V
     const int i4_first = lo / EPL, i4_last = (hi - 1) / EPL;
-    int4 nx_o[RB_U], nx_v[RB_U][2];
+    // a ring of RB_RING rounds of entry loads in flight, the buffers indexed by the constants of an unrolled group: see
+    // bin_sweep2_block (the round-4 loop `cur = next; LOAD(r + 1, next); process(cur)` waited out every round's full latency)
+    int4 rg_o[RB_RING][RB_U], rg_v[RB_RING][RB_U][2];
     auto LOAD = [&](int r, int4(&o)[RB_U], int4(&v)[RB_U][2]) {
 #pragma unroll
       for (int u = 0; u < RB_U; ++u) {
@@ -145,7 +158,8 @@ __device__ __forceinline__ void relax_sweep_block(const pipe_args& a, const bin_
         v[u][1] = val4[2 * (size_t)idx + 1];
       }
     };
-    LOAD(0, nx_o, nx_v);  // the first entries are on their way while the labels are copied
+#pragma unroll
+    for (int k = 0; k < RB_RING; ++k) LOAD(k, rg_o[k], rg_v[k]);  // the first entries are on their way while the labels are copied
     {
       // (all loads of the slice issued before the first LDS store: a loop of load -> store pairs is one memory round trip
       // per iteration, 16 of them per item -- measured: ~125 us of every sweep, whatever the level's size)
@@ -160,17 +174,8 @@ __device__ __forceinline__ void relax_sweep_block(const pipe_args& a, const bin_
         if (k * NT < nv) sm.d[k * NT + tid] = g16[k];
     }
     __syncthreads();
-    // A. entries -> minimum in LDS (loads one round ahead)
-    const int rounds = (i4_last - i4_first + RB_U * NT) / (RB_U * NT);
-    for (int r = 0; r < rounds; ++r) {
-      int4 co[RB_U], cv[RB_U][2];
-#pragma unroll
-      for (int u = 0; u < RB_U; ++u) {
-        co[u] = nx_o[u];
-        cv[u][0] = nx_v[u][0];
-        cv[u][1] = nx_v[u][1];
-      }
-      LOAD(r + 1, nx_o, nx_v);
+    // A. entries -> minimum in LDS
+    auto PROCESS = [&](int r, const int4(&co)[RB_U], const int4(&cv)[RB_U][2]) {
 #pragma unroll
       for (int u = 0; u < RB_U; ++u) {
         const int idx = i4_first + (r * RB_U + u) * NT + tid;
@@ -196,6 +201,14 @@ __device__ __forceinline__ void relax_sweep_block(const pipe_args& a, const bin_
 #pragma unroll
         for (int j = 0; j < EPL; ++j)
           if (x8[j] < cur[j]) (void)__hip_atomic_fetch_min(&sm.d[o8[j]], x8[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    };
+    const int rounds = (i4_last - i4_first + RB_U * NT) / (RB_U * NT);
+    for (int r0 = 0; r0 < rounds; r0 += RB_RING) {
+#pragma unroll
+      for (int k = 0; k < RB_RING; ++k) {
+        PROCESS(r0 + k, rg_o[k], rg_v[k]);   // (rounds past the end find every entry out of range)
+        LOAD(r0 + k + RB_RING, rg_o[k], rg_v[k]);
       }
     }
     __syncthreads();
