@@ -311,7 +311,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_source_kernel(pipe_args a, dobf
       if (m) {
         int at = 0;
         if (lane == 0) at = atomicAdd(&sm.cnt, __popcll(m));
-        at = __shfl(at, 0, 64);
+        at = dev::wave_bcast0(at);
         if (keep) {
           sm.out[at + dev::mask_rank(m)] = n_k[k];
           if (by_bit) pol.dist[n_k[k]] = pol.next_depth;
@@ -546,16 +546,16 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_bin_kernel(pipe_args a, b
 }
 
 // The scatter phase of a binned level, second version (grx_bin.hpp): 1024 threads, two workgroups = 32 waves per CU.
-template <bool DBG, bool E16>
+template <bool DBG, bool E16, bool UNI = false>
 __global__ __launch_bounds__(SC2_BLOCK, 8) void bfs_scatter2_kernel(pipe_args a, bin_args bn) {
   __shared__ __attribute__((aligned(16))) bin_scatter2_smem sm;
   const level_head h = load_level_head(a.ctrl);
   if (h.done || h.mode != 2) return;
   if (DBG && h.level != bn.debug_level) {
-    bin_scatter2_block<false, E16>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
+    bin_scatter2_block<false, E16, false, bin_scatter2_smem, UNI>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
     return;
   }
-  bin_scatter2_block<DBG, E16>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
+  bin_scatter2_block<DBG, E16, false, bin_scatter2_smem, UNI>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
 }
 
 __global__ __launch_bounds__(ADV_BLOCK) void bfs_claim_kernel(pipe_args a, bin_args bn, bfs_policy pol) {
@@ -660,7 +660,20 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   // cut the granule sequence into <= BIN_MAX bins of about `target` in-edges each, no wider than max_width
   std::vector<int> first;  // first granule of each bin
   long long target = (total + 223) / 224;
-  for (int attempt = 0; attempt < 64; ++attempt) {
+  // UNIFORM bins (round 5): when 16-bit entries are possible and the aligned 65536-vertex ranges are numerous enough to spread
+  // the scatter's LDS counters (>= 48 of them: graphs of 3.1 M .. 14.7 M vertices), the bins ARE those ranges -- the balanced
+  // cut below ends up there anyway wherever the width cap binds (74 of the LJ stand-in's 76 bins) -- and the scatter needs no
+  // granule table: bin = id >> 16, offset = id & 0xffff (bin_scatter2_block<.., UNI>).  A hub-heavy range is balanced where it
+  // always was: the sweep cuts a bin with more than its share of a level's candidates into parts.  GRX_BIN_UNIFORM=0: off.
+  bool uniform = false;
+  if (shift_max == 16 && env_int("GRX_BIN_UNIFORM", 1) != 0) {
+    const int nb_u = (int)(((long long)g->V + 65535) >> 16);
+    if (nb_u >= 48 && nb_u <= BIN_MAX - 32) {
+      uniform = true;
+      for (int i = 0; i < n_gran; i += max_width) first.push_back(i);
+    }
+  }
+  for (int attempt = 0; attempt < 64 && !uniform; ++attempt) {
     first.clear();
     long long acc = 0;
     int width = 0;
@@ -727,6 +740,7 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   g->bin_ngran = n_gran;
   g->bin_nb = nb;
   g->bin_entry16 = shift_max == 16 ? 1 : 0;
+  g->bin_uniform = uniform ? 1 : 0;
   g->bin_state = 1;
   return GRX_SUCCESS;
 }
@@ -1019,6 +1033,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.gshift = g->bin_shift;
     bn.n_gran = g->bin_ngran;
     bn.nb = g->bin_nb;
+    bn.uniform = g->bin_uniform;
     bn.xcc_mask = ctx->xcc_mask;
     bn.n_xcd = ctx->n_xcd;
     // The slice-wise claim (GRX_BIN_CLAIM=2) pays one scattered L2 access per id that is new to its 8192-entry
@@ -1143,7 +1158,9 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         // (four builds of each: tuning clocks on / off x 16-bit / 32-bit bin entries)
         auto launch2 = [&](auto dbg_c, auto e16_c) {
           constexpr bool DBG = decltype(dbg_c)::value, E16 = decltype(e16_c)::value;
-          if (grid_scatter2 > 0)
+          if (grid_scatter2 > 0 && E16 && bn.uniform)
+            hipLaunchKernelGGL((bfs_scatter2_kernel<DBG, E16, E16>), dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
+          else if (grid_scatter2 > 0)
             hipLaunchKernelGGL((bfs_scatter2_kernel<DBG, E16>), dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
           if (use_bins && claim_version == 2)
             hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_claim), dim3(ADV_BLOCK), 0, stream, a, bn, lp);

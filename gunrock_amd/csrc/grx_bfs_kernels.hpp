@@ -483,7 +483,7 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
       if (wcnt >= TILE) {  // at most TILE - 1 + 64 * BATCH staged: one tile leaves, from the end
         int k = 0;
         if (lane == 0) k = atomicAdd(&sm.tix_next, 1);
-        k = __shfl(k, 0, 64);
+        k = dev::wave_bcast0(k);
         wave_emit_tile(a, p ^ 1, tile_base + k, sm.sv[wid], sm.sd[wid], wcnt - TILE, TILE);
         wcnt -= TILE;
       }
@@ -495,7 +495,7 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
     __syncthreads();
     int at = 0;
     if (lane == 0 && wcnt) at = atomicAdd(&sm.bcnt, wcnt);
-    at = __shfl(at, 0, 64);
+    at = dev::wave_bcast0(at);
     for (int i = lane; i < wcnt; i += 64) {
       sm.bv[at + i] = sm.sv[wid][i];
       sm.bd[at + i] = sm.sd[wid][i];
@@ -719,7 +719,7 @@ __device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const do
     const long long te0 = clk(false);
     int k = 0;
     if (lane == 0) k = atomicAdd(&sm.tix_next, 1);
-    k = __shfl(k, 0, 64);
+    k = dev::wave_bcast0(k);
     const int dsum = wave_emit_tile_deg(a, p ^ 1, tile_base + k, sv, wcnt - TILE, TILE);
     if (lane == 0) my_deg += dsum;
     wcnt -= TILE;
@@ -897,7 +897,7 @@ __device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const do
   __syncthreads();  // (every wave is done with its lists: u.bv overlays them)
   int at = 0;
   if (lane == 0 && wcnt) at = atomicAdd(&sm.bcnt, wcnt);
-  at = __shfl(at, 0, 64);
+  at = dev::wave_bcast0(at);
   for (int i = lane; i < wcnt; i += 64) sm.u.bv[at + i] = sv[i];
   __syncthreads();
   const int total = sm.bcnt;

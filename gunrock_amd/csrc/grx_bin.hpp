@@ -67,6 +67,7 @@ struct bin_args {
   long long* debug;           // tuning aid (GRX_BIN_DEBUG=<level>): 8 words per workgroup and phase for that level, else null
   int32_t debug_level;
   int32_t allowed;            // this launch group carries the scatter / sweep kernels
+  int32_t uniform;            // every bin is the aligned 65536-vertex range [b << 16, (b + 1) << 16): bin and offset are the halves of the id
   int32_t no_level;           // ... and NO level kernel (exact schedule of a repeated search): a level that is not over plans mode 2
   int32_t max_degree;         // ... and whose frontier averages at most this many out-edges per vertex
   int32_t mid_v, mid_e;       // thresholds of the many-levels-per-launch body (grx_mid.hpp), 0: off (carried here for the head kernel)
@@ -475,7 +476,7 @@ __device__ __forceinline__ void bin_claim_block(const pipe_args& a, const bin_ar
         if (m) {
           int base = 0;
           if (lane == 0) base = atomicAdd(&sm.cnt, __popcll(m));
-          base = __shfl(base, 0, 64);
+          base = dev::wave_bcast0(base);
           if (keep) {
             sm.out[base + dev::mask_rank(m)] = n_k[k];
             bn.dist[n_k[k]] = depth;  // exactly one winner per vertex (bfs.hxx:117-119 assigns the same depth)
@@ -843,12 +844,17 @@ struct bin_scatter2_val_smem : bin_scatter2_smem {
 };
 
 // E16: the bins hold 16-bit offsets (half the bytes written here and streamed by the sweep)
-template <bool DBG, bool E16, bool VAL = false, class SM = bin_scatter2_smem>
+// UNI (round 5): the bins are the aligned 65536-vertex ranges (graph_build_bins: the width cap binds everywhere on a graph of a
+// few million vertices, e.g. 74 of the LJ stand-in's 76 balanced bins were that already), so the bin of a target is id >> 16 and
+// its offset id & 0xffff -- the sorted entry is the id itself: no granule-table read (a random 16-bit LDS read per edge, the most
+// conflict-prone of the eight LDS operations an edge costs) and none of the six VALU instructions that packed the entry.
+template <bool DBG, bool E16, bool VAL = false, class SM = bin_scatter2_smem, bool UNI = false>
 __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin_args& bn, SM& sm, int p,
                                                    int total_chunks, const int* chunk_tile) {
   static_assert(!VAL || E16, "values travel with 16-bit offsets");
+  static_assert(!UNI || (E16 && !VAL), "uniform bins: 16-bit offsets, no values");
   constexpr int BBITS = VAL ? 10 : 8;    // bits of a bin index in the granule table
-  constexpr int BSHIFT = VAL ? 14 : 24;  // ... and where it sits in a sorted entry (above the offset inside the bin)
+  constexpr int BSHIFT = UNI ? 16 : (VAL ? 14 : 24);  // ... and where it sits in a sorted entry (above the offset inside the bin)
   constexpr unsigned BMASK = (1u << BBITS) - 1u;
   // DBG (GRX_BIN_DEBUG, its own kernel build): wave 0's clock at the end of every phase, summed per workgroup
   long long dbg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_t = 0, dbg_t0 = 0;
@@ -870,8 +876,10 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
   const int32_t* in = a.frontier[p];
   const int gshift = bn.gshift;
   const unsigned gmask = (1u << gshift) - 1u;
-  for (int w = tid; w < (bn.n_gran + 1) / 2; w += SC2_BLOCK)
-    reinterpret_cast<unsigned*>(sm.g2b)[w] = reinterpret_cast<const unsigned*>(bn.g2b16)[w];
+  if constexpr (!UNI) {
+    for (int w = tid; w < (bn.n_gran + 1) / 2; w += SC2_BLOCK)
+      reinterpret_cast<unsigned*>(sm.g2b)[w] = reinterpret_cast<const unsigned*>(bn.g2b16)[w];
+  }
   const int sub_shift = bn.sub_shift;                     // 2: four sub-counters per bin, 0: one
   const int sub_mask = (1 << sub_shift) - 1;
   const int boff = (tid >> sub_shift) < bn.nb ? bn.off[tid >> sub_shift] : 0;   // static offset of the bin of counter `tid`
@@ -1079,14 +1087,21 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         dbg_mark(3);
       }
-      unsigned t_k[ADV_ITEMS];
+      if constexpr (UNI) {
+        // the entry is the id: bin = id >> 16 (a lane past the end holds column 0's id: a valid bin, counted as 0)
 #pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) t_k[k] = sm.g2b[e_k[k] >> gshift];
+        for (int k = 0; k < ADV_ITEMS; ++k)
+          r_k[k] = atomicAdd(&sm.hist[((e_k[k] >> 16) << sub_shift) | (unsigned)(lane & sub_mask)], (k * TILE + tq) < n_at ? 1 : 0);
+      } else {
+        unsigned t_k[ADV_ITEMS];
 #pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) {
-        const unsigned bb = t_k[k] & BMASK;
-        e_k[k] = (bb << BSHIFT) | ((t_k[k] >> BBITS) << gshift) | (e_k[k] & gmask);
-        r_k[k] = atomicAdd(&sm.hist[(bb << sub_shift) | (unsigned)(lane & sub_mask)], (k * TILE + tq) < n_at ? 1 : 0);
+        for (int k = 0; k < ADV_ITEMS; ++k) t_k[k] = sm.g2b[e_k[k] >> gshift];
+#pragma unroll
+        for (int k = 0; k < ADV_ITEMS; ++k) {
+          const unsigned bb = t_k[k] & BMASK;
+          e_k[k] = (bb << BSHIFT) | ((t_k[k] >> BBITS) << gshift) | (e_k[k] & gmask);
+          r_k[k] = atomicAdd(&sm.hist[(bb << sub_shift) | (unsigned)(lane & sub_mask)], (k * TILE + tq) < n_at ? 1 : 0);
+        }
       }
     }
     __syncthreads();
@@ -1101,8 +1116,8 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
     int gbase = 0;
     {
       int bt = cnt;
-      if (sub_shift >= 1) bt += __shfl_xor(bt, 1, 64);  // (uniform)
-      if (sub_shift >= 2) bt += __shfl_xor(bt, 2, 64);
+      if (sub_shift >= 1) bt += dev::lane_xor1(bt);  // (uniform)
+      if (sub_shift >= 2) bt += dev::lane_xor2(bt);
       if ((tid & sub_mask) == 0 && bt > 0) gbase = atomicAdd(&bn.fill[(unsigned)(my_bin * BIN_PAD)], bt);
     }
     const int inc2 = dev::wave_inclusive_sum(cnt);
@@ -1167,7 +1182,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
           bn.rval[(size_t)(d_k[k] + i)] = x_k[k];
         }
       }
-    } else if (bn.pair_stores) {
+    } else if (!UNI && bn.pair_stores) {
       // Two neighbouring sorted positions per thread: where both belong to the same bin and the first lands on an even
       // entry, the pair leaves as ONE store of twice the width (round 4: a 2-byte store instruction costs the memory
       // pipeline what a 4-byte one does, and every store sits in the in-order vmcnt queue the next batch's loads wait on).
@@ -1208,7 +1223,7 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) s_k[k] = sm.sorted[k * SC2_BLOCK + tid];
 #pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) d_k[k] = sm.delta[s_k[k] >> 24];
+      for (int k = 0; k < ADV_ITEMS; ++k) d_k[k] = sm.delta[(s_k[k] >> BSHIFT) & 0xffu];  // (a stale position may hold any bits)
 #pragma unroll
       for (int k = 0; k < ADV_ITEMS; ++k) {
         const int i = k * SC2_BLOCK + tid;

@@ -645,7 +645,7 @@ __device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Pol
       if (m) {
         int base = 0;
         if (lane == 0) base = atomicAdd(&sm.cnt, __popcll(m));
-        base = __shfl(base, 0, 64);
+        base = dev::wave_bcast0(base);
         if (keep) {
           sm.out[base + dev::mask_rank(m)] = n_k[k];
           if constexpr (policy_has_accept<Policy>::value) pol.on_accept(n_k[k]);
@@ -657,7 +657,7 @@ __device__ __forceinline__ void advance_block(const pipe_args& a, ctrl_t* c, Pol
         if (ms) {
           int base = 0;
           if (lane == 0) base = atomicAdd(&sm.side_cnt, __popcll(ms));
-          base = __shfl(base, 0, 64);
+          base = dev::wave_bcast0(base);
           if (aside) sm.side[base + dev::mask_rank(ms)] = n_k[k];
         }
       }
@@ -1016,7 +1016,7 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
         if (mk) {
           int at = 0;
           if (lane == 0) at = atomicAdd(&sm.n, __popcll(mk));
-          at = __shfl(at, 0, 64) + dev::mask_rank(mk);
+          at = dev::wave_bcast0(at) + dev::mask_rank(mk);
           if (keep) {
             if (at < CAP) nxt[at] = n_k[k];
             else spill[at] = n_k[k];

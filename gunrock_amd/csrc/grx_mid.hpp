@@ -344,7 +344,7 @@ GRX_MID_FN void mid_levels_body(const pipe_args& a, ctrl_t* c, Policy& pol, mid_
           if (m) {
             int at = 0;
             if (lane == 0) at = atomicAdd(&ad.cnt, __popcll(m));
-            at = __shfl(at, 0, 64);
+            at = dev::wave_bcast0(at);
             if (keep) {
               const int pos = at + dev::mask_rank(m);
               ad.out[pos] = n_k[k];
@@ -362,7 +362,7 @@ GRX_MID_FN void mid_levels_body(const pipe_args& a, ctrl_t* c, Policy& pol, mid_
             if (ms) {
               int at = 0;
               if (lane == 0) at = atomicAdd(&sm.side_cnt, __popcll(ms));
-              at = __shfl(at, 0, 64);
+              at = dev::wave_bcast0(at);
               if (aside) sm.side[at + dev::mask_rank(ms)] = n_k[k];
             }
           }
@@ -793,7 +793,7 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
             if (m) {
               int at = 0;
               if (lane == 0) at = atomicAdd(&ad.cnt, __popcll(m));
-              at = __shfl(at, 0, 64);
+              at = dev::wave_bcast0(at);
               if (keep) {
                 const int pos = at + dev::mask_rank(m);
                 ad.out[pos] = n_k[k];
@@ -812,7 +812,7 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
               if (ms) {
                 int at = 0;
                 if (lane == 0) at = atomicAdd(&sm.side_cnt, __popcll(ms));
-                at = __shfl(at, 0, 64);
+                at = dev::wave_bcast0(at);
                 if (aside) sm.side[at + dev::mask_rank(ms)] = n_k[k];
               }
             }

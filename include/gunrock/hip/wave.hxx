@@ -58,11 +58,22 @@ __device__ __forceinline__ int wave_shift_up1(int x) {
   return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false);
 }
 
+// Sum over the 64 lanes, the same value in every lane: the DPP scan above and one v_readlane of its last lane (round 5: the
+// butterfly of six __shfl_xor it replaces was six dependent trips through the LDS crossbar, each with its own lane-index
+// arithmetic -- 36 VALU instructions and ~0.3 us per call in the inner loops that reduce once per batch).  Wave-wide call.
 __device__ __forceinline__ int wave_sum(int x) {
-#pragma unroll
-  for (int o = WAVE / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
-  return x;
+  return __builtin_amdgcn_readlane(wave_inclusive_sum(x), WAVE - 1);
 }
+// 64-bit sum of non-negative 32-bit terms (degree sums), as two DPP sums of 16-bit halves.
+__device__ __forceinline__ long long wave_sum_u32_wide(unsigned x) {
+  const int lo = wave_sum((int)(x & 0xffffu)), hi = wave_sum((int)(x >> 16));
+  return ((long long)hi << 16) + (long long)lo;
+}
+// The value lane 0 holds, in every lane (v_readlane; __shfl(x, 0) is a ds_bpermute round trip).  Wave-wide call.
+__device__ __forceinline__ int wave_bcast0(int x) { return __builtin_amdgcn_readlane(x, 0); }
+// x of the lane whose index differs in bit 0 / bit 1 (quad permutes on the DPP path)
+__device__ __forceinline__ int lane_xor1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false); }
+__device__ __forceinline__ int lane_xor2(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false); }
 
 __device__ __forceinline__ float wave_sum_f(float x) {
 #pragma unroll
