@@ -660,19 +660,26 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   // cut the granule sequence into <= BIN_MAX bins of about `target` in-edges each, no wider than max_width
   std::vector<int> first;  // first granule of each bin
   long long target = (total + 223) / 224;
-  // UNIFORM bins (round 5): when 16-bit entries are possible and the aligned 65536-vertex ranges are numerous enough to spread
-  // the scatter's LDS counters (>= 48 of them: graphs of 3.1 M .. 14.7 M vertices), the bins ARE those ranges -- the balanced
-  // cut below ends up there anyway wherever the width cap binds (74 of the LJ stand-in's 76 bins) -- and the scatter needs no
-  // granule table: bin = id >> 16, offset = id & 0xffff (bin_scatter2_block<.., UNI>).  A hub-heavy range is balanced where it
-  // always was: the sweep cuts a bin with more than its share of a level's candidates into parts.  GRX_BIN_UNIFORM=0: off.
-  bool uniform = false;
-  if (shift_max == 16 && env_int("GRX_BIN_UNIFORM", 1) != 0) {
-    const int nb_u = (int)(((long long)g->V + 65535) >> 16);
-    if (nb_u >= 48 && nb_u <= BIN_MAX - 32) {
-      uniform = true;
-      for (int i = 0; i < n_gran; i += max_width) first.push_back(i);
+  // UNIFORM bins (round 5): when 16-bit entries are possible the bins are the aligned ranges of 2^k vertices, k the largest of
+  // 13 .. 16 that still gives >= 64 bins (enough to spread the scatter's LDS counters; LJ stand-in: k = 16, 74 bins), and the
+  // scatter needs no granule table: bin = id >> k, offset = id & (2^k - 1), the sorted entry is the id itself
+  // (bin_scatter2_block<.., UNI>).  Fewer, wider bins also mean longer runs per bin and batch in the scatter's copy-out: the
+  // balanced cut below (224 bins of ~21 k vertices on the LJ stand-in) costs the scatter 97 / 111 us on the two fat levels,
+  // 74 uniform bins 82 / 97 (profiles/r5_c7_kernel_times_by_bin_cut.txt).  A hub-heavy range is balanced by the sweep, which
+  // cuts a bin with more than its share of a level's candidates into parts.  GRX_BIN_UNIFORM=0: off; GRX_BIN_USHIFT=k: that width.
+  int ushift = 0;
+  if (shift_max == 16 && env_int("GRX_BIN_UNIFORM", 0) != 0) {
+    int k = 16;
+    while (k > 13 && k > gshift && (((long long)g->V + (1ll << k) - 1) >> k) < 64) --k;
+    const int forced = env_int("GRX_BIN_USHIFT", 0);
+    if (forced >= gshift && forced >= 10 && forced <= 16) k = forced;
+    const long long nb_u = ((long long)g->V + (1ll << k) - 1) >> k;
+    if (k >= gshift && nb_u >= 48 && nb_u <= BIN_MAX - 32) {
+      ushift = k;
+      for (int i = 0; i < n_gran; i += 1 << (k - gshift)) first.push_back(i);
     }
   }
+  const bool uniform = ushift > 0;
   for (int attempt = 0; attempt < 64 && !uniform; ++attempt) {
     first.clear();
     long long acc = 0;
@@ -740,7 +747,7 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   g->bin_ngran = n_gran;
   g->bin_nb = nb;
   g->bin_entry16 = shift_max == 16 ? 1 : 0;
-  g->bin_uniform = uniform ? 1 : 0;
+  g->bin_uniform = ushift;
   g->bin_state = 1;
   return GRX_SUCCESS;
 }
@@ -1034,6 +1041,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.n_gran = g->bin_ngran;
     bn.nb = g->bin_nb;
     bn.uniform = g->bin_uniform;
+    bn.sweep_balance = env_int("GRX_SW2_BALANCE", 0);  // measured slower (profiles/r5_c7_kernel_times_by_bin_cut.txt): off
     bn.xcc_mask = ctx->xcc_mask;
     bn.n_xcd = ctx->n_xcd;
     // The slice-wise claim (GRX_BIN_CLAIM=2) pays one scattered L2 access per id that is new to its 8192-entry
@@ -1093,7 +1101,8 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       // as the first version: a bin with more than 1/160 of the level's candidates is cut into parts, the grid is twice the
       // resident workgroups (the second half starts as the first finishes)
       grid_sweep3 = ctx->num_cus * 2;
-      bn.sweep_items = env_int("GRX_SW2_ITEMS", bn.nb + 160);
+      // (round 5: with balanced parts the whole chip, one item per CU; before: bins + 160, which came out as ~210 items)
+      bn.sweep_items = env_int("GRX_SW2_ITEMS", bn.sweep_balance ? std::max(ctx->num_cus, bn.nb + 32) : bn.nb + 160);
       if (bn.sweep_items > grid_sweep3) bn.sweep_items = grid_sweep3;
     }
   }

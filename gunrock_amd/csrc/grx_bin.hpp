@@ -67,7 +67,8 @@ struct bin_args {
   long long* debug;           // tuning aid (GRX_BIN_DEBUG=<level>): 8 words per workgroup and phase for that level, else null
   int32_t debug_level;
   int32_t allowed;            // this launch group carries the scatter / sweep kernels
-  int32_t uniform;            // every bin is the aligned 65536-vertex range [b << 16, (b + 1) << 16): bin and offset are the halves of the id
+  int32_t uniform;            // > 0: every bin is the aligned range [b << uniform, (b + 1) << uniform) (13 .. 16): bin = id >> uniform
+  int32_t sweep_balance;      // second sweep: size the parts so that a level is cut into sweep_items items (GRX_SW2_BALANCE)
   int32_t no_level;           // ... and NO level kernel (exact schedule of a repeated search): a level that is not over plans mode 2
   int32_t max_degree;         // ... and whose frontier averages at most this many out-edges per vertex
   int32_t mid_v, mid_e;       // thresholds of the many-levels-per-launch body (grx_mid.hpp), 0: off (carried here for the head kernel)
@@ -657,7 +658,7 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
   }
   if (tid == 0) sm.pre[BIN_MAX] = tot_items;
   __syncthreads();
-  int n_list = 0;  // uniform: entries waiting in sm.list (labels already stored)
+  int n_list = 0;  // uniform: entries waiting in sm.list (their labels are stored when they are emitted)
   const int4* src4 = reinterpret_cast<const int4*>(bn.bins);
   for (int item = (int)blockIdx.x; item < tot_items; item += (int)gridDim.x) {
     int b = 0;  // largest b with pre[b] <= item (bins without items are skipped over)
@@ -829,7 +830,7 @@ struct bin_scatter2_smem {
   int delta[BIN_MAX];
   int btot;
   int tick[4];                                 // units of the pipeline stages (tick[3]: the stage entering next)
-  alignas(4) unsigned short g2b[BIN_GRAN_MAX]; // granule -> bin | granule index inside the bin << 8 (loaded as 32-bit words)
+  unsigned g2d[BIN_GRAN_MAX];                  // granule -> (bin << BSHIFT) - first vertex of the bin: entry = id + g2d[granule of id]
   alignas(8) unsigned char own[SC2_Q][CHUNK];  // owner map: staged slot of every atom of the four chunks (8 bytes per thread)
   alignas(16) unsigned sorted[SC2_Q * CHUNK];  // (bin << 24 | offset inside the bin), grouped by bin
 };
@@ -854,7 +855,9 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
   static_assert(!VAL || E16, "values travel with 16-bit offsets");
   static_assert(!UNI || (E16 && !VAL), "uniform bins: 16-bit offsets, no values");
   constexpr int BBITS = VAL ? 10 : 8;    // bits of a bin index in the granule table
-  constexpr int BSHIFT = UNI ? 16 : (VAL ? 14 : 24);  // ... and where it sits in a sorted entry (above the offset inside the bin)
+  constexpr int BSHIFT_C = VAL ? 14 : 24;  // ... and where it sits in a sorted entry (above the offset inside the bin)
+  const int BSHIFT = UNI ? bn.uniform : BSHIFT_C;   // (UNI: a uniform run-time shift, the entry is the id)
+  const unsigned umask = (1u << (UNI ? bn.uniform : 16)) - 1u;
   constexpr unsigned BMASK = (1u << BBITS) - 1u;
   // DBG (GRX_BIN_DEBUG, its own kernel build): wave 0's clock at the end of every phase, summed per workgroup
   long long dbg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_t = 0, dbg_t0 = 0;
@@ -877,8 +880,14 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
   const int gshift = bn.gshift;
   const unsigned gmask = (1u << gshift) - 1u;
   if constexpr (!UNI) {
-    for (int w = tid; w < (bn.n_gran + 1) / 2; w += SC2_BLOCK)
-      reinterpret_cast<unsigned*>(sm.g2b)[w] = reinterpret_cast<const unsigned*>(bn.g2b16)[w];
+    // Round 5: the table holds, per granule, what turns an id into its sorted entry with ONE addition -- (bin << BSHIFT) minus
+    // the bin's first vertex: id + that = bin << BSHIFT | offset inside the bin (offsets stay below 2^16 <= 2^BSHIFT, nothing
+    // carries).  The 16-bit table of round 3 (bin | granule index inside the bin) cost two masks, two shifts and an or3 per edge
+    // behind the same LDS read; the scatter is bound by its instruction count (profiles/r5_c4_*).
+    for (int gi = tid; gi < bn.n_gran; gi += SC2_BLOCK) {
+      const unsigned t = bn.g2b16[gi];
+      sm.g2d[gi] = ((t & BMASK) << BSHIFT_C) - ((unsigned)(gi - (int)(t >> BBITS)) << gshift);
+    }
   }
   const int sub_shift = bn.sub_shift;                     // 2: four sub-counters per bin, 0: one
   const int sub_mask = (1 << sub_shift) - 1;
@@ -1091,16 +1100,15 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
         // the entry is the id: bin = id >> 16 (a lane past the end holds column 0's id: a valid bin, counted as 0)
 #pragma unroll
         for (int k = 0; k < ADV_ITEMS; ++k)
-          r_k[k] = atomicAdd(&sm.hist[((e_k[k] >> 16) << sub_shift) | (unsigned)(lane & sub_mask)], (k * TILE + tq) < n_at ? 1 : 0);
+          r_k[k] = atomicAdd(&sm.hist[((e_k[k] >> BSHIFT) << sub_shift) | (unsigned)(lane & sub_mask)], (k * TILE + tq) < n_at ? 1 : 0);
       } else {
         unsigned t_k[ADV_ITEMS];
 #pragma unroll
-        for (int k = 0; k < ADV_ITEMS; ++k) t_k[k] = sm.g2b[e_k[k] >> gshift];
+        for (int k = 0; k < ADV_ITEMS; ++k) t_k[k] = sm.g2d[e_k[k] >> gshift];
 #pragma unroll
         for (int k = 0; k < ADV_ITEMS; ++k) {
-          const unsigned bb = t_k[k] & BMASK;
-          e_k[k] = (bb << BSHIFT) | ((t_k[k] >> BBITS) << gshift) | (e_k[k] & gmask);
-          r_k[k] = atomicAdd(&sm.hist[(bb << sub_shift) | (unsigned)(lane & sub_mask)], (k * TILE + tq) < n_at ? 1 : 0);
+          e_k[k] += t_k[k];
+          r_k[k] = atomicAdd(&sm.hist[((e_k[k] >> BSHIFT_C) << sub_shift) | (unsigned)(lane & sub_mask)], (k * TILE + tq) < n_at ? 1 : 0);
         }
       }
     }
@@ -1228,7 +1236,8 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       for (int k = 0; k < ADV_ITEMS; ++k) {
         const int i = k * SC2_BLOCK + tid;
         if (i < btot) {
-          if constexpr (E16) reinterpret_cast<unsigned short*>(bn.bins)[(size_t)(d_k[k] + i)] = (unsigned short)(s_k[k] & 0xffffu);
+          if constexpr (UNI) reinterpret_cast<unsigned short*>(bn.bins)[(size_t)(d_k[k] + i)] = (unsigned short)(s_k[k] & umask);
+          else if constexpr (E16) reinterpret_cast<unsigned short*>(bn.bins)[(size_t)(d_k[k] + i)] = (unsigned short)(s_k[k] & 0xffffu);
           else bn.bins[(size_t)(d_k[k] + i)] = (int)(s_k[k] & 0xffffffu);
         }
       }
@@ -1298,8 +1307,13 @@ struct bin_sweep2_smem {
 
 // Emit list[0 .. n) as ceil(n / TILE) tiles of parity q (only the last one may be short) with their entries of the next
 // level's chunk map and their share of its counters (see sweep_emit).  Block-wide call.
+// label != nullptr (round 5): the labels of the emitted vertices are stored HERE, label[v] = depth, from the list -- lanes on
+// consecutive list entries, i.e. on ascending vertex ids a few apart (~10 cache lines per store instruction); the expansion
+// that built the list used to store them itself, one thread per BYTE of the bitmap (lanes 32 bytes of labels apart: a
+// store instruction touched up to 32 lines, eight of them per segment and thread).
 template <int NT, class S>
-__device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q, S& sm, int n) {
+__device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q, S& sm, int n, int32_t* label = nullptr,
+                                            int depth = 0) {
   static_assert(S::MAX_TILES <= 64, "one lane per tile of an emission");
   constexpr int PASSES = (S::LIST + NT - 1) / NT;
   constexpr int G = 3;  // passes whose row-offset loads travel together (6 measured equal: round 4, call 18)
@@ -1355,8 +1369,13 @@ __device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q
   // frontier slots first (they need only the tile base, which arrived with the row offsets): the reservation of the
   // chunk-map entries is on its way meanwhile
   const int base = __hip_atomic_load(&sm.tile_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  for (int idx = tid; idx < k * TILE; idx += NT)
-    a.frontier[q][(unsigned)((base + (idx >> 8)) * TILE + (idx & (TILE - 1)))] = idx < n ? sm.list[idx] : -1;
+  for (int idx = tid; idx < k * TILE; idx += NT) {
+    const int x = idx < n ? sm.list[idx] : -1;
+    a.frontier[q][(unsigned)((base + (idx >> 8)) * TILE + (idx & (TILE - 1)))] = x;
+    // (behind every load of the emission: nothing waits for these stores.  Inside the gather loop above they sat between the
+    // row-offset loads and the wave sums, whose wait then covered them too: emission 10 -> 21 us on the 31 M-edge level)
+    if (label && x >= 0) label[x] = depth;  // exactly one winner per vertex (bfs.hxx:117-119 assigns the same depth)
+  }
   __syncthreads();
   for (int t = tid; t < k; t += NT) {
     const int tot = sm.ttot[t];
@@ -1418,16 +1437,34 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
   }
   // every bin rounds its number of parts up: total / (sweep_items - nb) per part keeps the item count within sweep_items
   const int parts = max(1, bn.sweep_items - bn.nb);
-  const int PART = max(SW2_PART_MIN, ((tot_fill / parts) + 4) & ~3);
+  int PART = max(SW2_PART_MIN, ((tot_fill / parts) + 4) & ~3);  // never more than sweep_items items: every bin rounds up once
   int tot_items;
-  const int ex0 = dev::block_exclusive_sum<NT>((fill + PART - 1) / PART, sm.wave, &tot_items);
+  int ex0 = dev::block_exclusive_sum<NT>((fill + PART - 1) / PART, sm.wave, &tot_items);
+  // BALANCE (round 5).  That bound is loose -- most bins hold less than one part and still count as an item -- so the level
+  // came out as ~210 items on 256 CUs with the hot bins' parts a third larger than the mean, and a sweep is as slow as its
+  // largest item.  Aim at sweep_items exactly: start from the mean, grow the part until the count fits (two or three block
+  // scans, ~0.4 us each, the same in every workgroup).
+  if (bn.sweep_balance && tot_items < bn.sweep_items) {
+    int p2 = max(SW2_PART_MIN, ((tot_fill / bn.sweep_items) + 4) & ~3);
+    for (int it = 0; it < 4 && p2 < PART; ++it) {
+      int n2;
+      const int e2 = dev::block_exclusive_sum<NT>((fill + p2 - 1) / p2, sm.wave, &n2);
+      if (n2 <= bn.sweep_items) {
+        PART = p2;
+        tot_items = n2;
+        ex0 = e2;
+        break;
+      }
+      p2 = (int)(((long long)p2 * n2 / bn.sweep_items + 64) & ~3ll);  // (uniform: every thread holds the same counts)
+    }
+  }
   if (tid < BIN_MAX) {
     sm.pre[tid] = ex0;
     sm.fillv[tid] = fill;
   }
   if (tid == 0) sm.pre[BIN_MAX] = tot_items;
   __syncthreads();
-  int n_list = 0;  // uniform: entries waiting in sm.list (labels already stored)
+  int n_list = 0;  // uniform: entries waiting in sm.list (their labels are stored when they are emitted)
   const int4* src4 = reinterpret_cast<const int4*>(bn.bins);
   for (int item = (int)blockIdx.x; item < tot_items; item += (int)gridDim.x) {
     tid = tid0;
@@ -1584,7 +1621,7 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
     auto emit_list = [&](bool all) {
       const int k = all ? (n_list + TILE - 1) / TILE : n_list / TILE;
       const int n_emit = all ? n_list : k * TILE;
-      sweep2_emit<NT>(a, c, q, sm, n_emit);
+      sweep2_emit<NT>(a, c, q, sm, n_emit, bn.dist, depth);  // (the labels of the emitted vertices are stored there)
       const int rem = n_list - n_emit;
       int keep = 0;
       if (tid < rem) keep = sm.list[n_emit + tid];
@@ -1593,7 +1630,36 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
       n_list = rem;
       __syncthreads();
     };
-    for (int s0 = 0; s0 < words; s0 += S::SEG_WORDS) {
+    // ONE SHOT (round 5) when the item's discoveries fit the list behind what is waiting there: a thread takes wpt
+    // consecutive words, one block scan gives every thread its place, and the bits become ids in LDS only -- three barriers
+    // per item.  The segment loop below (a block scan and three barriers per 8192 vertices of the bin's range, eight rounds
+    // for a 65536-vertex bin whatever they hold) remains for items that overflow the list.
+    bool expanded = false;
+    {
+      const int wpt = (words + NT - 1) / NT;  // uniform, <= 4
+      const int w0 = tid * wpt;
+      int cnt = 0;
+      for (int j = 0; j < wpt; ++j) cnt += (w0 + j) < words ? __popc(sm.bm[w0 + j]) : 0;
+      int tot;
+      const int ex = dev::block_exclusive_sum<NT>(cnt, sm.wave, &tot);
+      if (tot == 0) {
+        expanded = true;
+      } else if (n_list + tot <= S::LIST) {
+        int pos = n_list + ex;
+        for (int j = 0; j < wpt; ++j) {
+          unsigned word = (w0 + j) < words ? sm.bm[w0 + j] : 0u;
+          const int v_first = vbase + ((w0 + j) << 5);
+          while (word) {
+            sm.list[pos++] = v_first + __ffs(word) - 1;
+            word &= word - 1u;
+          }
+        }
+        n_list += tot;
+        expanded = true;
+        __syncthreads();
+      }
+    }
+    for (int s0 = 0; s0 < words && !expanded; s0 += S::SEG_WORDS) {
       const int w = s0 + (tid >> 2);
       unsigned byte = w < words ? (sm.bm[w] >> ((tid & 3) * 8)) & 0xffu : 0u;
       int tot;
@@ -1603,10 +1669,8 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
       int pos = n_list + ex;
       const int v_first = vbase + (w << 5) + (tid & 3) * 8;
       while (byte) {
-        const int v = v_first + __ffs(byte) - 1;
+        sm.list[pos++] = v_first + __ffs(byte) - 1;
         byte &= byte - 1u;
-        sm.list[pos++] = v;
-        bn.dist[v] = depth;  // exactly one winner per vertex (bfs.hxx:117-119 assigns the same depth)
       }
       n_list += tot;
       __syncthreads();

@@ -199,7 +199,7 @@ struct grx_graph {
   std::atomic<uint64_t> bin_exact{0};
   std::atomic<int32_t> pr_iter_hint{0};  // iterations of the previous PageRank run on this handle: its first blind batch (grx_pr.hip)
   int32_t bin_entry16 = 0;      // every bin spans <= 65536 vertices: offsets inside a bin fit 16-bit entries
-  int32_t bin_uniform = 0;      // ... and every bin IS an aligned 65536-vertex range (bin = id >> 16)
+  int32_t bin_uniform = 0;      // > 0: every bin IS the aligned range of 2^bin_uniform vertices (bin = id >> bin_uniform)
   int32_t bin_state = 0;        // 0: not built, 1: usable, 2: not applicable to this graph, 3: a column index lies outside [0, V)
   // binned relaxation of weighted SSSP (grx_relax.hpp), built lazily; owned
   int32_t* rb_off = nullptr;          // off[1025], v0[1025]

@@ -88,15 +88,15 @@ if what & {"bfs", "do", "multi"}:
         bfs_line(G, d, "fwd default", gr.forward)
         bfs_line(G, d, "fwd exact schedule off (GRX_BIN_EXACT=0)", gr.forward, {"GRX_BIN_EXACT": 0})
         bfs_line(G, d, "fwd hints off (every group, all kernels)", gr.forward, {"GRX_BIN_EXACT": 0, "GRX_BIN_HINT": 0, "GRX_GROUP_HINT": 0})
-        bfs_line(G, d, "fwd sweep: 256 items (default bins + 160)", gr.forward, {"GRX_SW2_ITEMS": 256})
         bfs_line(G, d, "fwd default again", gr.forward)
     if "bfs" in what:
-        # the bin table is cut once per graph handle: a fresh handle for the balanced (round-4) cut
-        set_env({"GRX_BIN_UNIFORM": 0})
-        os.environ["GRX_BIN_UNIFORM"] = "0"
-        G2 = gr.build_graph(props, csr, ctx)
-        bfs_line(G2, d, "fwd balanced bins + granule table (GRX_BIN_UNIFORM=0)", gr.forward, {"GRX_BIN_UNIFORM": 0})
-        del G2
+        # the bin table is cut once per graph handle: a fresh handle per cut
+        for label, env in (("fwd uniform bins of 32768 (GRX_BIN_USHIFT=15)", {"GRX_BIN_USHIFT": 15}),
+                           ("fwd balanced bins + granule table (GRX_BIN_UNIFORM=0)", {"GRX_BIN_UNIFORM": 0})):
+            set_env(env)
+            G2 = gr.build_graph(props, csr, ctx)
+            bfs_line(G2, d, label, gr.forward, env)
+            del G2
         bfs_line(G, d, "fwd default, third time", gr.forward)
     if "do" in what:
         bfs_line(G, d, "DO  default", gr.optimized)

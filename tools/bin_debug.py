@@ -38,6 +38,16 @@ for phase, lo in (("scatter", 0), ("claim", 4096)):
     t0 = r[:, 2].min()
     tick_us = 0.01  # wall_clock64: 100 MHz
     print("%s: %d workgroups, span %.1f us" % (phase, len(r), (r[:, 3].max() - t0) * tick_us))
+    if phase == "claim" and (r[:, 7] == -2).all():
+        # the slowest workgroups of the second sweep, phase by phase (a sweep is as slow as its slowest item)
+        m32 = (1 << 32) - 1
+        for q in r[np.argsort(-(r[:, 3] - r[:, 2]))[:6]]:
+            print("  slow wg: xcc %d items %d entries %7d start %.1f busy %.1f us | stream %.1f merge %.1f expand %.1f emit %.1f"
+                  % (q[0], q[1], q[4], (q[2] - t0) * tick_us, (q[3] - q[2]) * tick_us, (q[5] & m32) * tick_us, (q[5] >> 32) * tick_us,
+                     (q[6] & m32) * tick_us, (q[6] >> 32) * tick_us))
+        one = r[r[:, 1] > 0]
+        print("  items %d, entries per item: mean %.0f max %d; busy of workgroups with an item: mean %.1f max %.1f us"
+              % (len(one), one[:, 4].mean(), one[:, 4].max(), ((one[:, 3] - one[:, 2]) * tick_us).mean(), ((one[:, 3] - one[:, 2]) * tick_us).max()))
     for x in sorted(set(r[:, 0].tolist())):
         q = r[r[:, 0] == x]
         dur = (q[:, 3] - q[:, 2]) * tick_us

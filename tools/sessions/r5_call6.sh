@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 5, call 6: uniform bins of 2^k vertices (k by graph size), sweep parts sized to one item per CU
+set -u
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
+T0=$(date +%s); el() { echo "[$(( $(date +%s) - T0 )) s] $*"; }
+timeout 170 python tools/ab_r5.py lj 20 bfs,do,ssspw 2>&1 | grep -v amdgpu.ids > gpurun_out/r5c6_ab_lj.log
+for lv in 1 2; do GRX_BIN_DEBUG=$lv timeout 90 python tools/bin_debug.py lj 2>&1 | grep -v amdgpu.ids | grep -A1 "^scatter\|^claim" | cut -c1-330 >> gpurun_out/r5c6_ab_lj.log; done
+el "ab lj"
+(timeout 300 python -m pytest -q -x -m gpu tests/test_bfs_gpu.py tests/test_target_matrix_gpu.py tests/test_relax_gpu.py --deselect tests/test_bfs_gpu.py::test_full_size_twitter_standin_properties > gpurun_out/r5c6_pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/r5c6_pytest.log)
+el "pytest"
+cut -c1-330 gpurun_out/r5c6_ab_lj.log; tail -12 gpurun_out/r5c6_pytest.log
