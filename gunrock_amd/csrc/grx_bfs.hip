@@ -668,7 +668,14 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
   // 74 uniform bins 82 / 97 (profiles/r5_c7_kernel_times_by_bin_cut.txt).  A hub-heavy range is balanced by the sweep, which
   // cuts a bin with more than its share of a level's candidates into parts.  GRX_BIN_UNIFORM=0: off; GRX_BIN_USHIFT=k: that width.
   int ushift = 0;
-  if (shift_max == 16 && env_int("GRX_BIN_UNIFORM", 0) != 0) {
+  // Which cut: measured both ways on two stand-ins (profiles/r5_c11_kernel_times_delta_table_vs_uniform.txt).  On the LJ stand-in
+  // (14 edges per vertex) the uniform bins save the scatter 10 / 1 us per fat level and cost the sweep 20 / 14: its items are
+  // the parts of 74 fat bins instead of ~214 whole bins of equal capacity -- a third larger at the top, and a part of a
+  // 65536-vertex bin can win more vertices than its list holds.  On the kron stand-in (87 edges per vertex) the scatter is
+  // nearly all of a fat level and the uniform cut wins 13 % of the search (697 -> 611 us).  So: uniform bins for graphs of
+  // >= 32 edges per vertex, the balanced cut below otherwise; GRX_BIN_UNIFORM=0 | 1 forces one.
+  const int uni_env = env_int("GRX_BIN_UNIFORM", -1);
+  if (shift_max == 16 && (uni_env > 0 || (uni_env < 0 && (long long)g->E >= 32ll * g->V))) {
     int k = 16;
     while (k > 13 && k > gshift && (((long long)g->V + (1ll << k) - 1) >> k) < 64) --k;
     const int forced = env_int("GRX_BIN_USHIFT", 0);
