@@ -624,14 +624,15 @@ static int env_int(const char* name, int dflt) {
 // granules with about equal numbers of in-edges -- their capacities, the XCD that claims each
 // bin (longest-processing-time assignment by capacity), the E-entry bin array and the counters.
 static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
+  std::lock_guard<std::recursive_mutex> lk(g->prep_mu);
   if (g->bin_state == 3) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: a column index lies outside [0, V)");
   if (g->bin_state != 0) return GRX_SUCCESS;
-  g->bin_state = 2;  // unusable until proven otherwise
+  lazy_state state(&g->bin_state);  // an error return leaves it at 0 (retried by the next search), done(2) = not applicable
   prep_timer tm("bfs: bin table (granule counts + cut)", ctx->stream);
-  if (g->V <= 0 || g->E <= 0 || ctx->n_xcd < 1) return GRX_SUCCESS;
+  if (g->V <= 0 || g->E <= 0 || ctx->n_xcd < 1) return state.done(2);
   int gshift = BIN_GSHIFT_MIN;
   while (gshift < 31 && (((long long)g->V + (1ll << gshift) - 1) >> gshift) > BIN_GRAN_MAX) ++gshift;
-  if (gshift > BIN_SHIFT_MAX) return GRX_SUCCESS;  // a bin's bitmap slice would not fit the claim kernel's LDS
+  if (gshift > BIN_SHIFT_MAX) return state.done(2);  // a bin's bitmap slice would not fit the claim kernel's LDS
   const int n_gran = (int)(((long long)g->V + (1ll << gshift) - 1) >> gshift);
   // widest bin: 65536 vertices when BIN_MAX such bins cover the graph -- then an offset inside a bin fits 16 bits and the
   // bins are written and streamed as 16-bit entries (second scatter + second sweep) -- else 131072 (32-bit entries)
@@ -641,22 +642,20 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
     if ((n_gran + mw16 - 1) / mw16 <= BIN_MAX - 32 && env_int("GRX_BIN_ENTRY16", 1) != 0) shift_max = 16;
   }
   const int max_width = 1 << (shift_max - gshift);  // granules per bin
-  if ((n_gran + max_width - 1) / max_width > BIN_MAX) return GRX_SUCCESS;
+  if ((n_gran + max_width - 1) / max_width > BIN_MAX) return state.done(2);
   hipStream_t s = ctx->stream;
-  int32_t* d_cnt = nullptr;
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt), BIN_GRAN_MAX * sizeof(int32_t)));
+  dev_scratch cnt_buf;
+  GRX_HIP(cnt_buf.alloc(BIN_GRAN_MAX * sizeof(int32_t)));
+  int32_t* d_cnt = cnt_buf.as<int32_t>();
   GRX_HIP(hipMemsetAsync(d_cnt, 0, BIN_GRAN_MAX * sizeof(int32_t), s));
   hipLaunchKernelGGL(bin_count_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, g->ci, (int64_t)g->E, gshift, n_gran, d_cnt);
   std::vector<int32_t> cnt(BIN_GRAN_MAX);
   GRX_HIP(hipMemcpyAsync(cnt.data(), d_cnt, BIN_GRAN_MAX * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   GRX_HIP(hipStreamSynchronize(s));
-  (void)hipFree(d_cnt);
   long long total = 0;
   for (int i = 0; i < n_gran; ++i) total += cnt[(size_t)i];
-  if (total != (long long)g->E) {
-    g->bin_state = 3;  // reported by every call, not only the first
-    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: a column index lies outside [0, V)");
-  }
+  if (total != (long long)g->E)  // (state 3: reported by every call, not only the first)
+    return state.done(3, fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: a column index lies outside [0, V)"));
   // cut the granule sequence into <= BIN_MAX bins of about `target` in-edges each, no wider than max_width
   std::vector<int> first;  // first granule of each bin
   long long target = (total + 223) / 224;
@@ -701,7 +700,7 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
     target += target / 4 + 1;
   }
   const int nb = (int)first.size();
-  if (nb < 1 || nb > BIN_MAX) return GRX_SUCCESS;
+  if (nb < 1 || nb > BIN_MAX) return state.done(2);
   first.push_back(n_gran);
   std::vector<unsigned char> g2b((size_t)BIN_GRAN_MAX, 0), owner((size_t)BIN_MAX, 0);
   std::vector<int32_t> off((size_t)BIN_MAX + 1, 0), v0((size_t)BIN_MAX + 1, 0);
@@ -740,23 +739,27 @@ static grx_status_t graph_build_bins(grx_context_t ctx, grx_graph_t g) {
       g2b16[(size_t)i] = (unsigned short)(b | ((i - first[(size_t)b]) << 8));
   static_assert((1 << (BIN_SHIFT_MAX - BIN_GSHIFT_MIN)) <= 256, "granule index inside a bin fits 8 bits");
   const size_t tab_bytes = (size_t)BIN_GRAN_MAX + (size_t)BIN_MAX + (size_t)BIN_GRAN_MAX * sizeof(unsigned short);  // g2b, owner, g2b16
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_tab8), tab_bytes));
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->bin_off), 2 * ((size_t)BIN_MAX + 1) * sizeof(int32_t)));  // off, v0
-  GRX_HIP(hipMemcpyAsync(g->bin_tab8, g2b.data(), (size_t)BIN_GRAN_MAX, hipMemcpyHostToDevice, s));
-  GRX_HIP(hipMemcpyAsync(g->bin_tab8 + BIN_GRAN_MAX, owner.data(), (size_t)BIN_MAX, hipMemcpyHostToDevice, s));
+  dev_scratch tab8, offs;  // adopted by the handle once everything has arrived
+  GRX_HIP(tab8.alloc(tab_bytes));
+  GRX_HIP(offs.alloc(2 * ((size_t)BIN_MAX + 1) * sizeof(int32_t)));  // off, v0
+  unsigned char* d_tab8 = tab8.as<unsigned char>();
+  int32_t* d_off = offs.as<int32_t>();
+  GRX_HIP(hipMemcpyAsync(d_tab8, g2b.data(), (size_t)BIN_GRAN_MAX, hipMemcpyHostToDevice, s));
+  GRX_HIP(hipMemcpyAsync(d_tab8 + BIN_GRAN_MAX, owner.data(), (size_t)BIN_MAX, hipMemcpyHostToDevice, s));
   static_assert((BIN_GRAN_MAX + BIN_MAX) % 4 == 0, "the 16-bit table is read as 32-bit words");
-  GRX_HIP(hipMemcpyAsync(g->bin_tab8 + BIN_GRAN_MAX + BIN_MAX, g2b16.data(), (size_t)BIN_GRAN_MAX * sizeof(unsigned short),
+  GRX_HIP(hipMemcpyAsync(d_tab8 + BIN_GRAN_MAX + BIN_MAX, g2b16.data(), (size_t)BIN_GRAN_MAX * sizeof(unsigned short),
                          hipMemcpyHostToDevice, s));
-  GRX_HIP(hipMemcpyAsync(g->bin_off, off.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  GRX_HIP(hipMemcpyAsync(g->bin_off + BIN_MAX + 1, v0.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  GRX_HIP(hipMemcpyAsync(d_off, off.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  GRX_HIP(hipMemcpyAsync(d_off + BIN_MAX + 1, v0.data(), ((size_t)BIN_MAX + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
   GRX_HIP(hipStreamSynchronize(s));
+  g->bin_tab8 = reinterpret_cast<unsigned char*>(tab8.release());
+  g->bin_off = reinterpret_cast<int32_t*>(offs.release());
   g->bin_shift = gshift;
   g->bin_ngran = n_gran;
   g->bin_nb = nb;
   g->bin_entry16 = shift_max == 16 ? 1 : 0;
   g->bin_uniform = ushift;
-  g->bin_state = 1;
-  return GRX_SUCCESS;
+  return state.done(1);
 }
 
 // Workgroups of the per-level kernel: exactly what is RESIDENT (persistent workgroups
@@ -854,7 +857,19 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   if (st != GRX_SUCCESS) return st;
   // bottom-up pays off on low-diameter graphs; with fewer than 4 edges per vertex the
   // frontier never gets heavy enough to switch and the extra per-level kernels only cost
-  const bool dopt = opt.advance_direction == GRX_DIR_OPTIMIZED && variant == 0 && (long long)g->E >= 4ll * g->V;
+  bool dopt = opt.advance_direction == GRX_DIR_OPTIMIZED && variant == 0 && (long long)g->E >= 4ll * g->V;
+  if (dopt) {
+    // in-edges of the bottom-up step: the cached transpose (built on first use).  When it cannot be had -- the stable sort
+    // needs 16-24 transient bytes per edge beside the 4-8 it keeps -- the search runs FORWARD-ONLY instead of failing: same
+    // depths, the reference's own advance direction (the binned levels fall back the same way).
+    st = graph_build_transpose(ctx, g);
+    if (st == GRX_ERROR_OUT_OF_MEMORY) {
+      (void)hipGetLastError();
+      dopt = false;
+    } else if (st != GRX_SUCCESS) {
+      return st;
+    }
+  }
   const size_t bm_words = 4 * (((size_t)g->V + 127) / 128);  // whole 16-byte groups: 64-vertex chunks, uint4 clears
   hipStream_t s = ctx->stream;
   // Forward-only runs on dense graphs keep a visited bitmap too: it pre-filters the label probes of
@@ -904,8 +919,6 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     // Round 4: always the transpose -- built by the stable sort in a few ms, its in-lists hubs first (the likeliest
     // parents are probed first).  GRX_BU_SYMMETRIC_CSR=1: a graph declared symmetric uses its own CSR instead (rounds 1-3),
     // after the claim has been verified against the transpose.
-    st = graph_build_transpose(ctx, g);
-    if (st != GRX_SUCCESS) return st;
     bool use_csr = false;
     if (g->symmetric && env_int("GRX_BU_SYMMETRIC_CSR", 0) != 0) {
       st = graph_is_symmetric(ctx, g, &use_csr);
@@ -920,6 +933,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     d.fbits[1] = d.fbits[0] + bm_words;
     d.fbits[2] = d.fbits[1] + bm_words;
     d.rot3 = 1;
+    std::lock_guard<std::recursive_mutex> lk(g->prep_mu);  // the two per-graph arrays below are built on first use
     if (!g->closed0 || g->closed0_words != (int32_t)bm_words) {
       // static "no in-edges" bitmap, built once per graph and kept in the graph handle
       if (g->closed0) GRX_HIP(hipFree(g->closed0));

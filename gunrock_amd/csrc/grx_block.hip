@@ -870,12 +870,13 @@ grx_status_t grx::blk_prepare(grx_context_t ctx, grx_graph_t g, bool weighted, b
   *usable = false;
   const int k = weighted ? 1 : 0;
   if (blk_env("GRX_BLOCK", GRX_BLOCK_DEFAULT) == 0) return GRX_SUCCESS;
+  std::lock_guard<std::recursive_mutex> lk(g->prep_mu);
   if (g->blk_state[k] == 2) return GRX_SUCCESS;
   if (g->blk_state[k] == 1) { *usable = true; return GRX_SUCCESS; }
-  g->blk_state[k] = 2;
+  lazy_state state(&g->blk_state[k]);  // an error return (a bad GRX_BLOCK_NV, a failed allocation) leaves it at 0: retried
   // road-like: few edges per vertex, and big enough that the level-synchronous search is thousands of launches deep
-  if (g->V < blk_env("GRX_BLOCK_MIN_V", 1 << 16) || (long long)g->E >= 4ll * g->V || g->E <= 0) return GRX_SUCCESS;
-  if (weighted && (!g->w || g->weight_sum < 0.0 || !(g->weight_min >= 0.0f))) return GRX_SUCCESS;
+  if (g->V < blk_env("GRX_BLOCK_MIN_V", 1 << 16) || (long long)g->E >= 4ll * g->V || g->E <= 0) return state.done(2);
+  if (weighted && (!g->w || g->weight_sum < 0.0 || !(g->weight_min >= 0.0f))) return state.done(2);
   const int nv = weighted ? blk_env("GRX_BLOCK_NV_W", 2048) : blk_env("GRX_BLOCK_NV", 4096);
   if (nv != 2048 && nv != 4096 && nv != 8192) return fail(GRX_ERROR_INVALID_ARGUMENT, "GRX_BLOCK_NV: 2048, 4096 or 8192");
   if (weighted && nv == 8192) return fail(GRX_ERROR_INVALID_ARGUMENT, "GRX_BLOCK_NV_W: 2048 or 4096");
@@ -883,11 +884,10 @@ grx_status_t grx::blk_prepare(grx_context_t ctx, grx_graph_t g, bool weighted, b
   bool ok = false;
   grx_status_t st = blk_build(ctx, g, weighted, nv, 3 * nv, &bg, &ok);
   if (st != GRX_SUCCESS) return st;
-  if (!ok) return GRX_SUCCESS;
+  if (!ok) return state.done(2);
   g->blk[k] = bg;
-  g->blk_state[k] = 1;
   *usable = true;
-  return GRX_SUCCESS;
+  return state.done(1);
 }
 
 // One search.  weighted: float labels (d_out: float[V], FLT_MAX unreached), else depths (d_out: int32[V], INT_MAX).

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -163,8 +164,35 @@ struct grx_context {
   std::vector<grx::level_rec> levels;
 };
 
+// A device allocation that lives as long as a scope (scratch of the per-graph builders: an early error return frees it).
+struct dev_scratch {
+  void* p = nullptr;
+  dev_scratch() = default;
+  dev_scratch(const dev_scratch&) = delete;
+  dev_scratch& operator=(const dev_scratch&) = delete;
+  ~dev_scratch() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+  void* release() { void* q = p; p = nullptr; return q; }  // the caller adopts the allocation
+};
+// The state word of a lazily built per-graph structure (0: not built, 1: usable, 2: not applicable, ...) while it is being
+// built under grx_graph::prep_mu: an error return leaves it at 0, so the next call tries again (round 5; it used to be set to
+// "not applicable" up front, and one transient failure disabled the path for the life of the handle).
+struct lazy_state {
+  int32_t* st;
+  bool decided = false;
+  explicit lazy_state(int32_t* s) : st(s) {}
+  ~lazy_state() { if (!decided) *st = 0; }
+  grx_status_t done(int32_t v, grx_status_t rc = GRX_SUCCESS) { *st = v; decided = true; return rc; }
+};
+
 struct grx_graph {
   grx_context_t ctx = nullptr;
+  // Serialises the LAZY per-graph builds (transpose, bin tables, two-neighbour array, pull layouts, block structure, weight
+  // statistics).  Every builder takes it before it looks at its state word, builds into locals and publishes under it, so
+  // two contexts may make their first search on one handle at the same time: one builds, the other finds it built.
+  // (recursive: graph_is_symmetric builds the transpose.)
+  std::recursive_mutex prep_mu;
   int32_t V = 0, E = 0;
   const int32_t* ro = nullptr;
   const int32_t* ci = nullptr;

@@ -630,10 +630,11 @@ static grx_status_t build_pr_partition_device(grx_context_t ctx, const int32_t* 
                                               pr_partition* out, int32_t* list_begin) {
   hipStream_t s = ctx->stream;
   const int cpl = std::max(1, (n_rows + PR_DEV_CHUNK - 1) / PR_DEV_CHUNK), n_chunks = cpl * n_lists;
-  int32_t* cnt = nullptr;
-  int32_t* sums = nullptr;
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&cnt), (size_t)3 * (n_chunks + 1) * sizeof(int32_t)));
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&sums), ((size_t)scan_num_blocks(n_chunks) + 2) * sizeof(int32_t)));
+  dev_scratch cnt_buf, sums_buf, blocks_buf, piece_buf, long_buf;  // (an error return frees what has been allocated so far)
+  GRX_HIP(cnt_buf.alloc((size_t)3 * (n_chunks + 1) * sizeof(int32_t)));
+  GRX_HIP(sums_buf.alloc(((size_t)scan_num_blocks(n_chunks) + 2) * sizeof(int32_t)));
+  int32_t* cnt = cnt_buf.as<int32_t>();
+  int32_t* sums = sums_buf.as<int32_t>();
   pr_pack_args p{};
   p.ro = d_ro; p.list_stride = list_stride; p.n_rows = n_rows; p.n_lists = n_lists; p.chunks_per_list = cpl; p.cnt = cnt;
   const dim3 grid((unsigned)((n_chunks + 63) / 64)), block(64);
@@ -647,36 +648,39 @@ static grx_status_t build_pr_partition_device(grx_context_t ctx, const int32_t* 
   out->n_long = h[(size_t)2 * (n_chunks + 1) + n_chunks];
   if (list_begin)
     for (int l = 0; l <= n_lists; ++l) list_begin[l] = l < n_lists ? h[(size_t)l * cpl] : out->n_blocks;
-  GRX_HIP(hipMalloc(&out->blocks, std::max<size_t>(1, (size_t)out->n_blocks) * sizeof(int4)));
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&out->piece), std::max<size_t>(1, (size_t)out->n_blocks) * sizeof(int32_t)));
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&out->longrows), std::max<size_t>(1, (size_t)out->n_long * 3) * sizeof(int32_t)));
-  p.blocks = reinterpret_cast<int4*>(out->blocks);
-  p.piece = out->piece;
-  p.longrows = out->longrows;
+  GRX_HIP(blocks_buf.alloc(std::max<size_t>(1, (size_t)out->n_blocks) * sizeof(int4)));
+  GRX_HIP(piece_buf.alloc(std::max<size_t>(1, (size_t)out->n_blocks) * sizeof(int32_t)));
+  GRX_HIP(long_buf.alloc(std::max<size_t>(1, (size_t)out->n_long * 3) * sizeof(int32_t)));
+  p.blocks = blocks_buf.as<int4>();
+  p.piece = piece_buf.as<int32_t>();
+  p.longrows = long_buf.as<int32_t>();
   hipLaunchKernelGGL(pr_pack_kernel<1>, grid, block, 0, s, p);
   GRX_HIP(hipStreamSynchronize(s));
-  (void)hipFree(cnt);
-  (void)hipFree(sums);
   GRX_HIP(hipGetLastError());
+  out->blocks = blocks_buf.release();
+  out->piece = reinterpret_cast<int32_t*>(piece_buf.release());
+  out->longrows = reinterpret_cast<int32_t*>(long_buf.release());
   return GRX_SUCCESS;
 }
 
 static grx_status_t build_pr_partition(grx_graph_t g) {
+  std::lock_guard<std::recursive_mutex> lk(g->prep_mu);
   if (g->pr_blocks) return GRX_SUCCESS;
   prep_timer tm("pagerank: static partition (device)", g->ctx->stream);
   pr_partition pt;
   grx_status_t st = build_pr_partition_device(g->ctx, g->t_ro, 0, g->V, 1, &pt, nullptr);
   if (st != GRX_SUCCESS) return st;
-  g->pr_blocks = pt.blocks;
   g->pr_piece = pt.piece;
   g->pr_long = pt.longrows;
   g->n_pr_blocks = pt.n_blocks;
   g->n_pr_pieces = pt.n_pieces;
   g->n_pr_long = pt.n_long;
+  g->pr_blocks = pt.blocks;  // (last: it is what says "built")
   return GRX_SUCCESS;
 }
 
 static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
+  std::lock_guard<std::recursive_mutex> lk(g->prep_mu);  // (has_xb is published last, below)
   if (g->has_xb) return GRX_SUCCESS;
   prep_timer tm("pagerank: XCD-blocked layout (rank + sort + partition)", ctx->stream);
   const int32_t V = g->V;
@@ -699,24 +703,22 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
     prep_timer t0("  xcd layout: hub-first ranking (device sort)", s);
     sort_buffers rb;
     if (rb.alloc(V, false) != hipSuccess) {
-      rb.release();
       (void)hipGetLastError();
       return fail(GRX_ERROR_OUT_OF_MEMORY, "pagerank: scratch for the hub-first ranking");
     }
-    GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_perm), (size_t)V * sizeof(int32_t)));
+    if (!g->xb_perm) GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_perm), (size_t)V * sizeof(int32_t)));  // (kept by a retry)
     hipLaunchKernelGGL(xb_rank_keys_kernel, dim3(1024), dim3(256), 0, s, g->ro, V, rb.keys[0], rb.vals[0]);
     const int rr = radix_sort_pairs(s, rb, 32);
     hipLaunchKernelGGL(xb_rank_perm_kernel, dim3(1024), dim3(256), 0, s, rb.vals[rr], V, per_block, g->xb_perm);
     GRX_HIP(hipStreamSynchronize(s));
     rb.release();
   }
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ro), (n_off + 2) * sizeof(int32_t)));
+  if (!g->xb_ro) GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ro), (n_off + 2) * sizeof(int32_t)));
   const bool unit = graph_unit_weights(g);  // no weight stream needed (graph_weight_stats ran)
   // stable radix sort of the edges by (source block, destination) (grx_sort.hpp): the round 1-3 version counted and filled
   // with one global atomic per edge -- 124 ms for the 182 M edges of the kron stand-in
   sort_buffers sb;
   if ((uint64_t)n_off >= (1ull << 31) || sb.alloc(E, !unit) != hipSuccess) {
-    sb.release();
     (void)hipGetLastError();
     return fail(GRX_ERROR_OUT_OF_MEMORY, "pagerank: scratch for the XCD-blocked layout");
   }
@@ -731,6 +733,9 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   hipLaunchKernelGGL(sort_boundaries_kernel, dim3(2048), dim3(256), 0, s, sb.keys[res], E, 0, (int32_t)n_off, g->xb_ro);
   GRX_HIP(hipStreamSynchronize(s));
   GRX_HIP(hipGetLastError());
+  if (g->xb_ci) (void)hipFree(g->xb_ci);  // (left by an attempt that failed behind this point)
+  if (g->xb_w) (void)hipFree(g->xb_w);
+  g->xb_w = nullptr;
   g->xb_ci = reinterpret_cast<int32_t*>(sb.vals[res]);
   if (!unit) g->xb_w = reinterpret_cast<float*>(sb.vals2[res]);
   sb.release(g->xb_ci, g->xb_w);

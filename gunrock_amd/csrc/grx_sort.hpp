@@ -239,6 +239,10 @@ struct sort_buffers {
   int32_t* hist = nullptr;                  // (1 << SORT_MAX_BITS) * n_tiles + 1 ints, scanned in place
   int32_t* sums = nullptr;                  // block sums of that scan
   int64_t n = 0;
+  sort_buffers() = default;
+  sort_buffers(const sort_buffers&) = delete;
+  sort_buffers& operator=(const sort_buffers&) = delete;
+  ~sort_buffers() { release(); }  // whatever was not adopted by the caller (an early error return included)
   hipError_t alloc(int64_t n_, bool second_value) {
     n = n_;
     const size_t bytes = (size_t)std::max<int64_t>(n, 4) * sizeof(uint32_t);
@@ -259,7 +263,9 @@ struct sort_buffers {
     void* all[] = {keys[0], keys[1], vals[0], vals[1], vals2[0], vals2[1], hist, sums};
     for (void* p : all)
       if (p && p != keep0 && p != keep1 && p != keep2) (void)hipFree(p);
-    *this = sort_buffers();
+    keys[0] = keys[1] = vals[0] = vals[1] = vals2[0] = vals2[1] = nullptr;
+    hist = sums = nullptr;
+    n = 0;
   }
 };
 

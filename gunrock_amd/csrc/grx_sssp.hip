@@ -551,14 +551,20 @@ __global__ void weight_sum_kernel(const float* w, int64_t n, double* out, unsign
 // (the sum every shortest path gives the reference's relaxation, sssp.hxx:121-123).  Depths -> distances, in place (the
 // caller's float buffer held the int32 depths of the BFS engine).  table == nullptr: w is exactly 1.0, the k-fold sum is
 // min(k, 2^24) (16777216 + 1 rounds back to 16777216: the additions stall there, as the reference's do).
-__global__ void sssp_depth_to_dist_kernel(float* dist, int64_t n, const float* table, int32_t table_n) {
+// A depth beyond the table means the search under-reported its depth: the pass then raises mailbox word 10 (the host turns it
+// into an error) instead of returning the last entry's distance for it.
+__global__ void sssp_depth_to_dist_kernel(float* dist, int64_t n, const float* table, int32_t table_n, int32_t* mailbox) {
   int32_t* as_int = reinterpret_cast<int32_t*>(dist);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t k = as_int[i];
     float d = FLT_MAX;  // unreached (sssp.hxx:72-73)
     if (k != INT_MAX) {
-      if (table) d = table[k < table_n ? k : table_n - 1];
-      else d = (float)(k < (1 << 24) ? k : (1 << 24));
+      if (table) {
+        if (k < 0 || k >= table_n) mailbox[10] = 3;
+        d = table[k < 0 ? 0 : (k < table_n ? k : table_n - 1)];
+      } else {
+        d = (float)(k < (1 << 24) ? k : (1 << 24));
+      }
     }
     dist[i] = d;
   }
@@ -572,6 +578,7 @@ using namespace grx;
 // weights are all 1.0 -- what the reference loader makes of a pattern .mtx, io/matrix_market.hxx:170-171
 // -- need no weight stream at all).
 grx_status_t grx::graph_weight_stats(grx_context_t ctx, grx_graph_t g) {
+  std::lock_guard<std::recursive_mutex> lk(g->prep_mu);
   if (g->weight_sum >= 0.0 || !g->w || g->E <= 0) return GRX_SUCCESS;
   GRX_HIP(ctx->misc.reserve(64));
   double* d_sum = reinterpret_cast<double*>(ctx->misc.as<unsigned char>());
@@ -582,12 +589,12 @@ grx_status_t grx::graph_weight_stats(grx_context_t ctx, grx_graph_t g) {
   unsigned char h[16];
   GRX_HIP(hipMemcpyAsync(h, d_sum, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   GRX_HIP(hipStreamSynchronize(ctx->stream));
-  memcpy(&g->weight_sum, h, sizeof(double));
   unsigned lohi[2];
   memcpy(lohi, h + 8, sizeof(lohi));
   g->uniform_weights = lohi[0] == lohi[1];
   memcpy(&g->weight_min, &lohi[0], sizeof(float));
   memcpy(&g->weight_max, &lohi[1], sizeof(float));
+  memcpy(&g->weight_sum, h, sizeof(double));  // (last: weight_sum >= 0 is what says "the statistics are there")
   return GRX_SUCCESS;
 }
 
@@ -600,28 +607,29 @@ static int sssp_env_int(const char* name, int dflt) {
 // in-edges, none wider than RB_WIDTH vertices, at most RB_MAX_BINS of them; capacities = the in-edges of the range (an edge is
 // relaxed at most once per level).  Not applicable (state 2) to graphs beyond RB_MAX_BINS * RB_WIDTH = 16.7 M vertices.
 static grx_status_t graph_build_relax_bins(grx_context_t ctx, grx_graph_t g) {
+  std::lock_guard<std::recursive_mutex> lk(g->prep_mu);
   if (g->rb_state != 0) return GRX_SUCCESS;
-  g->rb_state = 2;
+  lazy_state state(&g->rb_state);  // an error return leaves it at 0 (the next search tries again), done(2) = not applicable
   prep_timer tm("sssp: relax-bin table (granule counts + cut)", ctx->stream);
-  if (g->V <= 0 || g->E <= 0) return GRX_SUCCESS;
+  if (g->V <= 0 || g->E <= 0) return state.done(2);
   int gshift = BIN_GSHIFT_MIN;
   while (gshift < 31 && (((long long)g->V + (1ll << gshift) - 1) >> gshift) > BIN_GRAN_MAX) ++gshift;
-  if (gshift > RB_SHIFT) return GRX_SUCCESS;
+  if (gshift > RB_SHIFT) return state.done(2);
   const int n_gran = (int)(((long long)g->V + (1ll << gshift) - 1) >> gshift);
   const int max_width = 1 << (RB_SHIFT - gshift);  // granules per bin
-  if ((n_gran + max_width - 1) / max_width > RB_MAX_BINS) return GRX_SUCCESS;
+  if ((n_gran + max_width - 1) / max_width > RB_MAX_BINS) return state.done(2);
   hipStream_t s = ctx->stream;
-  int32_t* d_cnt = nullptr;
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt), BIN_GRAN_MAX * sizeof(int32_t)));
+  dev_scratch cnt_buf;
+  GRX_HIP(cnt_buf.alloc(BIN_GRAN_MAX * sizeof(int32_t)));
+  int32_t* d_cnt = cnt_buf.as<int32_t>();
   GRX_HIP(hipMemsetAsync(d_cnt, 0, BIN_GRAN_MAX * sizeof(int32_t), s));
   hipLaunchKernelGGL(bin_count_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, g->ci, (int64_t)g->E, gshift, n_gran, d_cnt);
   std::vector<int32_t> cnt(BIN_GRAN_MAX);
   GRX_HIP(hipMemcpyAsync(cnt.data(), d_cnt, BIN_GRAN_MAX * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   GRX_HIP(hipStreamSynchronize(s));
-  (void)hipFree(d_cnt);
   long long total = 0;
   for (int i = 0; i < n_gran; ++i) total += cnt[(size_t)i];
-  if (total != (long long)g->E) return GRX_SUCCESS;  // a column index outside [0, V): the relax-per-edge path reports it as before
+  if (total != (long long)g->E) return state.done(2);  // a column index outside [0, V): the relax-per-edge path reports it as before
   std::vector<int> first;
   const int want_bins = std::max(1, std::min(RB_MAX_BINS, sssp_env_int("GRX_RBIN_BINS", 448)));  // (tuning aid; read when the table is built)
   long long target = (total + want_bins - 1) / want_bins;
@@ -639,7 +647,7 @@ static grx_status_t graph_build_relax_bins(grx_context_t ctx, grx_graph_t g) {
     target += target / 4 + 1;
   }
   const int nb = (int)first.size();
-  if (nb < 1 || nb > RB_MAX_BINS) return GRX_SUCCESS;
+  if (nb < 1 || nb > RB_MAX_BINS) return state.done(2);
   first.push_back(n_gran);
   std::vector<int32_t> offv0(2 * ((size_t)RB_MAX_BINS + 1), 0);
   int32_t* off = offv0.data();
@@ -659,16 +667,18 @@ static grx_status_t graph_build_relax_bins(grx_context_t ctx, grx_graph_t g) {
     }
   }
   static_assert(RB_MAX_BINS <= 1024 && (1 << (RB_SHIFT - BIN_GSHIFT_MIN)) <= 64, "bin | granule index fit 16 bits");
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->rb_off), offv0.size() * sizeof(int32_t)));
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->rb_g2b16), (size_t)BIN_GRAN_MAX * sizeof(unsigned short)));
-  GRX_HIP(hipMemcpyAsync(g->rb_off, offv0.data(), offv0.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  GRX_HIP(hipMemcpyAsync(g->rb_g2b16, g2b16.data(), (size_t)BIN_GRAN_MAX * sizeof(unsigned short), hipMemcpyHostToDevice, s));
+  dev_scratch d_off, d_tab;  // adopted by the handle once everything has arrived
+  GRX_HIP(d_off.alloc(offv0.size() * sizeof(int32_t)));
+  GRX_HIP(d_tab.alloc((size_t)BIN_GRAN_MAX * sizeof(unsigned short)));
+  GRX_HIP(hipMemcpyAsync(d_off.p, offv0.data(), offv0.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  GRX_HIP(hipMemcpyAsync(d_tab.p, g2b16.data(), (size_t)BIN_GRAN_MAX * sizeof(unsigned short), hipMemcpyHostToDevice, s));
   GRX_HIP(hipStreamSynchronize(s));
+  g->rb_off = reinterpret_cast<int32_t*>(d_off.release());
+  g->rb_g2b16 = reinterpret_cast<unsigned short*>(d_tab.release());
   g->rb_shift = gshift;
   g->rb_ngran = n_gran;
   g->rb_nb = nb;
-  g->rb_state = 1;
-  return GRX_SUCCESS;
+  return state.done(1);
 }
 
 static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, const grx_options_t& opt,
@@ -878,6 +888,10 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
 static grx_status_t sssp_uniform_as_bfs(grx_context_t ctx, grx_graph_t g, int32_t src, const grx_options_t& opt,
                                         float* d_dist, float w, float* elapsed_ms) {
   grx_options_t bo = opt;
+  // only the bits the BFS engine knows: the SSSP schedule bits 0x10 .. 0x80 mean nothing to it, and bits 0x100 .. 0x700 select
+  // its kernel VARIANT
+  bo.engine_flags &= (GRX_FLAG_UNFUSED | GRX_FLAG_PROFILE | GRX_FLAG_SYNC_EACH_LEVEL | GRX_FLAG_ASYNC_RETURN | GRX_FLAG_LB_STRICT |
+                      GRX_FLAG_NO_BLOCK_ASYNC);
   // The search returns the moment the device has published its end (paced searches: depth and counters come with the flag
   // through the mailbox, which is all the table of a non-unit weight needs); the conversion pass is queued behind it at once
   // and THIS call blocks once, on the pass -- not twice (0.517 -> 0.49 ms on the LJ stand-in).  GRX_SSSP_BFS_ASYNC=0: the
@@ -912,9 +926,14 @@ static grx_status_t sssp_uniform_as_bfs(grx_context_t ctx, grx_graph_t g, int32_
   }
   hipEvent_t e0 = ctx->ev_begin, e1 = ctx->ev_end;
   GRX_HIP(hipEventRecord(e0, s));
-  hipLaunchKernelGGL(sssp_depth_to_dist_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, s, d_dist, (int64_t)g->V, d_table, table_n);
+  hipLaunchKernelGGL(sssp_depth_to_dist_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, s, d_dist, (int64_t)g->V, d_table, table_n,
+                     ctx->d_mailbox);
   GRX_HIP(hipEventRecord(e1, s));
   GRX_HIP(hipEventSynchronize(e1));
+  if (ctx->h_mailbox[10] == 3) {
+    ctx->h_mailbox[10] = 0;
+    return fail(GRX_ERROR_HIP, "grx_sssp: a depth beyond the reported search depth (uniform weights on the BFS engine)");
+  }
   float conv_ms = 0.0f;
   GRX_HIP(hipEventElapsedTime(&conv_ms, e0, e1));
   ctx->stats.elapsed_ms = bfs_ms + conv_ms;  // enact() scope: the search and the pass that writes the distances

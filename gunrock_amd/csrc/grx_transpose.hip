@@ -76,20 +76,21 @@ __global__ void sym_compare_rows_kernel(const int32_t* __restrict__ ro, const in
 using namespace grx;
 
 grx_status_t grx::graph_is_symmetric(grx_context_t ctx, grx_graph_t g, bool* result) {
+  std::lock_guard<std::recursive_mutex> lk(g->prep_mu);
   if (g->sym_checked == 0) {
     grx_status_t st = graph_build_transpose(ctx, g);  // needed anyway when the answer is "no"
     if (st != GRX_SUCCESS) return st;
     const int32_t V = g->V;
     hipStream_t s = ctx->stream;
     prep_timer tm("symmetry check (row hashes, CSR against transpose)", s);
-    int32_t* bad = nullptr;
-    GRX_HIP(hipMalloc(reinterpret_cast<void**>(&bad), sizeof(int32_t)));
+    dev_scratch bad_buf;
+    GRX_HIP(bad_buf.alloc(sizeof(int32_t)));
+    int32_t* bad = bad_buf.as<int32_t>();
     GRX_HIP(hipMemsetAsync(bad, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(sym_compare_rows_kernel, dim3(2048), dim3(256), 0, s, g->ro, g->ci, g->t_ro, g->t_ci, V, bad);
     int32_t hb = 0;
     GRX_HIP(hipMemcpyAsync(&hb, bad, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     GRX_HIP(hipStreamSynchronize(s));
-    (void)hipFree(bad);
     GRX_HIP(hipGetLastError());
     g->sym_checked = hb ? 2 : 1;
   }
@@ -98,6 +99,9 @@ grx_status_t grx::graph_is_symmetric(grx_context_t ctx, grx_graph_t g, bool* res
 }
 
 grx_status_t grx::graph_build_transpose(grx_context_t ctx, grx_graph_t g) {
+  // (round 5) under the handle's build lock, into locals, published together at the end: a second context that makes its
+  // first search meanwhile finds either nothing or the finished transpose, and an error return leaves nothing behind.
+  std::lock_guard<std::recursive_mutex> lk(g->prep_mu);
   if (g->has_transpose) return GRX_SUCCESS;
   const int32_t V = g->V;
   const int64_t E = g->E;
@@ -105,19 +109,25 @@ grx_status_t grx::graph_build_transpose(grx_context_t ctx, grx_graph_t g) {
   prep_timer tm("transpose (expand + radix sort + offsets)", s);
   const bool weighted = g->w != nullptr;
   if (V >= (1 << 29)) return fail(GRX_ERROR_UNSUPPORTED, "transpose: more than 2^29 vertices");
-  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->t_ro), ((size_t)V + 2) * sizeof(int32_t)));
+  // test aid: GRX_TR_FAIL_ALLOC=1 makes the build fail as an out-of-memory condition would (what callers fall back on)
+  if (const char* e = getenv("GRX_TR_FAIL_ALLOC"); e && *e == '1') return fail(GRX_ERROR_OUT_OF_MEMORY, "transpose: scratch for the sort (forced)");
+  dev_scratch t_ro, t_ci, t_w;
+  if (t_ro.alloc(((size_t)V + 2) * sizeof(int32_t)) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(GRX_ERROR_OUT_OF_MEMORY, "transpose: offsets");
+  }
   if (E <= 0) {
-    GRX_HIP(hipMemsetAsync(g->t_ro, 0, ((size_t)V + 2) * sizeof(int32_t), s));
-    GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->t_ci), sizeof(int32_t)));
-    if (weighted) GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->t_w), sizeof(float)));
+    GRX_HIP(hipMemsetAsync(t_ro.p, 0, ((size_t)V + 2) * sizeof(int32_t), s));
+    GRX_HIP(t_ci.alloc(sizeof(int32_t)));
+    if (weighted) GRX_HIP(t_w.alloc(sizeof(float)));
+    GRX_HIP(hipStreamSynchronize(s));
   } else {
     // STABLE radix sort of the edges by (destination, hub tier of the source): no atomic decides an order, so the
     // transpose -- and every fp32 sum taken over a column -- is the same on every run and every handle (grx_sort.hpp)
-    sort_buffers sb;
+    sort_buffers sb;  // (frees what is not adopted below when it goes out of scope)
     {
       prep_timer t0("  transpose: scratch allocation", s);
       if (sb.alloc(E, weighted) != hipSuccess) {
-        sb.release();
         (void)hipGetLastError();
         return fail(GRX_ERROR_OUT_OF_MEMORY, "transpose: scratch for the sort");
       }
@@ -135,14 +145,17 @@ grx_status_t grx::graph_build_transpose(grx_context_t ctx, grx_graph_t g) {
       prep_timer t2("  transpose: radix sort", s);
       res = radix_sort_pairs(s, sb, bits_for((uint64_t)V) + 2);
     }
-    hipLaunchKernelGGL(sort_boundaries_kernel, dim3(2048), dim3(256), 0, s, sb.keys[res], E, 2, V, g->t_ro);
+    hipLaunchKernelGGL(sort_boundaries_kernel, dim3(2048), dim3(256), 0, s, sb.keys[res], E, 2, V, t_ro.as<int32_t>());
     GRX_HIP(hipStreamSynchronize(s));
     GRX_HIP(hipGetLastError());
-    g->t_ci = reinterpret_cast<int32_t*>(sb.vals[res]);  // the sorted sources ARE the column array
-    if (weighted) g->t_w = reinterpret_cast<float*>(sb.vals2[res]);
-    sb.release(g->t_ci, g->t_w);
+    t_ci.p = sb.vals[res];  // the sorted sources ARE the column array
+    if (weighted) t_w.p = sb.vals2[res];
+    sb.release(t_ci.p, t_w.p);
   }
   // (the host copy of the offsets is taken by the one consumer that needs it: PageRank's static partition)
+  g->t_ro = reinterpret_cast<int32_t*>(t_ro.release());
+  g->t_ci = reinterpret_cast<int32_t*>(t_ci.release());
+  g->t_w = reinterpret_cast<float*>(t_w.release());
   g->has_transpose = true;
   return GRX_SUCCESS;
 }

@@ -100,7 +100,7 @@ typedef struct grx_options {
                                         With this flag and MERGE_PATH every level runs the chunked merge-path advance (the
                                         reference pipeline of BASELINE configs[1] as written); with BLOCK_MAPPED the
                                         block-staged bodies are preferred wherever the frontier fits them */
-#define GRX_FLAG_NO_BLOCK_ASYNC 0x2000 /* road-like graphs: keep the level-synchronous kernels (see grx_get_block_stats) */
+#define GRX_FLAG_NO_BLOCK_ASYNC 0x2000 /* with GRX_BLOCK=1 (opt-in): keep the level-synchronous kernels for this call (see grx_get_block_stats) */
 #define GRX_FLAG_ASYNC_RETURN 0x8    /* grx_bfs may return as soon as the device has PUBLISHED the end
                                         of the search (results final) instead of after its stream drained;
                                         see grx_bfs.  Off by default: the reference's run() returns after a
@@ -237,8 +237,10 @@ typedef struct grx_run_stats {
 } grx_run_stats_t;
 grx_status_t grx_get_run_stats(grx_context_t ctx, grx_run_stats_t* out);
 
-/* Road-like graphs (fewer than 4 edges per vertex, >= 65536 vertices) are searched BLOCK-ASYNCHRONOUSLY by default
- * (gunrock_amd/csrc/grx_block.hip; GRX_FLAG_NO_BLOCK_ASYNC / GRX_BLOCK=0: the level-synchronous kernels): blocks of a few
+/* OPT-IN (environment GRX_BLOCK=1; the default is the level-synchronous kernels, which measured as fast or faster --
+ * DESIGN.md, "block-asynchronous relaxation"): road-like graphs (fewer than 4 edges per vertex, >= 65536 vertices) are then
+ * searched BLOCK-ASYNCHRONOUSLY (gunrock_amd/csrc/grx_block.hip; GRX_FLAG_NO_BLOCK_ASYNC keeps the level-synchronous kernels
+ * for one call even with GRX_BLOCK=1, and does nothing without it): blocks of a few
  * thousand vertices relax to their local fixed point in LDS, supersteps synchronise only between blocks, global buckets
  * keep wrong labels from flooding.  Statistics of the last such search on the context (supersteps == 0: the last search
  * took another path).  For these searches grx_run_stats_t::edges_visited is the reference's count for BFS (out-edges of

@@ -268,6 +268,44 @@ def test_binned_kernels_follow_the_previous_search(gr, gpu_ctx, monkeypatch):
     assert sum(1 for l in gr.level_profile(gpu_ctx) if l["bottom_up"] == 2) >= binned[hub][1]
 
 
+def test_exact_schedule_of_a_repeated_source_and_uniform_bins(gr, gpu_ctx, monkeypatch):
+    """Round 5.  (a) A forward search from the SAME source as the last one on the handle launches exactly the kernels that search
+    needed (grx_graph::bin_exact: fat groups without a level kernel, thin groups without scatter + sweep); a prediction that no
+    longer holds -- the binning threshold moved between two searches -- must only be slow: a thin level in a group without a
+    level kernel is binned, a fat one in a group without the two kernels runs on the claim-per-edge advance.  (b) Both bin cuts
+    -- the balanced one with its granule table and the uniform 2^k-vertex ranges (bin = id >> k) -- give the oracle's depths."""
+    import torch
+    _, c = gr.generate("rmat_sym", 1 << 19, 9_000_000, seed=5)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    deg = np.diff(g.row_offsets)
+    hub = int(np.argmax(deg))
+    other = int(np.nonzero(deg == 2)[0][0])
+    want = {s: O.bfs_queue(g, s) for s in (hub, other)}
+    dist = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda:0")
+    for uniform in ("0", "1"):
+        monkeypatch.setenv("GRX_BIN_UNIFORM", uniform)
+        monkeypatch.setenv("GRX_BIN_MIN_EDGES", "200000")
+        G = gr.build_graph(gr.graph_properties_t(directed=True, weighted=False, symmetric=False),
+                           gr.csr_t.from_arrays(g.row_offsets, g.column_indices, None), gpu_ctx)
+        launches = []
+        for src, flags, min_edges in ((hub, 0, 200000), (hub, gr.FLAG_ASYNC_RETURN, 200000), (hub, 0, 200000),
+                                      (hub, 0, 1 << 30),          # nothing is fat any more: the fat groups bin thin levels
+                                      (hub, 0, 1 << 30), (hub, 0, 20000),  # more levels fat than predicted
+                                      (hub, 0, 20000), (other, 0, 20000), (hub, 0, 20000), (hub, gr.FLAG_PROFILE, 20000), (hub, 0, 20000)):
+            monkeypatch.setenv("GRX_BIN_MIN_EDGES", str(min_edges))
+            gr.bfs(G, src, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.forward, engine_flags=flags))
+            gpu_ctx.synchronize()
+            assert np.array_equal(dist.cpu().numpy(), want[src][0]), (uniform, src, flags, min_edges)
+            st = gr.run_stats(gpu_ctx)
+            assert st["edges_visited"] == want[src][2]
+            launches.append(int(st["aux"]))
+        monkeypatch.setenv("GRX_BIN_EXACT", "0")
+        gr.bfs(G, hub, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.forward))
+        assert np.array_equal(dist.cpu().numpy(), want[hub][0])
+        monkeypatch.delenv("GRX_BIN_EXACT")
+        del G
+
+
 def test_symmetric_property_is_verified(gr, gpu_ctx, monkeypatch):
     """graph_properties_t defaults to symmetric=true (inert in the reference).  Round 4: the bottom-up step always reads the
     transpose (stable sort, hubs first); with GRX_BU_SYMMETRIC_CSR=1 a graph declared symmetric uses its own CSR as the
@@ -368,6 +406,72 @@ def test_two_contexts_search_one_graph_handle_concurrently(gr, gpu_ctx):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_first_searches_of_two_contexts_race_on_a_fresh_handle(gr, gpu_ctx):
+    """Round 5: the lazy per-graph builds -- transpose, bin table, two-neighbour array, weight statistics, pull
+    layout -- are serialised by the handle's build lock and published only when complete.  Two contexts make their FIRST
+    searches (direction-optimising BFS, forward BFS, SSSP, PageRank) on a handle nobody has prepared, at the same time."""
+    import threading
+    import torch
+    _, c = gr.generate("rmat_sym", 1 << 17, 3_000_000, seed=41)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    src = int(np.argmax(np.diff(g.row_offsets)))
+    want, _ = O.bfs(g, src)
+    for trial in range(3):
+        G = gr.build_graph(gr.graph_properties_t(directed=True, weighted=False, symmetric=False),
+                           gr.csr_t.from_arrays(g.row_offsets, g.column_indices, None), gpu_ctx)
+        errors = []
+        barrier = threading.Barrier(2)
+
+        def worker(idx):
+            try:
+                ctx = gr.multi_context_t(0)
+                d = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda:0")
+                f = torch.empty(g.n_vertices, dtype=torch.float32, device="cuda:0")
+                barrier.wait()
+                order = (gr.optimized, gr.forward) if (idx + trial) % 2 else (gr.forward, gr.optimized)
+                for direction in order:
+                    gr.bfs(G, src, d, None, ctx, gr.options_t(advance_direction=direction))
+                    if not np.array_equal(d.cpu().numpy(), want):
+                        errors.append((idx, "bfs", int(direction)))
+                gr.sssp(G, src, f, None, ctx, gr.options_t())
+                reached = want != np.iinfo(np.int32).max
+                if not np.array_equal(f.cpu().numpy()[reached], want[reached].astype(np.float32)):
+                    errors.append((idx, "sssp"))
+                gr.pr_run(G, gr.pr_param_t(0.85, 1e-6), gr.pr_result_t(f), ctx)
+            except Exception as e:  # noqa: BLE001
+                errors.append((idx, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        del G
+
+
+def test_direction_optimising_search_without_a_transpose_runs_forward(gr, gpu_ctx, monkeypatch):
+    """Round 5: when the transpose cannot be built (its sort needs 16-24 transient bytes per edge) a
+    direction-optimising search runs forward-only instead of failing; the next call, with memory to spare, builds it."""
+    import torch
+    _, c = gr.generate("rmat_sym", 1 << 16, 1_500_000, seed=43)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    src = int(np.argmax(np.diff(g.row_offsets)))
+    want, _ = O.bfs(g, src)
+    G = gr.build_graph(gr.graph_properties_t(directed=True, weighted=False, symmetric=True),
+                       gr.csr_t.from_arrays(g.row_offsets, g.column_indices, None), gpu_ctx)
+    d = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda:0")
+    monkeypatch.setenv("GRX_TR_FAIL_ALLOC", "1")
+    for flags in (0, gr.FLAG_PROFILE):
+        gr.bfs(G, src, d, None, gpu_ctx, gr.options_t(advance_direction=gr.optimized, engine_flags=flags))
+        assert np.array_equal(d.cpu().numpy(), want)
+    assert all(l["bottom_up"] != 1 for l in gr.level_profile(gpu_ctx))  # no bottom-up level ran
+    monkeypatch.delenv("GRX_TR_FAIL_ALLOC")
+    gr.bfs(G, src, d, None, gpu_ctx, gr.options_t(advance_direction=gr.optimized, engine_flags=gr.FLAG_PROFILE))
+    assert np.array_equal(d.cpu().numpy(), want)
+    assert any(l["bottom_up"] == 1 for l in gr.level_profile(gpu_ctx))
 
 
 def _with_tail(g, anchor, length):
