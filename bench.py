@@ -53,6 +53,11 @@ WORKLOADS = {
     "twitter": dict(file="soc-twitter-2010", kind="rmat_sym", V=21_297_772, entries=265_025_809, a=0.57, b=0.19, c=0.19,
                     name="soc-twitter-2010 stand-in C5': symmetric R-MAT(0.57,0.19,0.19,0.05) 21,297,772 V / "
                          "265,025,809 entries (~530 M edges)"),
+    # round 5: the same V / E as C2' with the DEPTH of the published graph -- R-MAT core + a long-tailed
+    # periphery (gunrock_amd/csrc/grx_host.cpp, kind 3): 14 levels from the hub where C2' has 7
+    "deep": dict(kind="rmat_deep", V=4_847_571, entries=68_993_773, a=0.57, b=0.19, c=0.19,
+                 name="deep scale-free stand-in: R-MAT(0.57,0.19,0.19,0.05) core on 9/10 of 4,847,571 V + a periphery whose "
+                      "population falls by 0.3 per hop (68,993,773 E; 14 levels from the max out-degree vertex)"),
     "small": dict(kind="rmat", V=1 << 18, entries=4_000_000, a=0.57, b=0.19, c=0.19,
                   name="R-MAT 262,144 V / 4,000,000 E (smoke size)"),
 }
@@ -216,7 +221,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="lj", choices=sorted(WORKLOADS),
                     help="graph of the top-level BFS line (default: BASELINE configs[1])")
-    ap.add_argument("--only", default="bfs,bfs_do,multi,sssp,sssp_lj,sssp_kron,pr,pr_lj,c5",
+    ap.add_argument("--only", default="bfs,bfs_do,multi,bfs_deep,sssp,sssp_lj,sssp_kron,pr,pr_lj,c5",
                     help="comma list of the sections to run at N = 1 (bfs = the top-level forward search, always run)")
     ap.add_argument("--data-dir", default=os.environ.get("GRX_DATA_DIR", ""),
                     help="directory holding the published graphs (soc-LiveJournal1.mtx, road_usa.mtx, "
@@ -426,6 +431,8 @@ def main():
         del csr_k
     if "c5" in only:
         detail["c5_single_gpu"] = bench_c5(gr, torch, ctx, dev, sync, cpu_on, args)
+    if "bfs_deep" in only:
+        detail["bfs_deep"] = bench_bfs_deep(env)
 
     # ------------------------------------------------------------------ output: the full objects to a file, ONE compact line to stdout
     path = args.detail or (os.path.join(ROOT, "gpurun_out", "bench_detail.json")
@@ -468,6 +475,13 @@ def main():
                           "fwd_frac": (c5["forward"]["roofline"] or {}).get("frac"),
                           "do_ms": c5["direction_optimized"]["ms_per_step"], "do_mteps": c5["direction_optimized"]["mteps"],
                           "viol": c5.get("property_check_violations")}
+    bd = detail.get("bfs_deep")
+    if bd:
+        sec["bfs_deep"] = {"levels": bd["forward"]["search_depth"], "fwd_ms": bd["forward"]["ms_per_step"],
+                           "fwd_mteps": bd["forward"]["mteps"], "fwd_frac": bd["forward"]["roofline"]["frac"],
+                           "do_ms": bd["direction_optimized"]["ms_per_step"], "do_mteps": bd["direction_optimized"]["mteps"],
+                           "us_per_thin_level": bd["forward"]["thin_levels_us_per_level"],
+                           "eq_cpu": (bd.get("cpu_baseline") or {}).get("matches_gpu")}
     cfg["sections"] = sec
     cfg["sections_note"] = ("ms = ms per step (search / run), frac = roofline fraction of the section's dominant kernels, "
                             "cpu1 = 1-core oracle on the same workload, eq_cpu = GPU result == oracle's, viol = oracle "
@@ -791,6 +805,59 @@ def bench_c5(gr, torch, ctx, dev, sync, cpu_on, args):
     return item
 
 
+def bench_bfs_deep(env):
+    """Round 5: BFS on a graph of the C2' size with the DEPTH of the published soc-LiveJournal1 (14 levels
+    from the hub instead of 7; WORKLOADS["deep"]), forward and direction-optimising, each level's kernel + head time -- what
+    a search pays per THIN level is what the 7-level stand-in hides.  Depths compared with the oracle's, array for array."""
+    gr, torch, ctx, dev, sync, cpu_on, O, args = (env[k] for k in ("gr", "torch", "ctx", "dev", "sync", "cpu_on", "O", "args"))
+    t0 = time.time()
+    props, csr, src, info = load_workload(gr, "deep", None)
+    G = gr.build_graph(props, csr, ctx, device=dev)
+    V, E = G.get_number_of_vertices(), G.get_number_of_edges()
+    d = torch.empty(V, dtype=torch.int32, device=dev)
+    lb = getattr(gr, args.lb)
+    item = {"workload": "BFS on " + info["name"], "data": info["data"], "n_vertices": V, "n_edges": E, "source": src,
+            "steps": args.steps}
+    depths = {}
+    for label, direction in (("forward", gr.forward), ("direction_optimized", gr.optimized)):
+        o = gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact,
+                         advance_direction=direction, engine_flags=gr.FLAG_ASYNC_RETURN)
+        sync()
+        t1 = time.perf_counter()
+        gr.bfs(G, src, d, None, ctx, o)  # first call on the handle: per-graph preprocessing of this direction
+        sync()
+        first = (time.perf_counter() - t1) * 1e3
+        ms = timed(lambda: gr.bfs(G, src, d, None, ctx, o), sync, args.steps, args.warmup)
+        st = gr.run_stats(ctx)
+        depths[label] = d.cpu().numpy().copy()
+        po = gr.options_t(advance_load_balance=lb, enable_filter=True, filter_algorithm=gr.compact,
+                          advance_direction=direction, engine_flags=gr.FLAG_PROFILE)
+        prof = best_profile(lambda: gr.bfs(G, src, d, None, ctx, po), lambda: gr.level_profile(ctx))
+        td = [l for l in prof if l["bottom_up"] != 1]
+        r_td = roof(td, lambda l: 12 * l["frontier_size"] + 12 * l["edges"], "top-down level kernels (advance_block / "
+                    "binned scatter + sweep / many levels per launch)", "12 B per frontier slot + 12 B per traversed edge")
+        thin = [l for l in prof if l["edges"] < (1 << 20)]
+        item[label] = {"ms_per_step": round(ms, 4), "mteps": round(st["edges_visited"] / (ms * 1e3), 1),
+                       "edges_visited_per_step": st["edges_visited"], "search_depth": st["search_depth"],
+                       "enact_ms_last": round(st["elapsed_ms"], 4), "first_call_ms": round(first, 3),
+                       "launch_groups_last": int(st.get("aux", 0)), "roofline": r_td,
+                       # (profiled search: one launch group per level, no level merged into a head or a multi-level launch)
+                       "thin_levels_us_per_level": round(sum(l["advance_ms"] + l["other_ms"] for l in thin) * 1e3 / max(1, len(thin)), 2),
+                       "levels": [[l["frontier_size"], l["edges"], int(l["bottom_up"]), round(l["advance_ms"], 4),
+                                   round(l["other_ms"], 4)] for l in prof]}
+    item["forward_equals_direction_optimized"] = bool(np.array_equal(depths["forward"], depths["direction_optimized"]))
+    item["setup_s"] = round(time.time() - t0, 1)
+    if cpu_on:
+        g = O.Csr(csr.row_offsets, csr.column_indices, csr.nonzero_values)
+        d_q, ms_q, ev_q = O.bfs_queue(g, src)
+        item["cpu_baseline"] = {
+            "value": round(ev_q / (ms_q * 1e3), 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+            "sample": "1 full BFS of the same workload/source on one core (oracle/oracle.c orc_bfs_queue), %.1f s" % (ms_q / 1e3),
+            "matches_gpu": bool(np.array_equal(d_q, depths["forward"]) and np.array_equal(d_q, depths["direction_optimized"]))}
+    del G, d
+    return item
+
+
 def bench_multi_gpu(args, gr, torch, rank, local_rank, world):
     """N > 1: ONE graph, vertex-range partitioned over the ranks (gunrock_amd/distributed.py).
     N = 8: BASELINE.json configs[4], the soc-twitter-2010 stand-in C5'.  N = 2, 4: N x the single-GPU C2' size
@@ -923,6 +990,23 @@ def bench_multi_gpu(args, gr, torch, rank, local_rank, world):
                                        "all-reduce ms (max over ranks | mean over ranks)",
                             "max_over_ranks": [[round(float(x), 4) for x in row] for row in mx.tolist()],
                             "mean_over_ranks": [[round(float(x) / world, 4) for x in row] for row in sm.tolist()]}
+        # PREDICTION of the step from a model (profiles/dist_comm_model.json: small-message latency of the two collectives of a
+        # level group + the bitmap bytes over one xGMI link) and the kernel times just measured: sum over the level groups of
+        # max-over-ranks kernel time + all-to-all + all-reduce.  Printed beside the measured ms_per_step so that the record
+        # of a multi-GPU run checks the model.
+        try:
+            cm = json.load(open(os.path.join(ROOT, "profiles", "dist_comm_model.json")))
+            per_pair = eng.S // 8
+            t_x = cm["alpha_all_to_all_us"] * 1e-3 + per_pair / (cm["link_GBs"] * cm["link_efficiency"] * 1e9) * 1e3
+            t_r = cm["alpha_all_reduce_us"] * 1e-3
+            kern = [row[0] + row[2] for row in mx.tolist()]
+            levels_breakdown["predicted_ms"] = round(sum(kern) + len(kern) * (t_x * eng.parts + t_r), 4)
+            levels_breakdown["predicted_from"] = ("sum over %d level groups of (max-over-ranks kernels %.3f ms total) + %d x "
+                                                  "(all-to-all %.4f ms x %d + all-reduce %.4f ms); model: profiles/dist_comm_model.json"
+                                                  % (len(kern), sum(kern), len(kern), t_x, eng.parts, t_r))
+        except Exception as e:  # noqa: BLE001
+            levels_breakdown["predicted_ms"] = None
+            levels_breakdown["predicted_from"] = "model not available: %s" % str(e)[:120]
     except Exception as e:  # noqa: BLE001  (diagnostics only)
         levels_breakdown = {"error": str(e)[:200]}
     check = None
@@ -956,8 +1040,10 @@ def bench_multi_gpu(args, gr, torch, rank, local_rank, world):
         print(json.dumps({
             "metric": "MTEPS (million traversed edges/sec) BFS", "value": round(mteps, 1), "unit": "MTEPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
-            "data": "synthetic",
+            # N = 8 runs ONE fixed graph (BASELINE configs[4]; its single-GPU point is c5_1gpu of the N = 1 line): strong
+            # scaling.  Other N run N x the single-GPU graph: weak scaling.
+            "higher_is_better": True, "scaling": "strong" if name == "twitter" else "weak", "vs_baseline": None, "dtype": "int32",
+            "data": "synthetic", "predicted_ms": (levels_breakdown or {}).get("predicted_ms"),
             "config": {"workload": wname, "n_vertices": V, "n_edges": e_total, "source": src,
                        "per_gpu_edges": e_total // world,
                        "parallelism": "vertex-range partition over %d GPUs, labels sharded (V/P per rank); per level "

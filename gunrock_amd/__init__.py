@@ -483,8 +483,9 @@ def generate_rows(kind, n_vertices, n_entries, row_lo, row_hi, a=0.57, b=0.19, c
 def generate(kind, n_vertices, n_entries=0, a=0.57, b=0.19, c=0.19, seed=42):
     """Seeded synthetic stand-ins for the BASELINE graphs.
     kind: 'rmat' (directed pattern), 'rmat_sym' (symmetric pattern), 'road'
-    (lattice, p_keep=a, weighted iff c>0).  Returns (graph_properties_t, csr_t)."""
-    kinds = {"rmat": 0, "rmat_sym": 1, "road": 2}
+    (lattice, p_keep=a, weighted iff c>0), 'rmat_deep' (directed R-MAT core + a long-tailed periphery: ~15 levels
+    from a hub where the plain R-MAT has 7).  Returns (graph_properties_t, csr_t)."""
+    kinds = {"rmat": 0, "rmat_sym": 1, "road": 2, "rmat_deep": 3}
     L = _capi.lib()
     h = C.c_void_p()
     _capi.check(L.grx_host_csr_generate(kinds[kind], int(n_vertices), int(n_entries),

@@ -1154,13 +1154,13 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   // stand-in spent ~25 us on six no-op launches (the level kernel in front of either fat level, scatter + sweep of the slack
   // group behind them).  A wrong prediction is only slow: a fat level in a group without the two kernels runs on the
   // claim-per-edge advance (bin_args::allowed), a thin one in a group without a level kernel is binned (bin_args::no_level).
-  // GRX_BIN_EXACT=0: off.  Profiled runs keep every kernel (their records are per launch group).
+  // GRX_BIN_EXACT=0: off.  Profiled runs (GRX_FLAG_PROFILE: one group per level, level 0 included) keep their own record, so
+  // that the per-level times they report are those of the kernels a repeated search launches.
   uint32_t exact_groups = 0u;
   bool exact = false;
   {
-    const uint64_t ex = g->bin_exact.load(std::memory_order_relaxed);
-    if (use_bins && hint0 && !(opt.engine_flags & GRX_FLAG_PROFILE) && (uint32_t)(ex >> 32) == (uint32_t)src + 1u &&
-        env_int("GRX_BIN_EXACT", 1) != 0) {
+    const uint64_t ex = g->bin_exact[profile ? 1 : 0].load(std::memory_order_relaxed);
+    if (use_bins && hint0 && (uint32_t)(ex >> 32) == (uint32_t)src + 1u && env_int("GRX_BIN_EXACT", 1) != 0) {
       exact = true;
       exact_groups = (uint32_t)ex;
       bin_groups = exact_groups;
@@ -1289,8 +1289,8 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     const uint32_t want = returned_fast ? (uint32_t)ctx->h_mailbox[11] : (uint32_t)ctx->h_ctrl->bin_want;
     if (env_int("GRX_BIN_HINT_REPLACE", 0) != 0) g->bin_hint.store(want, std::memory_order_relaxed);
     else g->bin_hint.fetch_or(want, std::memory_order_relaxed);
-    if (!dopt && variant == 0 && opt.max_iterations == 0 && !profile)
-      g->bin_exact.store(((uint64_t)((uint32_t)src + 1u) << 32) | (uint64_t)want, std::memory_order_relaxed);
+    if (!dopt && variant == 0 && opt.max_iterations == 0)
+      g->bin_exact[profile ? 1 : 0].store(((uint64_t)((uint32_t)src + 1u) << 32) | (uint64_t)want, std::memory_order_relaxed);
   }
   float ms = 0;
   if (returned_fast) {

@@ -577,6 +577,89 @@ static grx_status_t generate_impl(int32_t kind, int32_t V, int64_t n_entries, fl
       }
     }
     h->directed = 0; h->symmetric = 1; h->weighted = weighted ? 1 : 0;
+  } else if (kind == 3) {
+    // DEEP scale-free stand-in (round 5): the R-MAT stand-ins reach everything within 6-7 levels of a hub,
+    // the published soc-LiveJournal1 takes ~15 -- a core of the same shape plus a long-tailed PERIPHERY.  One vertex in ten
+    // is a periphery vertex; it has a depth d >= 1 (the number at depth d falls by 0.3 per step: 70 %, 21 %, 6.3 %, ... down to
+    // a handful at d = 11), hangs under a random vertex of depth d - 1 (d = 1: under a random core vertex) with an edge each
+    // way, and points at two popular core vertices (R-MAT targets) -- out-edges that lead back into the visited core and
+    // shorten nothing.  The core is R-MAT(a, b, c) on the other nine tenths with the remaining entries.  All ids go through one
+    // affine permutation, so the periphery is spread over the id space.  Seeded; not sliceable.
+    if (sliced) { delete h; return fail(GRX_ERROR_INVALID_ARGUMENT, "deep stand-in: whole graph only"); }
+    const int32_t V_per = V / 10, V_core = V - V_per;
+    const int64_t n_core = n_entries - 4ll * V_per;
+    if (V_core < 16 || n_core < 0 || n_entries >= (int64_t)INT32_MAX) { delete h; return fail(GRX_ERROR_INVALID_ARGUMENT, "deep stand-in: too small / edge_t overflow"); }
+    int scale = 0;
+    while (((int64_t)1 << scale) < (int64_t)V_core) ++scale;
+    const uint32_t ta = (uint32_t)std::lround(a * 65536.0);
+    const uint32_t tb = ta + (uint32_t)std::lround(b * 65536.0);
+    const uint32_t tc = tb + (uint32_t)std::lround(c * 65536.0);
+    uint64_t mulc = 0x9E3779B1ull % (uint64_t)V_core;
+    if (mulc == 0) mulc = 1;
+    while (std::gcd(mulc, (uint64_t)V_core) != 1) ++mulc;
+    const uint64_t addc = mix64(seed) % (uint64_t)V_core;
+    auto core_pair = [&](uint64_t stream, int64_t e, int32_t* pu, int32_t* pw) {
+      uint64_t u = 0, v = 0, word = 0;
+      for (int l = 0; l < scale; ++l) {
+        if ((l & 3) == 0) word = rnd(seed ^ stream, (uint64_t)e, (uint64_t)(l >> 2));
+        const uint32_t r = (uint32_t)(word & 0xFFFF);
+        word >>= 16;
+        u = (u << 1) | (r >= tb ? 1u : 0u);
+        v = (v << 1) | (((r >= ta && r < tb) || r >= tc) ? 1u : 0u);
+      }
+      *pu = (int32_t)(((u % (uint64_t)V_core) * mulc + addc) % (uint64_t)V_core);
+      *pw = (int32_t)(((v % (uint64_t)V_core) * mulc + addc) % (uint64_t)V_core);
+    };
+    // depth quotas of the periphery: n_d = 0.7 * 0.3^(d-1) * V_per while that is >= 1; what is left over joins depth 1
+    std::vector<int32_t> first_of;  // first periphery index (0-based inside the periphery) of depth d = 1, 2, ...
+    {
+      double q = 0.7 * (double)V_per;
+      int64_t used = 0;
+      std::vector<int64_t> n_d;
+      while (q >= 1.0 && (int)n_d.size() < 16) { n_d.push_back((int64_t)q); used += (int64_t)q; q *= 0.3; }
+      if (n_d.empty()) n_d.push_back(0);
+      n_d[0] += (int64_t)V_per - used;
+      int64_t at = 0;
+      for (int64_t n : n_d) { first_of.push_back((int32_t)at); at += n; }
+      first_of.push_back((int32_t)at);  // == V_per
+    }
+    I.resize((size_t)n_entries);
+    J.resize((size_t)n_entries);
+    parallel_for(n_core, [&](int64_t lo, int64_t hi) {
+      for (int64_t e = lo; e < hi; ++e) core_pair(0ull, e, &I[(size_t)e], &J[(size_t)e]);
+    });
+    const int n_depths = (int)first_of.size() - 1;
+    parallel_for((int64_t)V_per, [&](int64_t lo, int64_t hi) {
+      for (int64_t j = lo; j < hi; ++j) {
+        int d = 0;
+        while (d + 1 < n_depths && j >= first_of[(size_t)d + 1]) ++d;  // depth d + 1
+        const uint64_t r = rnd(seed ^ 0x70657269ull, (uint64_t)j, 0);
+        int32_t parent;
+        if (d == 0) parent = (int32_t)(r % (uint64_t)V_core);
+        else parent = V_core + first_of[(size_t)d - 1] + (int32_t)(r % (uint64_t)(first_of[(size_t)d] - first_of[(size_t)d - 1]));
+        const int32_t me = V_core + (int32_t)j;
+        const size_t at = (size_t)n_core + 4 * (size_t)j;
+        I[at] = parent; J[at] = me;
+        I[at + 1] = me; J[at + 1] = parent;
+        int32_t u0, w0, u1, w1;
+        core_pair(0x68756273ull, 2 * j, &u0, &w0);
+        core_pair(0x68756273ull, 2 * j + 1, &u1, &w1);
+        I[at + 2] = me; J[at + 2] = w0;
+        I[at + 3] = me; J[at + 3] = w1;
+      }
+    });
+    // one affine permutation of all ids
+    uint64_t mul = 0x9E3779B1ull % (uint64_t)V;
+    if (mul == 0) mul = 1;
+    while (std::gcd(mul, (uint64_t)V) != 1) ++mul;
+    const uint64_t add = mix64(seed ^ 0x64656570ull) % (uint64_t)V;
+    parallel_for(n_entries, [&](int64_t lo, int64_t hi) {
+      for (int64_t e = lo; e < hi; ++e) {
+        I[(size_t)e] = (int32_t)(((uint64_t)I[(size_t)e] * mul + add) % (uint64_t)V);
+        J[(size_t)e] = (int32_t)(((uint64_t)J[(size_t)e] * mul + add) % (uint64_t)V);
+      }
+    });
+    h->directed = 1; h->symmetric = 0; h->weighted = 0;
   } else {
     delete h;
     return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_host_csr_generate: unknown kind");
