@@ -340,6 +340,7 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->pr_piece) (void)hipFree(g->pr_piece);
   if (g->pr_long) (void)hipFree(g->pr_long);
   if (g->xb_ro) (void)hipFree(g->xb_ro);
+  if (g->xb_pos) (void)hipFree(g->xb_pos);
   if (g->xb_ci) (void)hipFree(g->xb_ci);
   if (g->xb_w) (void)hipFree(g->xb_w);
   if (g->xb_blocks) (void)hipFree(g->xb_blocks);

@@ -1079,7 +1079,9 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       bn.debug = ctx->far[1].as<long long>();
       GRX_HIP(hipMemsetAsync(bn.debug, 0, (size_t)8 * 16384 * sizeof(long long), s));
     }
-    bn.min_edges = (long long)env_int("GRX_BIN_MIN_EDGES", 1 << 20);
+    // (round 5: 2^21, was 2^20 -- the 1.29 M-edge fourth level of the deep stand-in costs scatter 24 + sweep 55 us binned and
+    // 44 us on the claim-per-edge advance: profiles/r5_c15_kernel_sequences.txt)
+    bn.min_edges = (long long)env_int("GRX_BIN_MIN_EDGES", 1 << 21);
     if (bn.min_edges < 1) bn.min_edges = 1;
     bn.visited = visited;
     bn.visited_words = (int32_t)bm_words;

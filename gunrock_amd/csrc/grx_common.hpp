@@ -255,6 +255,7 @@ struct grx_graph {
   int32_t* xb_piece = nullptr;
   int32_t* xb_long = nullptr;   // {block-major row index, first piece, n pieces}
   int32_t* xb_perm = nullptr;   // hub-first relabelling of the gathered vector (position of v's value in x[])
+  uint16_t* xb_pos = nullptr;   // per entry of xb_ci: its position inside its block BEFORE the block was sorted by source (null: unsorted)
   int32_t xb_begin[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int32_t n_xb_pieces = 0, n_xb_long = 0;
   bool has_xb = false;

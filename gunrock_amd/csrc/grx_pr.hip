@@ -61,6 +61,9 @@ struct pr_args {
   int32_t n_xb_long;
   float* partial_y;      // NB * V partial sums, block-major
   const int32_t* x_perm; // XCD-blocked variant: position of vertex v's value in x[] (null: v)
+  const uint16_t* xb_pos; // XCD-blocked variant: entry i of a row block belongs at position xb_pos[i] of the block (null: i)
+  int32_t xb_per_block;   // XCD-blocked variant: x[] positions of source block s begin at s * xb_per_block (hub-first order)
+  int32_t hot_n;          // ... and the first hot_n of them are kept in LDS by every workgroup (0: none)
   // partitioned run (grx_pr_dist_*): this rank prepares / updates the rows [row_lo, row_hi) only; the dangling mass and
   // the convergence norm are combined over the ranks' {dsum, err} pairs in `gathered` (null: single GPU)
   int32_t row_lo, row_hi;
@@ -189,12 +192,7 @@ __device__ __forceinline__ void pr_block_prefix(double* s_pre, double* s_wtot) {
     v[k] = run;  // exclusive inside the thread
     run += x;
   }
-  double inc = run;  // inclusive across the wave
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const double y = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += y;
-  }
+  const double inc = dev::wave_inclusive_sum_f64(run);  // inclusive across the wave (DPP: include/gunrock/hip/wave.hxx)
   if (lane == 63) s_wtot[wid] = inc;
   __syncthreads();
   double carry = inc - run;
@@ -321,10 +319,20 @@ __global__ void pr_long_kernel(pr_args a, int iter) {
 // slice of x[] they gather from (V/8 floats: 1 MB for 2 M vertices) stays resident in
 // THEIR L2 instead of 8 MB of x[] thrashing through every L2.  Each (s, row) gets a partial
 // sum; pr_combine_kernel adds the 8 partials of a row in fixed order.
+//
+// THE HOT HEAD OF THE SLICE IN LDS (round 5).  What bounds this kernel, from the counters (profiles/r5_c18_pr_counters.md): the
+// CU's L1 is busy 92 % of the launch and stalled on pending misses 61 % of it -- 244 k L2 requests per CU and launch at 228
+// cycles each, against the few dozen misses an L1 keeps in flight.  Not occupancy (4 workgroups per CU run within 3 % of 8),
+// not address coalescing (row blocks sorted by source changed nothing on this graph).  The sources are ranked hub-first, so the
+// first hot_n positions of the slice receive most of the gathers: every workgroup copies them into LDS once per launch and
+// gathers from there; only the cold tail goes through the L1.  (Round 2 measured an LDS copy SLOWER -- on a kernel that still
+// depended on its resident workgroups.)
+template <bool HOT>
 __global__ __launch_bounds__(PR_BLOCK) void pr_pull_xcd_kernel(pr_args a) {
   __shared__ double s_pre[PR_PRE_DOUBLES];
   __shared__ double s_wtot[PR_BLOCK / 64];
   __shared__ float s_w[PR_BLOCK / 64];
+  extern __shared__ float s_hot[];  // hot_n floats (dynamic)
   if (a.ctrl->done) return;
   const int tid = threadIdx.x;
   const int s = blockIdx.x % XB;
@@ -332,6 +340,21 @@ __global__ __launch_bounds__(PR_BLOCK) void pr_pull_xcd_kernel(pr_args a) {
   const int32_t* ro = a.xb_ro + (size_t)s * ((size_t)a.V + 1);
   float* y = a.partial_y + (size_t)s * (size_t)a.V;
   constexpr int PER = PR_NNZ / PR_BLOCK;
+  const int hot_n = HOT ? a.hot_n : 0;
+  const int hot_base = s * a.xb_per_block;
+  if constexpr (HOT) {
+    for (int i = tid; i < hot_n; i += PR_BLOCK) s_hot[i] = a.x[hot_base + i];
+    __syncthreads();
+  }
+  // x[src], from LDS when src lies in the hot head of this slice (src < 0: a lane past the end of the block)
+  auto gather = [&](int src) -> float {
+    if constexpr (!HOT) return src >= 0 ? a.x[src] : 0.0f;
+    const unsigned loc = (unsigned)(src - hot_base);
+    float v = 0.0f;
+    if (src >= 0 && loc >= (unsigned)hot_n) v = a.x[src];          // (exec-masked: hot lanes issue no request)
+    const float h = s_hot[loc < (unsigned)hot_n ? loc : 0u];        // (unconditional LDS read from a clamped index)
+    return (src >= 0 && loc < (unsigned)hot_n) ? h : v;
+  };
   for (int b = a.xb_begin[s] + lane_b; b < a.xb_begin[s + 1]; b += stride_b) {
     const int4 d = a.xb_blocks[b];  // {row0, nrows, e0, e1}; nrows == 0 => piece of a long row
     const int n = d.w - d.z;
@@ -344,13 +367,23 @@ __global__ __launch_bounds__(PR_BLOCK) void pr_pull_xcd_kernel(pr_args a) {
       wv[k] = (a.xb_w && i < n) ? __builtin_nontemporal_load(&a.xb_w[d.z + i]) : 1.0f;
     }
     if (d.y > 0) {
-      float xv[PER];
-#pragma unroll
-      for (int k = 0; k < PER; ++k) xv[k] = src[k] >= 0 ? a.x[src[k]] : 0.0f;
+      // The entries of a row block are stored SORTED BY SOURCE (round 5, build_pr_xcd_layout): lanes on consecutive entries
+      // gather from ascending addresses, and the sources most entries point at -- the hub-first head of the slice -- sit
+      // in a few lines that neighbouring lanes now share.  Every entry carries the position it had in row order (16 bits);
+      // its product goes THERE, so the prefix sums and every row sum see exactly the order they always saw.
+      int pos[PER];
 #pragma unroll
       for (int k = 0; k < PER; ++k) {
         const int i = tid + k * PR_BLOCK;
-        s_pre[pr_slot(i)] = i < n ? (double)(a.xb_w ? xv[k] * wv[k] : xv[k]) : 0.0;
+        pos[k] = (a.xb_pos && i < n) ? (int)__builtin_nontemporal_load(&a.xb_pos[d.z + i]) : i;
+      }
+      float xv[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) xv[k] = gather(src[k]);
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * PR_BLOCK;
+        s_pre[pr_slot(pos[k])] = i < n ? (double)(a.xb_w ? xv[k] * wv[k] : xv[k]) : 0.0;
       }
       __syncthreads();
       pr_block_prefix(s_pre, s_wtot);
@@ -364,7 +397,7 @@ __global__ __launch_bounds__(PR_BLOCK) void pr_pull_xcd_kernel(pr_args a) {
       float acc = 0.0f;
 #pragma unroll
       for (int k = 0; k < PER; ++k) {
-        const float xv = src[k] >= 0 ? a.x[src[k]] : 0.0f;
+        const float xv = gather(src[k]);
         acc += a.xb_w ? xv * wv[k] : xv;
       }
       acc = dev::wave_sum_f(acc);
@@ -679,6 +712,51 @@ static grx_status_t build_pr_partition(grx_graph_t g) {
   return GRX_SUCCESS;
 }
 
+// Sort the entries of every ROW block of the XCD-blocked layout by source (= by the address they gather from), remembering
+// where each came from (xb_pos).  One workgroup per block, bitonic network over (source << 16 | position) in LDS: the keys are
+// distinct, so the result does not depend on the schedule.  Pieces of long rows (nrows == 0) keep their order -- they are one
+// row's ascending sources already, and their sums are taken in storage order.  Once per graph.  <<<n_blocks, 256>>>
+__global__ __launch_bounds__(256) void xb_sort_blocks_kernel(const int4* __restrict__ blocks, int n_blocks, int32_t* ci, float* w,
+                                                             uint16_t* pos) {
+  __shared__ unsigned long long key[PR_NNZ];
+  __shared__ float wv[PR_NNZ];
+  const int tid = threadIdx.x;
+  for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+    const int4 d = blocks[b];
+    const int n = d.w - d.z;
+    if (d.y == 0) {
+      for (int i = tid; i < n; i += 256) pos[d.z + i] = (uint16_t)i;
+      continue;
+    }
+    for (int i = tid; i < PR_NNZ; i += 256) {
+      key[i] = i < n ? (((unsigned long long)(unsigned)ci[d.z + i] << 16) | (unsigned long long)i) : ~0ull;
+      if (w) wv[i] = i < n ? w[d.z + i] : 0.0f;
+    }
+    __syncthreads();
+    for (int k = 2; k <= PR_NNZ; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < PR_NNZ; i += 256) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const unsigned long long x = key[i], y = key[ixj];
+            const bool up = (i & k) == 0;
+            if ((x > y) == up) { key[i] = y; key[ixj] = x; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < n; i += 256) {
+      const unsigned long long kv = key[i];
+      const int from = (int)(kv & 0xffffull);
+      ci[d.z + i] = (int32_t)(kv >> 16);
+      pos[d.z + i] = (uint16_t)from;
+      if (w) w[d.z + i] = wv[from];
+    }
+    __syncthreads();
+  }
+}
+
 static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   std::lock_guard<std::recursive_mutex> lk(g->prep_mu);  // (has_xb is published last, below)
   if (g->has_xb) return GRX_SUCCESS;
@@ -749,6 +827,21 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   g->xb_long = pt.longrows;
   g->n_xb_pieces = pt.n_pieces;
   g->n_xb_long = pt.n_long;
+  // Row blocks sorted by source (xb_sort_blocks_kernel): OPT-IN, GRX_PR_SORT_BLOCKS=1.  Measured (profiles/
+  // r5_c17_pr_sorted_blocks.txt): LJ stand-in 0.486 -> 0.457 ms per iteration, kron stand-in 0.691 -> 0.690 -- for 3.1 / 7.2 ms
+  // of preprocessing, i.e. more than a whole run costs: it pays only for a graph that is ranked many times.  Results are
+  // bit-identical either way (same products at the same positions of the same prefix sums).
+  {
+    const char* sb_env = getenv("GRX_PR_SORT_BLOCKS");
+    if (sb_env && *sb_env == '1' && pt.n_blocks > 0) {
+      prep_timer t3("  xcd layout: row blocks sorted by source", s);
+      if (!g->xb_pos) GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_pos), (size_t)std::max<int64_t>(E, 1) * sizeof(uint16_t)));
+      hipLaunchKernelGGL(xb_sort_blocks_kernel, dim3(std::min(pt.n_blocks, ctx->num_cus * 8)), dim3(256), 0, s,
+                         reinterpret_cast<const int4*>(pt.blocks), pt.n_blocks, g->xb_ci, g->xb_w, g->xb_pos);
+      GRX_HIP(hipStreamSynchronize(s));
+      GRX_HIP(hipGetLastError());
+    }
+  }
   g->has_xb = true;
   return GRX_SUCCESS;
 }
@@ -756,6 +849,14 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
 }  // namespace grx
 
 using namespace grx;
+
+template <class K>
+static int pr_resident_per_cu(K kernel) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, PR_BLOCK, 0) != hipSuccess || n < 1) n = 4;
+  (void)hipGetLastError();
+  return n > 8 ? 8 : n;
+}
 
 extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, float tol,
                                const grx_options_t* options, float* d_p, int32_t* iterations,
@@ -820,6 +921,8 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   a.err_bits = ctx->misc.as<unsigned>();
   a.base = reinterpret_cast<float*>(ctx->misc.as<unsigned>() + 4);
   a.xb_ro = g->xb_ro; a.xb_ci = g->xb_ci; a.xb_w = unit ? nullptr : g->xb_w;
+  a.xb_pos = g->xb_pos;
+  a.xb_per_block = (g->V + XB - 1) / XB;
   a.xb_blocks = reinterpret_cast<const int4*>(g->xb_blocks);
   a.xb_piece = g->xb_piece; a.xb_long = g->xb_long;
   for (int i = 0; i <= XB; ++i) a.xb_begin[i] = g->xb_begin[i];
@@ -835,7 +938,34 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   GRX_HIP(hipEventRecord(ctx->ev_begin, s));
   hipLaunchKernelGGL(pr_init_kernel, dim3(1), dim3(64), 0, s, a);
 
-  const int pull_grid = std::max(1, std::min(std::max(1, g->n_pr_blocks), ctx->num_cus * 8));
+  // Persistent workgroups stride over the blocks with gridDim: the grid is exactly what is RESIDENT (round 5: it was 8 per CU
+  // while the kernels' 70 VGPRs let 7 in -- the eighth of every CU ran alone behind the others, a second round for an eighth
+  // of the work).  GRX_PR_WG_PER_CU: another number (tuning aid).  The block -> workgroup map does not enter any result.
+  static const int per_cu_plain = pr_resident_per_cu(pr_pull_kernel), per_cu_xcd = pr_resident_per_cu(pr_pull_xcd_kernel<false>);
+  int wg_env = 0;
+  if (const char* e = getenv("GRX_PR_WG_PER_CU")) wg_env = atoi(e);
+  const int pull_grid = std::max(1, std::min(std::max(1, g->n_pr_blocks), ctx->num_cus * (wg_env > 0 ? wg_env : per_cu_plain)));
+  // hot head of every slice in LDS (pr_pull_xcd_kernel): GRX_PR_HOT entries (default 3072 = 12 KB: five workgroups per CU; measured: profiles/r5_c19_pr_hot_head_in_lds.txt, r5_c20_pr_hot_head_sizes.txt);
+  // needs the hub-first order of the gathered vector
+  int hot_n = 0, xcd_wg = wg_env > 0 ? wg_env : per_cu_xcd;
+  if (xcd_blocked && g->xb_perm) {
+    hot_n = 3072;
+    if (const char* e = getenv("GRX_PR_HOT")) hot_n = atoi(e);
+    hot_n = std::max(0, std::min(hot_n, std::min((g->V + XB - 1) / XB, 36864)));
+    if (hot_n > 0) {
+      const size_t dyn = (size_t)hot_n * sizeof(float);
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(pr_pull_xcd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+        (void)hipGetLastError();
+        hot_n = 0;
+      } else if (wg_env <= 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pr_pull_xcd_kernel<true>, PR_BLOCK, dyn) == hipSuccess && n >= 1) xcd_wg = std::min(n, 8);
+        (void)hipGetLastError();
+      }
+    }
+  }
+  a.hot_n = hot_n;
+  const int xcd_grid = std::max(XB, ctx->num_cus * xcd_wg / XB * XB);
   const int max_iter = opt.max_iterations > 0 ? opt.max_iterations : 0x7fffffff;
   // GRX_FLAG_PROFILE: one record per iteration from events on this stream -- advance_ms = the pull
   // (the SpMV-shaped gather incl. long-row pieces and the combine), other_ms = prepare + scalar
@@ -860,7 +990,10 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
       hipLaunchKernelGGL(pr_scalar_kernel, dim3(1), dim3(PR_BLOCK), 0, s, a, launched);
       if (profile) (void)hipEventRecord(pe[1], s);
       if (xcd_blocked) {
-        hipLaunchKernelGGL(pr_pull_xcd_kernel, dim3(ctx->num_cus * 8), dim3(PR_BLOCK), 0, s, a);
+        if (a.hot_n > 0)
+          hipLaunchKernelGGL(pr_pull_xcd_kernel<true>, dim3(xcd_grid), dim3(PR_BLOCK), (size_t)a.hot_n * sizeof(float), s, a);
+        else
+          hipLaunchKernelGGL(pr_pull_xcd_kernel<false>, dim3(xcd_grid), dim3(PR_BLOCK), 0, s, a);
         if (g->n_xb_long > 0)
           hipLaunchKernelGGL(pr_long_xcd_kernel, dim3((g->n_xb_long + 255) / 256), dim3(256), 0, s, a);
         hipLaunchKernelGGL(pr_combine_kernel, dim3(combine_grid), dim3(256), 0, s, a, launched);
@@ -1002,7 +1135,8 @@ grx_status_t grx_pr_dist_post(grx_pr_dist* h) {
   if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_pr_dist_post: no run in progress");
   hipStream_t s = h->ctx->stream;
   hipLaunchKernelGGL(pr_scalar_kernel, dim3(1), dim3(PR_BLOCK), 0, s, h->a, h->launched);
-  const int pull_grid = std::max(1, std::min(std::max(1, h->part.n_blocks), h->ctx->num_cus * 8));
+  static const int per_cu_plain = pr_resident_per_cu(pr_pull_kernel);
+  const int pull_grid = std::max(1, std::min(std::max(1, h->part.n_blocks), h->ctx->num_cus * per_cu_plain));
   hipLaunchKernelGGL(pr_pull_kernel, dim3(pull_grid), dim3(PR_BLOCK), 0, s, h->a, h->launched);
   if (h->part.n_long > 0)
     hipLaunchKernelGGL(pr_long_kernel, dim3((h->part.n_long + 255) / 256), dim3(256), 0, s, h->a, h->launched);

@@ -42,6 +42,26 @@ __device__ __forceinline__ int wave_inclusive_sum(int x) {
   return x;
 }
 
+// The same scan for doubles: each DPP step moves the two halves of the operand separately (the DPP path is 32 bits wide) and
+// one v_add_f64 follows; lanes without a source receive +0.0.  18 VALU instructions where six __shfl_up of a double were
+// twelve trips through the LDS crossbar with their lane arithmetic (round 5: the PageRank pull kernel spent a quarter of its
+// instructions there).  The association of the sum is fixed by the schedule: the same bits on every run.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_inclusive_sum_f64(double x) {
+  x += dpp_f64<0x111, 0xf>(x);  // row_shr:1
+  x += dpp_f64<0x112, 0xf>(x);  // row_shr:2
+  x += dpp_f64<0x114, 0xf>(x);  // row_shr:4
+  x += dpp_f64<0x118, 0xf>(x);  // row_shr:8
+  x += dpp_f64<0x142, 0xa>(x);  // row_bcast:15 -> rows 1, 3
+  x += dpp_f64<0x143, 0xc>(x);  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
 // Inclusive running maximum of NON-NEGATIVE values across the wave (same DPP schedule; 0 is the identity).
 __device__ __forceinline__ int wave_inclusive_max_nonneg(int x) {
   x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));
