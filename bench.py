@@ -20,7 +20,7 @@ roofline objects: algorithmic bytes (SURVEY.md 8d / BASELINE.md) of the launches
 divided by their HIP-event time on the engine's stream (GRX_FLAG_PROFILE), against 8 TB/s HBM.
 `traffic` = FETCH_SIZE + WRITE_SIZE per launch from the committed rocprofv3 --pmc passes of this
 command, attached only while the engine sources still hash to what those passes profiled
-(profiles/r2_bench_pmc.json: source_sha), else null.
+(profiles/history/r2_bench_pmc.json: source_sha), else null.
 cpu_baseline = the oracle (port of the reference's CPU path), 1 core, bounded sample;
 cpu_baseline_ncore = the reference's operator loop on all host cores (oracle/oracle_omp.c).
 """

@@ -781,7 +781,7 @@ static level_build* level_kernel_build() {
 }
 // second bottom-up body (grx_bfs_kernels.hpp): one round trip per round, unsettled lanes deferred.  GRX_BU2=0: first version
 static level_build* level_kernel_build2(bool debug) {
-  // 7 workgroups fit a CU; 4 measured fastest on all three scale-free stand-ins (profiles/r3_ab_bottomup_second_body.txt)
+  // 7 workgroups fit a CU; 4 measured fastest on all three scale-free stand-ins (profiles/history/r3_ab_bottomup_second_body.txt)
   static level_build builds[2] = {{bfs_level_kernel<2, true>, 0, 4}, {bfs_level_kernel<2, true, true>, 0, 4}};
   return &builds[debug ? 1 : 0];
 }

@@ -545,7 +545,7 @@ __device__ __forceinline__ void bfs_bottomup_block(const pipe_args& a, const dob
 // ---------------------------------------------------------------------------------------------------------------
 // Bottom-up level, second version (round 3, single GPU): dense groups of OPEN vertices, one round trip per group.
 //
-// What the counters said about the first version (profiles/r3_bench_pmc.json, class bottom_up): 72 % of the wave cycles
+// What the counters said about the first version (profiles/history/r3_bench_pmc.json, class bottom_up): 72 % of the wave cycles
 // waiting, 80 G L2 requests/s, 1.5 TB/s -- neither bandwidth nor request rate.  A wave there walks, per round of BATCH
 // 64-vertex chunks,  visited word -> row offsets (+ two first in-neighbours) -> frontier words  and then, for the FEW lanes
 // that the first two probes did not settle (5-10 % of the open vertices), two more probe groups (column indices -> frontier

@@ -790,7 +790,7 @@ __device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_ar
 // ---------------------------------------------------------------------------------------------------------------
 // SCATTER, second version (round 3): the same multisplit on workgroups of 1024 threads.
 //
-// What the counters said about the first version (profiles/r2_bench_pmc.json, class topdown_fat): VALU 15 % busy, the
+// What the counters said about the first version (profiles/history/r2_bench_pmc.json, class topdown_fat): VALU 15 % busy, the
 // LDS array ~45 %, HBM at a quarter of its rate -- and the waves parked in s_waitcnt / s_barrier 59 % of their cycles.
 // Nothing is saturated; the kernel is a chain of ~12 barrier-separated phases per batch executed by THREE workgroups
 // (12 waves) per CU, because a thread carries 32 edges (id + bin/rank) through the sort and a software pipeline four
@@ -812,7 +812,7 @@ constexpr int SC2_BLOCK = 1024;
 constexpr int SC2_Q = SC2_BLOCK / TILE;  // quarters = chunks per batch
 // SUB-COUNTERS (round 4).  With 16-bit entries the LJ stand-in has 76 bins: the 64 lanes of a wave hit a handful of hot bins
 // several times each, and a returning LDS atomic on one word serialises (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.51 in
-// profiles/r3_bench_pmc.json, class topdown_fat).  Every bin gets SC2_SUB counters in neighbouring words (= banks); a lane
+// profiles/history/r3_bench_pmc.json, class topdown_fat).  Every bin gets SC2_SUB counters in neighbouring words (= banks); a lane
 // uses counter lane % SC2_SUB.  A bin's run in the sorted buffer is the concatenation of its sub-runs, so everything behind
 // the histogram -- one reservation per bin, one `delta` per bin, the copy-out -- is unchanged.  256 bins x 4 = one counter
 // per thread of the 1024-thread workgroup.  bin_args::sub_shift = 0 switches it off (GRX_BIN_SUB=1, for the A/B).
@@ -853,7 +853,7 @@ template <bool DBG, bool E16, bool VAL = false, class SM = bin_scatter2_smem, bo
 __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin_args& bn, SM& sm, int p,
                                                    int total_chunks, const int* chunk_tile) {
   static_assert(!VAL || E16, "values travel with 16-bit offsets");
-  static_assert(!UNI || (E16 && !VAL), "uniform bins: 16-bit offsets, no values");
+  static_assert(!UNI || E16, "uniform bins: 16-bit offsets");
   constexpr int BBITS = VAL ? 10 : 8;    // bits of a bin index in the granule table
   constexpr int BSHIFT_C = VAL ? 14 : 24;  // ... and where it sits in a sorted entry (above the offset inside the bin)
   const int BSHIFT = UNI ? bn.uniform : BSHIFT_C;   // (UNI: a uniform run-time shift, the entry is the id)
@@ -1084,8 +1084,8 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       for (int k = 0; k < ADV_ITEMS; ++k) {
         const int al = k * TILE + tq;
         const int e = al < n_at ? a0 + al + ob[k] : 0;  // lanes past the end read edge 0
-        e_k[k] = (unsigned)a.ci[e];
-        if constexpr (VAL) w_k[k] = bn.rw[e];
+        e_k[k] = (unsigned)a.ci[(unsigned)e];  // (unsigned: a 32-bit offset on the scalar base, no 64-bit address arithmetic)
+        if constexpr (VAL) w_k[k] = bn.rw[(unsigned)e];
       }
       if constexpr (VAL) {
         // the relaxation's arithmetic, exactly (sssp.hxx:121-123): fl(label of the source + weight)
@@ -1186,8 +1186,8 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       for (int k = 0; k < ADV_ITEMS; ++k) {
         const int i = k * SC2_BLOCK + tid;
         if (i < btot) {
-          reinterpret_cast<unsigned short*>(bn.bins)[(size_t)(d_k[k] + i)] = (unsigned short)(s_k[k] & 0xffffu);
-          bn.rval[(size_t)(d_k[k] + i)] = x_k[k];
+          reinterpret_cast<unsigned short*>(bn.bins)[(unsigned)(d_k[k] + i)] = (unsigned short)(s_k[k] & (UNI ? umask : 0xffffu));
+          bn.rval[(unsigned)(d_k[k] + i)] = x_k[k];
         }
       }
     } else if (!UNI && bn.pair_stores) {
@@ -1236,9 +1236,9 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
       for (int k = 0; k < ADV_ITEMS; ++k) {
         const int i = k * SC2_BLOCK + tid;
         if (i < btot) {
-          if constexpr (UNI) reinterpret_cast<unsigned short*>(bn.bins)[(size_t)(d_k[k] + i)] = (unsigned short)(s_k[k] & umask);
-          else if constexpr (E16) reinterpret_cast<unsigned short*>(bn.bins)[(size_t)(d_k[k] + i)] = (unsigned short)(s_k[k] & 0xffffu);
-          else bn.bins[(size_t)(d_k[k] + i)] = (int)(s_k[k] & 0xffffffu);
+          if constexpr (UNI) reinterpret_cast<unsigned short*>(bn.bins)[(unsigned)(d_k[k] + i)] = (unsigned short)(s_k[k] & umask);
+          else if constexpr (E16) reinterpret_cast<unsigned short*>(bn.bins)[(unsigned)(d_k[k] + i)] = (unsigned short)(s_k[k] & 0xffffu);
+          else bn.bins[(unsigned)(d_k[k] + i)] = (int)(s_k[k] & 0xffffffu);
         }
       }
     }

@@ -233,6 +233,7 @@ struct grx_graph {
   int32_t* rb_off = nullptr;          // off[1025], v0[1025]
   unsigned short* rb_g2b16 = nullptr; // granule -> bin (10 bits) | index of the granule inside its bin << 10
   int32_t rb_shift = 0, rb_ngran = 0, rb_nb = 0;
+  int32_t rb_uniform = 0;             // > 0: the relax bins are the aligned ranges of 2^rb_uniform vertices
   int32_t rb_state = 0;               // 0: not built, 1: usable, 2: not applicable to this graph
   std::atomic<uint32_t> rb_hint{0};   // launch groups in which a weighted search on this graph met a fat level
   void* blk[2] = {nullptr, nullptr};  // block structure of the block-asynchronous searches: [0] BFS depths, [1] weighted; owned

@@ -960,7 +960,7 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
 // Which body a build carries.  ONE by default (the second version): the launch-bound searches turned out to be sensitive to
 // the sheer size of the level kernel's code -- with both bodies inlined (58 KB) a near-far iteration of the road stand-in
 // took 42.6 us against 31.5 us with one body (45 KB), although the extra code is never executed in that run
-// (tools/ab_mid.py, GRX_MID=0, libraries built from the same sources).  -DGRX_MID_BOTH builds both (then
+// (tools/history/ab_mid.py, GRX_MID=0, libraries built from the same sources).  -DGRX_MID_BOTH builds both (then
 // GRX_MID_VERSION=1|2 selects at run time), -DGRX_MID_FIRST_VERSION the first one only.
 template <class Policy>
 __device__ __forceinline__ void mid_levels_run(const pipe_args& a, ctrl_t* c, Policy& pol, mid_smem<Policy>& sm,

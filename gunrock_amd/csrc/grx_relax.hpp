@@ -45,7 +45,7 @@ constexpr int RB_QUEUE_SLOT = 15;               // bin_args::queue word (x BIN_P
 
 // (Measured and removed, round 4 call 17: a software-pipelined build of the scatter -- owner map and column / weight loads of batch
 // i + 1 issued ahead of the reservation, sort and copy-out of batch i, same phases and barriers, +25 VGPRs -- was correct and 2-3 %
-// SLOWER on the LJ and kron stand-ins: profiles/r4_ab_relax_scatter_pipelined_rejected.txt.  The scatter is
+// SLOWER on the LJ and kron stand-ins: profiles/history/r4_ab_relax_scatter_pipelined_rejected.txt.  The scatter is
 // bin_scatter2_block<.., VAL = true> of grx_bin.hpp.)
 
 struct relax_sweep_smem {

@@ -508,11 +508,12 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_level_kernel(pipe_args a, sssp
 
 // A fat level of the plain schedule as a binned relaxation (grx_relax.hpp): scatter, then sweep.  No-ops unless the head chose
 // mode 2.  One workgroup of 1024 threads per CU each (96 KB / 108 KB of LDS).
+template <bool UNI>
 __global__ __launch_bounds__(SC2_BLOCK) void sssp_rscatter_kernel(pipe_args a, bin_args bn) {
   __shared__ __attribute__((aligned(16))) bin_scatter2_val_smem sm;
   const level_head h = load_level_head(a.ctrl);
   if (h.done || h.mode != 2) return;
-  bin_scatter2_block<false, true, true>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
+  bin_scatter2_block<false, true, true, bin_scatter2_val_smem, UNI>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
 }
 
 __global__ __launch_bounds__(RB_BLOCK) void sssp_rsweep_kernel(pipe_args a, bin_args bn) {
@@ -633,7 +634,22 @@ static grx_status_t graph_build_relax_bins(grx_context_t ctx, grx_graph_t g) {
   std::vector<int> first;
   const int want_bins = std::max(1, std::min(RB_MAX_BINS, sssp_env_int("GRX_RBIN_BINS", 448)));  // (tuning aid; read when the table is built)
   long long target = (total + want_bins - 1) / want_bins;
-  for (int attempt = 0; attempt < 64; ++attempt) {
+  // UNIFORM bins (round 5, as for the BFS: grx_bfs.hip graph_build_bins): the aligned 16384-vertex ranges -- bin = id >> 14, the
+  // entry is the id, no granule table in the scatter.  Measured on the two dense stand-ins (profiles/r5_c21_relax_uniform_bins.txt):
+  // LJ' (14 edges per vertex) 2.995 -> 2.760 ms per search (scatter 1830 -> 1563 us, sweep 851 -> 989), kron' (87) 5.29 -> 5.41 --
+  // the value scatter runs one workgroup per CU and feels every instruction; on the kron stand-in the hub ranges' parts cost the
+  // sweep more than the scatter gains.  So: uniform below 32 edges per vertex (the opposite of the BFS rule, whose sweep pays per
+  // discovered vertex, not per changed label).  GRX_RBIN_UNIFORM=1 | 0 forces one.
+  int ushift = 0;
+  {
+    const int uni_env = sssp_env_int("GRX_RBIN_UNIFORM", -1);
+    const long long nb_u = ((long long)g->V + RB_WIDTH - 1) >> RB_SHIFT;
+    if ((uni_env > 0 || (uni_env < 0 && (long long)g->E < 32ll * g->V)) && RB_SHIFT >= gshift && nb_u >= 48 && nb_u <= RB_MAX_BINS) {
+      ushift = RB_SHIFT;
+      for (int i = 0; i < n_gran; i += 1 << (RB_SHIFT - gshift)) first.push_back(i);
+    }
+  }
+  for (int attempt = 0; attempt < 64 && ushift == 0; ++attempt) {
     first.clear();
     long long acc = 0;
     int width = 0;
@@ -675,6 +691,7 @@ static grx_status_t graph_build_relax_bins(grx_context_t ctx, grx_graph_t g) {
   GRX_HIP(hipStreamSynchronize(s));
   g->rb_off = reinterpret_cast<int32_t*>(d_off.release());
   g->rb_g2b16 = reinterpret_cast<unsigned short*>(d_tab.release());
+  g->rb_uniform = ushift;
   g->rb_shift = gshift;
   g->rb_ngran = n_gran;
   g->rb_nb = nb;
@@ -755,6 +772,7 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     rb.gshift = g->rb_shift;
     rb.n_gran = g->rb_ngran;
     rb.nb = g->rb_nb;
+    rb.uniform = g->rb_uniform;
     rb.local_ids = 1;
     rb.entry16 = 1;
     // sub-counters per bin in the scatter's LDS histogram (grx_bin.hpp: a hot bin's ranking atomics serialise on one word): as
@@ -841,7 +859,8 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
             [&] {
               hipLaunchKernelGGL(sssp_level_kernel, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol, ctx->xcc_mask);
               if (bins_here) {
-                hipLaunchKernelGGL(sssp_rscatter_kernel, dim3(grid_rscatter), dim3(SC2_BLOCK), 0, stream, a, rb);
+                if (rb.uniform) hipLaunchKernelGGL(sssp_rscatter_kernel<true>, dim3(grid_rscatter), dim3(SC2_BLOCK), 0, stream, a, rb);
+                else hipLaunchKernelGGL(sssp_rscatter_kernel<false>, dim3(grid_rscatter), dim3(SC2_BLOCK), 0, stream, a, rb);
                 hipLaunchKernelGGL(sssp_rsweep_kernel, dim3(grid_rsweep), dim3(RB_BLOCK), 0, stream, a, rb);
               }
             });
@@ -997,7 +1016,7 @@ extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
     // GRX_NF_DELTA_SCALE: tuning knob (bucket width multiplier)
     const char* dsc = getenv("GRX_NF_DELTA_SCALE");
     // Width 128 x mean weight / mean degree: four times Davidson et al.'s constant.  Measured on the
-    // weighted road stand-in (tools/ab_sssp_delta.py), width / iterations / relaxations / time:
+    // weighted road stand-in (tools/history/ab_sssp_delta.py), width / iterations / relaxations / time:
     //   16: 10417 / 65 M / 192 ms   32: 8603 / 74 M / 164 ms   64: 7463 / 92 M / 150 ms
     //   128: 6749 / 130 M / 143 ms   256: 6313 / 213 M / 144 ms
     // -- an iteration is ~19 us of launch and latency, so fewer, fatter iterations win until the

@@ -291,7 +291,7 @@ grx_status_t grx_debug_radix_sort(grx_context_t ctx, uint32_t* d_keys, uint32_t*
  * kernels, recorded when GRX_BIN_DEBUG=<level> is set; tools/bin_debug.py). */
 grx_status_t grx_debug_read(grx_context_t ctx, long long* out, int64_t n);
 /* Tuning aid: the first n (<= 5) spare counters of the device control block (GRX_MID_DEBUG=1: wall-clock ticks the
- * leader of a multi-level launch spent per phase, and the levels it ran; tools/ab_mid.py). */
+ * leader of a multi-level launch spent per phase, and the levels it ran; tools/history/ab_mid.py). */
 grx_status_t grx_debug_ctrl(grx_context_t ctx, int32_t* out, int32_t n);
 
 /* ---- multi-GPU: level-group interface of the partitioned BFS enactor ------------------

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void histogram_kernel(const edge_t* segments, 
     unsigned long long todo = grx::dev::ballot(true);
     while (todo) {
       const int leader = __builtin_ctzll(todo);
-      const int lb = __shfl(b, leader, 64);
+      const int lb = __builtin_amdgcn_readlane(b, leader);
       const unsigned long long same = grx::dev::ballot(b == lb) & todo;
       if (grx::dev::lane_id() == leader) atomicAdd(&s_bins[lb], (unsigned)__popcll(same));
       todo &= ~same;

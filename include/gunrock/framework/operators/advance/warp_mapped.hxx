@@ -38,9 +38,9 @@ __global__ __launch_bounds__(256) void kernel(graph_t G, operator_t op, const ty
     while (m) {
       const int l = __builtin_ctzll(m);
       m &= m - 1ull;
-      const type_t rv = (type_t)__shfl((int)v, l, 64);
-      const edge_t rf = (edge_t)__shfl((int)first, l, 64), rd = (edge_t)__shfl((int)deg, l, 64),
-                   rb = (edge_t)__shfl((int)base, l, 64);
+      const type_t rv = (type_t)__builtin_amdgcn_readlane((int)v, l);
+      const edge_t rf = (edge_t)__builtin_amdgcn_readlane((int)first, l), rd = (edge_t)__builtin_amdgcn_readlane((int)deg, l),
+                   rb = (edge_t)__builtin_amdgcn_readlane((int)base, l);
       for (edge_t k = lane; k < rd; k += 64) {
         // mutable lvalues: user operators may take (vertex_t&, vertex_t&, edge_t const&, weight_t const&)
         // like the reference's hits.hxx:137

@@ -51,7 +51,7 @@ def test_per_level_kernels_stay_below_64k_lds_and_off_scratch(tmp_path):
     missing = [k for k in PER_LEVEL if k not in seen]
     assert not missing, missing
     # the second sweep (round 3) deliberately takes 82 KB for a list that holds one item's discoveries (one emission per
-    # item); its no-op launches were measured at 4.1 us like every other kernel's (profiles/r3_bfs_kernel_stats.csv), so the
+    # item); its no-op launches were measured at 4.1 us like every other kernel's (profiles/history/r3_bfs_kernel_stats.csv), so the
     # 64 KB rule is not applied to it -- but it must not spill either, and the scatter must fit twice into a CU's 160 KB
     sweep2 = [(m, v) for m, v in meta.items() if "bfs_sweep2_kernel" in m]
     assert sweep2

@@ -179,7 +179,7 @@ def test_kron_c4_full_size_and_reference_gpu_path(gr, gpu_ctx):
         here as |ref_k - float64_k| and as the spread between two runs of the reference -- so the assertion is
             |ours_k - ref_k| <= 1e-6 + |ref_k - float64_k|     with     |ours_k - float64_k| <= 1e-6 (in fact ~1e-10),
         i.e. everything beyond north_star's 1e-6 must be the reference's own distance from exact arithmetic at
-        that iterate.  All numbers go to gpurun_out/pr_parity_c4.json (committed as profiles/r3_pr_parity_c4.json)."""
+        that iterate.  All numbers go to gpurun_out/pr_parity_c4.json (committed as profiles/history/r3_pr_parity_c4.json)."""
     import json
     g = _c4_graph(gr)
     assert g.n_edges > 180_000_000

@@ -7,7 +7,7 @@ set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out profiles
 export TMPDIR=/tmp
 bash tools/profile_r4.sh > gpurun_out/final_profile.log 2>&1
-cp gpurun_out/r4_bench_pmc.json profiles/r4_bench_pmc.json
+cp gpurun_out/r4_bench_pmc.json profiles/history/r4_bench_pmc.json
 (timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/final_pytest_gpu.log 2>&1; echo "pytest rc $?" >> gpurun_out/final_pytest_gpu.log)
 (timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final_smoke.log 2>&1; echo "smoke rc $?" >> gpurun_out/final_smoke.log)
 timeout 900 python bench.py > gpurun_out/final_bench.log 2> gpurun_out/final_bench.err; echo "rc $?" >> gpurun_out/final_bench.log

@@ -95,6 +95,13 @@ def classify(rows):
                 continue
             sc = [d for d, n in s["kernels"] if "bfs_scatter2_kernel" in n]
             cl = [d for d, n in s["kernels"] if "bfs_claim_kernel" in n or "bfs_sweep" in n]
+            if sc and len(sc) == len(cl) and len(sc) < len(lv) + 2 and len(sc) <= 4:
+                # round 5, exact schedule of a repeated source (grx_graph::bin_exact; profiled searches too): scatter + sweep are
+                # launched in the fat groups ONLY, and those groups carry no level kernel -- every pair is one fat level
+                for pos, (d_sc, d_cl) in enumerate(zip(sc, cl)):
+                    cls[d_sc] = ("topdown_fat", pos)
+                    cls[d_cl] = ("topdown_fat", pos)
+                continue
             for pos in (1, 2):
                 for group in (lv, sc, cl):
                     if pos < len(group):

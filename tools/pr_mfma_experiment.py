@@ -15,7 +15,7 @@ in-degree) that come from the top-K sources (by out-degree).  This script
      edge x the edges inside the block) and against the bytes each form moves.
 fp32 is required: ranks are ~1e-7 .. 1e-3 and the tolerance is 1e-6 absolute; bf16 / f16 inputs (the fast MFMA
 rates) carry 2^-8 .. 2^-11 relative error per product and cannot meet it.
-Prints one JSON object; DESIGN.md section 3.2 quotes it."""
+Prints one JSON object; DESIGN.md section 3.4 (HISTORY.md section 3.4) quotes it."""
 import json
 import os
 import sys

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 rocprofv3 evidence: kernel-trace stats + separate PMC passes for the bench workloads, then
-# profiles/r4_bench_pmc.json (tools/pmc_json.py) and the per-target summaries.
+# profiles/history/r4_bench_pmc.json (tools/pmc_json.py) and the per-target summaries.
 #   tools/profile_r4.sh [bfs] [ssspu] [sssp] [ssspd] [pr]      (ssspd: weighted SSSP on the LJ stand-in = binned relaxation)
 set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out

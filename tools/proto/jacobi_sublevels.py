@@ -1,7 +1,7 @@
 """Driver of tools/proto/jacobi_sublevels.c (CPU design study, no GPU): relaxations and passes of the level-synchronous
 weighted SSSP on a bench stand-in when a fat level runs as K sequential sub-levels.
     python tools/proto/jacobi_sublevels.py [lj|kron] [K ...]
-Model of the time, from profiles/r4_relax_kernel_trace_lj.txt (scatter + sweep of the binned levels: 3150 us for 306 M
+Model of the time, from profiles/history/r4_relax_kernel_trace_lj.txt (scatter + sweep of the binned levels: 3150 us for 306 M
 relaxations = 10.3 us per million; head + no-op level kernel + launches: ~14 us per pass):  t = 10.3 us x Medges + 14 us x passes."""
 import ctypes as C
 import os

@@ -2,7 +2,7 @@
 # round 4, call 22 (second session; 14.7 GPU-minutes left): the host-side schedule changes -- launch groups / first batches that
 # follow the previous search, reset + seed of a forward search in one launch, the source kernel writing level 1's chunk map.
 # Parity tests of the new paths first, then the same-process A/B, a bench line on these sources, and -- if time is left -- the
-# kernel-trace + FETCH/WRITE passes of the BFS command (profiles/r4_bench_pmc.json for these sources) with a kernel timeline.
+# kernel-trace + FETCH/WRITE passes of the BFS command (profiles/history/r4_bench_pmc.json for these sources) with a kernel timeline.
 set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 T0=$(date +%s); el() { echo "[$(( $(date +%s) - T0 )) s] $*"; }
