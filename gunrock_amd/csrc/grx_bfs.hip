@@ -1030,7 +1030,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     hipLaunchKernelGGL(bfs_reset_seed_kernel, dim3(ctx->num_cus * 8), dim3(TILE), 0, s, d_dist, (int64_t)g->V, d, g->closed0, a, src,
                        source_level);
   else if (fwd_seed_in_reset)
-    hipLaunchKernelGGL(bfs_fwd_reset_seed_kernel, dim3(ctx->num_cus * 8), dim3(TILE), 0, s, d_dist, (int64_t)g->V, visited,
+    hipLaunchKernelGGL(bfs_fwd_reset_seed_kernel, dim3(ctx->num_cus * env_int("GRX_RESET_WG_PER_CU", 8)), dim3(TILE), 0, s, d_dist, (int64_t)g->V, visited,
                        (int)bm_words, a, src, d, source_level);
   else
     hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(TILE), 0, s, a, d_dist, visited, src, d, source_level);

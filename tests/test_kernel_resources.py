@@ -12,7 +12,6 @@ import pytest
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 PER_LEVEL = ("bfs_head_kernel", "bfs_level_kernel", "bfs_level_bin_kernel", "bfs_sweep_kernel", "bfs_source_kernel",
-             "bfs_scatter2_kernel",
              "sssp_head_kernel", "sssp_level_kernel", "sssp_nf_head_kernel", "sssp_nf_level_kernel",
              "pr_pull_kernel", "pr_pull_xcd_kernel", "pr_combine_kernel", "pr_scalar_kernel",
              "dist_head_kernel", "dist_prep_kernel", "dist_advance_kernel", "dist_post_kernel", "dist_stats_kernel",
@@ -57,6 +56,11 @@ def test_per_level_kernels_stay_below_64k_lds_and_off_scratch(tmp_path):
     assert sweep2
     for m, (lds, scratch) in sweep2:
         assert scratch == 0 and lds <= 160 * 1024, (m, lds, scratch)
-    for m, (lds, scratch) in meta.items():
-        if "bfs_scatter2_kernel" in m:
-            assert 2 * lds <= 160 * 1024, (m, lds)
+    # the second scatter: 71 KB since round 5 (the granule table holds 32-bit deltas: one LDS read + one add per edge) -- beyond
+    # the 64 KB rule like the sweep, and like the sweep measured: a forward search that carries scatter + sweep in EVERY group
+    # (GRX_BIN_HINT=0: ten no-op launches of the pair) is 36 us slower than one that carries none of them, ~2.3 us per launch
+    # (profiles/r5_c11_ab_lj.txt).  What it must keep: no scratch, and two workgroups per CU.
+    sc2 = [(m, v) for m, v in meta.items() if "bfs_scatter2_kernel" in m]
+    assert sc2
+    for m, (lds, scratch) in sc2:
+        assert scratch == 0 and 2 * lds <= 160 * 1024, (m, lds, scratch)
