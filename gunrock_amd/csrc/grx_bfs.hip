@@ -526,14 +526,13 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
 // not cost the direction-optimising path its resident workgroups.
 __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_bin_kernel(pipe_args a, bin_args bn, bfs_policy pol) {
   using td_smem = mid_smem<bfs_policy>;
-  constexpr size_t LDS_BYTES = sizeof(td_smem) > sizeof(bin_scatter_smem) ? sizeof(td_smem) : sizeof(bin_scatter_smem);
+  constexpr size_t LDS_BYTES = sizeof(td_smem);
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
   ctrl_t* c = a.ctrl;
   const level_head h = load_level_head(c);
   if (h.done) return;
   if (h.mode == 2) {
-    if (bn.local_ids) return;  // the scatter of this level is bfs_scatter2_kernel, the next launch of the group
-    bin_scatter_block(a, bn, *reinterpret_cast<bin_scatter_smem*>(lds_raw), h.level & 1, h.total_chunks, a.chunk_tile);
+    return;  // a binned level: its kernels are bfs_scatter2_kernel + bfs_sweep2_kernel, the next launches of the group
   } else if (h.mode == 3) {
     pol.ctrl = c;
     mid_levels_run(a, c, pol, *reinterpret_cast<td_smem*>(lds_raw), h, bn.xcc_mask);
@@ -558,29 +557,8 @@ __global__ __launch_bounds__(SC2_BLOCK, 8) void bfs_scatter2_kernel(pipe_args a,
   bin_scatter2_block<DBG, E16, false, bin_scatter2_smem, UNI>(a, bn, sm, h.level & 1, h.total_chunks, a.chunk_tile);
 }
 
-__global__ __launch_bounds__(ADV_BLOCK) void bfs_claim_kernel(pipe_args a, bin_args bn, bfs_policy pol) {
-  __shared__ bin_claim_smem sm;
-  ctrl_t* c = a.ctrl;
-  const level_head h = load_level_head(c);
-  if (h.done || h.mode != 2) return;
-  (void)pol;
-  bin_claim_block(a, bn, c, h.level + 1, sm, h.level & 1);
-}
-
-// The claim phase as a sweep (grx_bin.hpp, third version): one workgroup of 1024 threads per bin (or part of a fat bin).
-__global__ __launch_bounds__(SWEEP_BLOCK) void bfs_sweep_kernel(pipe_args a, bin_args bn) {
-  __shared__ bin_sweep_smem sm;
-  ctrl_t* c = a.ctrl;
-  const level_head h = load_level_head(c);
-  if (h.done || h.mode != 2) return;
-  bin_sweep_block(a, bn, c, h.level + 1, sm, h.level & 1);
-}
-
-// The claim phase as a sweep, second version (grx_bin.hpp), in two geometries:
-//   NT = 512, <= 64 VGPRs, 8448-entry list: up to three workgroups per CU, two parts per bin;
-//   NT = 1024, <= 128 VGPRs, 16128-entry list (82 KB of LDS): one workgroup per CU like the first version, one part per bin
-//   unless it is fat -- what it changes against the first version is ONE emission per item (the first version's 8448-entry
-//   list was emitted up to three times per item on the 31 M-edge level, plus once more for the short tile at the end).
+// The claim phase as a sweep (grx_bin.hpp): NT = 1024 threads, <= 128 VGPRs, a 16128-entry list (82 KB of LDS): one workgroup
+// per CU, one part per bin unless it is fat, ONE emission per item.
 template <int NT, int LE, int WAVES_PER_SIMD, bool DBG, bool E16>
 __global__ __launch_bounds__(NT, WAVES_PER_SIMD) void bfs_sweep2_kernel(pipe_args a, bin_args bn) {
   __shared__ __attribute__((aligned(16))) bin_sweep2_smem<NT, LE> sm;
@@ -593,7 +571,6 @@ __global__ __launch_bounds__(NT, WAVES_PER_SIMD) void bfs_sweep2_kernel(pipe_arg
   }
   bin_sweep2_block<NT, LE, DBG, E16>(a, bn, c, h.level + 1, sm, h.level & 1);
 }
-constexpr int SW2_BLOCK = 512, SW2_LIST = 8192 + TILE;
 constexpr int SW3_BLOCK = 1024, SW3_LIST = 63 * TILE;
 
 }  // namespace grx
@@ -1046,17 +1023,13 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.mid_v = env_int("GRX_MID_V", MID_ENTER_V);
     bn.mid_e = env_int("GRX_MID_E", MID_ENTER_E);
   }
-  int grid_scatter = 0, grid_claim = 0, grid_scatter2 = 0, grid_sweep2 = 0, grid_sweep3 = 0;
-  // claim phase of a binned level: 3 = sweep (one workgroup per bin, vertex-ordered output), 2 = slices claimed in the owning XCD's L2
-  const int claim_version = env_int("GRX_BIN_CLAIM", 3);
+  int grid_scatter = 0, grid_scatter2 = 0, grid_sweep3 = 0;
   if (use_bins) {
     bn.bins = ctx->bins.as<int32_t>();
     bn.off = g->bin_off;
     bn.v0 = g->bin_off + BIN_MAX + 1;
     bn.fill = ctx->bin_fill.as<int32_t>();
     bn.queue = ctx->bin_fill.as<int32_t>() + (size_t)BIN_MAX * BIN_PAD;
-    bn.g2b = g->bin_tab8;
-    bn.owner = g->bin_tab8 + BIN_GRAN_MAX;
     bn.g2b16 = reinterpret_cast<const unsigned short*>(g->bin_tab8 + BIN_GRAN_MAX + BIN_MAX);
     bn.gshift = g->bin_shift;
     bn.n_gran = g->bin_ngran;
@@ -1065,12 +1038,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.sweep_balance = env_int("GRX_SW2_BALANCE", 0);  // measured slower (profiles/r5_c7_kernel_times_by_bin_cut.txt): off
     bn.xcc_mask = ctx->xcc_mask;
     bn.n_xcd = ctx->n_xcd;
-    // The slice-wise claim (GRX_BIN_CLAIM=2) pays one scattered L2 access per id that is new to its 8192-entry
-    // slice: when a few thousand hubs are expanded into a mostly unvisited graph nearly every entry is such an id and
-    // the claim-per-edge advance was as fast or faster (kron stand-in, 148 M-edge level: 1.31 ms vs 1.52 ms binned),
-    // hence a limit on the frontier's mean out-degree for that version.  The sweep claim pays per DISCOVERED VERTEX
-    // and wins on that level too (1.45 -> 0.80 ms): no limit.
-    bn.max_degree = env_int("GRX_BIN_MAX_DEGREE", claim_version == 2 ? 512 : 0);
+    bn.max_degree = env_int("GRX_BIN_MAX_DEGREE", 0);  // (a limit on the frontier's mean out-degree for binning: none)
     bn.debug_level = env_int("GRX_BIN_DEBUG", 0);
     if (bn.debug_level != 0) {
       // per-workgroup records of the LAST binned level: scatter at [0, 4096), claim at [4096 + grid, ...); read
@@ -1086,11 +1054,8 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.visited = visited;
     bn.visited_words = (int32_t)bm_words;
     bn.dist = d_dist;
-    static const int per_cu_claim = resident_per_cu(bfs_claim_kernel);
-    grid_claim = ctx->num_cus * per_cu_claim;
-    // scatter phase: 2 = 1024-thread workgroups in their own launch (bins hold offsets inside the bin), 1 = first
-    // version inside the level kernel.  The slice claim (GRX_BIN_CLAIM=2) reads global ids: first version only.
-    if (env_int("GRX_BIN_SCATTER", 2) == 2 && claim_version != 2) {
+    {
+      // scatter: 1024-thread workgroups, two per CU (the bins hold offsets inside the bin)
       static const int per_cu_sc2 = [] {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_scatter2_kernel<false, false>, SC2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
@@ -1104,34 +1069,15 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       bn.static_units = (ctx->sc2_static || grid_scatter2 < 4 * ctx->n_xcd || env_int("GRX_SC2_STATIC", 0) != 0) ? 1 : 0;
       bn.fault_xcd = ctx->sc2_static ? 0 : env_int("GRX_SC2_FAULT_XCD", 0);
       bn.sub_shift = env_int("GRX_BIN_SUB", 4) == 1 ? 0 : 2;
-      bn.pair_stores = env_int("GRX_BIN_PAIR", 0);  // measured slower (round 4: LJ 0.467 vs 0.450 ms per search): off
-    }
-    // sweep claim: 1 = first version; 2 = second version on 512-thread workgroups, two parts per bin; 3 = second version on
-    // 1024-thread workgroups, one per CU, one emission per item
-    const int sweep_version = claim_version == 3 ? env_int("GRX_BIN_SWEEP", 3) : 0;
-    if (sweep_version == 2) {
-      static const int per_cu_sw2 = [] {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bfs_sweep2_kernel<SW2_BLOCK, SW2_LIST, 8, false, false>, SW2_BLOCK, 0) != hipSuccess || n < 1) n = 1;
-        return n > 4 ? 4 : n;
-      }();
-      grid_sweep2 = ctx->num_cus * env_int("GRX_SW2_WG_PER_CU", per_cu_sw2 > 2 ? 2 : per_cu_sw2);
-      // parts per bin: every part of a bin finds the bin's hubs again and pays the merging atomics for them, so few,
-      // large parts (call 2 of round 3: 1024 items 73 us, 512 items 58 us on the 31 M-edge level)
-      bn.sweep_items = env_int("GRX_SW2_ITEMS", bn.nb * (1 + env_int("GRX_SW2_PARTS_PER_BIN", 2)));
-      if (bn.sweep_items > grid_sweep2) bn.sweep_items = grid_sweep2;
-    } else if (sweep_version == 3) {
-      // as the first version: a bin with more than 1/160 of the level's candidates is cut into parts, the grid is twice the
-      // resident workgroups (the second half starts as the first finishes)
+      // sweep: a bin with more than 1/160 of the level's candidates is cut into parts; the grid is twice the resident
+      // workgroups (one per CU), so that a level cut into more items than CUs still runs
       grid_sweep3 = ctx->num_cus * 2;
-      // (round 5: with balanced parts the whole chip, one item per CU; before: bins + 160, which came out as ~210 items)
       bn.sweep_items = env_int("GRX_SW2_ITEMS", bn.sweep_balance ? std::max(ctx->num_cus, bn.nb + 32) : bn.nb + 160);
       if (bn.sweep_items > grid_sweep3) bn.sweep_items = grid_sweep3;
     }
   }
   // 16-bit bin entries need the second scatter (writes them) and the second sweep (reads them)
-  bn.entry16 = (use_bins && g->bin_entry16 && bn.local_ids && (grid_sweep2 > 0 || grid_sweep3 > 0) &&
-                env_int("GRX_BIN_E16", 1) != 0) ? 1 : 0;  // (GRX_BIN_E16=0: 32-bit entries in the same bins, for A/B)
+  bn.entry16 = (use_bins && g->bin_entry16 && env_int("GRX_BIN_E16", 1) != 0) ? 1 : 0;  // (GRX_BIN_E16=0: 32-bit entries in the same bins, for A/B)
   if (!dopt && variant == 0) {
     static const int per_cu_scatter = resident_per_cu(bfs_level_bin_kernel);
     const int resident = ctx->num_cus * per_cu_scatter;
@@ -1176,7 +1122,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (profile) (void)hipEventRecord(pe[0], stream);
     const bool bins_here = use_bins && (seq >= 32 || ((bin_groups >> seq) & 1u) != 0u);
     // (the second scatter + a sweep: the first versions of the two kernels share the level kernel's launch)
-    const bool level_here = !(exact && bins_here && seq < 32 && grid_scatter2 > 0 && claim_version == 3);
+    const bool level_here = !(exact && bins_here && seq < 32);
     bn.allowed = bins_here ? 1 : 0;
     bn.no_level = level_here ? 0 : 1;
     if (variant == 0) {
@@ -1194,14 +1140,8 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
             hipLaunchKernelGGL((bfs_scatter2_kernel<DBG, E16, E16>), dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
           else if (grid_scatter2 > 0)
             hipLaunchKernelGGL((bfs_scatter2_kernel<DBG, E16>), dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
-          if (use_bins && claim_version == 2)
-            hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_claim), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
-          else if (use_bins && grid_sweep2 > 0)
-            hipLaunchKernelGGL((bfs_sweep2_kernel<SW2_BLOCK, SW2_LIST, 8, DBG, E16>), dim3(grid_sweep2), dim3(SW2_BLOCK), 0, stream, a, bn);
-          else if (use_bins && grid_sweep3 > 0)
+          if (use_bins)
             hipLaunchKernelGGL((bfs_sweep2_kernel<SW3_BLOCK, SW3_LIST, 4, DBG, E16>), dim3(grid_sweep3), dim3(SW3_BLOCK), 0, stream, a, bn);
-          else if (use_bins)
-            hipLaunchKernelGGL(bfs_sweep_kernel, dim3(ctx->num_cus * 2), dim3(SWEEP_BLOCK), 0, stream, a, bn);
         };
         using std::true_type;
         using std::false_type;

@@ -10,24 +10,19 @@
 // the fabric (rocprofv3, round 1: 1.88 GB of L2-miss traffic for 0.41 GB of algorithmic bytes,
 // L2 hit rate 35 %, 0.54 ms).  More than 90 % of those probes only learn "already visited".
 // Here a fat level runs in two kernels whose global traffic is all coalesced streams:
-//   1. SCATTER (bin_scatter_block, inside the level kernel): the frontier is expanded exactly as
-//      in advance_block (tiles, 2048-edge chunks, lanes on consecutive edges), but a neighbour id
-//      is not probed -- it is appended to the BIN of its vertex range (<= 256 bins).  A workgroup
-//      sorts 4 chunks (8192 ids) by bin in LDS (histogram + rank with LDS atomics, block scan) and
-//      writes each bin's run with ONE reservation atomic per bin and batch; runs leave LDS as
-//      contiguous segments.  Bins are runs of GRANULES (>= 1024 vertices = one 128-byte line of the
-//      visited bitmap), cut once per graph so that every bin receives about the same number of
-//      in-edges (hub regions get narrow bins, sparse regions wide ones); their capacities are
-//      STATIC -- the in-edges of the vertex range, each edge is traversed at most once per level --
-//      so the bins are one E-entry array that can never overflow and needs no size pass.
-//   2. CLAIM (bin_claim_block, its own launch): a workgroup takes a slice of <= 8192 entries of
-//      ONE bin, copies that bin's slice of the visited bitmap into LDS (<= 16 KB), filters its
-//      entries there, and claims the survivors with an XCD-local (L2) atomic on the global bitmap:
-//      every bin is claimed from ONE XCD only.  Winners get their label and are compacted into
-//      frontier tiles exactly as advance_block does.
-// The head kernel chooses per level (degree sum of the frontier >= bin_args::min_edges); all other
-// levels of the run go through advance_block, whose discoveries keep the same visited bitmap
-// current (bfs_policy::on_accept), so the formats never need converting.
+//   1. SCATTER (bin_scatter2_block, bfs_scatter2_kernel): the frontier is expanded exactly as in advance_block (tiles,
+//      2048-edge chunks, lanes on consecutive edges), but a neighbour id is not probed -- it is appended to the BIN of its
+//      vertex range (<= 256 bins) as an offset inside the bin.  A workgroup sorts 4 chunks (8192 ids) by bin in LDS and
+//      writes each bin's run with ONE reservation atomic per bin and batch.  Bins are runs of GRANULES (>= 1024 vertices)
+//      cut once per graph; their capacities are STATIC -- the in-edges of the vertex range -- so the bins are one E-entry
+//      array that can never overflow and needs no size pass.
+//   2. SWEEP (bin_sweep2_block, bfs_sweep2_kernel): one workgroup per bin (or part of a fat bin) copies the bin's slice of
+//      the visited bitmap into LDS, streams the candidates through it, merges the new bits with one global atomic per word
+//      and emits the discoveries in ascending vertex order as tiles of the next frontier, with their chunk-map entries.
+// The head kernel chooses per level (degree sum of the frontier >= bin_args::min_edges); all other levels of the run go
+// through advance_block, whose discoveries keep the same visited bitmap current (bfs_policy::on_accept).
+// Round 5 removed the first generations of both kernels (round-2 scatter inside the level kernel, slice claim, first sweep,
+// the 512-thread sweep geometry, pair stores): HISTORY.md section 3.2 / 3.2.1 and profiles/history/r3_ab_* are their record.
 #pragma once
 
 #include "grx_bfs_kernels.hpp"
@@ -37,7 +32,6 @@ namespace grx {
 constexpr int BIN_MAX = ADV_BLOCK;   // bins: one thread of a workgroup per bin
 constexpr int BIN_BATCH = 4;         // chunks sorted together (one reservation atomic per bin and batch:
                                      // a single word sustains only ~90 atomics/us)
-constexpr int BIN_SLICE = 8192;      // entries per claim work item
 constexpr int BIN_PAD = 32;          // ints between two counters (each in its own 128-byte line)
 constexpr int BIN_SHIFT_MAX = 17;    // widest vertex range per bin: 131072 vertices = 16 KB of bitmap in LDS
 constexpr int BIN_GRAN_MAX = 4096;   // granules (>= 1024 vertices each: one 128-byte line of the bitmap) per graph
@@ -48,9 +42,7 @@ struct bin_args {
   const int32_t* off;         // nb + 1 static offsets (capacity = in-edges of the bin's vertex range)
   int32_t* fill;              // entries in bin b this level at fill[b * BIN_PAD] (zeroed by the head kernel)
   int32_t* queue;             // claim work queue head of XCD x at queue[x * BIN_PAD] (zeroed by the head kernel)
-  const unsigned char* g2b;   // granule -> bin (bins are runs of granules: capacity-balanced, variable width)
   const int32_t* v0;          // nb + 1: first vertex of each bin
-  const unsigned char* owner; // bin -> dense index of the XCD that claims its vertices
   const unsigned short* g2b16;  // second scatter: granule -> bin | (index of the granule inside its bin) << 8
   int32_t local_ids;          // 1: the bins hold ids RELATIVE to the first vertex of their bin (second scatter), 0: global ids
   int32_t sweep_items;        // second sweep: work items a level is cut into at most (<= its grid: one item per workgroup)
@@ -75,7 +67,6 @@ struct bin_args {
   int32_t static_units;       // second scatter: units strided statically over the workgroups instead of drawn from per-XCD ticket
                               // queues (the fallback when a launch cannot be trusted to put a workgroup on every XCD)
   int32_t sub_shift;          // second scatter: log2 of the sub-counters per bin (2 | 1 | 0; GRX_BIN_SUB; nb << sub_shift <= 1024)
-  int32_t pair_stores;        // second scatter: neighbouring entries of a bin leave as one store of twice the width (GRX_BIN_PAIR)
   int32_t fault_xcd;          // test aid (GRX_SC2_FAULT_XCD=k): workgroups on dense XCD index k - 1 take no units (0: off)
   // binned RELAXATION (weighted SSSP on dense graphs, grx_relax.hpp): an entry is the 16-bit offset of the target inside its
   // bin (in `bins`) and, at the same index of rval, the tentative distance fl(dist[source] + weight) as ordered bits
@@ -85,706 +76,11 @@ struct bin_args {
   int32_t* rstamp;            // per-level stamp of a vertex (parts of one bin agree on who emits an improved vertex)
 };
 
-struct bin_scatter_smem {
-  int dlt[BIN_BATCH][TILE];        // per staged slot: row start - exclusive degree prefix (edge = atom + dlt[owner])
-  int wtot[BIN_BATCH][ADV_BLOCK / 64];
-  int wmax[BIN_BATCH][ADV_BLOCK / 64];
-  int wave[ADV_BLOCK / 64 + 1];
-  int hist[BIN_MAX];
-  int off[BIN_MAX];
-  int delta[BIN_MAX];
-  unsigned g2b[BIN_GRAN_MAX / 4];
-  // the sorted ids of a batch; before that, its first 8 KB hold the OWNER MAP of the batch: one byte per atom
-  // (edge slot) of the four chunks = the staged slot the atom belongs to
-  int sorted[BIN_BATCH * CHUNK];
-};
-static_assert(TILE <= 256, "owner map entries are bytes");
-
-__device__ __forceinline__ int bin_of(const unsigned* s_g2b, int n, int gshift) {
-  const unsigned g = (unsigned)n >> gshift;
-  return (int)((s_g2b[g >> 2] >> ((g & 3u) * 8u)) & 0xffu);
-}
-
-// Phase 1.  Chunks blockIdx.x, + gridDim.x, ... of the frontier with parity p, BIN_BATCH at a time.
-// The global loads of a batch travel together, one dependent round trip per stage for all its chunks
-// (chunk descriptors -> frontier slots -> row offsets -> column indices): the first version walked
-// the chunks one after the other and was bound by those four round trips per chunk.
-__device__ __forceinline__ void bin_scatter_block(const pipe_args& a, const bin_args& bn, bin_scatter_smem& sm, int p,
-                                                  int total_chunks, const int* chunk_tile) {
-  static_assert(BIN_MAX == ADV_BLOCK, "one thread per bin");
-  const int tid = threadIdx.x;
-  const int32_t* in = a.frontier[p];
-  const int stride = (int)gridDim.x;
-  const int gshift = bn.gshift;
-  for (int w = tid; w < (bn.n_gran + 3) / 4; w += ADV_BLOCK) sm.g2b[w] = reinterpret_cast<const unsigned*>(bn.g2b)[w];
-  const bool dbg = bn.debug && a.ctrl->level == bn.debug_level;
-  const long long dbg_t0 = dbg ? (long long)wall_clock64() : 0ll;
-  int dbg_batches = 0;
-  long long dbg_ph[7] = {0, 0, 0, 0, 0, 0, 0}, dbg_t = dbg_t0;  // front wait | (4: degree scans, 5: owner search, 6: column indices arrive) histogram | reserve + scan + sort | copy-out
-  auto dbg_mark = [&](int i) {
-    if (dbg) {
-      const long long now = (long long)wall_clock64();
-      dbg_ph[i] += now - dbg_t;
-      dbg_t = now;
-    }
-  };
-  // SOFTWARE PIPELINE of the front of a batch.  Chunk descriptors -> frontier slots -> row offsets are three
-  // DEPENDENT round trips; issued in one place they serialise (first version: ~27 us per batch, of which the
-  // sort itself is a few).  Here iteration i issues the row-offset loads of batch i + 1, the frontier-slot loads
-  // of batch i + 2 and the descriptor loads of batch i + 3 -- every one from values that arrived an iteration
-  // ago -- together with its own column-index loads: one round trip per batch for all four.
-  const int first = (int)blockIdx.x;
-  // The chunk descriptors are the same for the whole workgroup; as SCALAR loads they would be counted in lgkmcnt,
-  // and the barrier a few instructions later (s_waitcnt lgkmcnt(0)) would wait out their full latency in every
-  // batch (measured: 2.6 us of a 26 us batch).  An index the compiler cannot prove uniform keeps them vector loads.
-  int vzero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-  const int boff = tid < bn.nb ? bn.off[tid] : 0;  // static offset of bin `tid`
-  auto S1 = [&](int t, int2 (&tl)[BIN_BATCH]) {
-#pragma unroll
-    for (int j = 0; j < BIN_BATCH; ++j) {
-      const long long unit = (long long)first + ((long long)t * BIN_BATCH + j) * stride;  // uniform over the workgroup
-      tl[j] = reinterpret_cast<const int2*>(chunk_tile)[(unit < total_chunks ? unit : 0) + vzero];
-      if (unit >= total_chunks) tl[j].y = -1;  // not a chunk of this level: contributes no atoms (its tile is a real one)
-    }
-  };
-  auto S2 = [&](const int2 (&tl)[BIN_BATCH], int (&v)[BIN_BATCH]) {
-#pragma unroll
-    for (int j = 0; j < BIN_BATCH; ++j) v[j] = in[(size_t)tl[j].x * TILE + tid];
-  };
-  auto S3 = [&](const int (&v)[BIN_BATCH], int (&rs)[BIN_BATCH], int (&re)[BIN_BATCH]) {
-#pragma unroll
-    for (int j = 0; j < BIN_BATCH; ++j) {
-      const int vv = v[j] >= 0 ? v[j] : 0;  // unconditional loads from a clamped index (vertex 0 exists)
-      rs[j] = a.ro[vv];
-      re[j] = a.ro[vv + 1];
-    }
-  };
-  int2 tl0[BIN_BATCH], tl1[BIN_BATCH], tl2[BIN_BATCH], tl3[BIN_BATCH];
-  int v0[BIN_BATCH], v1[BIN_BATCH], v2[BIN_BATCH];
-  int rs0[BIN_BATCH], re0[BIN_BATCH], rs1[BIN_BATCH], re1[BIN_BATCH];
-  S1(0, tl0); S1(1, tl1); S1(2, tl2);
-  S2(tl0, v0); S2(tl1, v1);
-  S3(v0, rs0, re0);
-  for (int t = 0; (long long)first + (long long)t * BIN_BATCH * stride < total_chunks; ++t) {
-    ++dbg_batches;
-    sm.hist[tid] = 0;
-    int2 tl_c[BIN_BATCH];
-    int rs_c[BIN_BATCH], dg_c[BIN_BATCH];
-#pragma unroll
-    for (int j = 0; j < BIN_BATCH; ++j) {
-      tl_c[j] = tl0[j];
-      rs_c[j] = rs0[j];
-      dg_c[j] = (v0[j] >= 0 && tl0[j].y >= 0) ? re0[j] - rs0[j] : 0;
-    }
-    S3(v1, rs1, re1);
-    S2(tl2, v2);
-    S1(t + 3, tl3);
-    __syncthreads();
-    dbg_mark(0);
-    // --- owner of every atom (edge slot) of the four chunks.  The first version searched the degree prefix per
-    // atom (8 dependent LDS probes each: 12 of the 26 us a batch took on the LJ stand-in's fat level).  Here the
-    // slots mark where their rows begin in a byte map of the chunk and a running maximum fills the gaps: one
-    // 8-byte read-modify-write per thread and chunk, then one byte + one word per atom.
-    int tot[BIN_BATCH], ex_c[BIN_BATCH];
-    const int lane = dev::lane_id();
-    const int wid = tid >> 6;
-    {
-      int inc[BIN_BATCH];
-#pragma unroll
-      for (int j = 0; j < BIN_BATCH; ++j) inc[j] = dev::wave_inclusive_sum(dg_c[j]);
-      if (lane == 63) {
-#pragma unroll
-        for (int j = 0; j < BIN_BATCH; ++j) sm.wtot[j][wid] = inc[j];
-      }
-      unsigned char* own0 = reinterpret_cast<unsigned char*>(sm.sorted);
-#pragma unroll
-      for (int j = 0; j < BIN_BATCH; ++j) reinterpret_cast<uint2*>(own0 + j * CHUNK)[tid] = make_uint2(0u, 0u);
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < BIN_BATCH; ++j) {
-        int base = 0, t_all = 0;
-#pragma unroll
-        for (int i = 0; i < ADV_BLOCK / 64; ++i) {
-          const int x = sm.wtot[j][i];
-          if (i < wid) base += x;
-          t_all += x;
-        }
-        tot[j] = t_all;
-        ex_c[j] = base + inc[j] - dg_c[j];
-        sm.dlt[j][tid] = rs_c[j] - ex_c[j];
-      }
-    }
-    unsigned char* own = reinterpret_cast<unsigned char*>(sm.sorted);
-#pragma unroll
-    for (int j = 0; j < BIN_BATCH; ++j) {
-      if (tl_c[j].y >= 0 && dg_c[j] > 0) {
-        const int pos = ex_c[j] - tl_c[j].y * CHUNK;  // where this slot's row begins inside the chunk's window
-        if (pos > 0) {
-          if (pos < CHUNK) own[j * CHUNK + pos] = (unsigned char)tid;
-        } else if (pos + dg_c[j] > 0) {
-          own[j * CHUNK] = (unsigned char)tid;  // the one row that is under way where the window begins
-        }
-      }
-    }
-    __syncthreads();
-    dbg_mark(4);
-    {
-      unsigned m_k[BIN_BATCH][8];
-      int excl[BIN_BATCH];
-#pragma unroll
-      for (int j = 0; j < BIN_BATCH; ++j) {
-        const uint2 w8 = reinterpret_cast<const uint2*>(own + j * CHUNK)[tid];
-        unsigned run = 0u;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const unsigned b = ((i < 4 ? w8.x : w8.y) >> ((i & 3) * 8)) & 0xffu;
-          run = b > run ? b : run;
-          m_k[j][i] = run;
-        }
-        int inc = (int)run;  // inclusive running maximum across the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int y = __shfl_up(inc, o, 64);
-          if (lane >= o) inc = y > inc ? y : inc;
-        }
-        const int up = __shfl_up(inc, 1, 64);
-        excl[j] = lane == 0 ? 0 : up;
-        if (lane == 63) sm.wmax[j][wid] = inc;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < BIN_BATCH; ++j) {
-        unsigned carry = (unsigned)excl[j];
-#pragma unroll
-        for (int i = 0; i < ADV_BLOCK / 64; ++i) {
-          const unsigned x = (unsigned)sm.wmax[j][i];
-          if (i < wid && x > carry) carry = x;
-        }
-        uint2 r8 = make_uint2(0u, 0u);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const unsigned v = m_k[j][i] > carry ? m_k[j][i] : carry;
-          if (i < 4) r8.x |= v << (i * 8);
-          else r8.y |= v << ((i - 4) * 8);
-        }
-        reinterpret_cast<uint2*>(own + j * CHUNK)[tid] = r8;
-      }
-      __syncthreads();
-    }
-    int n_k[BIN_BATCH][ADV_ITEMS], r_k[BIN_BATCH][ADV_ITEMS];
-#pragma unroll
-    for (int j = 0; j < BIN_BATCH; ++j) {
-      const int a0 = tl_c[j].y * CHUNK;
-      const int n_at = tl_c[j].y >= 0 ? min(tot[j] - a0, CHUNK) : 0;  // atoms of this chunk
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) {
-        const int al = k * ADV_BLOCK + tid;
-        int e = -1;
-        if (al < n_at) e = a0 + al + sm.dlt[j][own[j * CHUNK + al]];
-        r_k[j][k] = e;  // >= 0: a real edge
-        n_k[j][k] = a.ci[e >= 0 ? e : 0];  // lanes past the end read edge 0
-      }
-    }
-    if (dbg) {  // (debug runs only: split the phase at the points where the LDS searches / the loads have completed)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      dbg_mark(5);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      dbg_mark(6);
-    }
-    // bin + rank inside the bin, packed as (bin << 16 | rank): rank < 8192
-#pragma unroll
-    for (int j = 0; j < BIN_BATCH; ++j)
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k)
-        if (r_k[j][k] >= 0) {
-          const int b = bin_of(sm.g2b, n_k[j][k], gshift);
-          r_k[j][k] = (b << 16) | atomicAdd(&sm.hist[b], 1);
-        }
-    __syncthreads();
-    dbg_mark(1);
-    // one reservation per non-empty bin, issued ahead of the scan so that its round trip overlaps
-    const int cnt = sm.hist[tid];
-    int gbase = 0;
-    if (cnt > 0) gbase = atomicAdd(&bn.fill[tid * BIN_PAD], cnt);
-    int btot;
-    const int ex = dev::block_exclusive_sum<ADV_BLOCK>(cnt, sm.wave, &btot);
-    sm.off[tid] = ex;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < BIN_BATCH; ++j)
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k)
-        if (r_k[j][k] >= 0) sm.sorted[sm.off[r_k[j][k] >> 16] + (r_k[j][k] & 0xffff)] = n_k[j][k];
-    sm.delta[tid] = boff + gbase - ex;  // global slot of sorted position i of this bin: delta + i (the reservation's
-                                        // round trip was covered by the sort)
-    __syncthreads();
-    dbg_mark(2);
-    for (int i = tid; i < btot; i += ADV_BLOCK) {
-      const int n = sm.sorted[i];
-      bn.bins[(size_t)(sm.delta[bin_of(sm.g2b, n, gshift)] + i)] = n;
-    }
-#pragma unroll
-    for (int j = 0; j < BIN_BATCH; ++j) {
-      tl0[j] = tl1[j]; tl1[j] = tl2[j]; tl2[j] = tl3[j];
-      v0[j] = v1[j]; v1[j] = v2[j];
-      rs0[j] = rs1[j]; re0[j] = re1[j];
-    }
-    __syncthreads();
-    dbg_mark(3);
-  }
-  if (dbg && tid == 0) {
-    long long* d = bn.debug + 8 * (size_t)blockIdx.x;
-    d[0] = (long long)((unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u);
-    d[1] = dbg_batches;
-    d[2] = dbg_t0;
-    d[3] = (long long)wall_clock64();
-    d[4] = dbg_ph[0];
-    d[5] = dbg_ph[1] | (dbg_ph[4] << 40) | (dbg_ph[5] << 20);  // histogram | degree scans | owner search (ticks < 2^20)
-    d[6] = dbg_ph[2] | (dbg_ph[6] << 40);                         // reserve + scan + sort | column indices arrive
-    d[7] = dbg_ph[3];
-  }
-}
-
-struct bin_claim_smem {
-  unsigned bm[1 << (BIN_SHIFT_MAX - 5)];
-  int pre[BIN_MAX + 1];
-  int fillv[BIN_MAX];
-  int out[TILE + CHUNK];
-  int wave[ADV_BLOCK / 64 + 1];
-  int cnt;
-  int res[3];
-  int item;
-  emit_smem emit;
-};
-
 // hardware XCC id of this wave's CU -> dense index 0 .. n_xcd - 1 (s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4))
 __device__ __forceinline__ int xcd_index(uint32_t xcc_mask, int n_xcd) {
   const unsigned id = (unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u;
   const int dense = __popc(xcc_mask & ((1u << id) - 1u));
   return ((xcc_mask >> id) & 1u) ? dense : (int)(id % (unsigned)n_xcd);
-}
-
-// Phase 2.  A bin's vertices are claimed ONLY by workgroups running on the XCD that owns the bin
-// (bin_args::owner, against the hardware XCC id -- so this holds under any dispatch order), which makes
-// the claim an L2-LOCAL atomic: a workgroup-scope atomicOr on the global visited bitmap executes in the
-// owning XCD's L2, where every other claimant of the same word runs too, and returns the exact old
-// word.  No fabric atomic per candidate (an agent-scope atomic is a memory-side operation at ~20 G/s
-// for the whole device: the first version spent 416 us of a 31 M-edge level on ~9 M of them), and no
-// duplicates across the slices of a bin.  Bins own whole 128-byte lines of the bitmap (granules of
-// >= 1024 vertices), so no line is ever touched from two XCDs within the launch; the words written
-// through L2 reach memory at the end of the kernel like any other store.
-// Work: the slices (<= BIN_SLICE entries) of the bins an XCD owns form that XCD's queue; workgroups pop it
-// with one atomic per slice.  A slice first filters its entries against an LDS copy of the bin's bitmap
-// (read past the L1: `sc1`), then claims the survivors in L2; winners store their label plainly and are
-// compacted into frontier tiles of parity p ^ 1 exactly as advance_block does.
-__device__ __forceinline__ void bin_claim_block(const pipe_args& a, const bin_args& bn, ctrl_t* c, int depth,
-                                                bin_claim_smem& sm, int p) {
-  const int tid = threadIdx.x;
-  const int lane = dev::lane_id();
-  const int x = xcd_index(bn.xcc_mask, bn.n_xcd);
-  const bool dbg = bn.debug && c->level == bn.debug_level;
-  const long long dbg_t0 = dbg ? (long long)wall_clock64() : 0ll;
-  long long dbg_items = 0, dbg_entries = 0, dbg_words = 0;
-  if (tid == 0) { sm.cnt = 0; sm.res[0] = 0; sm.res[1] = 0; }
-  // this XCD's work items: bin b (owned by x) contributes ceil(fill[b] / BIN_SLICE) slices
-  int fill = 0;
-  if (tid < bn.nb && (int)bn.owner[tid] == x) fill = bn.fill[tid * BIN_PAD];
-  int tot_items;
-  const int ex = dev::block_exclusive_sum<ADV_BLOCK>((fill + BIN_SLICE - 1) / BIN_SLICE, sm.wave, &tot_items);
-  sm.pre[tid] = ex;
-  sm.fillv[tid] = fill;
-  if (tid == 0) {
-    sm.pre[BIN_MAX] = tot_items;
-    sm.item = tot_items > 0 ? atomicAdd(&bn.queue[x * BIN_PAD], 1) : 0;
-  }
-  __syncthreads();
-  for (;;) {
-    const int item = sm.item;
-    if (item >= tot_items) break;
-    __syncthreads();
-    int next_item = 0;
-    if (tid == 0) next_item = atomicAdd(&bn.queue[x * BIN_PAD], 1);  // its round trip overlaps this slice
-    int b = 0;  // largest b with pre[b] <= item: the bin the item belongs to (bins without items are skipped over)
-#pragma unroll
-    for (int step = BIN_MAX / 2; step >= 1; step >>= 1)
-      if (sm.pre[b + step] <= item) b += step;
-    const int e0 = (item - sm.pre[b]) * BIN_SLICE;
-    const int n_e = min(sm.fillv[b], e0 + BIN_SLICE) - e0;
-    const int32_t* src = bn.bins + (size_t)bn.off[b] + e0;
-    const int vbase = bn.v0[b];
-    const int words = (bn.v0[b + 1] - vbase) >> 5;
-    ++dbg_items;
-    dbg_entries += n_e;
-    dbg_words += words;
-    // this bin's slice of the visited bitmap -> LDS (words past the end of the bitmap: all visited)
-    for (int w = tid; w < words; w += ADV_BLOCK) {
-      const int gw = (vbase >> 5) + w;
-      sm.bm[w] = gw < bn.visited_words
-                     ? __hip_atomic_load(&bn.visited[gw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                     : ~0u;
-    }
-    __syncthreads();
-    int n_next[ADV_ITEMS];  // the entries of a round are loaded one round ahead
-#pragma unroll
-    for (int k = 0; k < ADV_ITEMS; ++k) {
-      const int i = k * ADV_BLOCK + tid;
-      n_next[k] = src[i < n_e ? i : 0];  // n_e > 0: entry 0 exists
-    }
-    for (int r0 = 0; r0 < n_e; r0 += CHUNK) {
-      int n_k[ADV_ITEMS];
-      unsigned old_k[ADV_ITEMS];
-      bool cand_k[ADV_ITEMS];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) n_k[k] = n_next[k];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) {
-        const int i = r0 + CHUNK + k * ADV_BLOCK + tid;
-        n_next[k] = src[i < n_e ? i : 0];
-      }
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) {
-        const int i = r0 + k * ADV_BLOCK + tid;
-        cand_k[k] = false;
-        if (i < n_e) {
-          const int local = n_k[k] - vbase;
-          const unsigned bit = 1u << (local & 31);
-          // plain read first: visited hubs are hit by many lanes at once, and a read broadcasts
-          // where an atomic on one word would serialise
-          if (!(sm.bm[local >> 5] & bit)) cand_k[k] = (atomicOr(&sm.bm[local >> 5], bit) & bit) == 0u;
-        }
-      }
-      // ids new to this slice.  The other slices of the bin run at the same time on other CUs of this XCD and
-      // most of them find the same vertices: re-read the global word past the L1 (one more L2 round trip for
-      // the round, unconditional loads) and keep only what is STILL unclaimed -- an L2 reads an order of
-      // magnitude more words than it can serve atomics (measured: ~15 M candidate atomics for 2.0 M discoveries
-      // on the 31 M-edge level without this, 22 us per round instead of 6)
-      // (Measured and dropped: re-reading the global word right before the claim, to skip ids another slice of the
-      // bin has claimed meanwhile -- sc1, nt and plain loads alike made the 31 M-edge level 2-3x SLOWER: the phase
-      // is bound by the number of scattered L2 accesses per round, and a load costs what the atomic costs.)
-      // claim in the owning XCD's L2, all issued before any result is used
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) {
-        old_k[k] = ~0u;
-        if (cand_k[k])
-          old_k[k] = __hip_atomic_fetch_or(&bn.visited[n_k[k] >> 5], 1u << (n_k[k] & 31), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS; ++k) {
-        const bool keep = cand_k[k] && ((old_k[k] >> (n_k[k] & 31)) & 1u) == 0u;
-        const unsigned long long m = dev::ballot(keep);
-        if (m) {
-          int base = 0;
-          if (lane == 0) base = atomicAdd(&sm.cnt, __popcll(m));
-          base = dev::wave_bcast0(base);
-          if (keep) {
-            sm.out[base + dev::mask_rank(m)] = n_k[k];
-            bn.dist[n_k[k]] = depth;  // exactly one winner per vertex (bfs.hxx:117-119 assigns the same depth)
-          }
-        }
-      }
-      __syncthreads();
-      int cnt = sm.cnt;
-      if (cnt >= TILE) {
-        const int k = cnt / TILE;
-        emit_full_tiles(a, c, p ^ 1, sm.out, cnt - k * TILE, k, sm.emit, sm.res);
-        cnt -= k * TILE;
-      }
-      if (tid == 0) sm.cnt = cnt;
-      __syncthreads();
-    }
-    if (tid == 0) sm.item = next_item;
-    __syncthreads();
-  }
-  const int rem = sm.cnt;
-  if (rem > 0) emit_tile(a, c, p ^ 1, sm.out, 0, rem, sm.wave, sm.res);
-  __syncthreads();
-  release_tiles(a, sm.res);
-  if (dbg && tid == 0) {
-    long long* d = bn.debug + 8 * (4096 + (size_t)blockIdx.x);
-    d[0] = (long long)((unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u);
-    d[1] = dbg_items;
-    d[2] = dbg_t0;
-    d[3] = (long long)wall_clock64();
-    d[4] = dbg_entries;
-    d[5] = dbg_words;
-    d[6] = tot_items;
-    d[7] = x;
-  }
-}
-
-// Phase 2, third version (default): SWEEP claim.  What the slice-wise claim above still pays per candidate that is
-// new to its slice -- an L2 atomic on the global bitmap, a scattered label store, two scattered row-offset loads
-// for the tile it is emitted into -- this version pays per DISCOVERED VERTEX, and in vertex order:
-//   A. a workgroup of 1024 threads owns one work item = one bin (a bin with more than SWEEP_PART candidates is cut
-//      into parts claimed by several workgroups).  It copies the bin's slice of the visited bitmap into LDS and
-//      streams the candidates through it: 16-byte loads two rounds ahead, a plain LDS read and -- only when the
-//      bit is still clear -- a fire-and-forget LDS atomicOr.  No result is consumed: nothing in the loop waits
-//      for anything but the candidate stream itself.
-//   B. the LDS words are compared with the global ones; a word with new bits is merged with ONE atomicOr whose
-//      return value tells which of the bits this workgroup was first to set (parts of a fat bin race here, and
-//      only here: <= 4096 atomics per item, ~150 k per level on the LJ stand-in against millions before).
-//   C. the new-bit masks are expanded 256 words at a time into a list of vertex ids IN ASCENDING ORDER: labels are
-//      stored to neighbouring addresses, row offsets of a tile are neighbouring loads, and the NEXT level's
-//      scatter walks rows that are adjacent in the CSR arrays.
-// Tiles are reserved exactly (one atomic per emission of up to 33 tiles); a workgroup carries its partial tile
-// from item to item and emits at most one short tile at the end.
-constexpr int SWEEP_BLOCK = 1024;
-constexpr int SWEEP_PART_MIN = 1 << 15;  // a bin with more candidates than total / 160 (at least this many) is claimed in parts
-constexpr int SWEEP_SEG_WORDS = 256;
-constexpr int SWEEP_LIST = SWEEP_SEG_WORDS * 32 + TILE;
-constexpr int SWEEP_PASSES = (SWEEP_LIST + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-constexpr int SWEEP_U = 2;  // 16-byte loads per thread and round
-
-struct bin_sweep_smem {
-  unsigned bm[1 << (BIN_SHIFT_MAX - 5)];
-  int list[SWEEP_LIST];
-  int pre[BIN_MAX + 1];
-  int fillv[BIN_MAX];
-  int wave[SWEEP_BLOCK / 64 + 1];
-  int sum[64][4];       // per tile of an emission (<= 34) and wave of the tile: degree sums
-  int ttot[64];         // per tile: degree sum
-  int cpre[64];         // per tile: chunks of the tiles before it
-  int tile_base;
-  int chunk_base;
-  int n_chunks;
-};
-static_assert(SWEEP_LIST / TILE + 1 <= 64, "one lane per tile of an emission");
-
-// Emit list[0 .. n) as ceil(n / TILE) tiles of parity q (only the last one may be short) AND everything the next
-// head kernel would otherwise have to derive from them: their entries of the chunk map (space reserved with one
-// atomic on ctrl.map_chunks) and their share of the next frontier's vertex / out-edge counts.  Block-wide call.
-__device__ __forceinline__ void sweep_emit(const pipe_args& a, ctrl_t* c, int q, bin_sweep_smem& sm, int n) {
-  const int tid = threadIdx.x;
-  const int lane = dev::lane_id();
-  const int wid = tid >> 6;
-  const int k = (n + TILE - 1) / TILE;
-  if (tid == 0) sm.tile_base = atomicAdd(&c->n_tiles[q], k);  // travels together with the degree loads
-  int x[SWEEP_PASSES], deg[SWEEP_PASSES];
-#pragma unroll
-  for (int j = 0; j < SWEEP_PASSES; ++j) {
-    const int idx = j * SWEEP_BLOCK + tid;
-    x[j] = idx < n ? sm.list[idx] : -1;
-  }
-#pragma unroll
-  for (int j = 0; j < SWEEP_PASSES; ++j) {
-    const int xx = x[j] >= 0 ? x[j] : 0;  // unconditional loads from a clamped index
-    deg[j] = a.ro[xx + 1] - a.ro[xx];
-  }
-#pragma unroll
-  for (int j = 0; j < SWEEP_PASSES; ++j) {
-    const int idx = j * SWEEP_BLOCK + tid;
-    if (idx - lane < k * TILE) {  // wave-uniform: tiles are multiples of the wave size
-      const int t = dev::wave_sum(x[j] >= 0 ? deg[j] : 0);
-      if (lane == 0) sm.sum[idx >> 8][wid & 3] = t;
-    }
-  }
-  __syncthreads();
-  if (tid < 64) {  // k <= 34 tiles: one lane each
-    int tot = 0, ch = 0;
-    if (lane < k) {
-      tot = sm.sum[lane][0] + sm.sum[lane][1] + sm.sum[lane][2] + sm.sum[lane][3];
-      ch = (tot + CHUNK - 1) / CHUNK;
-    }
-    const int inc = dev::wave_inclusive_sum(ch);
-    long long es = (long long)tot;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) es += __shfl_xor(es, o, 64);
-    sm.ttot[lane] = tot;
-    sm.cpre[lane] = inc - ch;
-    if (lane == 63) {
-      sm.n_chunks = inc;
-      sm.chunk_base = inc > 0 ? atomicAdd(&c->map_chunks, inc) : 0;
-    }
-    if (lane == 0) {
-      atomicAdd(reinterpret_cast<unsigned long long*>(&c->q_edges[q]), (unsigned long long)es);
-      atomicAdd(&c->n_items[q], n);
-    }
-  }
-  __syncthreads();
-  const int base = sm.tile_base;
-#pragma unroll
-  for (int j = 0; j < SWEEP_PASSES; ++j) {
-    const int idx = j * SWEEP_BLOCK + tid;
-    if (idx < k * TILE) {
-      const int tix = base + (idx >> 8);
-      a.frontier[q][(size_t)tix * TILE + (idx & (TILE - 1))] = x[j];
-      if ((idx & (TILE - 1)) == 0) {
-        const int tot = sm.ttot[idx >> 8];
-        a.tile_sums[tix] = tot;
-        a.tile_chunks[tix] = (tot + CHUNK - 1) / CHUNK;
-        a.tile_count[tix] = min(TILE, n - (idx >> 8) * TILE);
-      }
-    }
-  }
-  {
-    int2* map = reinterpret_cast<int2*>(a.chunk_tile) + sm.chunk_base;
-    const int nc = sm.n_chunks;
-    for (int ci = tid; ci < nc; ci += SWEEP_BLOCK) {
-      int t = 0;  // largest t with cpre[t] <= ci (tiles without chunks are skipped over): 64 entries, 6 steps
-#pragma unroll
-      for (int step = 32; step >= 1; step >>= 1)
-        if (t + step < k && sm.cpre[t + step] <= ci) t += step;
-      map[ci] = make_int2(base + t, ci - sm.cpre[t]);
-    }
-  }
-  __syncthreads();
-}
-
-__device__ __forceinline__ void bin_sweep_block(const pipe_args& a, const bin_args& bn, ctrl_t* c, int depth,
-                                                bin_sweep_smem& sm, int p) {
-  static_assert(TILE == 256 && SWEEP_BLOCK == 4 * SWEEP_SEG_WORDS, "a thread expands one byte of a bitmap word");
-  const int tid = threadIdx.x;
-  const int lane = dev::lane_id();
-  const int wid = tid >> 6;
-  const int q = p ^ 1;
-  if (blockIdx.x == 0 && tid == 0) c->map_level = depth;  // the chunk map and the counters of level `depth` come from this kernel
-  const bool dbg = bn.debug && c->level == bn.debug_level;
-  const long long dbg_t0 = dbg ? (long long)wall_clock64() : 0ll;
-  long long dbg_items = 0, dbg_entries = 0, dbg_words = 0, dbg_tA = 0, dbg_tB = 0;
-  int fill = 0;
-  if (tid < bn.nb) fill = bn.fill[tid * BIN_PAD];
-  // part size: about as many work items as there are CUs (one workgroup of this size is resident per CU), none much
-  // heavier than the average -- bins have about equal CAPACITIES, but what a level sends them differs
-  int tot_fill;
-  (void)dev::block_exclusive_sum<SWEEP_BLOCK>(fill, sm.wave, &tot_fill);
-  const int SWEEP_PART = max(SWEEP_PART_MIN, ((tot_fill / 160) + 3) & ~3);
-  int tot_items;
-  const int ex0 = dev::block_exclusive_sum<SWEEP_BLOCK>((fill + SWEEP_PART - 1) / SWEEP_PART, sm.wave, &tot_items);
-  if (tid < BIN_MAX) {
-    sm.pre[tid] = ex0;
-    sm.fillv[tid] = fill;
-  }
-  if (tid == 0) sm.pre[BIN_MAX] = tot_items;
-  __syncthreads();
-  int n_list = 0;  // uniform: entries waiting in sm.list (their labels are stored when they are emitted)
-  const int4* src4 = reinterpret_cast<const int4*>(bn.bins);
-  for (int item = (int)blockIdx.x; item < tot_items; item += (int)gridDim.x) {
-    int b = 0;  // largest b with pre[b] <= item (bins without items are skipped over)
-#pragma unroll
-    for (int step = BIN_MAX / 2; step >= 1; step >>= 1)
-      if (sm.pre[b + step] <= item) b += step;
-    const int e0 = (item - sm.pre[b]) * SWEEP_PART;
-    const int n_e = min(sm.fillv[b], e0 + SWEEP_PART) - e0;
-    const int lo = bn.off[b] + e0, hi = lo + n_e;
-    const int vbase = bn.v0[b];
-    const int vsub = bn.local_ids ? 0 : vbase;  // second scatter: the candidates are offsets inside the bin already
-    const int words = (bn.v0[b + 1] - vbase) >> 5;
-    const int gw0 = vbase >> 5;
-    ++dbg_items;
-    dbg_entries += n_e;
-    dbg_words += words;
-    // first candidates on their way while the bitmap slice is copied
-    const int i4_first = lo >> 2, i4_last = (hi - 1) >> 2;
-    int4 nx[SWEEP_U], nx2[SWEEP_U];
-    auto LOAD = [&](int r, int4(&v)[SWEEP_U]) {
-#pragma unroll
-      for (int u = 0; u < SWEEP_U; ++u) {
-        const int idx = i4_first + (r * SWEEP_U + u) * SWEEP_BLOCK + tid;
-        v[u] = src4[idx < i4_last ? idx : i4_last];
-      }
-    };
-    LOAD(0, nx);
-    LOAD(1, nx2);
-    for (int w = tid; w < words; w += SWEEP_BLOCK) sm.bm[w] = (gw0 + w) < bn.visited_words ? bn.visited[gw0 + w] : ~0u;
-    __syncthreads();
-    // A. candidates -> LDS bitmap
-    const int rounds = (i4_last - i4_first + SWEEP_U * SWEEP_BLOCK) / (SWEEP_U * SWEEP_BLOCK);
-    for (int r = 0; r < rounds; ++r) {
-      int4 cur[SWEEP_U];
-#pragma unroll
-      for (int u = 0; u < SWEEP_U; ++u) { cur[u] = nx[u]; nx[u] = nx2[u]; }
-      LOAD(r + 2, nx2);
-#pragma unroll
-      for (int u = 0; u < SWEEP_U; ++u) {
-        const int idx = i4_first + (r * SWEEP_U + u) * SWEEP_BLOCK + tid;
-        const int g0 = idx << 2;
-        const int n4[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int gi = g0 + j;
-          if (idx <= i4_last && gi >= lo && gi < hi) {
-            const int local = n4[j] - vsub;
-            const unsigned bit = 1u << (local & 31);
-            // plain read first: a visited hub is hit by many lanes at once, and a read broadcasts where an
-            // atomic on one word serialises
-            if (!(sm.bm[local >> 5] & bit)) atomicOr(&sm.bm[local >> 5], bit);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (dbg) dbg_tA += (long long)wall_clock64();
-    // B. words with bits the global bitmap lacks: one atomic each; what it returns decides between the parts of a bin
-    for (int w0 = 0; w0 < words; w0 += 4 * SWEEP_BLOCK) {
-      unsigned cand[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int w = w0 + j * SWEEP_BLOCK + tid;
-        cand[j] = 0u;
-        if (w < words && gw0 + w < bn.visited_words) cand[j] = sm.bm[w] & ~bn.visited[gw0 + w];
-      }
-      unsigned old[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int w = w0 + j * SWEEP_BLOCK + tid;
-        old[j] = 0u;
-        if (cand[j]) old[j] = atomicOr(&bn.visited[gw0 + w], cand[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int w = w0 + j * SWEEP_BLOCK + tid;
-        if (w < words) sm.bm[w] = cand[j] & ~old[j];
-      }
-    }
-    __syncthreads();
-    if (dbg) dbg_tB += (long long)wall_clock64();
-    // C. new bits -> ascending vertex ids -> labels, tiles.  The list is emitted when the next 256 words might not fit
-    // and at the end of the item: one reservation and one round of row-offset loads for up to 33 tiles.
-    auto emit_list = [&]() {
-      const int k = n_list / TILE;
-      sweep_emit(a, c, q, sm, k * TILE);
-      const int rem = n_list - k * TILE;
-      int keep = 0;
-      if (tid < rem) keep = sm.list[k * TILE + tid];
-      __syncthreads();
-      if (tid < rem) sm.list[tid] = keep;
-      n_list = rem;
-      __syncthreads();
-    };
-    for (int s0 = 0; s0 < words; s0 += SWEEP_SEG_WORDS) {
-      const int w = s0 + (tid >> 2);
-      unsigned byte = w < words ? (sm.bm[w] >> ((tid & 3) * 8)) & 0xffu : 0u;
-      int tot;
-      const int ex = dev::block_exclusive_sum<SWEEP_BLOCK>(__popc(byte), sm.wave, &tot);
-      if (tot == 0) continue;
-      if (n_list + tot > SWEEP_LIST) emit_list();  // n_list >= TILE here: tot <= SWEEP_LIST - TILE
-      int pos = n_list + ex;
-      const int v_first = vbase + (w << 5) + (tid & 3) * 8;
-      while (byte) {
-        const int v = v_first + __ffs(byte) - 1;
-        byte &= byte - 1u;
-        sm.list[pos++] = v;
-        bn.dist[v] = depth;  // exactly one winner per vertex (bfs.hxx:117-119 assigns the same depth)
-      }
-      n_list += tot;
-      __syncthreads();
-    }
-    if (n_list >= TILE) emit_list();
-  }
-  if (n_list > 0) sweep_emit(a, c, q, sm, n_list);  // the one short tile of this workgroup
-  if (dbg && tid == 0) {
-    long long* d = bn.debug + 8 * (4096 + (size_t)blockIdx.x);
-    d[0] = (long long)((unsigned)__builtin_amdgcn_s_getreg(0x1814) & 15u);
-    d[1] = dbg_items;
-    d[2] = dbg_t0;
-    d[3] = (long long)wall_clock64();
-    d[4] = dbg_entries;
-    d[5] = dbg_words;
-    d[6] = dbg_tA;
-    d[7] = dbg_tB;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1190,40 +486,6 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
           bn.rval[(unsigned)(d_k[k] + i)] = x_k[k];
         }
       }
-    } else if (!UNI && bn.pair_stores) {
-      // Two neighbouring sorted positions per thread: where both belong to the same bin and the first lands on an even
-      // entry, the pair leaves as ONE store of twice the width (round 4: a 2-byte store instruction costs the memory
-      // pipeline what a 4-byte one does, and every store sits in the in-order vmcnt queue the next batch's loads wait on).
-      const int btot = sm.btot;
-      uint2 p_k[ADV_ITEMS / 2];
-      int d0_k[ADV_ITEMS / 2], d1_k[ADV_ITEMS / 2];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS / 2; ++k) p_k[k] = reinterpret_cast<const uint2*>(sm.sorted)[k * SC2_BLOCK + tid];
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS / 2; ++k) {
-        d0_k[k] = sm.delta[p_k[k].x >> 24];
-        d1_k[k] = sm.delta[p_k[k].y >> 24];
-      }
-#pragma unroll
-      for (int k = 0; k < ADV_ITEMS / 2; ++k) {
-        const int i0 = 2 * (k * SC2_BLOCK + tid), i1 = i0 + 1;
-        const int a0 = d0_k[k] + i0, a1 = d1_k[k] + i1;
-        const bool both = i1 < btot && a1 == a0 + 1 && (a0 & 1) == 0;
-        if constexpr (E16) {
-          unsigned short* b16 = reinterpret_cast<unsigned short*>(bn.bins);
-          if (both) reinterpret_cast<unsigned*>(bn.bins)[(size_t)(a0 >> 1)] = (p_k[k].x & 0xffffu) | (p_k[k].y << 16);
-          else {
-            if (i0 < btot) b16[(size_t)a0] = (unsigned short)(p_k[k].x & 0xffffu);
-            if (i1 < btot) b16[(size_t)a1] = (unsigned short)(p_k[k].y & 0xffffu);
-          }
-        } else {
-          if (both) reinterpret_cast<uint2*>(bn.bins)[(size_t)(a0 >> 1)] = make_uint2(p_k[k].x & 0xffffffu, p_k[k].y & 0xffffffu);
-          else {
-            if (i0 < btot) bn.bins[(size_t)a0] = (int)(p_k[k].x & 0xffffffu);
-            if (i1 < btot) bn.bins[(size_t)a1] = (int)(p_k[k].y & 0xffffffu);
-          }
-        }
-      }
     } else {
       const int btot = sm.btot;
       unsigned s_k[ADV_ITEMS];
@@ -1306,7 +568,7 @@ struct bin_sweep2_smem {
 };
 
 // Emit list[0 .. n) as ceil(n / TILE) tiles of parity q (only the last one may be short) with their entries of the next
-// level's chunk map and their share of its counters (see sweep_emit).  Block-wide call.
+// level's chunk map and their share of its counters.  Block-wide call.
 // label != nullptr (round 5): the labels of the emitted vertices are stored HERE, label[v] = depth, from the list -- lanes on
 // consecutive list entries, i.e. on ascending vertex ids a few apart (~10 cache lines per store instruction); the expansion
 // that built the list used to store them itself, one thread per BYTE of the bitmap (lanes 32 bytes of labels apart: a
