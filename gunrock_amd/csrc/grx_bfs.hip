@@ -460,6 +460,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
     in.bin_pad = BIN_PAD;
     in.bin_allowed = bn.allowed;
     in.bin_forced = bn.no_level;
+    in.only_finish = bn.only_finish;
     in.seq = seq;
     plan_body<PLAN_BLOCK>(a, c, 0, s_wave, &s_red[0], in);
     return;
@@ -1116,15 +1117,22 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   }
   // Paced searches: enqueue as many groups as the previous search on this graph (same direction rule) needed, then wait
   // for the end instead of queueing two more behind it (run_levels: hold_after).  GRX_GROUP_HINT=0: off
-  const int hold_after = (pace > 0 && env_int("GRX_GROUP_HINT", 1) != 0) ? g->group_hint[dopt ? 1 : 0].load(std::memory_order_relaxed) : 0;
+  int hold_after = (pace > 0 && env_int("GRX_GROUP_HINT", 1) != 0) ? g->group_hint[dopt ? 1 : 0].load(std::memory_order_relaxed) : 0;
+  if (hold_after > 0 && env_int("GRX_GROUP_HINT_FORCE", 0) > 0) hold_after = env_int("GRX_GROUP_HINT_FORCE", 0);  // (test aid: a wrong prediction)
   int groups_used = 0;
   st = run_levels(ctx, opt, [&](hipStream_t stream, int seq) {
     if (profile) (void)hipEventRecord(pe[0], stream);
     const bool bins_here = use_bins && (seq >= 32 || ((bin_groups >> seq) & 1u) != 0u);
     // (the second scatter + a sweep: the first versions of the two kernels share the level kernel's launch)
-    const bool level_here = !(exact && bins_here && seq < 32);
+    // ... and the group in which the previous search from this source ENDED is its head alone: `done` is always set by a head
+    // kernel (the tiny levels inside it, or its plan step finding the frontier empty), so the level kernel behind that head was a
+    // 4 us no-op in front of the next search.  A search that does not end there after all is left untouched by that head
+    // (plan_in::only_finish) and continues in the next group.  GRX_LAST_HEAD_ONLY=0: off
+    const bool only_head = exact && !profile && hold_after > 0 && seq == hold_after - 1 && !bins_here && env_int("GRX_LAST_HEAD_ONLY", 1) != 0;
+    const bool level_here = !(exact && bins_here && seq < 32) && !only_head;
     bn.allowed = bins_here ? 1 : 0;
-    bn.no_level = level_here ? 0 : 1;
+    bn.no_level = (level_here || only_head) ? 0 : 1;
+    bn.only_finish = only_head ? 1 : 0;
     if (variant == 0) {
       // head (tiny levels + decide + plan) -> level
       hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, lp, (profile || strict_mp) ? 0 : 1, seq, bn);

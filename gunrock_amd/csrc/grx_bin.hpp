@@ -62,6 +62,7 @@ struct bin_args {
   int32_t uniform;            // > 0: every bin is the aligned range [b << uniform, (b + 1) << uniform) (13 .. 16): bin = id >> uniform
   int32_t sweep_balance;      // second sweep: size the parts so that a level is cut into sweep_items items (GRX_SW2_BALANCE)
   int32_t no_level;           // ... and NO level kernel (exact schedule of a repeated search): a level that is not over plans mode 2
+  int32_t only_finish;        // the group is its head alone (where the previous search from this source ended): plan_in::only_finish
   int32_t max_degree;         // ... and whose frontier averages at most this many out-edges per vertex
   int32_t mid_v, mid_e;       // thresholds of the many-levels-per-launch body (grx_mid.hpp), 0: off (carried here for the head kernel)
   int32_t static_units;       // second scatter: units strided statically over the workgroups instead of drawn from per-XCD ticket
@@ -174,7 +175,6 @@ __device__ __forceinline__ void bin_scatter2_block(const pipe_args& a, const bin
   int wq = (tid >> 6) & 3;   // wave inside the quarter
   const int32_t* in = a.frontier[p];
   const int gshift = bn.gshift;
-  const unsigned gmask = (1u << gshift) - 1u;
   if constexpr (!UNI) {
     // Round 5: the table holds, per granule, what turns an id into its sorted entry with ONE addition -- (bin << BSHIFT) minus
     // the bin's first vertex: id + that = bin << BSHIFT | offset inside the bin (offsets stay below 2^16 <= 2^BSHIFT, nothing

@@ -153,6 +153,8 @@ struct plan_in {
   // previous search on the graph had no fat level); seq: index of the group
   int bin_allowed = 1, seq = 0;
   int bin_forced = 0;            // the group has no level kernel (exact schedule, grx_graph::bin_exact): mode 2 whatever the size
+  int only_finish = 0;           // the group has NO kernel behind its head (the last group of a repeated search): a search that is
+                                 // not over is left exactly as it is -- the head of the next group plans the level
   int32_t* bin_fill = nullptr;
   int32_t* bin_queue = nullptr;  // per-XCD claim queue heads (16 slots, bin_pad apart), zeroed with the fill counters
   int bin_nb = 0, bin_pad = 0;
@@ -177,6 +179,7 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
     }
     return;
   }
+  if (in.only_finish) return;
   if (in.bin_min > 0) {
     if (tid < in.bin_nb) in.bin_fill[tid * in.bin_pad] = 0;
     if (tid < 16) in.bin_queue[tid * in.bin_pad] = 0;

@@ -299,6 +299,15 @@ def test_exact_schedule_of_a_repeated_source_and_uniform_bins(gr, gpu_ctx, monke
             st = gr.run_stats(gpu_ctx)
             assert st["edges_visited"] == want[src][2]
             launches.append(int(st["aux"]))
+        # the group in which the previous search from this source ended is launched as its head alone; a search that does not
+        # end in that group after all (here: the prediction is forced to be too short) must continue in the next one
+        for forced in ("1", "2", "3", "4"):
+            monkeypatch.setenv("GRX_GROUP_HINT_FORCE", forced)
+            for flags in (0, gr.FLAG_ASYNC_RETURN):
+                gr.bfs(G, hub, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.forward, engine_flags=flags))
+                gpu_ctx.synchronize()
+                assert np.array_equal(dist.cpu().numpy(), want[hub][0]), (uniform, forced, flags)
+        monkeypatch.delenv("GRX_GROUP_HINT_FORCE")
         monkeypatch.setenv("GRX_BIN_EXACT", "0")
         gr.bfs(G, hub, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.forward))
         assert np.array_equal(dist.cpu().numpy(), want[hub][0])

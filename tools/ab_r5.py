@@ -49,7 +49,8 @@ def timed(fn, n):
 
 
 def set_env(env):
-    for k in [k for k in os.environ if k.startswith("GRX_") and k not in ("GRX_LIB_PATH",)]:
+    keep = ("GRX_LIB_PATH", "GRX_KEEP") + tuple(os.environ.get("GRX_KEEP", "").split(","))  # GRX_KEEP=VAR,VAR: switches of the whole process
+    for k in [k for k in os.environ if k.startswith("GRX_") and k not in keep]:
         os.environ.pop(k)
     for k, v in (env or {}).items():
         os.environ[k] = str(v)

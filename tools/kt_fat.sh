@@ -12,7 +12,7 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)
 if not f:
     print(sys.argv[2], "NO TRACE"); sys.exit(0)
 rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "reset_seed_kernel" in r["Kernel_Name"] or "_init_kernel" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "reset_seed_kernel" in r["Kernel_Name"] or "_init_kernel" in r["Kernel_Name"] or "fwd_start_kernel" in r["Kernel_Name"]]
 a, b = starts[-2], starts[-1]
 t0 = int(rows[a]["Start_Timestamp"])
 parts = []

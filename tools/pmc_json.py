@@ -52,7 +52,7 @@ def searches_of(rows):
         if "bfs_reset_seed_kernel" in name:  # problem.reset() + seed of a direction-optimising search, one launch
             kind = "bfs"
             reset_seen = True
-        elif "bfs_init_kernel" in name or "bfs_fwd_reset_seed_kernel" in name:  # (the latter: reset + seed of a forward search in one launch)
+        elif "bfs_init_kernel" in name or "bfs_fwd_reset_seed_kernel" in name or "bfs_fwd_start_kernel" in name:  # (reset + seed [+ level 0] of a forward search in one launch)
             kind = "bfs"
         elif "sssp_init_kernel" in name:
             kind = "sssp"

@@ -9,7 +9,7 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
 need = sys.argv[3] if len(sys.argv) > 3 else None
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-inits = [i for i, r in enumerate(rows) if "_init_kernel" in r["Kernel_Name"] or "reset_seed_kernel" in r["Kernel_Name"]]
+inits = [i for i, r in enumerate(rows) if "_init_kernel" in r["Kernel_Name"] or "reset_seed_kernel" in r["Kernel_Name"] or "fwd_start_kernel" in r["Kernel_Name"]]
 spans = [(a, inits[k + 1] if k + 1 < len(inits) else len(rows)) for k, a in enumerate(inits)]
 if need:
     spans = [(a, b) for a, b in spans if any(need in r["Kernel_Name"] for r in rows[a:b])]
