@@ -346,8 +346,10 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_source_kernel(pipe_args a, dobf
 // counter atomics.
 // s_red: 4 LDS words, zeroed and synchronised on entry.
 // s_dec (3 LDS ints) receives {done, direction of this level, level} for every thread.
+// only_finish (the group is this head alone, plan_in::only_finish): a search that is over is finished as usual, one that is not
+// is left exactly as it is (s_dec[1] = -1: nothing follows) for the head of the next group.
 __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_args& d, unsigned long long* s_red,
-                                                const ctrl_head& h, int* s_dec) {
+                                                const ctrl_head& h, int* s_dec, int only_finish = 0) {
   ctrl_t* c = a.ctrl;
   const int tid = threadIdx.x;
   const int done = h.done;
@@ -388,6 +390,9 @@ __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_
   __syncthreads();
   if (tid == 0) {
     const long long n_f = (long long)s_red[0], m_f = (long long)s_red[1];
+    if (only_finish && n_f != 0) {
+      s_dec[1] = -1;
+    } else {
     c->bu_open += (long long)s_red[2];
     c->bu_probes += (long long)s_red[3];
     if (n_f == 0) {
@@ -417,6 +422,7 @@ __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_
       c->n_tiles[p ^ 1] = 0;
       a.mailbox[1] = level;
       a.mailbox[2] = (int)n_f;
+    }
     }
   }
   __syncthreads();
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
     plan_body<PLAN_BLOCK>(a, c, 0, s_wave, &s_red[0], in);
     return;
   }
-  bfs_decide_body(a, d, s_red, h, s_dec);
+  bfs_decide_body(a, d, s_red, h, s_dec, bn.only_finish);
   if (s_dec[0] || s_dec[1] != 0) return;
   if (threadIdx.x < 2) s_red[threadIdx.x] = 0ull;
   __syncthreads();
@@ -1117,6 +1123,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   }
   // Paced searches: enqueue as many groups as the previous search on this graph (same direction rule) needed, then wait
   // for the end instead of queueing two more behind it (run_levels: hold_after).  GRX_GROUP_HINT=0: off
+  const bool do_repeat = dopt && variant == 0 && g->do_last_src.load(std::memory_order_relaxed) == (uint32_t)src + 1u;
   int hold_after = (pace > 0 && env_int("GRX_GROUP_HINT", 1) != 0) ? g->group_hint[dopt ? 1 : 0].load(std::memory_order_relaxed) : 0;
   if (hold_after > 0 && env_int("GRX_GROUP_HINT_FORCE", 0) > 0) hold_after = env_int("GRX_GROUP_HINT_FORCE", 0);  // (test aid: a wrong prediction)
   int groups_used = 0;
@@ -1128,7 +1135,8 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     // kernel (the tiny levels inside it, or its plan step finding the frontier empty), so the level kernel behind that head was a
     // 4 us no-op in front of the next search.  A search that does not end there after all is left untouched by that head
     // (plan_in::only_finish) and continues in the next group.  GRX_LAST_HEAD_ONLY=0: off
-    const bool only_head = exact && !profile && hold_after > 0 && seq == hold_after - 1 && !bins_here && env_int("GRX_LAST_HEAD_ONLY", 1) != 0;
+    // (direction-optimising searches: the same source as the last such search on the handle, grx_graph::do_last_src)
+    const bool only_head = (exact || do_repeat) && !profile && hold_after > 0 && seq == hold_after - 1 && !bins_here && env_int("GRX_LAST_HEAD_ONLY", 1) != 0;
     const bool level_here = !(exact && bins_here && seq < 32) && !only_head;
     bn.allowed = bins_here ? 1 : 0;
     bn.no_level = (level_here || only_head) ? 0 : 1;
@@ -1159,7 +1167,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         else if (bn.entry16) launch2(false_type{}, true_type{});
         else launch2(false_type{}, false_type{});
       } else {
-        hipLaunchKernelGGL(lbuild->fn, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
+        if (!only_head) hipLaunchKernelGGL(lbuild->fn, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
       }
     } else {
       hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
@@ -1212,6 +1220,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
      &returned_fast, hold_after, &groups_used);
   if (st != GRX_SUCCESS) return st;
   if (pace > 0 && groups_used > 0) g->group_hint[dopt ? 1 : 0].store(groups_used, std::memory_order_relaxed);
+  if (dopt && variant == 0) g->do_last_src.store((pace > 0 && groups_used > 0 && opt.max_iterations == 0) ? (uint32_t)src + 1u : 0u, std::memory_order_relaxed);
   if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));
   if (ctx->h_mailbox[10] != 0 || (!returned_fast && ctx->h_ctrl->mid_err != 0)) {
     const int code = ctx->h_mailbox[10] != 0 ? (int)ctx->h_mailbox[10] : (int)ctx->h_ctrl->mid_err;

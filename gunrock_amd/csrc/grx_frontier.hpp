@@ -825,7 +825,11 @@ __device__ __forceinline__ int tiny_levels_body(const pipe_args& a, Policy& pol,
   // hand-back paths below leave mode / bu_R untouched).  On a 256-CU part the ranges span more
   // than TINY_MAX_TILES indices anyway; on a smaller grid they might not.  (mode 2, a binned
   // top-down level, leaves ordinary dense tiles.)
-  if (h.mode == 1 || h.bu_R > 0) return 0;
+  // (Round 5: `mode` alone decides.  bu_R stays set through the FIRST top-down level behind a bottom-up one -- its plan step
+  // reads the ranges -- but what that level emits are ordinary tiles: declining on bu_R > 0 cost a direction-optimising
+  // search on the LJ stand-in a launch pair for each of its last two levels, 49 and 1 vertices.  Every reader of bu_R is
+  // guarded by mode: bfs_head_kernel `in.R = h.mode ? h.bu_R : 0`, bfs_decide_body zeroes it behind a top-down level.)
+  if (h.mode == 1) return 0;
   int level = h.level + 1;          // next level to run
   {
     // ---- entry: gather the tiled queue into LDS ---------------------------------------

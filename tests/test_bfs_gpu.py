@@ -308,6 +308,17 @@ def test_exact_schedule_of_a_repeated_source_and_uniform_bins(gr, gpu_ctx, monke
                 gpu_ctx.synchronize()
                 assert np.array_equal(dist.cpu().numpy(), want[hub][0]), (uniform, forced, flags)
         monkeypatch.delenv("GRX_GROUP_HINT_FORCE")
+        # the same for a repeated direction-optimising search (grx_graph::do_last_src; its head finishes or leaves the search alone)
+        for forced in (None, None, "1", "2", "3", "4", None):
+            if forced is None:
+                monkeypatch.delenv("GRX_GROUP_HINT_FORCE", raising=False)
+            else:
+                monkeypatch.setenv("GRX_GROUP_HINT_FORCE", forced)
+            for flags in (0, gr.FLAG_ASYNC_RETURN):
+                gr.bfs(G, hub, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.optimized, engine_flags=flags))
+                gpu_ctx.synchronize()
+                assert np.array_equal(dist.cpu().numpy(), want[hub][0]), (uniform, "optimized", forced, flags)
+        monkeypatch.delenv("GRX_GROUP_HINT_FORCE", raising=False)
         monkeypatch.setenv("GRX_BIN_EXACT", "0")
         gr.bfs(G, hub, dist, None, gpu_ctx, gr.options_t(advance_direction=gr.forward))
         assert np.array_equal(dist.cpu().numpy(), want[hub][0])
