@@ -1123,6 +1123,8 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   }
   // Paced searches: enqueue as many groups as the previous search on this graph (same direction rule) needed, then wait
   // for the end instead of queueing two more behind it (run_levels: hold_after).  GRX_GROUP_HINT=0: off
+  // (the previous search on the handle, same direction rule, ended in a head kernel -- not in the many-levels body of a level kernel)
+  const bool ended_in_head = g->end_in_head[dopt ? 1 : 0].load(std::memory_order_relaxed) != 0;
   const bool do_repeat = dopt && variant == 0 && g->do_last_src.load(std::memory_order_relaxed) == (uint32_t)src + 1u;
   int hold_after = (pace > 0 && env_int("GRX_GROUP_HINT", 1) != 0) ? g->group_hint[dopt ? 1 : 0].load(std::memory_order_relaxed) : 0;
   if (hold_after > 0 && env_int("GRX_GROUP_HINT_FORCE", 0) > 0) hold_after = env_int("GRX_GROUP_HINT_FORCE", 0);  // (test aid: a wrong prediction)
@@ -1131,12 +1133,12 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (profile) (void)hipEventRecord(pe[0], stream);
     const bool bins_here = use_bins && (seq >= 32 || ((bin_groups >> seq) & 1u) != 0u);
     // (the second scatter + a sweep: the first versions of the two kernels share the level kernel's launch)
-    // ... and the group in which the previous search from this source ENDED is its head alone: `done` is always set by a head
-    // kernel (the tiny levels inside it, or its plan step finding the frontier empty), so the level kernel behind that head was a
-    // 4 us no-op in front of the next search.  A search that does not end there after all is left untouched by that head
+    // ... and the group in which the previous search from this source ENDED is its head alone when `done` was set by that head
+    // (the tiny levels inside it, or its plan step finding the frontier empty; mailbox[12] says so -- the many-levels body of a
+    // level kernel may end a search too): the level kernel behind that head was a 4 us no-op in front of the next search.  A search that does not end there after all is left untouched by that head
     // (plan_in::only_finish) and continues in the next group.  GRX_LAST_HEAD_ONLY=0: off
     // (direction-optimising searches: the same source as the last such search on the handle, grx_graph::do_last_src)
-    const bool only_head = (exact || do_repeat) && !profile && hold_after > 0 && seq == hold_after - 1 && !bins_here && env_int("GRX_LAST_HEAD_ONLY", 1) != 0;
+    const bool only_head = (exact || do_repeat) && ended_in_head && !profile && hold_after > 0 && seq == hold_after - 1 && !bins_here && env_int("GRX_LAST_HEAD_ONLY", 1) != 0;
     const bool level_here = !(exact && bins_here && seq < 32) && !only_head;
     bn.allowed = bins_here ? 1 : 0;
     bn.no_level = (level_here || only_head) ? 0 : 1;
@@ -1219,7 +1221,10 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   }, /*first_batch=*/dense ? 8 : 4, /*pace_depth=*/pace, /*fast_return=*/pace > 0 && ((opt.engine_flags & GRX_FLAG_ASYNC_RETURN) != 0 || env_int("GRX_FAST_RETURN", 0) != 0),
      &returned_fast, hold_after, &groups_used);
   if (st != GRX_SUCCESS) return st;
-  if (pace > 0 && groups_used > 0) g->group_hint[dopt ? 1 : 0].store(groups_used, std::memory_order_relaxed);
+  if (pace > 0 && groups_used > 0) {
+    g->group_hint[dopt ? 1 : 0].store(groups_used, std::memory_order_relaxed);
+    g->end_in_head[dopt ? 1 : 0].store(ctx->h_mailbox[12] == 0 ? 1 : 0, std::memory_order_relaxed);
+  }
   if (dopt && variant == 0) g->do_last_src.store((pace > 0 && groups_used > 0 && opt.max_iterations == 0) ? (uint32_t)src + 1u : 0u, std::memory_order_relaxed);
   if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));
   if (ctx->h_mailbox[10] != 0 || (!returned_fast && ctx->h_ctrl->mid_err != 0)) {

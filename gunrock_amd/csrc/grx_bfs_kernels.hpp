@@ -17,7 +17,12 @@ __device__ __forceinline__ T* pick3(T* const (&arr)[3], int i) {
 }
 
 constexpr int BU_MORE = 1 << 30;  // dobfs_args::heads: flag in the second entry, "more than two in-edges"
-constexpr int DO_ALPHA = 14;
+// Beamer's alpha: a top-down level hands over to bottom-up when its frontier has more out-edges than 1 / alpha of the edges of
+// the unexplored vertices.  14 is the paper's value for its kernels; here a bottom-up level costs 20-36 us on the LJ / deep
+// stand-ins whatever the frontier, a claim-per-edge top-down level ~17 us per million edges: the break-even lies at a smaller
+// frontier.  Measured, alpha = 14 / 28 / 56 / 112 (profiles/r5_c28_do_alpha.txt): 16 other sources of the LJ stand-in 253 / 270 /
+// 266 / 243 GTEPS, deep stand-in 0.326 / 0.309 / 0.311 / 0.311 ms, hub source and twitter stand-in unchanged.  GRX_DO_ALPHA.
+constexpr int DO_ALPHA = 28;
 constexpr int DO_BETA = 24;
 
 // VARIANT 0: the reference's claim, atomicMin on the label array with a stale

@@ -225,6 +225,7 @@ struct grx_graph {
   // the binned body whatever it finds) and the other groups head + level kernel only -- no no-op launches at all.  Any other
   // source falls back to the OR-ed hint above with its slack.  Packed into one word so that concurrent searches read a pair.
   std::atomic<uint64_t> bin_exact[2] = {{0}, {0}};  // [1]: profiled searches (one launch group per level, level 0 included: other groups)
+  std::atomic<int32_t> end_in_head[2] = {{0}, {0}};  // the last paced search (forward | direction-optimising) ended in a head kernel
   std::atomic<uint32_t> do_last_src{0};  // source + 1 of the last direction-optimising search (the group it ended in is launched as a head alone)
   std::atomic<int32_t> pr_iter_hint{0};  // iterations of the previous PageRank run on this handle: its first blind batch (grx_pr.hip)
   int32_t bin_entry16 = 0;      // every bin spans <= 65536 vertices: offsets inside a bin fit 16-bit entries
@@ -260,6 +261,7 @@ struct grx_graph {
   uint16_t* xb_pos = nullptr;   // per entry of xb_ci: its position inside its block BEFORE the block was sorted by source (null: unsorted)
   int32_t xb_begin[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int32_t n_xb_pieces = 0, n_xb_long = 0;
+  int32_t xb_n = 8;             // source blocks of that layout (8 = one per XCD; GRX_PR_XB)
   bool has_xb = false;
 };
 

@@ -72,6 +72,7 @@ __device__ __forceinline__ void publish_done(const pipe_args& a, ctrl_t* c, int 
   mb64[2] = (long long)wall_clock64() - c->t_start;
   a.mailbox[1] = level;
   a.mailbox[11] = c->bin_want;
+  a.mailbox[12] = 0;  // the search ended in a head kernel (the many-levels body of a level kernel, grx_mid.hpp: 1)
   __threadfence_system();
   a.mailbox[0] = 1;
 }

@@ -463,6 +463,7 @@ GRX_MID_FN void mid_levels_body(const pipe_args& a, ctrl_t* c, Policy& pol, mid_
       mb64[2] = (long long)wall_clock64() - c->t_start;
       a.mailbox[1] = level;
       a.mailbox[11] = c->bin_want;  // (as publish_done: the host's hint for the next forward search on the graph)
+      a.mailbox[12] = 1;            // the search ended in a LEVEL kernel (publish_done, the head kernels: 0)
       __threadfence_system();
       a.mailbox[0] = 1;
     }
@@ -909,6 +910,7 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
       mb64[2] = (long long)wall_clock64() - c->t_start;
       a.mailbox[1] = level;
       a.mailbox[11] = c->bin_want;  // (as publish_done: the host's hint for the next forward search on the graph)
+      a.mailbox[12] = 1;            // the search ended in a LEVEL kernel (publish_done, the head kernels: 0)
       __threadfence_system();
       a.mailbox[0] = 1;
     }

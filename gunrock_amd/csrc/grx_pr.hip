@@ -64,6 +64,7 @@ struct pr_args {
   const uint16_t* xb_pos; // XCD-blocked variant: entry i of a row block belongs at position xb_pos[i] of the block (null: i)
   int32_t xb_per_block;   // XCD-blocked variant: x[] positions of source block s begin at s * xb_per_block (hub-first order)
   int32_t hot_n;          // ... and the first hot_n of them are kept in LDS by every workgroup (0: none)
+  int32_t xb;             // XCD-blocked variant: source blocks (grx_graph::xb_n: 8 = one per XCD, or 4 / 2 / 1)
   // partitioned run (grx_pr_dist_*): this rank prepares / updates the rows [row_lo, row_hi) only; the dangling mass and
   // the convergence norm are combined over the ranks' {dsum, err} pairs in `gathered` (null: single GPU)
   int32_t row_lo, row_hi;
@@ -72,7 +73,7 @@ struct pr_args {
   const unsigned* gathered;  // n_ranks pairs after the all-gather
 };
 
-constexpr int XB = 8;  // source blocks == XCDs
+constexpr int XB = 8;  // source blocks at most == XCDs (the number a graph uses: grx_graph::xb_n, pr_args::xb)
 
 // iweights (pr.hxx:78-88): wave per 64 rows; long rows summed cooperatively.
 __global__ void pr_iweights_kernel(pr_args a) {
@@ -335,8 +336,8 @@ __global__ __launch_bounds__(PR_BLOCK) void pr_pull_xcd_kernel(pr_args a) {
   extern __shared__ float s_hot[];  // hot_n floats (dynamic)
   if (a.ctrl->done) return;
   const int tid = threadIdx.x;
-  const int s = blockIdx.x % XB;
-  const int lane_b = blockIdx.x / XB, stride_b = gridDim.x / XB;
+  const int s = blockIdx.x % a.xb;
+  const int lane_b = blockIdx.x / a.xb, stride_b = gridDim.x / a.xb;
   const int32_t* ro = a.xb_ro + (size_t)s * ((size_t)a.V + 1);
   float* y = a.partial_y + (size_t)s * (size_t)a.V;
   constexpr int PER = PR_NNZ / PR_BLOCK;
@@ -434,8 +435,12 @@ __global__ __launch_bounds__(256) void pr_combine_kernel(pr_args a, int iter) {
   float err = 0.0f, dang = 0.0f;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < a.V; v += (int64_t)gridDim.x * 256) {
     float acc = 0.0f;
+    if (a.xb == XB) {
 #pragma unroll
-    for (int s = 0; s < XB; ++s) acc += a.partial_y[(size_t)s * (size_t)a.V + v];
+      for (int s = 0; s < XB; ++s) acc += a.partial_y[(size_t)s * (size_t)a.V + v];
+    } else {
+      for (int s = 0; s < a.xb; ++s) acc += a.partial_y[(size_t)s * (size_t)a.V + v];
+    }
     const float np = base + acc;
     err = fmaxf(err, fabsf(np - a.p[v]));
     a.p[v] = np;
@@ -477,9 +482,9 @@ __global__ void xb_rank_keys_kernel(const int32_t* __restrict__ ro, int32_t V, u
     vals[v] = (uint32_t)v;
   }
 }
-__global__ void xb_rank_perm_kernel(const uint32_t* __restrict__ order, int32_t V, int32_t per_block, int32_t* perm) {
+__global__ void xb_rank_perm_kernel(const uint32_t* __restrict__ order, int32_t V, int32_t per_block, int32_t xb, int32_t* perm) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < V; r += (int64_t)gridDim.x * blockDim.x)
-    perm[order[r]] = (int32_t)((r % XB) * per_block + r / XB);
+    perm[order[r]] = (int32_t)((r % xb) * per_block + r / xb);
 }
 
 __global__ void pr_init_kernel(pr_args a) {
@@ -763,8 +768,19 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   prep_timer tm("pagerank: XCD-blocked layout (rank + sort + partition)", ctx->stream);
   const int32_t V = g->V;
   const int64_t E = g->E;
-  const size_t n_off = (size_t)XB * ((size_t)V + 1);
-  const int32_t per_block = (V + XB - 1) / XB;
+  // SOURCE BLOCKS (round 5): 8 -- one per XCD, every slice of the gathered vector resident in one L2 -- costs 8 V row visits
+  // and 8 V partial sums per iteration; where a row has few entries per block those rival the E gathers.  Measured (profiles/
+  // r5_c25_pr_source_blocks.txt), ms per iteration with 8 / 4 / 2 / 1 blocks: LJ stand-in (14 edges per vertex) 0.452 / 0.390 /
+  // 0.433 / 0.450, kron stand-in (87) 0.610 / 0.618 / 0.700 / 0.869 -- four blocks below 32 edges per vertex, else eight.
+  // GRX_PR_XB = 1 | 2 | 4 | 8: that many.
+  int xbn = (E < 32ll * V) ? 4 : XB;
+  if (const char* e = getenv("GRX_PR_XB")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 8) xbn = v;
+  }
+  g->xb_n = xbn;
+  const size_t n_off = (size_t)xbn * ((size_t)V + 1);
+  const int32_t per_block = (V + xbn - 1) / xbn;
   hipStream_t s = ctx->stream;
   // HUB-FIRST RELABELLING OF THE SOURCES.  The gathers of a bucket go to one slice of x[] (V/8
   // floats); on a scale-free graph most of them go to a few thousand hub vertices, which the
@@ -787,7 +803,7 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
     if (!g->xb_perm) GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_perm), (size_t)V * sizeof(int32_t)));  // (kept by a retry)
     hipLaunchKernelGGL(xb_rank_keys_kernel, dim3(1024), dim3(256), 0, s, g->ro, V, rb.keys[0], rb.vals[0]);
     const int rr = radix_sort_pairs(s, rb, 32);
-    hipLaunchKernelGGL(xb_rank_perm_kernel, dim3(1024), dim3(256), 0, s, rb.vals[rr], V, per_block, g->xb_perm);
+    hipLaunchKernelGGL(xb_rank_perm_kernel, dim3(1024), dim3(256), 0, s, rb.vals[rr], V, per_block, xbn, g->xb_perm);
     GRX_HIP(hipStreamSynchronize(s));
     rb.release();
   }
@@ -820,7 +836,7 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
   // static partition, one list per source block (same packing rule as the plain layout), built on the device
   pr_partition pt;
   prep_timer t2("  xcd layout: partition (device)", s);
-  grx_status_t pst = build_pr_partition_device(ctx, g->xb_ro, (int64_t)V + 1, V, XB, &pt, g->xb_begin);
+  grx_status_t pst = build_pr_partition_device(ctx, g->xb_ro, (int64_t)V + 1, V, xbn, &pt, g->xb_begin);
   if (pst != GRX_SUCCESS) return pst;
   g->xb_blocks = pt.blocks;
   g->xb_piece = pt.piece;
@@ -922,7 +938,8 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   a.base = reinterpret_cast<float*>(ctx->misc.as<unsigned>() + 4);
   a.xb_ro = g->xb_ro; a.xb_ci = g->xb_ci; a.xb_w = unit ? nullptr : g->xb_w;
   a.xb_pos = g->xb_pos;
-  a.xb_per_block = (g->V + XB - 1) / XB;
+  a.xb = xcd_blocked ? g->xb_n : XB;
+  a.xb_per_block = (g->V + a.xb - 1) / a.xb;
   a.xb_blocks = reinterpret_cast<const int4*>(g->xb_blocks);
   a.xb_piece = g->xb_piece; a.xb_long = g->xb_long;
   for (int i = 0; i <= XB; ++i) a.xb_begin[i] = g->xb_begin[i];
@@ -951,7 +968,7 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
   if (xcd_blocked && g->xb_perm) {
     hot_n = 3072;
     if (const char* e = getenv("GRX_PR_HOT")) hot_n = atoi(e);
-    hot_n = std::max(0, std::min(hot_n, std::min((g->V + XB - 1) / XB, 36864)));
+    hot_n = std::max(0, std::min(hot_n, std::min((g->V + a.xb - 1) / a.xb, 36864)));
     if (hot_n > 0) {
       const size_t dyn = (size_t)hot_n * sizeof(float);
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(pr_pull_xcd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
@@ -965,7 +982,7 @@ extern "C" grx_status_t grx_pr(grx_context_t ctx, grx_graph_t g, float alpha, fl
     }
   }
   a.hot_n = hot_n;
-  const int xcd_grid = std::max(XB, ctx->num_cus * xcd_wg / XB * XB);
+  const int xcd_grid = std::max(a.xb, ctx->num_cus * xcd_wg / a.xb * a.xb);
   const int max_iter = opt.max_iterations > 0 ? opt.max_iterations : 0x7fffffff;
   // GRX_FLAG_PROFILE: one record per iteration from events on this stream -- advance_ms = the pull
   // (the SpMV-shaped gather incl. long-row pieces and the combine), other_ms = prepare + scalar

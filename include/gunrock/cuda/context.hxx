@@ -34,6 +34,7 @@ class standard_context_t {
   bool _own_stream = true;
   util::timer_t _timer;
   int* _mailbox = nullptr;  // pinned host, 64 ints
+  int* _mailbox_dev = nullptr;  // the same words as kernels address them (null: not mapped -- sizes come back by copy)
   void* _scratch[4] = {nullptr, nullptr, nullptr, nullptr};  // growable device scratch slots
   std::size_t _scratch_bytes[4] = {0, 0, 0, 0};
   // state another layer ties to THIS context's lifetime (the pre-compiled engine keeps its
@@ -47,8 +48,11 @@ class standard_context_t {
       error::throw_if_exception(hipStreamCreateWithFlags(&_stream, hipStreamNonBlocking), "stream create");
     error::throw_if_exception(hipEventCreateWithFlags(&_event, hipEventDisableTiming), "event create");
     error::throw_if_exception(hipGetDeviceProperties(&_props, _ordinal), "device properties");
-    error::throw_if_exception(hipHostMalloc(reinterpret_cast<void**>(&_mailbox), 64 * sizeof(int), hipHostMallocDefault),
+    error::throw_if_exception(hipHostMalloc(reinterpret_cast<void**>(&_mailbox), 64 * sizeof(int), hipHostMallocMapped),
                               "pinned mailbox");
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, _mailbox, 0) == hipSuccess) _mailbox_dev = reinterpret_cast<int*>(dev);
+    (void)hipGetLastError();
   }
 
  public:
@@ -99,6 +103,15 @@ class standard_context_t {
       _scratch_bytes[slot] = want;
     }
     return reinterpret_cast<type_t*>(_scratch[slot]);
+  }
+
+  // Words [32, 64) of the mailbox as a kernel writes them (a size a single-workgroup kernel computes goes straight to the
+  // host: no copy behind it); wait_mailbox() = the stream has drained, the words are current.  Null when the mailbox is not
+  // device-visible.
+  int* mailbox_device(int slot) { return _mailbox_dev ? _mailbox_dev + 32 + slot : nullptr; }
+  const int* wait_mailbox(int slot) {
+    synchronize();
+    return _mailbox + 32 + slot;
   }
 
   // Read `count` ints from device memory through the pinned mailbox (one sync).

@@ -36,6 +36,40 @@ __global__ void degrees_kernel(graph_t G, const type_t* input, std::size_t n, ed
   }
 }
 
+// SMALL frontiers (round 5): degrees + scan + total in ONE launch of one workgroup, the total written where the host reads it.
+// The general path is four launches (degrees, three-launch scan) and a device-to-host copy; on an algorithm of thousands of
+// short iterations (the reference's k-core on these operators: ~2300 advances of a few hundred vertices) that overhead was
+// most of the run.  <<<1, SMALL_BLOCK>>>, n <= SMALL_N
+constexpr int SMALL_BLOCK = 1024, SMALL_PER = 8, SMALL_N = SMALL_BLOCK * SMALL_PER;
+template <typename graph_t, typename type_t, typename edge_t>
+__global__ __launch_bounds__(SMALL_BLOCK) void degrees_scan_small_kernel(graph_t G, const type_t* input, int n, edge_t* segments,
+                                                                         int* host_total) {
+  __shared__ int s_w[SMALL_BLOCK / 64 + 1];
+  int deg[SMALL_PER], local = 0;
+  const int first = (int)threadIdx.x * SMALL_PER;
+#pragma unroll
+  for (int k = 0; k < SMALL_PER; ++k) {
+    const int i = first + k;
+    deg[k] = 0;
+    if (i < n) {
+      const type_t v = input ? input[i] : (type_t)i;
+      if (gunrock::util::limits::is_valid(v)) deg[k] = (int)G.get_number_of_neighbors(v);
+    }
+    local += deg[k];
+  }
+  int tot;
+  int ex = grx::dev::block_exclusive_sum<SMALL_BLOCK>(local, s_w, &tot);
+#pragma unroll
+  for (int k = 0; k < SMALL_PER; ++k) {
+    if (first + k < n) segments[first + k] = (edge_t)ex;
+    ex += deg[k];
+  }
+  if (threadIdx.x == 0) {
+    segments[n] = (edge_t)tot;
+    *host_total = tot;
+  }
+}
+
 // Expand the edges ("atoms") [atom_lo, atom_hi) of a staged window of up to
 // BLOCK input slots.  s_seg[0..nslots] is the window-relative exclusive degree
 // scan, s_start the first edge id of each slot, s_src the slot's vertex.  Lanes
@@ -174,6 +208,13 @@ std::size_t compute_output_offsets(graph_t& G, const type_t* input, std::size_t 
   edge_t* seg = memory::raw_pointer_cast(segments.data());
   if (n == 0) return 0;
   hipStream_t s = context.stream();
+  if (n <= (std::size_t)detail::SMALL_N) {
+    if (int* host_total = context.mailbox_device(0)) {
+      hipLaunchKernelGGL((detail::degrees_scan_small_kernel<graph_t, type_t, edge_t>), dim3(1), dim3(detail::SMALL_BLOCK), 0, s, G,
+                         input, (int)n, seg, host_total);
+      return (std::size_t)context.wait_mailbox(0)[0];
+    }
+  }
   int32_t* block_sums = context.scratch<int32_t>(0, (std::size_t)grx::scan_num_blocks((int64_t)n) + 2);
   std::size_t g = (n + 255) / 256;
   if (g > 2048) g = 2048;

@@ -145,6 +145,48 @@ __global__ __launch_bounds__(BLOCK) void compact_kernel(operator_t op, const typ
   }
 }
 
+// SMALL inputs (round 5): predicate, scan, ordered scatter and the count in ONE launch of one workgroup; the count goes
+// straight to the host's mailbox.  Stable, so it serves every compacting algorithm (predicated / remove: flag + three-launch
+// scan + scatter + copy were six launches; compact: memset + kernel + copy).  <<<1, SMALL_BLOCK>>>, n <= SMALL_N
+constexpr int SMALL_BLOCK = 1024, SMALL_PER = 8, SMALL_N = SMALL_BLOCK * SMALL_PER;
+template <typename operator_t, typename type_t>
+__global__ __launch_bounds__(SMALL_BLOCK) void compact_small_kernel(operator_t op, const type_t* in, int n, type_t* out,
+                                                                    int* host_count) {
+  __shared__ int s_w[SMALL_BLOCK / 64 + 1];
+  type_t v[SMALL_PER];
+  bool keep[SMALL_PER];
+  int local = 0;
+  const int first = (int)threadIdx.x * SMALL_PER;  // a thread owns consecutive elements: the output keeps the input's order
+#pragma unroll
+  for (int k = 0; k < SMALL_PER; ++k) {
+    const int i = first + k;
+    v[k] = gunrock::numeric_limits<type_t>::invalid();
+    keep[k] = false;
+    if (i < n) {
+      v[k] = in[i];
+      keep[k] = gunrock::util::limits::is_valid(v[k]) && op(v[k]);
+    }
+    local += keep[k] ? 1 : 0;
+  }
+  int tot;
+  int at = grx::dev::block_exclusive_sum<SMALL_BLOCK>(local, s_w, &tot);
+#pragma unroll
+  for (int k = 0; k < SMALL_PER; ++k)
+    if (keep[k]) out[at++] = v[k];
+  if (threadIdx.x == 0) *host_count = tot;
+}
+// returns false when the small path does not apply (the caller takes the general one)
+template <typename operator_t, typename type_t>
+bool compact_small(operator_t op, const type_t* in, std::size_t n, type_t* out, gcuda::standard_context_t& ctx, std::size_t* kept) {
+  if (n > (std::size_t)SMALL_N) return false;
+  int* host_count = ctx.mailbox_device(1);
+  if (!host_count) return false;
+  hipLaunchKernelGGL((compact_small_kernel<operator_t, type_t>), dim3(1), dim3(SMALL_BLOCK), 0, ctx.stream(), op, in, (int)n, out,
+                     host_count);
+  *kept = (std::size_t)ctx.wait_mailbox(1)[0];
+  return true;
+}
+
 inline unsigned strided_grid(std::size_t n, int per_block, gcuda::standard_context_t& ctx) {
   std::size_t g = (n + (std::size_t)per_block - 1) / (std::size_t)per_block;
   const std::size_t cap = (std::size_t)ctx.props().multiProcessorCount * 8;
@@ -158,6 +200,8 @@ template <typename operator_t, typename type_t>
 std::size_t stable_compact(operator_t op, const type_t* in, std::size_t n, type_t* out,
                            gcuda::standard_context_t& ctx) {
   if (n == 0) return 0;
+  std::size_t kept_small;
+  if (compact_small(op, in, n, out, ctx, &kept_small)) return kept_small;
   const std::size_t tiles = (n + TILE - 1) / TILE;
   unsigned char* flags = ctx.scratch<unsigned char>(1, n);
   int32_t* counts = ctx.scratch<int32_t>(2, tiles + 2);
@@ -211,6 +255,11 @@ void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, g
   if (!detail::prepare_output(input, output)) return;
   error::throw_if_exception(output == input, "compact filter cannot run in place");
   const std::size_t n = input->get_number_of_elements();
+  std::size_t kept_small;
+  if (detail::compact_small(op, input->data(), n, output->data(), context, &kept_small)) {
+    output->set_number_of_elements(kept_small);
+    return;
+  }
   int32_t* counter = context.template scratch<int32_t>(2, 4);
   error::throw_if_exception(hipMemsetAsync(counter, 0, sizeof(int32_t), context.stream()), "counter reset");
   hipLaunchKernelGGL((detail::compact_kernel<operator_t, type_t>), dim3(detail::strided_grid(n, detail::TILE, context)),
