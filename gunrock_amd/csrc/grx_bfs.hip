@@ -518,9 +518,13 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
     }
   }
   if (mode_now == 0) {
+    // (a frontier left by a bottom-up level sits in that launch's static tile ranges: thousands of chunks of a few vertices each,
+    // cheapest at one per workgroup -- 9 against 12 us on the LJ stand-in's fourth level)
+    const int n_act = c->bu_R > 0 ? (int)gridDim.x : thin_workgroups(h.total_chunks, (int)gridDim.x, d.thin_div, d.thin_min);
+    if ((int)blockIdx.x >= n_act) return;
     pol.ctrl = c;
     pol.set_level(level);
-    advance_block<bfs_policy, false>(a, c, pol, sm, level & 1, blockIdx.x, gridDim.x, h.total_chunks, a.chunk_tile);
+    advance_block<bfs_policy, false>(a, c, pol, sm, level & 1, blockIdx.x, n_act, h.total_chunks, a.chunk_tile);
   } else {
     if constexpr (BU2) bfs_bottomup2_block<BATCH, DBG>(a, d, c, bsm);
     else bfs_bottomup_block<BATCH, true>(a, d, c, bsm);
@@ -544,10 +548,12 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_bin_kernel(pipe_args a, b
     pol.ctrl = c;
     mid_levels_run(a, c, pol, *reinterpret_cast<td_smem*>(lds_raw), h, bn.xcc_mask);
   } else {
+    const int n_act = thin_workgroups(h.total_chunks, (int)gridDim.x, bn.thin_div, bn.thin_min);
+    if ((int)blockIdx.x >= n_act) return;
     pol.ctrl = c;
     pol.set_level(h.level);
     advance_block<bfs_policy, false>(a, c, pol, reinterpret_cast<td_smem*>(lds_raw)->adv, h.level & 1, blockIdx.x,
-                                     gridDim.x, h.total_chunks, a.chunk_tile);
+                                     n_act, h.total_chunks, a.chunk_tile);
   }
 }
 
@@ -1090,7 +1096,12 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     const int resident = ctx->num_cus * per_cu_scatter;
     const int full = advance_grid_for(ctx, g);  // one workgroup per CU on road-like graphs
     grid_scatter = full < resident ? full : resident;
+    if (const int k = env_int("GRX_LEVEL_WG_PER_CU", 0); k > 0) grid_scatter = std::min(grid_scatter, ctx->num_cus * k);  // (tuning aid)
   }
+  // thin top-down levels run on as many workgroups as their chunk count asks for (thin_workgroups, grx_bfs_kernels.hpp);
+  // GRX_THIN_CHUNKS_PER_WG=0: every workgroup of the launch takes chunks
+  bn.thin_div = d.thin_div = (variant == 0 && !strict_mp) ? env_int("GRX_THIN_CHUNKS_PER_WG", 1) : 0;
+  bn.thin_min = d.thin_min = ctx->num_cus;
   hipError_t launch_err = hipSuccess;
   bool returned_fast = false;
   const int pace = (dense && variant == 0) ? env_int("GRX_PACE_DEPTH", 2) : 0;

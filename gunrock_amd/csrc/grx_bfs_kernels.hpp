@@ -183,7 +183,25 @@ struct dobfs_args {
   // tuning aid (GRX_BU_DEBUG=<level>): per-wave phase clocks of the second bottom-up body at that level, 8 words per wave
   long long* debug;
   int32_t debug_level;
+  int32_t thin_div, thin_min;  // thin top-down levels: thin_workgroups() of the launch take chunks (0: all of them)
 };
+
+// WORKGROUPS OF A THIN CLAIM-PER-EDGE LEVEL (round 5).  The level kernels are launched with the resident grid (4 workgroups per
+// CU) whatever the level holds; every workgroup that discovers anything ends with a tile reservation on one control word and
+// leaves a short tile behind, which the next head has to walk and the next level stages as a chunk of its own.  Measured
+// (profiles/r5_c32_thin_level_workgroups.txt, r5_c33_*), workgroups -> us: a level of ~1300 chunks 1024 -> 23, 512 -> 18;
+// 1940 chunks 1024 -> 33, 768 -> 29, 256 -> 41; ~2700 chunks 1024 -> 43, 512 -> 50 -- about 2.5 chunks per workgroup -- but a level
+// of ~650 chunks that discovers next to nothing 1024 -> 8, 256 -> 14: one chunk per workgroup.  So: one chunk per workgroup up
+// to 768 chunks, 2.5 from 1280 on, linear in between; the other workgroups of the launch leave at once.  div == 0: off.
+__device__ __forceinline__ int thin_workgroups(int total_chunks, int grid, int div, int min_wgs) {
+  (void)min_wgs;
+  if (div <= 0 || total_chunks < 0) return grid;
+  int per10 = 10;  // chunks per workgroup, times ten
+  if (total_chunks >= 1280) per10 = 25;
+  else if (total_chunks > 768) per10 = 10 + 15 * (total_chunks - 768) / 512;
+  const int want = (int)(((long long)total_chunks * 10 + per10 - 1) / per10);
+  return min(grid, max(1, want));
+}
 
 // Bottom-up level.  A wave owns 64 consecutive vertices (one "chunk") and works on
 // BATCH chunks at a time so that the dependent load chain (visited word -> in-offsets

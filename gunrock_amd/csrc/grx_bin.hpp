@@ -62,6 +62,7 @@ struct bin_args {
   int32_t uniform;            // > 0: every bin is the aligned range [b << uniform, (b + 1) << uniform) (13 .. 16): bin = id >> uniform
   int32_t sweep_balance;      // second sweep: size the parts so that a level is cut into sweep_items items (GRX_SW2_BALANCE)
   int32_t no_level;           // ... and NO level kernel (exact schedule of a repeated search): a level that is not over plans mode 2
+  int32_t thin_div, thin_min; // thin claim-per-edge levels: thin_workgroups() (grx_bfs_kernels.hpp)
   int32_t only_finish;        // the group is its head alone (where the previous search from this source ended): plan_in::only_finish
   int32_t max_degree;         // ... and whose frontier averages at most this many out-edges per vertex
   int32_t mid_v, mid_e;       // thresholds of the many-levels-per-launch body (grx_mid.hpp), 0: off (carried here for the head kernel)
