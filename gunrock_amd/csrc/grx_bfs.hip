@@ -460,6 +460,8 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
     in.bin_max_degree = bn.max_degree;
     in.mid_v = bn.mid_v;
     in.mid_e = bn.mid_e;
+    in.mid_tile_e = bn.mid_tile_e;
+    in.bin_early_div = bn.bin_early_div;
     in.bin_fill = bn.fill;
     in.bin_queue = bn.queue;
     in.bin_nb = bn.nb;
@@ -1035,6 +1037,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   if (!dopt && !strict_mp && variant == 0 && env_int("GRX_MID", 1) != 0) {
     bn.mid_v = env_int("GRX_MID_V", MID_ENTER_V);
     bn.mid_e = env_int("GRX_MID_E", MID_ENTER_E);
+    bn.mid_tile_e = env_int("GRX_MID_TILE_E", MID_TILE_E);  // 0: frontiers with heavy tiles enter that body too (before round 5's last session)
   }
   int grid_scatter = 0, grid_scatter2 = 0, grid_sweep3 = 0;
   if (use_bins) {
@@ -1064,6 +1067,10 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     // 44 us on the claim-per-edge advance: profiles/r5_c15_kernel_sequences.txt)
     bn.min_edges = (long long)env_int("GRX_BIN_MIN_EDGES", 1 << 21);
     if (bn.min_edges < 1) bn.min_edges = 1;
+    // ... and EARLY levels (less than a quarter of the graph visited) from half of that: they discover a third of their targets,
+    // which is what the claim-per-edge body pays for (plan_in::bin_early_div).  GRX_BIN_EARLY_DIV=1: one threshold
+    bn.bin_early_div = env_int("GRX_BIN_EARLY_DIV", 2);
+    if (bn.bin_early_div < 1) bn.bin_early_div = 1;
     bn.visited = visited;
     bn.visited_words = (int32_t)bm_words;
     bn.dist = d_dist;

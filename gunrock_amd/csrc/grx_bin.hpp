@@ -66,6 +66,8 @@ struct bin_args {
   int32_t only_finish;        // the group is its head alone (where the previous search from this source ended): plan_in::only_finish
   int32_t max_degree;         // ... and whose frontier averages at most this many out-edges per vertex
   int32_t mid_v, mid_e;       // thresholds of the many-levels-per-launch body (grx_mid.hpp), 0: off (carried here for the head kernel)
+  int32_t mid_tile_e;         // ... which no level enters with a tile of more than this many out-edges (plan_in::mid_tile_e; 0: no rule)
+  int32_t bin_early_div;      // early levels are binned from min_edges / bin_early_div on (plan_in::bin_early_div; <= 1: one threshold)
   int32_t static_units;       // second scatter: units strided statically over the workgroups instead of drawn from per-XCD ticket
                               // queues (the fallback when a launch cannot be trusted to put a workgroup on every XCD)
   int32_t sub_shift;          // second scatter: log2 of the sub-counters per bin (2 | 1 | 0; GRX_BIN_SUB; nb << sub_shift <= 1024)

@@ -150,6 +150,20 @@ struct plan_in {
   // many mid-size levels in one launch (grx_mid.hpp; external_control == 0 only): a level with at most mid_v
   // frontier vertices and mid_e out-edges runs as mode 3 (0: off)
   int mid_v = 0, mid_e = 0;
+  // ... and no tile (256 frontier slots = the block ONE workgroup of that body stages) with more than mid_tile_e out-edges
+  // (0: no such rule).  Round 5, last session: a search from a low-degree vertex of a scale-free graph meets, two or three
+  // levels in, a frontier of ~10 vertices with 10-30 k out-edges -- it qualified (<= mid_v vertices, <= mid_e edges) and ONE
+  // workgroup then walked its 11-16 chunks one after the other, ~12 us each, where the regular level kernel spreads them over as
+  // many workgroups: the three sources of bench.py's multi_source section with such a level were its slowest in every round
+  // (85-97 GTEPS against 125-150).  The body is written for road-like frontiers: a tile of 256 vertices there has < 1 k edges.
+  int mid_tile_e = 0;
+  // EARLY levels -- less than a quarter of the graph visited so far -- are binned from bin_min / bin_early_div out-edges on
+  // (1: same threshold everywhere).  The threshold went from 2^20 to 2^21 this round because a LATE level of the deep stand-in
+  // (1.29 M edges, next to nothing left to discover) is cheaper on the claim-per-edge advance; an early level of that size
+  // discovers a third of its targets, and each discovery costs the claim-per-edge body a successful atomic, a compaction slot
+  // and its share of a tile reservation (source 269895 of multi_source: level 918 vertices / 1.71 M edges -> 563 k discoveries,
+  // 140 GTEPS with the level binned in round 4, 108-117 with the one threshold of round 5).
+  int bin_early_div = 1;
   // the launch group of this level carries the scatter / sweep kernels (the host leaves them out of groups where the
   // previous search on the graph had no fat level); seq: index of the group
   int bin_allowed = 1, seq = 0;
@@ -244,6 +258,8 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
         mine += ch[k];
         esum += (long long)ts[k];
         vsum += (long long)tc[k];
+        if (in.mid_tile_e > 0 && ts[k] > in.mid_tile_e) vsum += 1ll << 32;  // tiles too heavy for the many-levels body: counted
+                                                                             // above the vertex count (< 2^31) of the same sum
       }
     }
   }
@@ -289,14 +305,17 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
     c->total_chunks = carry;
     if (external_control != 1) {
       const long long edges = (long long)s_esum[0];
-      const int nitems = (int)s_esum[1];
+      const int nitems = (int)(s_esum[1] & 0xffffffffull);
+      const int heavy_tiles = (int)(s_esum[1] >> 32);  // (plan_in::mid_tile_e)
       c->edges_visited += edges;
       c->vertices_visited += nitems;
       c->n_items[p] = nitems;
       c->q_edges[p] = edges;
       if (in.bin_min > 0 || in.mid_v > 0) {
         int mode = 0;
-        const bool fat = in.bin_min > 0 && edges >= in.bin_min &&
+        const bool early = in.bin_early_div > 1 && c->vertices_visited * 4 < (long long)a.V;  // (this frontier included)
+        const long long bin_from = early ? in.bin_min / in.bin_early_div : in.bin_min;
+        const bool fat = in.bin_min > 0 && edges >= bin_from &&
                          (in.bin_max_degree <= 0 || edges <= (long long)in.bin_max_degree * nitems);
         if (fat && in.seq < 32) c->bin_want |= 1 << in.seq;
         if ((fat || in.bin_forced) && in.bin_allowed)
@@ -305,7 +324,7 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
         // level of the regular kernels on a wide grid leaves thousands of nearly empty tiles behind -- such a level
         // is expanded by the regular kernels once more, which compacts it)
         else if (!fat && !in.bin_forced && in.mid_v > 0 && nitems > 0 && nitems <= in.mid_v && edges <= (long long)in.mid_e &&
-                 nt <= 4 * ((nitems + TILE - 1) / TILE) + 256)
+                 heavy_tiles == 0 && nt <= 4 * ((nitems + TILE - 1) / TILE) + 256)
           mode = 3;
         c->mode = mode;
         if (mode == 2) {  // the sweep claim of this level accumulates the next level's counters and chunk map

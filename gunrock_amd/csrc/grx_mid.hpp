@@ -58,6 +58,7 @@ namespace grx {
 constexpr int MID_WGS = 32;          // workgroups that stay (the rest of the grid leaves at once)
 constexpr int MID_ENTER_V = 8192;    // a level enters with at most this many frontier vertices ...
 constexpr int MID_ENTER_E = 65536;   // ... and out-edges
+constexpr int MID_TILE_E = 4096;     // ... none of its tiles (the 256 slots one workgroup stages) holding more than two chunks of them
 constexpr int MID_EXIT_V = 131072;   // a frontier beyond this goes back to the regular kernels
 constexpr int MID_EXIT_E = 4 * MID_ENTER_E;  // ... and so does one with more out-edges than this (8 chunks per workgroup)
 constexpr int MID_SPIN_LIMIT = 1 << 22;

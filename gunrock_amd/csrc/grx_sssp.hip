@@ -481,6 +481,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void sssp_head_kernel(pipe_args a, sssp
   in.T = 0;
   in.mid_v = mid_v;  // frontiers of a few thousand vertices: many levels per launch (grx_mid.hpp)
   in.mid_e = mid_e;
+  in.mid_tile_e = bn.mid_tile_e;  // ... unless a tile of the frontier is too heavy for one workgroup of that body (plan_in)
   // fat levels of a weighted search on a dense graph: binned relaxation (mode 2, grx_relax.hpp)
   in.bin_min = bn.min_edges;
   in.bin_fill = bn.fill;
@@ -737,6 +738,7 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
   const int mid_e = mid_on ? ((me && atoi(me) > 0) ? atoi(me) : MID_ENTER_E) : 0;
   // Binned relaxation of the fat levels (grx_relax.hpp): plain schedule, non-negative weights, dense graphs
   bin_args rb{};
+  rb.mid_tile_e = sssp_env_int("GRX_MID_TILE_E", MID_TILE_E);
   rb.xcc_mask = ctx->xcc_mask;
   rb.n_xcd = ctx->n_xcd;
   int grid_rscatter = 0, grid_rsweep = 0;
