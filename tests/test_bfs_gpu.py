@@ -555,3 +555,49 @@ def test_launch_groups_follow_the_previous_search(gr, gpu_ctx, monkeypatch):
     # a repeated search launches exactly the groups it needs with the prediction, and never fewer without it
     for direction in (gr.forward, gr.optimized):
         assert 1 <= groups[("1", direction)] <= groups[("0", direction)], groups
+
+
+def test_plan_rules_for_searches_from_low_degree_sources(gr, gpu_ctx, monkeypatch):
+    """The two plan rules of round 5's last session (grx_frontier.hpp plan_in::mid_tile_e / bin_early_div; DESIGN 9): a frontier
+    with a tile of more than 4096 out-edges does not enter the many-levels body (two hops from a low-degree source of a
+    scale-free graph: a dozen vertices with 20-45 k out-edges, which ONE workgroup of that body would walk alone), and a level
+    met while less than a quarter of the graph is visited is binned from half the usual number of out-edges.  Either rule only
+    chooses between bodies that are all exact: depths and counters equal the oracle's with the rules on and off; for the
+    second rule the profile shows which body ran."""
+    _, c = gr.generate("rmat", 1 << 19, 8_000_000, seed=21)
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    deg = np.diff(g.row_offsets).astype(np.int64)
+    knobs = ("GRX_MID_TILE_E", "GRX_BIN_MIN_EDGES", "GRX_BIN_EARLY_DIV")
+    # sources 8 and 15: level 2 is 15 / 11 vertices with 44920 / 20588 out-edges; source 3: level 1 is 3 vertices with 4443;
+    # source 0: level 2 is 399 vertices with 491807 out-edges, 401 vertices visited by then
+    for src, heavy_level, early_level in ((8, 2, None), (15, 2, None), (3, 1, None), (0, None, 2)):
+        want, _, ev = O.bfs_queue(g, src)
+        reached = want != INF
+        ne = np.bincount(want[reached], weights=deg[reached]).astype(np.int64)
+        nv = np.bincount(want[reached])
+        if heavy_level is not None:
+            assert nv[heavy_level] <= 256 and 4096 < ne[heavy_level] <= 65536, "the generator changed: pick another source"
+        if early_level is not None:
+            assert 400_000 <= ne[early_level] < 800_000 and nv[:early_level + 1].sum() * 4 < g.n_vertices
+        for env in ({}, {"GRX_MID_TILE_E": "0"}, {"GRX_BIN_MIN_EDGES": "800000"},
+                    {"GRX_BIN_MIN_EDGES": "800000", "GRX_BIN_EARLY_DIV": "1"}):
+            for k in knobs:
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            for flags in (0, gr.FLAG_PROFILE):
+                d, st = run_bfs(gr, gpu_ctx, g.row_offsets, g.column_indices, src,
+                                gr.options_t(advance_direction=gr.forward, engine_flags=flags))
+                assert np.array_equal(d, want), (src, env, flags)
+                assert st["edges_visited"] == ev and st["vertices_visited"] == int(reached.sum()), (src, env, flags)
+            # Which body ran is visible in the profile only for the second rule: a PROFILED run has no tiny levels in its heads, so
+            # level 0 itself enters the many-levels body and that body keeps going level after level on its own exit rules (total
+            # vertices / out-edges) -- the first rule is a rule of the heads (profiles/r5_c36_ms_trace.txt has the kernel sequences
+            # of unprofiled searches with and without it).
+            prof = gr.level_profile(gpu_ctx)  # of the profiled run
+            modes = {int(l["edges"]): int(l["bottom_up"]) for l in prof}
+            if early_level is not None and env.get("GRX_BIN_MIN_EDGES") == "800000":
+                m = modes.get(int(ne[early_level]))
+                assert m == (0 if env.get("GRX_BIN_EARLY_DIV") == "1" else 2), (src, env, prof[:5])
+    for k in knobs:
+        monkeypatch.delenv(k, raising=False)
