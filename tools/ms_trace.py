@@ -25,14 +25,17 @@ ctx = gr.multi_context_t(0)
 G = gr.build_graph(props, csr, ctx)
 d = torch.empty(G.get_number_of_vertices(), dtype=torch.int32, device="cuda")
 o = gr.options_t(advance_load_balance=gr.merge_path, enable_filter=True, filter_algorithm=gr.compact,
-                 advance_direction=gr.forward, engine_flags=gr.FLAG_ASYNC_RETURN)
+                 advance_direction=gr.optimized if os.environ.get("MS_DIR") == "do" else gr.forward, engine_flags=gr.FLAG_ASYNC_RETURN)
 for _ in range(3):
     gr.bfs(G, hub, d, None, ctx, o)
 ctx.synchronize()
 # A/B inside one process (the engine reads its knobs per call): the rules of round 5's last session -- no heavy tile in the
 # many-levels body, early levels binned from 2^20 edges -- against the sources without them
 OLD = {"GRX_MID_TILE_E": "0", "GRX_BIN_EARLY_DIV": "1"}
-for rep, (tag, env) in enumerate([("new", {}), ("old", OLD), ("new", {}), ("old", OLD)]):
+ROUNDS = [("new", {}), ("old", OLD), ("new", {}), ("old", OLD)]
+if os.environ.get("MS_DIR") == "do":  # direction-optimising searches: the two rules do not apply, one setting, two rounds
+    ROUNDS = [("do", {}), ("do", {})]
+for rep, (tag, env) in enumerate(ROUNDS):
     for k in OLD:
         os.environ.pop(k, None)
     os.environ.update(env)

@@ -21,8 +21,9 @@ for k in range(3, min(len(starts) - 1, 3 + 16)):  # rounds 0 (new rules) and 1 (
     for r in rows[a:b]:
         n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("grx::", "")
         n = n.replace("bfs_", "").replace("_kernel", "").split("<")[0]
+        if n.startswith("at::") or n.startswith("__amd"): continue
         parts.append("%s %.0f" % (n, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     span = (int(rows[b - 1]["End_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e3
-    print("  %s search %d span %.1f us | %s" % ("new" if k - 3 < 8 else "old", (k - 3) % 8, span, " ".join(parts)))
+    print("  %s search %d span %.1f us | %s" % ("round0" if k - 3 < 8 else "round1", (k - 3) % 8, span, " ".join(parts)))
 PY
 rm -rf "$OUT"
