@@ -925,27 +925,41 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     d.fbits[1] = d.fbits[0] + bm_words;
     d.fbits[2] = d.fbits[1] + bm_words;
     d.rot3 = 1;
-    std::lock_guard<std::recursive_mutex> lk(g->prep_mu);  // the two per-graph arrays below are built on first use
-    if (!g->closed0 || g->closed0_words != (int32_t)bm_words) {
-      // static "no in-edges" bitmap, built once per graph and kept in the graph handle
-      if (g->closed0) GRX_HIP(hipFree(g->closed0));
-      g->closed0 = nullptr;
-      GRX_HIP(hipMalloc((void**)&g->closed0, bm_words * sizeof(unsigned)));
-      g->closed0_words = (int32_t)bm_words;
-      hipLaunchKernelGGL(bfs_closed0_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, d.t_ro, g->V, g->closed0,
-                         (int)bm_words);
-    }
-    if (env_int("GRX_BU_HEADS", 1) != 0 && g->V < (1 << 29)) {
-      // the first two in-neighbours of every vertex as one dense array, built once per graph (8 V bytes)
-      if (!g->bu_heads || g->bu_heads_of != (const void*)d.t_ci) {
-        if (g->bu_heads) GRX_HIP(hipFree(g->bu_heads));
-        g->bu_heads = nullptr;
-        GRX_HIP(hipMalloc((void**)&g->bu_heads, (size_t)g->V * 2 * sizeof(int32_t)));
-        g->bu_heads_of = (const void*)d.t_ci;
-        hipLaunchKernelGGL(bfs_heads_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, s, d.t_ro, d.t_ci, g->V,
-                           reinterpret_cast<int2*>(g->bu_heads));
+    {
+      // The two per-graph arrays below are built on first use: into LOCALS, by kernels on this context's stream, and published
+      // under the handle's build lock only after that stream has drained (a second context on another stream that
+      // takes the lock next must find them BUILT, not merely allocated -- the transpose, bin and PageRank builders do the same).
+      std::lock_guard<std::recursive_mutex> lk(g->prep_mu);
+      const bool want_heads = env_int("GRX_BU_HEADS", 1) != 0 && g->V < (1 << 29);
+      const bool build_closed = !g->closed0 || g->closed0_words != (int32_t)bm_words;
+      const bool build_heads = want_heads && (!g->bu_heads || g->bu_heads_of != (const void*)d.t_ci);
+      if (build_closed || build_heads) {
+        dev_scratch closed_new, heads_new;
+        if (build_closed) {
+          // static "no in-edges" bitmap, built once per graph and kept in the graph handle
+          GRX_HIP(closed_new.alloc(bm_words * sizeof(unsigned)));
+          hipLaunchKernelGGL(bfs_closed0_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, d.t_ro, g->V, closed_new.as<unsigned>(),
+                             (int)bm_words);
+        }
+        if (build_heads) {
+          // the first two in-neighbours of every vertex as one dense array, built once per graph (8 V bytes)
+          GRX_HIP(heads_new.alloc((size_t)g->V * 2 * sizeof(int32_t)));
+          hipLaunchKernelGGL(bfs_heads_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, s, d.t_ro, d.t_ci, g->V, heads_new.as<int2>());
+        }
+        GRX_HIP(hipGetLastError());
+        GRX_HIP(hipStreamSynchronize(s));
+        if (build_closed) {
+          if (g->closed0) GRX_HIP(hipFree(g->closed0));
+          g->closed0 = reinterpret_cast<unsigned*>(closed_new.release());
+          g->closed0_words = (int32_t)bm_words;
+        }
+        if (build_heads) {
+          if (g->bu_heads) GRX_HIP(hipFree(g->bu_heads));
+          g->bu_heads = reinterpret_cast<int32_t*>(heads_new.release());
+          g->bu_heads_of = (const void*)d.t_ci;
+        }
       }
-      d.heads = reinterpret_cast<const int2*>(g->bu_heads);
+      if (want_heads) d.heads = reinterpret_cast<const int2*>(g->bu_heads);
     }
     if (d.heads && env_int("GRX_BU2", 1) != 0) {
       // second bottom-up body: needs the dense array and all chunks of a wave in 128 slots

@@ -60,6 +60,7 @@ struct pipe_args {
   int32_t mid_seg_cap;       // second version: entries of a private region in use (<= MID_SEG; tests shrink it to reach the overflow path)
   int32_t mid_exit_v;        // second version: a frontier beyond this many vertices goes back to the regular kernels (<= MID_EXIT_V)
   int32_t mid_exit_e;        // ... or beyond this many out-edges (MID_EXIT_E)
+  int32_t mid_hub_deg;       // ... or averaging more than this many out-edges per vertex (0: no such rule)
 };
 
 // The search is over: final counters and the elapsed device time go to the host-pinned mailbox

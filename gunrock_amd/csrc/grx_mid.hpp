@@ -875,7 +875,13 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
     // A level that has outgrown this body goes back to the regular kernels: too many vertices, or -- scale-free graphs: a
     // few thousand vertices a level before the hubs -- too many out-edges for the 32 workgroups of one XCD (round 4: three of
     // 16 random sources of the LJ stand-in spent 5 ms in here on levels of 10^5 vertices / 10^6 edges).
-    if (n_in == 0 || n_in > a.mid_exit_v || sm.next_edges > (a.mid_exit_e >> 7)) break;
+    // ... or (round 6) a next level of HUBS: the blocks of 256 entries are dealt out by entry, so a level that averages more than
+    // mid_hub_deg out-edges per vertex gives single workgroups several chunks to walk one after the other (0.35 ms for one such
+    // level two hops from a low-degree source of a scale-free graph, profiles/r5_c37_*); the regular level kernel spreads them
+    // over the grid.  (next_edges sums per-workgroup totals >> 7: a lower bound, exact enough for a rule of thumb.)
+    const long long e_next = (long long)sm.next_edges << 7;
+    if (n_in == 0 || n_in > a.mid_exit_v || sm.next_edges > (a.mid_exit_e >> 7) ||
+        (a.mid_hub_deg > 0 && e_next > 4096 && e_next > (long long)a.mid_hub_deg * n_in)) break;
   }
   // ---- leaving
   if (dbg) {

@@ -567,7 +567,7 @@ def test_plan_rules_for_searches_from_low_degree_sources(gr, gpu_ctx, monkeypatc
     _, c = gr.generate("rmat", 1 << 19, 8_000_000, seed=21)
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
     deg = np.diff(g.row_offsets).astype(np.int64)
-    knobs = ("GRX_MID_TILE_E", "GRX_BIN_MIN_EDGES", "GRX_BIN_EARLY_DIV")
+    knobs = ("GRX_MID_TILE_E", "GRX_BIN_MIN_EDGES", "GRX_BIN_EARLY_DIV", "GRX_MID_HUB_DEG")
     # sources 8 and 15: level 2 is 15 / 11 vertices with 44920 / 20588 out-edges; source 3: level 1 is 3 vertices with 4443;
     # source 0: level 2 is 399 vertices with 491807 out-edges, 401 vertices visited by then
     for src, heavy_level, early_level in ((8, 2, None), (15, 2, None), (3, 1, None), (0, None, 2)):
@@ -579,7 +579,7 @@ def test_plan_rules_for_searches_from_low_degree_sources(gr, gpu_ctx, monkeypatc
             assert nv[heavy_level] <= 256 and 4096 < ne[heavy_level] <= 65536, "the generator changed: pick another source"
         if early_level is not None:
             assert 400_000 <= ne[early_level] < 800_000 and nv[:early_level + 1].sum() * 4 < g.n_vertices
-        for env in ({}, {"GRX_MID_TILE_E": "0"}, {"GRX_BIN_MIN_EDGES": "800000"},
+        for env in ({}, {"GRX_MID_TILE_E": "0"}, {"GRX_MID_HUB_DEG": "0"}, {"GRX_BIN_MIN_EDGES": "800000"},
                     {"GRX_BIN_MIN_EDGES": "800000", "GRX_BIN_EARLY_DIV": "1"}):
             for k in knobs:
                 monkeypatch.delenv(k, raising=False)
@@ -599,5 +599,15 @@ def test_plan_rules_for_searches_from_low_degree_sources(gr, gpu_ctx, monkeypatc
             if early_level is not None and env.get("GRX_BIN_MIN_EDGES") == "800000":
                 m = modes.get(int(ne[early_level]))
                 assert m == (0 if env.get("GRX_BIN_EARLY_DIV") == "1" else 2), (src, env, prof[:5])
+            # Round 6: the body's own EXIT rule by mean out-degree (pipe_args::mid_hub_deg, GRX_MID_HUB_DEG; the patch round 5
+            # left unapplied).  A profiled search enters the body at level 0; with the rule it LEAVES in front of the level of
+            # hubs, which then is a record of its own on the regular level kernel (mode 0); without it (GRX_MID_HUB_DEG=0) the
+            # body walks that level itself -- no record with that level's edge count, or one of mode 3.
+            if heavy_level is not None and "GRX_BIN_MIN_EDGES" not in env and ne[heavy_level] > 16 * nv[heavy_level]:
+                m = modes.get(int(ne[heavy_level]))
+                if env.get("GRX_MID_HUB_DEG") == "0":
+                    assert m is None or m == 3, (src, env, prof[:5])
+                elif "GRX_MID_TILE_E" not in env:
+                    assert m == 0, (src, env, prof[:5])
     for k in knobs:
         monkeypatch.delenv(k, raising=False)
