@@ -151,6 +151,7 @@ def lib():
         "grx_bfs_dist_groups": (i32, [vp, i32]),
         "grx_bfs_dist_capture_group": (i32, [vp]),
         "grx_bfs_dist_group_is_captured": (i32, [vp]),
+        "grx_bfs_dist_run": (i32, [vp, i32, i32, vp, i32, P(grx_run_stats_t)]),
         "grx_sssp_dist_create": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
         "grx_sssp_dist_begin": (i32, [vp, i32, vp]),
         "grx_sssp_dist_pre": (i32, [vp]),

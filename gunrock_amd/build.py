@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libgrx.so")
 OBJ = os.path.join(HERE, "_obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["grx_api.hip", "grx_bfs.hip", "grx_sssp.hip", "grx_pr.hip", "grx_transpose.hip", "grx_dist.hip", "grx_dist_sssp.hip", "grx_block.hip",
+SOURCES = ["grx_api.hip", "grx_bfs.hip", "grx_sssp.hip", "grx_pr.hip", "grx_transpose.hip", "grx_dist_sssp.hip", "grx_block.hip",
            "grx_host.cpp"]
 FLAGS = ["-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics",
          "-ffp-contract=off", "-Wall", "-Wno-unused-function",

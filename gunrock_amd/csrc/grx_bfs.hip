@@ -116,6 +116,7 @@ __device__ __forceinline__ void bfs_seed_body(const pipe_args& a, int32_t* dist,
     c->map_level = -2;
     c->edges_visited = 0;
     c->vertices_visited = 0;
+    c->g_edges_visited = 0;
     c->spare[0] = 0;
     c->bin_want = 0;
     c->mode = 0;
@@ -348,8 +349,12 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_source_kernel(pipe_args a, dobf
 // s_dec (3 LDS ints) receives {done, direction of this level, level} for every thread.
 // only_finish (the group is this head alone, plan_in::only_finish): a search that is over is finished as usual, one that is not
 // is left exactly as it is (s_dec[1] = -1: nothing follows) for the head of the next group.
+// PART (partitioned searches, part_args): the sums above are this rank's share -- they feed its own counters -- while the end of
+// the search and the direction are decided from the ALL-REDUCED frontier statistics, so every rank takes the same branch.
+template <bool PART = false>
 __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_args& d, unsigned long long* s_red,
-                                                const ctrl_head& h, int* s_dec, int only_finish = 0) {
+                                                const ctrl_head& h, int* s_dec, int only_finish = 0,
+                                                const part_args* x = nullptr) {
   ctrl_t* c = a.ctrl;
   const int tid = threadIdx.x;
   const int done = h.done;
@@ -390,26 +395,30 @@ __device__ __forceinline__ void bfs_decide_body(const pipe_args& a, const dobfs_
   __syncthreads();
   if (tid == 0) {
     const long long n_f = (long long)s_red[0], m_f = (long long)s_red[1];
-    if (only_finish && n_f != 0) {
+    // what the rules below look at: the whole frontier (PART: all ranks' shares)
+    const long long gn = PART ? x->stats_global[0] : n_f, gm = PART ? x->stats_global[1] : m_f;
+    if (only_finish && gn != 0) {
       s_dec[1] = -1;
     } else {
     c->bu_open += (long long)s_red[2];
     c->bu_probes += (long long)s_red[3];
-    if (n_f == 0) {
+    if (gn == 0) {
       c->done = 1;
       c->level = level;
       s_dec[0] = 1;
       publish_done(a, c, level);
     } else {
       int mode = prev_bottom_up;
-      const long long m_u = (long long)d.n_edges - h.edges_visited;  // edges of still-unexpanded vertices
+      const long long e_all = PART ? x->e_global : (long long)d.n_edges;
+      const long long m_u = e_all - (PART ? c->g_edges_visited : h.edges_visited);  // edges of still-unexpanded vertices
+      if (PART) c->g_edges_visited += gm;
       if (mode == 0) {
-        if (m_f > m_u / d.alpha && n_f > 256) mode = 1;
+        if (gm > m_u / d.alpha && gn > 256) mode = 1;
       } else {
         // back to top-down: few frontier vertices (Beamer), or so few frontier out-edges that
         // expanding them beats another sweep over every open vertex's in-edges
-        if (n_f < (long long)a.V / d.beta) mode = 0;
-        if (d.back_div > 0 && m_f < (long long)d.n_edges / d.back_div) mode = 0;
+        if (gn < (long long)a.V / d.beta) mode = 0;
+        if (d.back_div > 0 && gm < e_all / d.back_div) mode = 0;
       }
       if (!prev_bottom_up) c->bu_R = 0;  // the queue of this level is a dense run of tiles
       s_dec[1] = mode;
@@ -486,10 +495,12 @@ __global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_kernel(pipe_args a, dobfs
 // One level, ONE launch: top-down (advance + fused compaction) or bottom-up, as the
 // head kernel decided.  Direction-optimising runs: every workgroup also clears its share of
 // the frontier bitmap the NEXT level will write into.
-template <int BATCH, bool BU2 = false, bool DBG = false>
-__global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs_args d, bfs_policy pol) {
+// only_mode (partitioned searches): -1 any; 0 | 1: this launch runs the level only when it is top-down | bottom-up -- the exchange
+// of a partitioned level sits BEHIND a top-down body and IN FRONT OF a bottom-up one, so such a group carries the kernel twice.
+template <int BATCH, bool BU2, bool DBG, class Pol>
+__device__ __forceinline__ void bfs_level_body(const pipe_args& a, const dobfs_args& d, Pol& pol, int only_mode) {
   // a launch runs ONE of the two bodies: their LDS is overlaid (24 KB instead of 38: 6 workgroups per CU)
-  using td_smem = advance_smem<bfs_policy>;
+  using td_smem = advance_smem<Pol>;
   using bu_smem = typename std::conditional<BU2, bottomup2_smem<BATCH>, bottomup_smem<BATCH, true>>::type;
   constexpr size_t LDS_BYTES = sizeof(td_smem) > sizeof(bu_smem) ? sizeof(td_smem) : sizeof(bu_smem);
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
@@ -500,6 +511,7 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
   if (h.done) return;
   const int level = h.level;
   const int mode_now = h.mode;
+  if (only_mode >= 0 && mode_now != only_mode) return;
 
   if (d.enabled) {
     uint4* z = reinterpret_cast<uint4*>(pick3(d.fbits, (level + 2) % 3));
@@ -526,11 +538,19 @@ __global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs
     if ((int)blockIdx.x >= n_act) return;
     pol.ctrl = c;
     pol.set_level(level);
-    advance_block<bfs_policy, false>(a, c, pol, sm, level & 1, blockIdx.x, n_act, h.total_chunks, a.chunk_tile);
+    advance_block<Pol, false>(a, c, pol, sm, level & 1, blockIdx.x, n_act, h.total_chunks, a.chunk_tile);
   } else {
     if constexpr (BU2) bfs_bottomup2_block<BATCH, DBG>(a, d, c, bsm);
     else bfs_bottomup_block<BATCH, true>(a, d, c, bsm);
   }
+}
+template <int BATCH, bool BU2 = false, bool DBG = false>
+__global__ __launch_bounds__(ADV_BLOCK) void bfs_level_kernel(pipe_args a, dobfs_args d, bfs_policy pol) {
+  bfs_level_body<BATCH, BU2, DBG>(a, d, pol, -1);
+}
+template <int BATCH, bool BU2 = false>
+__global__ __launch_bounds__(ADV_BLOCK) void bfs_level_part_kernel(pipe_args a, dobfs_args d, bfs_policy_part pol, int only_mode) {
+  bfs_level_body<BATCH, BU2, false>(a, d, pol, only_mode);
 }
 
 // Forward-only runs with binned fat levels: one level is this kernel (the claim-per-edge advance, or
@@ -587,6 +607,285 @@ __global__ __launch_bounds__(NT, WAVES_PER_SIMD) void bfs_sweep2_kernel(pipe_arg
   bin_sweep2_block<NT, LE, DBG, E16>(a, bn, c, h.level + 1, sm, h.level & 1);
 }
 constexpr int SW3_BLOCK = 1024, SW3_LIST = 63 * TILE;
+
+// ===============================================================================================================
+// PARTITIONED searches (round 6): the kernels a partition adds around the engine's bodies.  One level group of rank r:
+//   forward:   head -> level (claim-per-edge) | scatter + sweep  -> [exchange of `send`] -> post -> stats -> [all-reduce]
+//   direction-optimising: head -> prep -> level(top-down only) -> [exchange] -> level(bottom-up only) -> post -> stats -> [all-reduce]
+// The bracketed collectives are the host's (RCCL inside the library, or torch.distributed); nothing here depends on them
+// except through part_args::recv / stats_global.  See bfs_policy_part and part_args (grx_bfs_kernels.hpp).
+// ===============================================================================================================
+
+// Head of a partitioned level group: as bfs_head_kernel without the tiny levels (a level ends with an exchange), the end of
+// the search and the direction taken from the all-reduced statistics.  <<<1, 1024>>>
+__global__ __launch_bounds__(PLAN_BLOCK) void bfs_head_part_kernel(pipe_args a, dobfs_args d, int seq, bin_args bn, part_args x) {
+  __shared__ unsigned long long s_red[4];
+  __shared__ int s_wave[PLAN_BLOCK / 64 + 1];
+  __shared__ int s_dec[3];
+  ctrl_t* c = a.ctrl;
+  const ctrl_head h = load_ctrl_head(c);
+  if (threadIdx.x < 4) s_red[threadIdx.x] = 0ull;
+  if (threadIdx.x == 0 && !h.done) a.mailbox[3] = seq;
+  __syncthreads();
+  plan_in in;
+  in.done = h.done;
+  in.mode = 0;
+  in.R = 0;
+  in.T = h.bu_T;
+  in.part_P = x.P;
+  if (!d.enabled) {
+    in.level = h.level + 1;
+    in.nt = h.nt(in.level & 1);
+    in.g_n = x.stats_global[0];
+    in.bin_min = bn.min_edges;
+    in.bin_max_degree = bn.max_degree;
+    in.bin_early_div = bn.bin_early_div;
+    in.bin_fill = bn.fill;
+    in.bin_queue = bn.queue;
+    in.bin_nb = bn.nb;
+    in.bin_pad = BIN_PAD;
+    in.bin_allowed = bn.allowed;
+    in.seq = seq;
+    plan_body<PLAN_BLOCK>(a, c, 0, s_wave, &s_red[0], in);
+    return;
+  }
+  bfs_decide_body<true>(a, d, s_red, h, s_dec, 0, &x);
+  if (s_dec[0] || s_dec[1] != 0) return;
+  if (threadIdx.x < 2) s_red[threadIdx.x] = 0ull;
+  __syncthreads();
+  in.level = s_dec[2];
+  in.nt = h.nt(in.level & 1);
+  in.R = h.mode ? h.bu_R : 0;
+  plan_body<PLAN_BLOCK>(a, c, 1, s_wave, &s_red[0], in);
+}
+
+// Forward partitioned run, thin level: the claim-per-edge advance with the partition's claim (a binned level: no-op).
+__global__ __launch_bounds__(ADV_BLOCK) void bfs_level_bin_part_kernel(pipe_args a, bin_args bn, bfs_policy_part pol) {
+  __shared__ advance_smem<bfs_policy_part> sm;
+  ctrl_t* c = a.ctrl;
+  const level_head h = load_level_head(c);
+  if (h.done || h.mode != 0) return;
+  const int n_act = thin_workgroups(h.total_chunks, (int)gridDim.x, bn.thin_div, bn.thin_min);
+  if ((int)blockIdx.x >= n_act) return;
+  pol.ctrl = c;
+  pol.set_level(h.level);
+  advance_block<bfs_policy_part, false>(a, c, pol, sm, h.level & 1, blockIdx.x, n_act, h.total_chunks, a.chunk_tile);
+}
+
+// ... fat level: the engine's scatter (bfs_scatter2_kernel, unchanged: bins span the whole vertex range) and its sweep with the
+// partition's rule for words of other ranks' vertices (bin_sweep2_block<.., SLICED>).
+template <int NT, int LE, int WAVES_PER_SIMD, bool E16>
+__global__ __launch_bounds__(NT, WAVES_PER_SIMD) void bfs_sweep2_part_kernel(pipe_args a, bin_args bn) {
+  __shared__ __attribute__((aligned(16))) bin_sweep2_smem<NT, LE> sm;
+  ctrl_t* c = a.ctrl;
+  const level_head h = load_level_head(c);
+  if (h.done || h.mode != 2) return;
+  bin_sweep2_block<NT, LE, false, E16, true>(a, bn, c, h.level + 1, sm, h.level & 1);
+}
+
+// problem.reset() + seed of a partitioned search, one launch: labels of the OWNED range only (the label pointer may be the
+// base of a sharded array minus lo), bitmaps of the whole range, an empty outgoing bitmap; the frontier is {source} on the
+// owner and empty elsewhere; the first statistics record.  <<<any, TILE>>>
+__global__ void bfs_part_reset_seed_kernel(int32_t* dist, pipe_args a, dobfs_args d, part_args x, unsigned* visited, int n_words,
+                                           const unsigned* closed0, int src) {
+  const bool own = src >= x.lo && src < x.hi;
+  if (blockIdx.x == 0) {
+    bfs_seed_body(a, dist, nullptr, src, d, 0, false);
+    if (threadIdx.x == 0) {
+      ctrl_t* c = a.ctrl;
+      const int deg = own ? a.ro[src + 1] - a.ro[src] : 0;
+      if (!own) {
+        a.frontier[0][0] = -1;
+        a.tile_sums[0] = 0;
+        a.tile_chunks[0] = 0;
+        a.tile_count[0] = 0;
+        c->n_tiles[0] = 0;
+        c->n_items[0] = 0;
+        c->q_edges[0] = 0;
+      }
+      x.stats_local[0] = own ? 1 : 0;
+      x.stats_local[1] = deg;
+      x.stats_local[2] = 0;
+      x.stats_local[3] = 0;
+    }
+  }
+  const int64_t gsz = (int64_t)gridDim.x * blockDim.x, gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = (int64_t)x.lo + gid; i < (int64_t)x.hi; i += gsz) dist[i] = i == (int64_t)src ? 0 : INT_MAX;
+  const int64_t sw = src >> 5;
+  const unsigned sbit = 1u << (src & 31);
+  for (int64_t w = gid; w < n_words; w += gsz) {
+    const unsigned bit = w == sw ? sbit : 0u;  // (every rank marks the source: nobody reports it to its owner)
+    if (d.enabled) {
+      visited[w] = closed0[w] | bit;
+      d.fbits[0][w] = bit;
+      d.fbits[1][w] = 0u;
+    } else {
+      visited[w] = bit;
+    }
+  }
+  const int64_t all = (int64_t)x.P * x.slice_words;
+  for (int64_t w = gid; w < all; w += gsz) {
+    x.send[w] = 0u;
+    if (d.enabled) x.sent[w] = w == sw ? sbit : 0u;
+  }
+}
+
+// Direction-optimising partitioned run, in front of the exchange of a BOTTOM-UP level: this rank's slice of the frontier
+// bitmap goes to every peer (the all-to-all degenerates to an all-gather: afterwards `recv` is the whole-graph frontier).
+__global__ void bfs_part_prep_kernel(pipe_args a, dobfs_args d, part_args x) {
+  const level_head h = load_level_head(a.ctrl);
+  if (h.done || h.mode != 1) return;
+  const unsigned* f = pick3(d.fbits, h.level % 3) + (x.lo >> 5);
+  const int n_w = (x.hi - x.lo + 31) >> 5;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < x.slice_words; i += gridDim.x * blockDim.x) {
+    const unsigned v = i < n_w ? f[i] : 0u;
+    for (int j = 0; j < x.P; ++j) x.send[(size_t)j * x.slice_words + i] = v;
+  }
+}
+
+// Behind the exchange: what the peers reported in this rank's slice -- OR of the P - 1 received slices, minus what is
+// known (`visited`; direction-optimising runs: + the frontier bitmap being built) -- is claimed (exactly one thread looks at a
+// word), labelled and emitted in ascending vertex order as tiles of the next frontier; behind a BINNED level also with the
+// chunk-map entries and counters the sweep's own emission writes (sweep2_emit), so that the next head has nothing to walk.
+// Every launch also empties the outgoing bitmap for the next level.  <<<min(segments, 2 per CU), 1024>>>
+constexpr int PP_BLOCK = 1024, PP_SEG_WORDS = PP_BLOCK / 4;
+struct part_post_smem {
+  static constexpr int LIST = 34 * TILE;  // a segment's 8192 ids + what is waiting (a short tile at most after an emission)
+  static constexpr int MAX_TILES = LIST / TILE + 1;
+  int list[LIST];
+  unsigned words[PP_SEG_WORDS];
+  int wave[PP_BLOCK / 64 + 1];
+  int sum[MAX_TILES][4];
+  int ttot[64];
+  int cpre[64];
+  int tile_base;
+  int chunk_base;
+  int n_chunks;
+};
+static_assert(part_post_smem::LIST >= PP_SEG_WORDS * 32 + 2 * TILE, "a segment fits behind a short tile");
+__global__ __launch_bounds__(PP_BLOCK) void bfs_part_post_kernel(pipe_args a, dobfs_args d, part_args x, unsigned* visited) {
+  __shared__ __attribute__((aligned(16))) part_post_smem sm;
+  ctrl_t* c = a.ctrl;
+  const level_head h = load_level_head(c);
+  if (h.done) return;
+  const int tid = threadIdx.x;
+  {
+    uint4* z = reinterpret_cast<uint4*>(x.send);  // (slice_words is a multiple of 64)
+    const int64_t n4 = (int64_t)x.P * x.slice_words / 4;
+    for (int64_t i = (int64_t)blockIdx.x * PP_BLOCK + tid; i < n4; i += (int64_t)gridDim.x * PP_BLOCK) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (h.mode == 1) return;  // a bottom-up level: its discoveries are this rank's own
+  const int depth = h.level + 1;
+  const int q = depth & 1;
+  const bool with_map = !d.enabled && __hip_atomic_load(&c->map_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == depth;
+  unsigned* fnext = d.enabled ? pick3(d.fbits, depth % 3) : nullptr;
+  const int w_lo = x.lo >> 5;
+  const int n_w = (x.hi - x.lo + 31) >> 5;
+  const int n_seg = (n_w + PP_SEG_WORDS - 1) / PP_SEG_WORDS;
+  int n_list = 0;  // uniform
+  auto emit_list = [&](bool all) {
+    const int k = all ? (n_list + TILE - 1) / TILE : n_list / TILE;
+    const int n_emit = all ? n_list : k * TILE;
+    sweep2_emit<PP_BLOCK>(a, c, q, sm, n_emit, d.dist, depth, with_map);
+    const int rem = n_list - n_emit;
+    int keep = 0;
+    if (tid < rem) keep = sm.list[n_emit + tid];
+    __syncthreads();
+    if (tid < rem) sm.list[tid] = keep;
+    n_list = rem;
+    __syncthreads();
+  };
+  for (int seg = (int)blockIdx.x; seg < n_seg; seg += (int)gridDim.x) {
+    if (tid < PP_SEG_WORDS) {
+      const int w = seg * PP_SEG_WORDS + tid;
+      unsigned nw = 0u;
+      if (w < n_w) {
+        unsigned cand = 0u;
+        for (int j = 0; j < x.P; ++j)
+          if (j != x.rank) cand |= x.recv[(size_t)j * x.slice_words + w];
+        if (cand) {
+          unsigned known = visited[w_lo + w];
+          unsigned fn = 0u;
+          if (fnext) {
+            fn = fnext[w_lo + w];
+            known |= fn;
+          }
+          nw = cand & ~known;
+          if (nw) {
+            if (fnext) fnext[w_lo + w] = fn | nw;  // (joins `visited` when the level kernel expands that frontier)
+            else visited[w_lo + w] = known | nw;
+          }
+        }
+      }
+      sm.words[tid] = nw;
+    }
+    __syncthreads();
+    unsigned byte = (sm.words[tid >> 2] >> ((tid & 3) * 8)) & 0xffu;
+    int tot;
+    const int ex = dev::block_exclusive_sum<PP_BLOCK>(__popc(byte), sm.wave, &tot);
+    if (tot == 0) continue;  // (the scan's barriers separate this round's reads of `words` from the next round's writes)
+    if (n_list + tot > part_post_smem::LIST) emit_list(false);
+    int pos = n_list + ex;
+    const int v_first = x.lo + ((seg * PP_SEG_WORDS + (tid >> 2)) << 5) + (tid & 3) * 8;
+    while (byte) {
+      sm.list[pos++] = v_first + __ffs(byte) - 1;
+      byte &= byte - 1u;
+    }
+    n_list += tot;
+    __syncthreads();
+  }
+  if (n_list > 0) emit_list(true);
+}
+
+// This rank's share of the frontier the next level expands -> part_args::stats_local, the input of the all-reduce that
+// drives termination and direction on every rank.  <<<1, 1024>>>
+__global__ __launch_bounds__(PLAN_BLOCK) void bfs_part_stats_kernel(pipe_args a, dobfs_args d, part_args x) {
+  __shared__ unsigned long long s_red[2];
+  ctrl_t* c = a.ctrl;
+  const int tid = threadIdx.x;
+  if (tid < 2) s_red[tid] = 0ull;
+  __syncthreads();
+  const ctrl_head h = load_ctrl_head(c);
+  if (h.done) {
+    if (tid < 4) x.stats_local[tid] = 0;
+    return;
+  }
+  const int q = (h.level + 1) & 1;
+  long long n = 0, m = 0;
+  if (h.mode == 1) {
+    for (int i = tid; i < d.bu_grid; i += PLAN_BLOCK) {
+      n += d.bu_part[4 * i] & ((1ll << 40) - 1);
+      m += d.bu_part[4 * i + 1];
+    }
+  } else if (!d.enabled && c->map_level == h.level + 1) {
+    if (tid == 0) {  // the sweep and the post kernel summed them with the chunk map
+      n = c->n_items[q];
+      m = c->q_edges[q];
+    }
+  } else {
+    const int nt = h.nt(q);
+    for (int i = tid; i < nt; i += PLAN_BLOCK) {
+      n += a.tile_count[i];
+      m += a.tile_sums[i];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    n += __shfl_xor(n, o, 64);
+    m += __shfl_xor(m, o, 64);
+  }
+  if (dev::lane_id() == 0) {
+    atomicAdd(&s_red[0], (unsigned long long)n);
+    atomicAdd(&s_red[1], (unsigned long long)m);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    x.stats_local[0] = (long long)s_red[0];
+    x.stats_local[1] = (long long)s_red[1];
+    x.stats_local[2] = 0;
+    x.stats_local[3] = 0;
+  }
+}
 
 }  // namespace grx
 
@@ -819,38 +1118,113 @@ extern "C" grx_status_t grx_debug_read(grx_context_t ctx, long long* out, int64_
   return GRX_SUCCESS;
 }
 
-extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
-                                const grx_options_t* options, int32_t* d_dist,
-                                int32_t* d_pred, float* elapsed_ms) {
-  (void)d_pred;  // accepted and never written, like the reference (bfs.hxx:29)
-  if (!ctx || !g || !d_dist) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: null argument");
-  if (src < 0 || src >= g->V) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: source out of range");
-  grx_options_t opt;
+// ---------------------------------------------------------------------------------------------------------------
+// One BFS, as an object: everything grx_bfs() sets up once per search and the launch group it enqueues per level.  The
+// single-GPU entry point drives it with run_levels(); the partitioned entry points (grx_bfs_dist_*, below) drive the SAME
+// object with the exchange between launch_group() and launch_post() -- at one rank the two are the same code path.
+// ---------------------------------------------------------------------------------------------------------------
+// what grx_bfs_dist_create fixed for a partitioned handle
+struct bfs_part_cfg {
+  part_args x{};               // (sent / do_run are filled per search)
+  grx_graph_t g_in = nullptr;  // in-rows of the owned slice (null: the out-rows of a symmetric graph, or no direction switch)
+};
+
+static const grx_status_t BFS_RETRY_STATIC = static_cast<grx_status_t>(1000);  // internal: repeat the search with statically strided scatter units
+
+struct bfs_search {
+  grx_context_t ctx = nullptr;
+  grx_graph_t g = nullptr;
+  grx_options_t opt{};
+  int32_t src = 0;
+  int32_t* d_dist = nullptr;
+  bool part = false;        // more than one rank: partition kernels, exchange between launch_group and launch_post
+  bool api_driven = false;  // the level groups are enqueued by the caller (grx_bfs_dist_pre / _post): generic groups, no hints
+  bool answered = false;    // setup() ran the whole search on another path (block-asynchronous relaxation)
+
+  pipe_args a{};
+  dobfs_args d{};
+  bfs_policy lp{};
+  bfs_policy_part lpp{};
+  bin_args bn{};
+  part_args x{};
+  int variant = 0;
+  bool dopt = false, strict_mp = false, fwd_bm = false, use_bins = false, profile = false, dense = false;
+  level_build* lbuild = nullptr;
+  bool part_bu2 = false;
+  unsigned* visited = nullptr;
+  int grid = 0, grid_scatter = 0, grid_scatter2 = 0, grid_sweep3 = 0, grid_post = 0;
+  int pace = 0, hold_after = 0;
+  uint32_t bin_groups = ~0u, exact_groups = 0u;
+  bool exact = false, ended_in_head = false, do_repeat = false;
+  hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
+  hipError_t launch_err = hipSuccess;
+  int launches = 0;
+  int64_t prof_v = 0, prof_e = 0, prof_open = 0, prof_probe = 0;
+
+  grx_status_t setup(grx_context_t ctx_, grx_graph_t g_, int32_t src_, const grx_options_t* options, int32_t* d_dist_,
+                     const bfs_part_cfg* pc, bool api_driven_, float* elapsed_ms);
+  void launch_group(hipStream_t stream, int seq);
+  void launch_post(hipStream_t stream);
+  void after_sync(const ctrl_t& h);
+  grx_status_t finish(bool returned_fast, int groups_used, float* elapsed_ms);
+  void drop_events() {
+    for (auto& e : pe)
+      if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  }
+};
+
+using part_level_fn = void (*)(pipe_args, dobfs_args, bfs_policy_part, int);
+static int part_level_grid(grx_context_t ctx, grx_graph_t g, part_level_fn fn, int limit) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, ADV_BLOCK, 0) != hipSuccess || n < 1) n = 4;
+  if (n > limit) n = limit;
+  const int full = advance_grid_for(ctx, g);
+  const int resident = ctx->num_cus * n;
+  return full < resident ? full : resident;
+}
+
+grx_status_t bfs_search::setup(grx_context_t ctx_, grx_graph_t g_, int32_t src_, const grx_options_t* options, int32_t* d_dist_,
+                               const bfs_part_cfg* pc, bool api_driven_, float* elapsed_ms) {
+  ctx = ctx_;
+  g = g_;
+  src = src_;
+  d_dist = d_dist_;
+  api_driven = api_driven_;
+  part = pc != nullptr && pc->x.P > 1;
+  if (pc) x = pc->x;
   if (options) opt = *options; else grx_options_default(&opt);
   if (opt.advance_load_balance == GRX_LB_WORK_STEALING)
     return fail(GRX_ERROR_UNSUPPORTED, "Load balance type not supported.");
 
   GRX_HIP(hipSetDevice(ctx->device));
-  env_scan_guard env_guard;
   ctx->block_stats = grx_block_stats_t{};
-  const int variant = (opt.engine_flags >> 8) & 7;
+  variant = part ? 0 : (opt.engine_flags >> 8) & 7;
   grx_status_t st;
   // road-like graphs: block-asynchronous relaxation (grx_block.hip) instead of thousands of nearly empty levels
-  if (variant == 0 && opt.max_iterations == 0 &&
+  if (!part && !api_driven && variant == 0 && opt.max_iterations == 0 &&
       !(opt.engine_flags & (GRX_FLAG_NO_BLOCK_ASYNC | GRX_FLAG_UNFUSED | GRX_FLAG_SYNC_EACH_LEVEL | GRX_FLAG_LB_STRICT)) &&
       env_int("GRX_LB_STRICT", 0) == 0) {
     bool use = false;
     st = blk_prepare(ctx, g, false, &use);
     if (st != GRX_SUCCESS) return st;
-    if (use) return blk_search(ctx, g, src, opt, false, d_dist, elapsed_ms);
+    if (use) {
+      answered = true;
+      return blk_search(ctx, g, src, opt, false, d_dist, elapsed_ms);
+    }
   }
-  pipe_args a;
   st = pipeline_prepare(ctx, g, &a);
   if (st != GRX_SUCCESS) return st;
+  // edges of the WHOLE graph (a rank of a partition holds the rows of its slice only)
+  const long long e_all = part ? x.e_global : (long long)g->E;
   // bottom-up pays off on low-diameter graphs; with fewer than 4 edges per vertex the
   // frontier never gets heavy enough to switch and the extra per-level kernels only cost
-  bool dopt = opt.advance_direction == GRX_DIR_OPTIMIZED && variant == 0 && (long long)g->E >= 4ll * g->V;
-  if (dopt) {
+  dopt = opt.advance_direction == GRX_DIR_OPTIMIZED && variant == 0 && e_all >= 4ll * g->V;
+  grx_graph_t gt = g;  // the handle whose arrays are the in-edges (and that caches what is derived from them)
+  if (dopt && part) {
+    // a partition brings the in-rows of its slice (or is symmetric: its out-rows are its in-rows)
+    if (pc->g_in) gt = pc->g_in;
+    else if (!g->symmetric) dopt = false;
+  } else if (dopt) {
     // in-edges of the bottom-up step: the cached transpose (built on first use).  When it cannot be had -- the stable sort
     // needs 16-24 transient bytes per edge beside the 4-8 it keeps -- the search runs FORWARD-ONLY instead of failing: same
     // depths, the reference's own advance direction (the binned levels fall back the same way).
@@ -869,10 +1243,11 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   // Tuning knobs: GRX_TD_BITMAP=0 (no bitmap at all), GRX_TD_PRE=0 (no pre-filter), GRX_TD_BIN=0 (no
   // binned levels), GRX_BIN_MIN_EDGES (out-edges of a frontier from which a level is binned).
   // GRX_FLAG_LB_STRICT + merge_path: every level on the chunked merge-path advance, nothing else
-  const bool strict_mp = ((opt.engine_flags & GRX_FLAG_LB_STRICT) != 0 || env_int("GRX_LB_STRICT", 0) != 0) &&
-                         (opt.advance_load_balance == GRX_LB_MERGE_PATH || opt.advance_load_balance == GRX_LB_MERGE_PATH_V2);
-  const bool fwd_bm = !dopt && !strict_mp && variant == 0 && (long long)g->E >= 4ll * g->V && env_int("GRX_TD_BITMAP", 1) != 0;
-  bool use_bins = fwd_bm && env_int("GRX_TD_BIN", 1) != 0;
+  strict_mp = !part && ((opt.engine_flags & GRX_FLAG_LB_STRICT) != 0 || env_int("GRX_LB_STRICT", 0) != 0) &&
+              (opt.advance_load_balance == GRX_LB_MERGE_PATH || opt.advance_load_balance == GRX_LB_MERGE_PATH_V2);
+  // (a partitioned forward run always keeps the bitmap: its bits for other ranks' vertices are the record of what was reported)
+  fwd_bm = !dopt && !strict_mp && variant == 0 && (part || (e_all >= 4ll * g->V && env_int("GRX_TD_BITMAP", 1) != 0));
+  use_bins = fwd_bm && e_all >= 4ll * g->V && env_int("GRX_TD_BIN", 1) != 0;
   if (use_bins) {
     st = graph_build_bins(ctx, g);
     if (st != GRX_SUCCESS) return st;
@@ -892,7 +1267,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     }
   }
 
-  dobfs_args d{};
+  d = dobfs_args{};
   d.dist = d_dist;
   d.n_words = (int32_t)bm_words;
   d.n_edges = g->E;
@@ -902,8 +1277,8 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   d.back_div = env_int("GRX_DO_BACK_DIV", 0);
   if (d.alpha < 1) d.alpha = 1;
   if (d.beta < 1) d.beta = 1;
-  level_build* lbuild = level_kernel_build();
-  unsigned* visited = nullptr;
+  lbuild = level_kernel_build();
+  visited = nullptr;
   size_t visited_bytes = 0;
   if (dopt) {
     // in-edges: the CSR itself when the graph is symmetric (the property is caller-supplied and
@@ -912,12 +1287,17 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     // parents are probed first).  GRX_BU_SYMMETRIC_CSR=1: a graph declared symmetric uses its own CSR instead (rounds 1-3),
     // after the claim has been verified against the transpose.
     bool use_csr = false;
-    if (g->symmetric && env_int("GRX_BU_SYMMETRIC_CSR", 0) != 0) {
+    if (!part && g->symmetric && env_int("GRX_BU_SYMMETRIC_CSR", 0) != 0) {
       st = graph_is_symmetric(ctx, g, &use_csr);
       if (st != GRX_SUCCESS) return st;
     }
-    d.t_ro = use_csr ? g->ro : g->t_ro;
-    d.t_ci = use_csr ? g->ci : g->t_ci;
+    if (part) {
+      d.t_ro = gt->ro;
+      d.t_ci = gt->ci;
+    } else {
+      d.t_ro = use_csr ? g->ro : g->t_ro;
+      d.t_ci = use_csr ? g->ci : g->t_ci;
+    }
     GRX_HIP(ctx->bitmap[0].reserve(bm_words * sizeof(unsigned)));
     GRX_HIP(ctx->bitmap[1].reserve(3 * bm_words * sizeof(unsigned)));
     d.visited = ctx->bitmap[0].as<unsigned>();
@@ -929,10 +1309,10 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
       // The two per-graph arrays below are built on first use: into LOCALS, by kernels on this context's stream, and published
       // under the handle's build lock only after that stream has drained (a second context on another stream that
       // takes the lock next must find them BUILT, not merely allocated -- the transpose, bin and PageRank builders do the same).
-      std::lock_guard<std::recursive_mutex> lk(g->prep_mu);
+      std::lock_guard<std::recursive_mutex> lk(gt->prep_mu);
       const bool want_heads = env_int("GRX_BU_HEADS", 1) != 0 && g->V < (1 << 29);
-      const bool build_closed = !g->closed0 || g->closed0_words != (int32_t)bm_words;
-      const bool build_heads = want_heads && (!g->bu_heads || g->bu_heads_of != (const void*)d.t_ci);
+      const bool build_closed = !gt->closed0 || gt->closed0_words != (int32_t)bm_words || gt->closed0_of != (const void*)d.t_ro;
+      const bool build_heads = want_heads && (!gt->bu_heads || gt->bu_heads_of != (const void*)d.t_ci);
       if (build_closed || build_heads) {
         dev_scratch closed_new, heads_new;
         if (build_closed) {
@@ -949,32 +1329,45 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
         GRX_HIP(hipGetLastError());
         GRX_HIP(hipStreamSynchronize(s));
         if (build_closed) {
-          if (g->closed0) GRX_HIP(hipFree(g->closed0));
-          g->closed0 = reinterpret_cast<unsigned*>(closed_new.release());
-          g->closed0_words = (int32_t)bm_words;
+          if (gt->closed0) GRX_HIP(hipFree(gt->closed0));
+          gt->closed0 = reinterpret_cast<unsigned*>(closed_new.release());
+          gt->closed0_words = (int32_t)bm_words;
+          gt->closed0_of = (const void*)d.t_ro;
         }
         if (build_heads) {
-          if (g->bu_heads) GRX_HIP(hipFree(g->bu_heads));
-          g->bu_heads = reinterpret_cast<int32_t*>(heads_new.release());
-          g->bu_heads_of = (const void*)d.t_ci;
+          if (gt->bu_heads) GRX_HIP(hipFree(gt->bu_heads));
+          gt->bu_heads = reinterpret_cast<int32_t*>(heads_new.release());
+          gt->bu_heads_of = (const void*)d.t_ci;
         }
       }
-      if (want_heads) d.heads = reinterpret_cast<const int2*>(g->bu_heads);
+      if (want_heads) d.heads = reinterpret_cast<const int2*>(gt->bu_heads);
     }
-    if (d.heads && env_int("GRX_BU2", 1) != 0) {
-      // second bottom-up body: needs the dense array and all chunks of a wave in 128 slots
-      d.debug_level = env_int("GRX_BU_DEBUG", 0);  // per-wave phase clocks of that level (tools/bu_debug.py)
-      level_build* lb2 = level_kernel_build2(d.debug_level != 0);
-      if (d.debug_level != 0) {
-        GRX_HIP(ctx->far[1].reserve((size_t)8 * 16384 * sizeof(long long)));
-        d.debug = ctx->far[1].as<long long>();
-        GRX_HIP(hipMemsetAsync(d.debug, 0, (size_t)8 * 16384 * sizeof(long long), s));
+    if (part) {
+      // the partition's builds of the level kernel; the second bottom-up body under the same condition as below
+      part_bu2 = false;
+      if (d.heads && env_int("GRX_BU2", 1) != 0) {
+        const int grid2 = part_level_grid(ctx, g, bfs_level_part_kernel<2, true>, 4);
+        const long long chunks = (long long)bm_words / 2, per_round = (long long)grid2 * (ADV_BLOCK / 64) * 2;
+        if ((chunks + per_round - 1) / per_round * 2 <= 128) part_bu2 = true;
       }
-      const int grid2 = level_grid(ctx, g, lb2);
-      const long long chunks = (long long)bm_words / 2, per_round = (long long)grid2 * (ADV_BLOCK / 64) * 2;
-      if ((chunks + per_round - 1) / per_round * 2 <= 128) lbuild = lb2;
+      d.bu_grid = part_bu2 ? part_level_grid(ctx, g, bfs_level_part_kernel<2, true>, 4)
+                           : part_level_grid(ctx, g, bfs_level_part_kernel<2, false>, 8);
+    } else {
+      if (d.heads && env_int("GRX_BU2", 1) != 0) {
+        // second bottom-up body: needs the dense array and all chunks of a wave in 128 slots
+        d.debug_level = env_int("GRX_BU_DEBUG", 0);  // per-wave phase clocks of that level (tools/bu_debug.py)
+        level_build* lb2 = level_kernel_build2(d.debug_level != 0);
+        if (d.debug_level != 0) {
+          GRX_HIP(ctx->far[1].reserve((size_t)8 * 16384 * sizeof(long long)));
+          d.debug = ctx->far[1].as<long long>();
+          GRX_HIP(hipMemsetAsync(d.debug, 0, (size_t)8 * 16384 * sizeof(long long), s));
+        }
+        const int grid2 = level_grid(ctx, g, lb2);
+        const long long chunks = (long long)bm_words / 2, per_round = (long long)grid2 * (ADV_BLOCK / 64) * 2;
+        if ((chunks + per_round - 1) / per_round * 2 <= 128) lbuild = lb2;
+      }
+      d.bu_grid = level_grid(ctx, g, lbuild);
     }
-    d.bu_grid = level_grid(ctx, g, lbuild);
     GRX_HIP(ctx->bu_part.reserve((size_t)d.bu_grid * 4 * sizeof(long long)));
     d.bu_part = ctx->bu_part.as<long long>();
     a.bu_part = d.bu_part;
@@ -983,15 +1376,27 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     GRX_HIP(ctx->bitmap[0].reserve(visited_bytes));
     visited = ctx->bitmap[0].as<unsigned>();
   }
+  if (part) {
+    // what this rank has reported: the visited bitmap itself in a forward run, a bitmap of its own beside the three frontier
+    // bitmaps of a direction-optimising one (whose `visited` counts every vertex without local in-edges as closed)
+    x.do_run = dopt ? 1 : 0;
+    if (dopt) {
+      GRX_HIP(ctx->labels.reserve((size_t)x.P * x.slice_words * sizeof(unsigned)));
+      x.sent = ctx->labels.as<unsigned>();
+      d.fin_global = x.recv;
+    } else {
+      x.sent = visited;
+    }
+  }
 
   // problem.reset() -- outside the timed region, as in the reference; direction-optimising runs: one launch with the seed
   // (bfs_reset_seed_kernel, below: inside the timed region then).  GRX_SEED_IN_RESET=0: two launches
-  const bool seed_in_reset = dopt && variant == 0 && env_int("GRX_SEED_IN_RESET", 1) != 0;
+  const bool seed_in_reset = !part && dopt && variant == 0 && env_int("GRX_SEED_IN_RESET", 1) != 0;
   // forward-only runs with a visited bitmap: reset + seed in one launch too (bfs_fwd_reset_seed_kernel); GRX_FWD_SEED_IN_RESET=0:
   // fill + memset + seed kernel
-  const bool fwd_seed_in_reset = !dopt && variant == 0 && fwd_bm && visited != nullptr && (bm_words & 3) == 0 &&
+  const bool fwd_seed_in_reset = !part && !dopt && variant == 0 && fwd_bm && visited != nullptr && (bm_words & 3) == 0 &&
                                  (reinterpret_cast<uintptr_t>(d_dist) & 15) == 0 && env_int("GRX_FWD_SEED_IN_RESET", 1) != 0;
-  if (seed_in_reset || fwd_seed_in_reset) {
+  if (part || seed_in_reset || fwd_seed_in_reset) {
   } else if (dopt) {
     hipLaunchKernelGGL(bfs_reset_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, s, d_dist, (int64_t)g->V, d, g->closed0);
   } else {
@@ -999,18 +1404,18 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     if (visited) GRX_HIP(hipMemsetAsync(visited, 0, visited_bytes, s));
   }
 
-  const bool dense = g->V > 0 && (long long)g->E >= 8ll * g->V;  // few fat levels: paced enqueueing
+  dense = g->V > 0 && e_all >= 8ll * g->V;  // few fat levels: paced enqueueing
   ctx->h_mailbox[0] = 0;
   ctx->h_mailbox[3] = -1;
   GRX_HIP(hipEventRecord(ctx->ev_begin, s));
 
-  const int grid = (variant == 0) ? level_grid(ctx, g, lbuild) : advance_grid_for(ctx, g);
-  const bool profile = (opt.engine_flags & GRX_FLAG_PROFILE) != 0;
+  if (part) grid = dopt ? d.bu_grid : 0;
+  else grid = (variant == 0) ? level_grid(ctx, g, lbuild) : advance_grid_for(ctx, g);
+  profile = !part && !api_driven && (opt.engine_flags & GRX_FLAG_PROFILE) != 0;
   ctx->levels.clear();
-  hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
   if (profile) for (auto& e : pe) GRX_HIP(hipEventCreate(&e));
 
-  bfs_policy lp{};
+  lp = bfs_policy{};
   lp.dist = d_dist;
   if (dopt) {
     lp.bm_visited = d.visited;
@@ -1023,16 +1428,27 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     lp.fwd_bitmap = 1;
     // the read-only pre-filter of the label probe measured SLOWER (LJ stand-in, 31 M-edge level 525 -> 802 us:
     // a second dependent round trip per edge costs more than the label sectors it saves): off by default
-    lp.pre_bm = env_int("GRX_TD_PRE", 0) != 0 ? visited : nullptr;
+    lp.pre_bm = (!part && env_int("GRX_TD_PRE", 0) != 0) ? visited : nullptr;
+  }
+  if (part) {
+    lpp = bfs_policy_part{};
+    static_cast<bfs_policy&>(lpp) = lp;
+    lpp.lo = x.lo;
+    lpp.hi = x.hi;
+    lpp.sent = x.sent;
+    lpp.send = x.send;
   }
   // seed; then level 0 itself when the source is a hub (bfs_source_kernel: a no-op otherwise).  Profiled and
   // strict-merge-path runs keep one launch pair per level, level 0 included.
   // (2: the source kernel also writes level 1's chunk map and counters -- forward runs with binned levels, whose head takes
   // them from the producers; GRX_SOURCE_MAP=0: the head of level 1 walks the tiles)
-  const int source_level = (variant == 0 && !profile && !strict_mp && env_int("GRX_SOURCE_LEVEL", 1) != 0)
+  const int source_level = (!part && variant == 0 && !profile && !strict_mp && env_int("GRX_SOURCE_LEVEL", 1) != 0)
                                ? ((use_bins && !dopt && env_int("GRX_SOURCE_MAP", 1) != 0) ? 2 : 1) : 0;
   static_assert(TILE == 256, "the seed runs in a workgroup of the reset kernel");
-  if (seed_in_reset)
+  if (part)
+    hipLaunchKernelGGL(bfs_part_reset_seed_kernel, dim3(ctx->num_cus * 8), dim3(TILE), 0, s, d_dist, a, d, x,
+                       dopt ? d.visited : visited, (int)bm_words, dopt ? gt->closed0 : nullptr, src);
+  else if (seed_in_reset)
     hipLaunchKernelGGL(bfs_reset_seed_kernel, dim3(ctx->num_cus * 8), dim3(TILE), 0, s, d_dist, (int64_t)g->V, d, g->closed0, a, src,
                        source_level);
   else if (fwd_seed_in_reset)
@@ -1043,17 +1459,18 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   if (source_level)
     hipLaunchKernelGGL(bfs_source_kernel, dim3(ctx->num_cus * env_int("GRX_SOURCE_WG_PER_CU", 4)), dim3(ADV_BLOCK), 0, s, a, d, lp, src,
                        source_level == 2 ? 1 : 0);
-  bin_args bn{};
+  bn = bin_args{};
   bn.xcc_mask = ctx->xcc_mask;
   bn.n_xcd = ctx->n_xcd;
   d.xcc_mask = ctx->xcc_mask;
   // forward-only runs: frontiers of a few thousand vertices run many levels per launch (grx_mid.hpp); GRX_MID=0: off
-  if (!dopt && !strict_mp && variant == 0 && env_int("GRX_MID", 1) != 0) {
+  // (not in a partition: a level ends with an exchange)
+  if (!part && !dopt && !strict_mp && variant == 0 && env_int("GRX_MID", 1) != 0) {
     bn.mid_v = env_int("GRX_MID_V", MID_ENTER_V);
     bn.mid_e = env_int("GRX_MID_E", MID_ENTER_E);
     bn.mid_tile_e = env_int("GRX_MID_TILE_E", MID_TILE_E);  // 0: frontiers with heavy tiles enter that body too (before round 5's last session)
   }
-  int grid_scatter = 0, grid_scatter2 = 0, grid_sweep3 = 0;
+  grid_scatter = grid_scatter2 = grid_sweep3 = 0;
   if (use_bins) {
     bn.bins = ctx->bins.as<int32_t>();
     bn.off = g->bin_off;
@@ -1069,7 +1486,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.xcc_mask = ctx->xcc_mask;
     bn.n_xcd = ctx->n_xcd;
     bn.max_degree = env_int("GRX_BIN_MAX_DEGREE", 0);  // (a limit on the frontier's mean out-degree for binning: none)
-    bn.debug_level = env_int("GRX_BIN_DEBUG", 0);
+    bn.debug_level = part ? 0 : env_int("GRX_BIN_DEBUG", 0);
     if (bn.debug_level != 0) {
       // per-workgroup records of the LAST binned level: scatter at [0, 4096), claim at [4096 + grid, ...); read
       // back with grx_debug_read
@@ -1088,6 +1505,11 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     bn.visited = visited;
     bn.visited_words = (int32_t)bm_words;
     bn.dist = d_dist;
+    if (part) {
+      bn.part_send = x.send;
+      bn.part_wlo = x.lo >> 5;
+      bn.part_whi = (x.hi + 31) >> 5;
+    }
     {
       // scatter: 1024-thread workgroups, two per CU (the bins hold offsets inside the bin)
       static const int per_cu_sc2 = [] {
@@ -1119,23 +1541,28 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     grid_scatter = full < resident ? full : resident;
     if (const int k = env_int("GRX_LEVEL_WG_PER_CU", 0); k > 0) grid_scatter = std::min(grid_scatter, ctx->num_cus * k);  // (tuning aid)
   }
+  if (part) {
+    const int n_seg = ((x.hi - x.lo + 31) / 32 + PP_SEG_WORDS - 1) / PP_SEG_WORDS;
+    grid_post = std::max(1, std::min(n_seg, ctx->num_cus * 2));
+  }
   // thin top-down levels run on as many workgroups as their chunk count asks for (thin_workgroups, grx_bfs_kernels.hpp);
   // GRX_THIN_CHUNKS_PER_WG=0: every workgroup of the launch takes chunks
   bn.thin_div = d.thin_div = (variant == 0 && !strict_mp) ? env_int("GRX_THIN_CHUNKS_PER_WG", 1) : 0;
   bn.thin_min = d.thin_min = ctx->num_cus;
-  hipError_t launch_err = hipSuccess;
-  bool returned_fast = false;
-  const int pace = (dense && variant == 0) ? env_int("GRX_PACE_DEPTH", 2) : 0;
-  int64_t prof_v = 0, prof_e = 0, prof_open = 0, prof_probe = 0;
-  int launches = 0;
+  launch_err = hipSuccess;
+  launches = 0;
+  pace = (dense && variant == 0 && !part && !api_driven) ? env_int("GRX_PACE_DEPTH", 2) : 0;
   // The scatter and sweep kernels of a binned level are launched blindly with every group and cost a launch each where the
   // level is thin (two no-op kernels, ~4 us each, on four of the six levels of the LJ stand-in).  The head kernels
   // record in which groups they met a fat level (ctrl_t::bin_want, published with `done`); the next forward search on the
   // graph leaves the two kernels out of the other groups, one group of slack either side.  A fat level in a group
   // without them runs on the claim-per-edge advance (the head is told: bin_args::allowed) and is recorded for the next
   // search.  GRX_BIN_HINT=0: every group carries them.
-  const uint32_t hint0 = (use_bins && env_int("GRX_BIN_HINT", 1) != 0) ? g->bin_hint.load(std::memory_order_relaxed) : 0u;
-  uint32_t bin_groups = hint0 ? (hint0 | (hint0 << 1) | (hint0 >> 1)) : ~0u;
+  // (Level groups a caller enqueues itself, and the groups of a partition -- every rank must enqueue the same kernels around
+  // the same collectives -- are always the full generic group.)
+  const bool hints = !part && !api_driven;
+  const uint32_t hint0 = (hints && use_bins && env_int("GRX_BIN_HINT", 1) != 0) ? g->bin_hint.load(std::memory_order_relaxed) : 0u;
+  bin_groups = hint0 ? (hint0 | (hint0 << 1) | (hint0 >> 1)) : ~0u;
   // The same source as the last forward search on this handle: the groups with a fat level are known EXACTLY (grx_graph::
   // bin_exact).  Those groups carry head + scatter + sweep, the others head + level kernel: a forward search on the LJ
   // stand-in spent ~25 us on six no-op launches (the level kernel in front of either fat level, scatter + sweep of the slack
@@ -1143,9 +1570,9 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   // claim-per-edge advance (bin_args::allowed), a thin one in a group without a level kernel is binned (bin_args::no_level).
   // GRX_BIN_EXACT=0: off.  Profiled runs (GRX_FLAG_PROFILE: one group per level, level 0 included) keep their own record, so
   // that the per-level times they report are those of the kernels a repeated search launches.
-  uint32_t exact_groups = 0u;
-  bool exact = false;
-  {
+  exact_groups = 0u;
+  exact = false;
+  if (hints) {
     const uint64_t ex = g->bin_exact[profile ? 1 : 0].load(std::memory_order_relaxed);
     if (use_bins && hint0 && (uint32_t)(ex >> 32) == (uint32_t)src + 1u && env_int("GRX_BIN_EXACT", 1) != 0) {
       exact = true;
@@ -1156,122 +1583,177 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   // Paced searches: enqueue as many groups as the previous search on this graph (same direction rule) needed, then wait
   // for the end instead of queueing two more behind it (run_levels: hold_after).  GRX_GROUP_HINT=0: off
   // (the previous search on the handle, same direction rule, ended in a head kernel -- not in the many-levels body of a level kernel)
-  const bool ended_in_head = g->end_in_head[dopt ? 1 : 0].load(std::memory_order_relaxed) != 0;
-  const bool do_repeat = dopt && variant == 0 && g->do_last_src.load(std::memory_order_relaxed) == (uint32_t)src + 1u;
-  int hold_after = (pace > 0 && env_int("GRX_GROUP_HINT", 1) != 0) ? g->group_hint[dopt ? 1 : 0].load(std::memory_order_relaxed) : 0;
+  ended_in_head = hints && g->end_in_head[dopt ? 1 : 0].load(std::memory_order_relaxed) != 0;
+  do_repeat = hints && dopt && variant == 0 && g->do_last_src.load(std::memory_order_relaxed) == (uint32_t)src + 1u;
+  hold_after = (pace > 0 && env_int("GRX_GROUP_HINT", 1) != 0) ? g->group_hint[dopt ? 1 : 0].load(std::memory_order_relaxed) : 0;
   if (hold_after > 0 && env_int("GRX_GROUP_HINT_FORCE", 0) > 0) hold_after = env_int("GRX_GROUP_HINT_FORCE", 0);  // (test aid: a wrong prediction)
-  int groups_used = 0;
-  st = run_levels(ctx, opt, [&](hipStream_t stream, int seq) {
-    if (profile) (void)hipEventRecord(pe[0], stream);
-    const bool bins_here = use_bins && (seq >= 32 || ((bin_groups >> seq) & 1u) != 0u);
-    // (the second scatter + a sweep: the first versions of the two kernels share the level kernel's launch)
-    // ... and the group in which the previous search from this source ENDED is its head alone when `done` was set by that head
-    // (the tiny levels inside it, or its plan step finding the frontier empty; mailbox[12] says so -- the many-levels body of a
-    // level kernel may end a search too): the level kernel behind that head was a 4 us no-op in front of the next search.  A search that does not end there after all is left untouched by that head
-    // (plan_in::only_finish) and continues in the next group.  GRX_LAST_HEAD_ONLY=0: off
-    // (direction-optimising searches: the same source as the last such search on the handle, grx_graph::do_last_src)
-    const bool only_head = (exact || do_repeat) && ended_in_head && !profile && hold_after > 0 && seq == hold_after - 1 && !bins_here && env_int("GRX_LAST_HEAD_ONLY", 1) != 0;
-    const bool level_here = !(exact && bins_here && seq < 32) && !only_head;
-    bn.allowed = bins_here ? 1 : 0;
-    bn.no_level = (level_here || only_head) ? 0 : 1;
-    bn.only_finish = only_head ? 1 : 0;
-    if (variant == 0) {
-      // head (tiny levels + decide + plan) -> level
-      hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, lp, (profile || strict_mp) ? 0 : 1, seq, bn);
-      if (profile) (void)hipEventRecord(pe[1], stream);
-      if (!dopt) {
-        // forward-only run.  level = claim-per-edge advance, many mid-size levels (grx_mid.hpp), or the SCATTER phase of
-        // a binned level; the CLAIM phase is launched only when levels can be binned (a no-op unless the head did)
-        if (level_here) hipLaunchKernelGGL(bfs_level_bin_kernel, dim3(grid_scatter), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
-        // (four builds of each: tuning clocks on / off x 16-bit / 32-bit bin entries)
-        auto launch2 = [&](auto dbg_c, auto e16_c) {
-          constexpr bool DBG = decltype(dbg_c)::value, E16 = decltype(e16_c)::value;
-          if (grid_scatter2 > 0 && E16 && bn.uniform)
-            hipLaunchKernelGGL((bfs_scatter2_kernel<DBG, E16, E16>), dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
-          else if (grid_scatter2 > 0)
-            hipLaunchKernelGGL((bfs_scatter2_kernel<DBG, E16>), dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
-          if (use_bins)
-            hipLaunchKernelGGL((bfs_sweep2_kernel<SW3_BLOCK, SW3_LIST, 4, DBG, E16>), dim3(grid_sweep3), dim3(SW3_BLOCK), 0, stream, a, bn);
-        };
-        using std::true_type;
-        using std::false_type;
-        if (!bins_here) { /* thin level expected */ }
-        else if (bn.debug && bn.entry16) launch2(true_type{}, true_type{});
-        else if (bn.debug) launch2(true_type{}, false_type{});
-        else if (bn.entry16) launch2(false_type{}, true_type{});
-        else launch2(false_type{}, false_type{});
-      } else {
-        if (!only_head) hipLaunchKernelGGL(lbuild->fn, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
+  GRX_HIP(hipGetLastError());
+  return GRX_SUCCESS;
+}
+
+// One level group.  Single GPU: everything of the level.  Partition: what precedes the exchange of the outgoing bitmap.
+void bfs_search::launch_group(hipStream_t stream, int seq) {
+  if (part) {
+    bn.allowed = use_bins ? 1 : 0;
+    bn.no_level = 0;
+    bn.only_finish = 0;
+    hipLaunchKernelGGL(bfs_head_part_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, seq, bn, x);
+    if (!dopt) {
+      hipLaunchKernelGGL(bfs_level_bin_part_kernel, dim3(grid_scatter), dim3(ADV_BLOCK), 0, stream, a, bn, lpp);
+      if (use_bins) {
+        if (bn.entry16 && bn.uniform)
+          hipLaunchKernelGGL((bfs_scatter2_kernel<false, true, true>), dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
+        else if (bn.entry16)
+          hipLaunchKernelGGL((bfs_scatter2_kernel<false, true>), dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
+        else
+          hipLaunchKernelGGL((bfs_scatter2_kernel<false, false>), dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
+        if (bn.entry16)
+          hipLaunchKernelGGL((bfs_sweep2_part_kernel<SW3_BLOCK, SW3_LIST, 4, true>), dim3(grid_sweep3), dim3(SW3_BLOCK), 0, stream, a, bn);
+        else
+          hipLaunchKernelGGL((bfs_sweep2_part_kernel<SW3_BLOCK, SW3_LIST, 4, false>), dim3(grid_sweep3), dim3(SW3_BLOCK), 0, stream, a, bn);
       }
     } else {
-      hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
-      if (profile) (void)hipEventRecord(pe[1], stream);
-      auto adv = [&](auto pol) {
-        hipLaunchKernelGGL((advance_kernel<decltype(pol)>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
-      };
-      switch (variant) {
-        case 1: { bfs_policy_t<1> q{}; q.dist = d_dist; q.visited = visited; adv(q); break; }
-        case 2: { bfs_policy_t<2> q{}; q.dist = d_dist; q.visited = visited; adv(q); break; }
-        case 3: { bfs_policy_t<3> q{}; q.dist = d_dist; q.visited = visited; adv(q); break; }
-        default: { bfs_policy_t<7> q{}; q.dist = d_dist; adv(q); }
-      }
+      hipLaunchKernelGGL(bfs_part_prep_kernel, dim3(ctx->num_cus * 2), dim3(256), 0, stream, a, d, x);
+      if (part_bu2) hipLaunchKernelGGL((bfs_level_part_kernel<2, true>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lpp, 0);
+      else hipLaunchKernelGGL((bfs_level_part_kernel<2, false>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lpp, 0);
     }
     ++launches;
-    if (profile) {
-      (void)hipEventRecord(pe[2], stream);
-      (void)hipEventSynchronize(pe[2]);
-      float t_plan = 0, t_adv = 0;
-      (void)hipEventElapsedTime(&t_plan, pe[0], pe[1]);
-      (void)hipEventElapsedTime(&t_adv, pe[1], pe[2]);
-      level_rec r{};
-      r.advance_ms = t_adv;
-      r.other_ms = t_plan;
-      ctx->levels.push_back(r);
-    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) launch_err = e;
-  }, [&](const ctrl_t& h) {
-    if (!profile || ctx->levels.empty()) return;
-    // bottom-up open/probe counters are reduced by the NEXT level's decide kernel:
-    // the delta seen now belongs to the previous level's record
-    if (ctx->levels.size() >= 2) {
-      level_rec& prev = ctx->levels[ctx->levels.size() - 2];
-      prev.bu_open = h.bu_open - prof_open;
-      prev.bu_probes = h.bu_probes - prof_probe;
+    return;
+  }
+  if (profile) (void)hipEventRecord(pe[0], stream);
+  const bool bins_here = use_bins && (seq >= 32 || ((bin_groups >> seq) & 1u) != 0u);
+  // (the second scatter + a sweep: the first versions of the two kernels share the level kernel's launch)
+  // ... and the group in which the previous search from this source ENDED is its head alone when `done` was set by that head
+  // (the tiny levels inside it, or its plan step finding the frontier empty; mailbox[12] says so -- the many-levels body of a
+  // level kernel may end a search too): the level kernel behind that head was a 4 us no-op in front of the next search.  A search that does not end there after all is left untouched by that head
+  // (plan_in::only_finish) and continues in the next group.  GRX_LAST_HEAD_ONLY=0: off
+  // (direction-optimising searches: the same source as the last such search on the handle, grx_graph::do_last_src)
+  const bool only_head = (exact || do_repeat) && ended_in_head && !profile && hold_after > 0 && seq == hold_after - 1 && !bins_here && env_int("GRX_LAST_HEAD_ONLY", 1) != 0;
+  const bool level_here = !(exact && bins_here && seq < 32) && !only_head;
+  bn.allowed = bins_here ? 1 : 0;
+  bn.no_level = (level_here || only_head) ? 0 : 1;
+  bn.only_finish = only_head ? 1 : 0;
+  if (variant == 0) {
+    // head (tiny levels + decide + plan) -> level
+    hipLaunchKernelGGL(bfs_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, lp, (profile || strict_mp) ? 0 : 1, seq, bn);
+    if (profile) (void)hipEventRecord(pe[1], stream);
+    if (!dopt) {
+      // forward-only run.  level = claim-per-edge advance, many mid-size levels (grx_mid.hpp), or the SCATTER phase of
+      // a binned level; the CLAIM phase is launched only when levels can be binned (a no-op unless the head did)
+      if (level_here) hipLaunchKernelGGL(bfs_level_bin_kernel, dim3(grid_scatter), dim3(ADV_BLOCK), 0, stream, a, bn, lp);
+      // (four builds of each: tuning clocks on / off x 16-bit / 32-bit bin entries)
+      auto launch2 = [&](auto dbg_c, auto e16_c) {
+        constexpr bool DBG = decltype(dbg_c)::value, E16 = decltype(e16_c)::value;
+        if (grid_scatter2 > 0 && E16 && bn.uniform)
+          hipLaunchKernelGGL((bfs_scatter2_kernel<DBG, E16, E16>), dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
+        else if (grid_scatter2 > 0)
+          hipLaunchKernelGGL((bfs_scatter2_kernel<DBG, E16>), dim3(grid_scatter2), dim3(SC2_BLOCK), 0, stream, a, bn);
+        if (use_bins)
+          hipLaunchKernelGGL((bfs_sweep2_kernel<SW3_BLOCK, SW3_LIST, 4, DBG, E16>), dim3(grid_sweep3), dim3(SW3_BLOCK), 0, stream, a, bn);
+      };
+      using std::true_type;
+      using std::false_type;
+      if (!bins_here) { /* thin level expected */ }
+      else if (bn.debug && bn.entry16) launch2(true_type{}, true_type{});
+      else if (bn.debug) launch2(true_type{}, false_type{});
+      else if (bn.entry16) launch2(false_type{}, true_type{});
+      else launch2(false_type{}, false_type{});
+    } else {
+      if (!only_head) hipLaunchKernelGGL(lbuild->fn, dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lp);
     }
-    prof_open = h.bu_open;
-    prof_probe = h.bu_probes;
-    level_rec& r = ctx->levels.back();
-    r.frontier_size = h.vertices_visited - prof_v;
-    r.edges = h.edges_visited - prof_e;
-    r.bottom_up = h.mode;
-    prof_v = h.vertices_visited;
-    prof_e = h.edges_visited;
-    // the group that only detected the empty frontier carries no work; a group that ran the last levels itself
-    // (many levels per launch, grx_mid.hpp) and found the end is a record like any other
-    if (h.done && r.frontier_size == 0 && r.edges == 0) ctx->levels.pop_back();
-  }, /*first_batch=*/dense ? 8 : 4, /*pace_depth=*/pace, /*fast_return=*/pace > 0 && ((opt.engine_flags & GRX_FLAG_ASYNC_RETURN) != 0 || env_int("GRX_FAST_RETURN", 0) != 0),
-     &returned_fast, hold_after, &groups_used);
-  if (st != GRX_SUCCESS) return st;
-  if (pace > 0 && groups_used > 0) {
+  } else {
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, 0);
+    if (profile) (void)hipEventRecord(pe[1], stream);
+    auto adv = [&](auto pol) {
+      hipLaunchKernelGGL((advance_kernel<decltype(pol)>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, pol);
+    };
+    switch (variant) {
+      case 1: { bfs_policy_t<1> q{}; q.dist = d_dist; q.visited = visited; adv(q); break; }
+      case 2: { bfs_policy_t<2> q{}; q.dist = d_dist; q.visited = visited; adv(q); break; }
+      case 3: { bfs_policy_t<3> q{}; q.dist = d_dist; q.visited = visited; adv(q); break; }
+      default: { bfs_policy_t<7> q{}; q.dist = d_dist; adv(q); }
+    }
+  }
+  ++launches;
+  if (profile) {
+    (void)hipEventRecord(pe[2], stream);
+    (void)hipEventSynchronize(pe[2]);
+    float t_plan = 0, t_adv = 0;
+    (void)hipEventElapsedTime(&t_plan, pe[0], pe[1]);
+    (void)hipEventElapsedTime(&t_adv, pe[1], pe[2]);
+    level_rec r{};
+    r.advance_ms = t_adv;
+    r.other_ms = t_plan;
+    ctx->levels.push_back(r);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) launch_err = e;
+}
+
+// Partition only: what follows the exchange -- a bottom-up level (it probes the whole-graph frontier the exchange assembled),
+// the claim of what the peers reported, this rank's statistics of the next frontier (the caller all-reduces them).
+void bfs_search::launch_post(hipStream_t stream) {
+  if (!part) return;
+  if (dopt) {
+    if (part_bu2) hipLaunchKernelGGL((bfs_level_part_kernel<2, true>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lpp, 1);
+    else hipLaunchKernelGGL((bfs_level_part_kernel<2, false>), dim3(grid), dim3(ADV_BLOCK), 0, stream, a, d, lpp, 1);
+  }
+  hipLaunchKernelGGL(bfs_part_post_kernel, dim3(grid_post), dim3(PP_BLOCK), 0, stream, a, d, x, dopt ? d.visited : visited);
+  hipLaunchKernelGGL(bfs_part_stats_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, d, x);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) launch_err = e;
+}
+
+void bfs_search::after_sync(const ctrl_t& h) {
+  if (!profile || ctx->levels.empty()) return;
+  // bottom-up open/probe counters are reduced by the NEXT level's decide kernel:
+  // the delta seen now belongs to the previous level's record
+  if (ctx->levels.size() >= 2) {
+    level_rec& prev = ctx->levels[ctx->levels.size() - 2];
+    prev.bu_open = h.bu_open - prof_open;
+    prev.bu_probes = h.bu_probes - prof_probe;
+  }
+  prof_open = h.bu_open;
+  prof_probe = h.bu_probes;
+  level_rec& r = ctx->levels.back();
+  r.frontier_size = h.vertices_visited - prof_v;
+  r.edges = h.edges_visited - prof_e;
+  r.bottom_up = h.mode;
+  prof_v = h.vertices_visited;
+  prof_e = h.edges_visited;
+  // the group that only detected the empty frontier carries no work; a group that ran the last levels itself
+  // (many levels per launch, grx_mid.hpp) and found the end is a record like any other
+  if (h.done && r.frontier_size == 0 && r.edges == 0) ctx->levels.pop_back();
+}
+
+// After the last group: hints for the next search on the handle, errors raised on the device, run statistics.  The control
+// block must be in ctx->h_ctrl (run_levels / grx_bfs_dist_end copied it, or the mailbox filled it: returned_fast).
+grx_status_t bfs_search::finish(bool returned_fast, int groups_used, float* elapsed_ms) {
+  hipStream_t s = ctx->stream;
+  const bool hints = !part && !api_driven;
+  if (hints && pace > 0 && groups_used > 0) {
     g->group_hint[dopt ? 1 : 0].store(groups_used, std::memory_order_relaxed);
     g->end_in_head[dopt ? 1 : 0].store(ctx->h_mailbox[12] == 0 ? 1 : 0, std::memory_order_relaxed);
   }
-  if (dopt && variant == 0) g->do_last_src.store((pace > 0 && groups_used > 0 && opt.max_iterations == 0) ? (uint32_t)src + 1u : 0u, std::memory_order_relaxed);
-  if (launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err));
+  if (hints && dopt && variant == 0) g->do_last_src.store((pace > 0 && groups_used > 0 && opt.max_iterations == 0) ? (uint32_t)src + 1u : 0u, std::memory_order_relaxed);
+  if (launch_err != hipSuccess) { drop_events(); return fail(GRX_ERROR_HIP, hipGetErrorString(launch_err)); }
   if (ctx->h_mailbox[10] != 0 || (!returned_fast && ctx->h_ctrl->mid_err != 0)) {
     const int code = ctx->h_mailbox[10] != 0 ? (int)ctx->h_mailbox[10] : (int)ctx->h_ctrl->mid_err;
     ctx->h_mailbox[10] = 0;
+    drop_events();
     if (code == 2) {
       // The sweep found that the bins did not receive exactly the level's out-edges: the per-XCD ticket queues of the
       // second scatter lost units (no workgroup of the launch ran on some XCD of the census).  Nothing wrong was
       // returned -- the search stopped there.  Repeat it with statically strided units, and keep that mode.
       GRX_HIP(hipStreamSynchronize(s));
       GRX_HIP(hipMemsetAsync(&ctx->d_ctrl->mid_err, 0, sizeof(int32_t), s));
-      if (profile) for (auto& e : pe) (void)hipEventDestroy(e);
       if (!ctx->sc2_static) {
         ctx->sc2_static = true;
-        return grx_bfs(ctx, g, src, options, d_dist, d_pred, elapsed_ms);
+        // (a rank of a partition cannot repeat its search alone: its caller gets the error and every later search of the
+        // context draws its units statically)
+        if (!part && !api_driven) return BFS_RETRY_STATIC;
       }
       return fail(GRX_ERROR_HIP, "grx_bfs: the binned scatter did not cover the level's edges (grx_bin.hpp)");
     }
@@ -1281,7 +1763,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   // OR-ed over the searches: a search from another source whose fat levels fall into other groups adds them
   // instead of replacing the set, so alternating sources do not keep evicting each other's groups.  A set bit costs
   // two no-op launches (~8 us) in a search that has no fat level there; GRX_BIN_HINT_REPLACE=1: the round-3 behaviour.
-  if (use_bins) {
+  if (hints && use_bins) {
     const uint32_t want = returned_fast ? (uint32_t)ctx->h_mailbox[11] : (uint32_t)ctx->h_ctrl->bin_want;
     if (env_int("GRX_BIN_HINT_REPLACE", 0) != 0) g->bin_hint.store(want, std::memory_order_relaxed);
     else g->bin_hint.fetch_or(want, std::memory_order_relaxed);
@@ -1298,7 +1780,7 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
     GRX_HIP(hipEventSynchronize(ctx->ev_end));
     GRX_HIP(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
   }
-  if (profile) for (auto& e : pe) (void)hipEventDestroy(e);
+  drop_events();
 
   ctx->stats.edges_visited = ctx->h_ctrl->edges_visited;
   ctx->stats.vertices_visited = ctx->h_ctrl->vertices_visited;
@@ -1309,3 +1791,407 @@ extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
   if (elapsed_ms) *elapsed_ms = ms;
   return GRX_SUCCESS;
 }
+
+// the whole search of one rank that needs no exchange: setup, the device-driven level loop (run_levels), finish
+static grx_status_t bfs_run_single(grx_context_t ctx, grx_graph_t g, int32_t src, const grx_options_t* options, int32_t* d_dist,
+                                   float* elapsed_ms) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    bfs_search S;
+    grx_status_t st = S.setup(ctx, g, src, options, d_dist, nullptr, false, elapsed_ms);
+    if (st != GRX_SUCCESS || S.answered) return st;
+    bool returned_fast = false;
+    int groups_used = 0;
+    st = run_levels(ctx, S.opt, [&](hipStream_t stream, int seq) { S.launch_group(stream, seq); },
+                    [&](const ctrl_t& h) { S.after_sync(h); }, /*first_batch=*/S.dense ? 8 : 4, /*pace_depth=*/S.pace,
+                    /*fast_return=*/S.pace > 0 && ((S.opt.engine_flags & GRX_FLAG_ASYNC_RETURN) != 0 || env_int("GRX_FAST_RETURN", 0) != 0),
+                    &returned_fast, S.hold_after, &groups_used);
+    if (st != GRX_SUCCESS) { S.drop_events(); return st; }
+    st = S.finish(returned_fast, groups_used, elapsed_ms);
+    if (st != BFS_RETRY_STATIC) return st;
+  }
+  return fail(GRX_ERROR_HIP, "grx_bfs: the binned scatter did not cover the level's edges (grx_bin.hpp)");
+}
+
+extern "C" grx_status_t grx_bfs(grx_context_t ctx, grx_graph_t g, int32_t src,
+                                const grx_options_t* options, int32_t* d_dist,
+                                int32_t* d_pred, float* elapsed_ms) {
+  (void)d_pred;  // accepted and never written, like the reference (bfs.hxx:29)
+  if (!ctx || !g || !d_dist) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: null argument");
+  if (src < 0 || src >= g->V) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs: source out of range");
+  env_scan_guard env_guard;
+  return bfs_run_single(ctx, g, src, options, d_dist, elapsed_ms);
+}
+
+// ===============================================================================================================
+// PARTITIONED (multi-GPU) BFS: the C ABI around bfs_search (include/grx.h, "multi-GPU").
+//
+// The reference is single-GPU only: every operator throws when `context.size() != 1`
+// (advance/advance.hxx:129-132, filter/filter.hxx:96-99) and no NCCL/RCCL/MPI call exists in its tree.  This is the
+// MI355X design:
+//   * one process per GPU; rank r owns the vertex slice [r * S, min((r + 1) * S, V)), S a multiple of 2048, the OUT-rows of
+//     that slice (global column ids) and -- for the bottom-up step -- its IN-rows (the same rows when the graph is symmetric);
+//   * a rank runs the single-GPU ENGINE on its rows (round 6: the binned scatter + sweep pair on fat levels, the second
+//     bottom-up body, the claim-per-edge advance on thin ones, chosen per rank and level by its own head kernel); at one rank
+//     the partitioned search IS the single-GPU search, same object, same kernels, same launch schedule;
+//   * every level moves exactly one fixed-size message per pair of GPUs: an S-bit bitmap.
+//       top-down level : bit v of the slice sent to owner(v) = "I discovered v" (each vertex reported at most once per
+//                        rank); the owner ORs the P - 1 slices it receives, claims the new ones and emits them as tiles;
+//       bottom-up level: every rank sends its frontier slice to everybody (the all-to-all degenerates to an all-gather),
+//                        so each rank holds the whole-graph frontier bitmap and scans the in-edges of its open vertices.
+//     Fixed sizes mean NO size exchange and no host round trip: the host enqueues level groups blindly (kernels + the
+//     bitmap all-to-all + a 4-word all-reduce of the frontier statistics) and reads `done` once per batch.  A slice is
+//     S / 8 bytes (0.33 MB at 8 ranks on the 21 M-vertex stand-in): ~2 us on one 153 GB/s xGMI link, and on the full mesh
+//     every pair has its own link;
+//   * the end of the search and the direction (Beamer) are decided ON THE DEVICE from the all-reduced statistics, so all
+//     ranks take the same branch without talking to the host; which BODY runs a level is each rank's own choice.
+// ===============================================================================================================
+#include <rccl/rccl.h>  // types only: the library is opened at run time (rccl_api below)
+
+#include <dlfcn.h>
+
+// RCCL, resolved at run time: libgrx.so carries no link-time dependency on it (single-GPU users
+// never load it), and the collectives of a level group can be issued from C -- one host call per
+// group, capturable into a HIP graph without any Python in between.
+struct rccl_api {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+static rccl_api& rccl() {
+  static rccl_api api = [] {
+    rccl_api a;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (a.lib) break;
+    }
+    if (!a.lib) return a;
+    auto sym = [&](const char* n) { return dlsym(a.lib, n); };
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv &&
+           a.AllReduce && a.GetErrorString;
+    return a;
+  }();
+  return api;
+}
+#define GRX_NCCL(expr)                                                                         \
+  do {                                                                                         \
+    ncclResult_t _r = (expr);                                                                  \
+    if (_r != ncclSuccess)                                                                     \
+      return ::grx::fail(GRX_ERROR_HIP, std::string("RCCL: ") + rccl().GetErrorString(_r) + "\t: " #expr); \
+  } while (0)
+
+constexpr int DIST_MAX_RANKS = 64;
+
+struct grx_bfs_dist {
+  ncclComm_t comm = nullptr;             // own communicator (grx_bfs_dist_comm_init), null: the caller runs the collectives
+  hipGraphExec_t group_graph = nullptr;  // one captured level group (kernels + both collectives)
+  int32_t* graph_labels = nullptr;       // label base pointer / direction the captured group was recorded for
+  int32_t graph_dir = -1;
+  bool graph_failed = false;
+  grx_context_t ctx = nullptr;
+  grx_graph_t g = nullptr;      // out-rows of the owned slice
+  bfs_part_cfg pc{};
+  int32_t parts = 1;
+  bfs_search S{};               // the search in flight
+  int32_t seq = 0;              // level groups enqueued by grx_bfs_dist_pre since begin
+  int32_t last_groups = 0;      // groups the previous whole-search call needed (grx_bfs_dist_run: its first batch)
+  bool active = false;
+};
+
+extern "C" {
+
+int32_t grx_bfs_dist_slice_bits(int32_t n_vertices, int32_t n_ranks) {
+  if (n_vertices < 0 || n_ranks < 1) return 0;
+  const long long per = ((long long)n_vertices + n_ranks - 1) / n_ranks;
+  const long long s = ((per + 2047) / 2048) * 2048;
+  return (int32_t)(s < 2048 ? 2048 : s);
+}
+
+grx_status_t grx_bfs_dist_create(grx_context_t ctx, grx_graph_t out_rows, grx_graph_t in_rows, int32_t n_ranks,
+                                 int32_t my_rank, long long n_edges_global, int32_t parts, void* d_send,
+                                 void* d_recv, long long* d_stats_local, const long long* d_stats_global,
+                                 grx_bfs_dist_t* out) {
+  if (!ctx || !out_rows || !d_send || !d_recv || !d_stats_local || !d_stats_global || !out)
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_create: null argument");
+  if (n_ranks < 1 || n_ranks > DIST_MAX_RANKS || my_rank < 0 || my_rank >= n_ranks)
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_create: bad rank layout");
+  if (parts != 1 && parts != 2) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_create: parts must be 1 or 2");
+  if (in_rows && in_rows->V != out_rows->V)
+    return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_create: in-rows and out-rows disagree on V");
+  GRX_HIP(hipSetDevice(ctx->device));
+  grx_bfs_dist* h = new grx_bfs_dist();
+  h->ctx = ctx;
+  h->g = out_rows;
+  h->parts = parts;
+  const int32_t S = grx_bfs_dist_slice_bits(out_rows->V, n_ranks);
+  const long long lo = (long long)my_rank * S, hi = lo + S;
+  part_args& x = h->pc.x;
+  x.P = n_ranks;
+  x.rank = my_rank;
+  x.lo = (int32_t)(lo < out_rows->V ? lo : out_rows->V);
+  x.hi = (int32_t)(hi < out_rows->V ? hi : out_rows->V);
+  x.slice_words = S / 32;
+  x.send = static_cast<unsigned*>(d_send);   // half 0 of [parts][n_ranks][slice_words] (see grx_bfs_dist_pre)
+  x.recv = static_cast<const unsigned*>(d_recv);
+  x.stats_local = d_stats_local;
+  x.stats_global = d_stats_global;
+  x.e_global = n_edges_global;
+  h->pc.g_in = in_rows;
+  *out = h;
+  return GRX_SUCCESS;
+}
+
+// problem.reset() + frontier seed.  The caller all-reduces stats_local into stats_global
+// before the first grx_bfs_dist_pre.  advance_direction: GRX_DIR_FORWARD keeps every level
+// top-down; GRX_DIR_OPTIMIZED enables the bottom-up step (needs in-rows or symmetry).
+// Sharded labels: d_local holds ONLY the owned slice (S = grx_bfs_dist_slice_bits entries, vertex v at
+// d_local[v - rank * S]).  Every kernel of a partitioned search dereferences labels of owned vertices only,
+// so they all work on the base pointer d_local - lo.
+grx_status_t grx_bfs_dist_begin_local(grx_bfs_dist_t h, int32_t source, int32_t advance_direction, int32_t* d_local) {
+  if (!h || !d_local) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_begin_local: null argument");
+  return grx_bfs_dist_begin(h, source, advance_direction, d_local - h->pc.x.lo);
+}
+
+grx_status_t grx_bfs_dist_begin(grx_bfs_dist_t h, int32_t source, int32_t advance_direction, int32_t* d_dist) {
+  if (!h || !d_dist) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_begin: null argument");
+  if (source < 0 || source >= h->g->V) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_begin: source out of range");
+  env_scan_guard env_guard;
+  grx_options_t opt;
+  grx_options_default(&opt);
+  opt.advance_direction = advance_direction;
+  h->S = bfs_search{};
+  h->seq = 0;
+  grx_status_t st = h->S.setup(h->ctx, h->g, source, &opt, d_dist, &h->pc, /*api_driven=*/true, nullptr);
+  if (st != GRX_SUCCESS) return st;
+  if (h->pc.x.P == 1) {
+    // one rank: the statistics words play no part (the heads look at the rank's own frontier), but the protocol reads them
+    GRX_HIP(hipMemsetAsync(h->pc.x.stats_local, 0, 4 * sizeof(long long), h->ctx->stream));
+  }
+  h->active = true;
+  return GRX_SUCCESS;
+}
+
+// Enqueue the part of a level group that precedes the exchange: head, level kernel(s) -- part 0.  After it the caller
+// exchanges send -> recv (all_to_all_single, n_ranks equal splits of slice_words words).  Asynchronous.
+// parts == 2 (kept for callers written against the two-halves protocol): half 1 of the buffers carries nothing -- every
+// report of a level travels in half 0 -- and part 1 is a no-op.
+grx_status_t grx_bfs_dist_pre(grx_bfs_dist_t h, int32_t part) {
+  if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_pre: no BFS in flight");
+  if (part < 0 || part >= h->parts) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_pre: bad part");
+  if (part != 0) return GRX_SUCCESS;
+  env_scan_guard env_guard;
+  // (group indices from 32 on: a generic group -- every kernel a level may need, no launch-schedule hints)
+  h->S.launch_group(h->ctx->stream, 32 + h->seq++);
+  if (h->S.launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(h->S.launch_err));
+  return GRX_SUCCESS;
+}
+
+// Enqueue the part of a level group that follows the exchange: bottom-up level / claim of the reports, then
+// the statistics kernel.  The caller then all-reduces stats_local into stats_global.
+grx_status_t grx_bfs_dist_post(grx_bfs_dist_t h) {
+  if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_post: no BFS in flight");
+  h->S.launch_post(h->ctx->stream);
+  if (h->S.launch_err != hipSuccess) return fail(GRX_ERROR_HIP, hipGetErrorString(h->S.launch_err));
+  return GRX_SUCCESS;
+}
+
+// Wait for everything enqueued so far and report the state of the search.
+grx_status_t grx_bfs_dist_poll(grx_bfs_dist_t h, int32_t* done, int32_t* level) {
+  if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_poll: no BFS in flight");
+  grx_context_t ctx = h->ctx;
+  GRX_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost, ctx->stream));
+  GRX_HIP(hipStreamSynchronize(ctx->stream));
+  if (done) *done = ctx->h_ctrl->done;
+  if (level) *level = ctx->h_ctrl->level;
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_bfs_dist_end(grx_bfs_dist_t h, grx_run_stats_t* stats) {
+  if (!h || !h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_end: no BFS in flight");
+  grx_context_t ctx = h->ctx;
+  env_scan_guard env_guard;
+  h->active = false;
+  GRX_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost, ctx->stream));
+  GRX_HIP(hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  grx_status_t st = h->S.finish(false, 0, &ms);
+  if (st != GRX_SUCCESS) return st;
+  ctx->stats.n_levels_recorded = 0;
+  if (stats) *stats = ctx->stats;
+  return GRX_SUCCESS;
+}
+
+// ---- RCCL transport inside the library --------------------------------------------------------
+int32_t grx_dist_unique_id_bytes(void) { return (int32_t)sizeof(ncclUniqueId); }
+
+grx_status_t grx_dist_unique_id(void* out) {
+  if (!out) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_dist_unique_id: null argument");
+  if (!rccl().ok) return fail(GRX_ERROR_UNSUPPORTED, "grx_dist_unique_id: librccl could not be opened");
+  GRX_NCCL(rccl().GetUniqueId(reinterpret_cast<ncclUniqueId*>(out)));
+  return GRX_SUCCESS;
+}
+
+grx_status_t grx_bfs_dist_comm_init(grx_bfs_dist_t h, const void* unique_id) {
+  if (!h || !unique_id) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_comm_init: null argument");
+  if (!rccl().ok) return fail(GRX_ERROR_UNSUPPORTED, "grx_bfs_dist_comm_init: librccl could not be opened");
+  GRX_HIP(hipSetDevice(h->ctx->device));
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  GRX_NCCL(rccl().CommInitRank(&h->comm, h->pc.x.P, id, h->pc.x.rank));
+  return GRX_SUCCESS;
+}
+
+// the two collectives of a level group on the context's stream: the bitmap all-to-all (grouped send / recv: every pair of
+// GPUs has its own xGMI link) and the 4-word statistics all-reduce
+static grx_status_t dist_exchange(grx_bfs_dist_t h) {
+  const part_args& x = h->pc.x;
+  hipStream_t s = h->ctx->stream;
+  GRX_NCCL(rccl().GroupStart());
+  for (int j = 0; j < x.P; ++j) {
+    GRX_NCCL(rccl().Send(x.send + (size_t)j * x.slice_words, (size_t)x.slice_words, ncclUint32, j, h->comm, s));
+    GRX_NCCL(rccl().Recv(const_cast<unsigned*>(x.recv) + (size_t)j * x.slice_words, (size_t)x.slice_words, ncclUint32, j,
+                         h->comm, s));
+  }
+  GRX_NCCL(rccl().GroupEnd());
+  return GRX_SUCCESS;
+}
+static grx_status_t dist_allreduce(grx_bfs_dist_t h) {
+  const part_args& x = h->pc.x;
+  GRX_NCCL(rccl().AllReduce(x.stats_local, const_cast<long long*>(x.stats_global), 4, ncclInt64, ncclSum, h->comm, h->ctx->stream));
+  return GRX_SUCCESS;
+}
+// one level group, everything on the context's stream
+static grx_status_t dist_group_enqueue(grx_bfs_dist_t h) {
+  grx_status_t st = grx_bfs_dist_pre(h, 0);
+  if (st != GRX_SUCCESS) return st;
+  if ((st = dist_exchange(h)) != GRX_SUCCESS) return st;
+  if ((st = grx_bfs_dist_post(h)) != GRX_SUCCESS) return st;
+  return dist_allreduce(h);
+}
+
+// the all-reduce that follows grx_bfs_dist_begin (frontier statistics of the seed)
+grx_status_t grx_bfs_dist_seed_stats(grx_bfs_dist_t h) {
+  if (!h || !h->comm) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_seed_stats: no communicator");
+  return dist_allreduce(h);
+}
+
+// Enqueue n level groups.  A group of a PARTITION takes no level-dependent argument, so once a search has finished the
+// group is captured into a HIP graph (grx_bfs_dist_capture_group) and later calls replay it: one graph
+// launch per level; without a captured graph the groups are enqueued eagerly.
+grx_status_t grx_bfs_dist_groups(grx_bfs_dist_t h, int32_t n) {
+  if (!h || !h->active || !h->comm) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_groups: no BFS in flight or no communicator");
+  const bool replay = h->group_graph && h->graph_labels == h->S.d_dist && h->graph_dir == (h->S.dopt ? 1 : 0);
+  for (int i = 0; i < n; ++i) {
+    if (replay) {
+      GRX_HIP(hipGraphLaunch(h->group_graph, h->ctx->stream));
+    } else {
+      grx_status_t st = dist_group_enqueue(h);
+      if (st != GRX_SUCCESS) return st;
+    }
+  }
+  return GRX_SUCCESS;
+}
+
+// Record one level group for the label buffer / direction of the search that just ended (every kernel of a
+// further group exits on `done`, and capture only records).  Must be called on every rank alike.  A failure
+// is remembered and leaves the eager path in place.
+grx_status_t grx_bfs_dist_capture_group(grx_bfs_dist_t h) {
+  if (!h || !h->comm) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_capture_group: no communicator");
+  if (h->graph_failed || !h->S.ctx) return GRX_SUCCESS;
+  const int dir = h->S.dopt ? 1 : 0;
+  if (h->group_graph && h->graph_labels == h->S.d_dist && h->graph_dir == dir) return GRX_SUCCESS;
+  if (h->group_graph) { (void)hipGraphExecDestroy(h->group_graph); h->group_graph = nullptr; }
+  hipStream_t s = h->ctx->stream;
+  hipGraph_t graph = nullptr;
+  const bool was_active = h->active;
+  h->active = true;
+  bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+  if (ok) {
+    ok = dist_group_enqueue(h) == GRX_SUCCESS;
+    ok = (hipStreamEndCapture(s, &graph) == hipSuccess) && ok && graph != nullptr;
+    if (ok) ok = hipGraphInstantiate(&h->group_graph, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) (void)hipGraphDestroy(graph);
+  }
+  (void)hipGetLastError();
+  h->S.launch_err = hipSuccess;
+  h->active = was_active;
+  if (!ok) {
+    h->group_graph = nullptr;
+    h->graph_failed = true;
+    return GRX_SUCCESS;
+  }
+  h->graph_labels = h->S.d_dist;
+  h->graph_dir = dir;
+  return GRX_SUCCESS;
+}
+
+int32_t grx_bfs_dist_group_is_captured(grx_bfs_dist_t h) { return (h && h->group_graph) ? 1 : 0; }
+
+// A WHOLE search in one call (round 6).  One rank: exactly grx_bfs -- the same object, kernels and paced launch schedule
+// (bfs_run_single); the partition of one slice is the graph.  More ranks: needs the in-library transport
+// (grx_bfs_dist_comm_init): reset + seed, the seed's all-reduce, then batches of level groups -- the first as long as the
+// previous search on the handle (every rank sees the same depth, so every rank enqueues the same number of collectives) --
+// with one look at `done` per batch.  labels_are_local != 0: d_labels is the owned slice (see grx_bfs_dist_begin_local).
+grx_status_t grx_bfs_dist_run(grx_bfs_dist_t h, int32_t source, int32_t advance_direction, int32_t* d_labels,
+                              int32_t labels_are_local, grx_run_stats_t* stats) {
+  if (!h || !d_labels) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_run: null argument");
+  if (h->active) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_run: a search driven by level groups is in flight");
+  if (source < 0 || source >= h->g->V) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_run: source out of range");
+  int32_t* d_dist = labels_are_local ? d_labels - h->pc.x.lo : d_labels;
+  if (h->pc.x.P == 1) {
+    env_scan_guard env_guard;
+    grx_options_t opt;
+    grx_options_default(&opt);
+    opt.advance_direction = advance_direction;
+    opt.engine_flags = GRX_FLAG_NO_BLOCK_ASYNC;
+    float ms = 0;
+    grx_status_t st = bfs_run_single(h->ctx, h->g, source, &opt, d_dist, &ms);
+    if (st != GRX_SUCCESS) return st;
+    if (stats) *stats = h->ctx->stats;
+    return GRX_SUCCESS;
+  }
+  if (!h->comm) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_bfs_dist_run: more than one rank needs grx_bfs_dist_comm_init (or the level-group calls)");
+  grx_status_t st = grx_bfs_dist_begin(h, source, advance_direction, d_dist);
+  if (st != GRX_SUCCESS) return st;
+  if ((st = dist_allreduce(h)) != GRX_SUCCESS) return st;
+  int batch = h->last_groups > 0 ? std::max(2, std::min(h->last_groups, 64)) : 4;
+  for (;;) {
+    if ((st = grx_bfs_dist_groups(h, batch)) != GRX_SUCCESS) return st;
+    int32_t done = 0;
+    if ((st = grx_bfs_dist_poll(h, &done, nullptr)) != GRX_SUCCESS) return st;
+    if (done) break;
+    batch = std::min(batch * 2, 32);
+  }
+  (void)grx_bfs_dist_capture_group(h);  // no-op once recorded for this buffer / direction
+  h->active = true;
+  st = grx_bfs_dist_end(h, stats);
+  if (st == GRX_SUCCESS) h->last_groups = h->ctx->stats.search_depth + 1;  // + the group whose head finds the frontier empty
+  return st;
+}
+
+grx_status_t grx_bfs_dist_destroy(grx_bfs_dist_t h) {
+  if (h) {
+    if (h->group_graph) (void)hipGraphExecDestroy(h->group_graph);
+    if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
+  }
+  delete h;
+  return GRX_SUCCESS;
+}
+
+}  // extern "C"

@@ -158,6 +158,62 @@ struct bfs_policy_t {
 };
 using bfs_policy = bfs_policy_t<0>;
 
+// ---------------------------------------------------------------------------------------------------------------
+// PARTITIONED searches (round 6).  The reference has no multi-GPU path at all
+// (operators/advance/advance.hxx:129-132 throws for context.size() != 1); here rank r of P owns the vertex slice
+// [lo, hi) = [r * S, min((r + 1) * S, V)), S a multiple of 2048, with the OUT-rows of that slice as a graph of the whole
+// vertex range (rows of other ranks' vertices are empty; column ids are global) -- and the single-GPU engine's own
+// bodies run on that graph: the claim-per-edge advance, the binned scatter + sweep pair, the second bottom-up body.
+// What a partition adds is what happens to a target the rank does not own: it is reported ONCE to its owner through
+// the outgoing bitmap `send` (P slices of S bits = one V-bit bitmap in global vertex order), deduplicated by `sent`
+// (forward runs: the visited bitmap itself -- a remote vertex's bit there means "reported").  After the exchange
+// bfs_part_post_kernel claims what the peers reported in this rank's slice and emits it as tiles like any other
+// producer of a frontier.
+struct part_args {
+  int32_t P, rank;
+  int32_t lo, hi;                // owned vertices
+  int32_t slice_words;           // S / 32
+  int32_t do_run;                // this search may switch direction (three frontier bitmaps, `sent` of its own)
+  unsigned* send;                // [P][slice_words]: bit v = "this rank discovered v at this level" (v not owned)
+  const unsigned* recv;          // [P][slice_words]: slice j = what rank j reported about THIS rank's vertices (local word
+                                 // index); on a bottom-up level: the whole-graph frontier bitmap, slice j from rank j
+  unsigned* sent;                // V bits: remote vertices this rank has reported (never reported twice)
+  long long* stats_local;        // {frontier vertices, frontier out-edges, 0, 0} of the NEXT level, this rank's share
+  const long long* stats_global; // ... summed over the ranks by the all-reduce that follows every level group
+  long long e_global;            // edges of the whole graph (Beamer's rule)
+};
+
+// The claim on a partitioned graph: owned targets exactly as bfs_policy (label probe, atomicMin, bitmap upkeep);
+// targets of other ranks: `sent` probe -> atomicOr on `sent` -> the winner sets the bit in `send` (fire and forget).
+// One load from a SELECTED address per phase, so the phases of advance_block keep their one round trip each.
+struct bfs_policy_part : bfs_policy {
+  int lo, hi;
+  unsigned* sent;
+  unsigned* send;
+  __device__ __forceinline__ bool owned(int n) const { return n >= lo && n < hi; }
+  __device__ __forceinline__ bool precheck(src_state, int n, int, int& cand) const {
+    const bool own = owned(n);
+    cand = own ? 0 : (int)(1u << (n & 31));
+    const unsigned* p = own ? reinterpret_cast<const unsigned*>(dist + n) : sent + (n >> 5);
+    const unsigned v = *p;
+    return own ? (int)v > next_depth : (v & (unsigned)cand) == 0u;
+  }
+  __device__ __forceinline__ int claim(int n, int cand) const {
+    if (cand == 0) return atomicMin(&dist[n], next_depth);
+    return (int)atomicOr(&sent[n >> 5], (unsigned)cand);
+  }
+  __device__ __forceinline__ int code(int raw, int, int n, int cand) const {
+    if (cand == 0) return next_depth < raw ? 1 : 0;
+    if (((unsigned)raw & (unsigned)cand) == 0u)
+      (void)__hip_atomic_fetch_or(&send[n >> 5], (unsigned)cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+  }
+  __device__ __forceinline__ int visit(src_state, int n, int) const {
+    const int cand = owned(n) ? 0 : (int)(1u << (n & 31));
+    return code(claim(n, cand), 0, n, cand);
+  }
+};
+
 struct dobfs_args {
   const int32_t* t_ro;   // in-edges (transpose; the CSR itself for symmetric graphs)
   const int32_t* t_ci;
@@ -175,7 +231,8 @@ struct dobfs_args {
   // partitioned runs (grx_dist.hip): this rank owns the 64-vertex chunks [ch_lo, ch_lo + n_words / 2);
   // visited / fbits are indexed by LOCAL chunk, labels / offsets / frontier probes by GLOBAL id
   int32_t ch_lo;               // 0 on a single GPU
-  const unsigned* fin_global;  // whole-graph frontier bitmap to probe; null: fbits[level & 1]
+  const unsigned* fin_global;  // partitioned runs: the whole-graph frontier bitmap a bottom-up level probes (assembled by the
+                               // all-to-all in part_args::recv); null: the rank's own fbits[]
   uint32_t xcc_mask;           // hardware XCC ids of this device (grx_mid.hpp)
   // single GPU, per graph: {first, second in-neighbour} of every vertex (-1: none), so that the first probe group of a
   // bottom-up level reads ONE coalesced 8-byte stream instead of two column indices per lane from 64 different rows
@@ -668,7 +725,7 @@ __device__ __forceinline__ void bfs_bottomup2_block(const pipe_args& a, const do
   const long long t_start = clk(false);
   const int level = c->level;
   const int p = level & 1;
-  const unsigned* __restrict__ fin = pick3(d.fbits, level % 3);
+  const unsigned* __restrict__ fin = d.fin_global ? d.fin_global : pick3(d.fbits, level % 3);
   unsigned* fout = pick3(d.fbits, (level + 1) % 3);
   const int n_chunks = d.n_words / 2;
   const int iters = (n_chunks + (int)gridDim.x * S::NW * BATCH - 1) / ((int)gridDim.x * S::NW * BATCH);

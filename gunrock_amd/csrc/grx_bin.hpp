@@ -78,6 +78,10 @@ struct bin_args {
   const float* rw;            // edge weights
   unsigned* rval;             // E (+ padding) tentative distances, laid out like `bins`
   int32_t* rstamp;            // per-level stamp of a vertex (parts of one bin agree on who emits an improved vertex)
+  // partitioned searches (round 6, part_args): the sweep hands the new bits of words outside [part_wlo, part_whi) -- vertices of
+  // other ranks -- to the outgoing bitmap instead of emitting them (null: single GPU)
+  unsigned* part_send;
+  int32_t part_wlo, part_whi;
 };
 
 // hardware XCC id of this wave's CU -> dense index 0 .. n_xcd - 1 (s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4))
@@ -576,9 +580,11 @@ struct bin_sweep2_smem {
 // consecutive list entries, i.e. on ascending vertex ids a few apart (~10 cache lines per store instruction); the expansion
 // that built the list used to store them itself, one thread per BYTE of the bitmap (lanes 32 bytes of labels apart: a
 // store instruction touched up to 32 lines, eight of them per segment and thread).
+// with_map == false (partitioned runs, bfs_part_post_kernel behind a level that was NOT binned): tiles only -- the next head
+// walks them like the tiles of any claim-per-edge level.
 template <int NT, class S>
 __device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q, S& sm, int n, int32_t* label = nullptr,
-                                            int depth = 0) {
+                                            int depth = 0, bool with_map = true) {
   static_assert(S::MAX_TILES <= 64, "one lane per tile of an emission");
   constexpr int PASSES = (S::LIST + NT - 1) / NT;
   constexpr int G = 3;  // passes whose row-offset loads travel together (6 measured equal: round 4, call 18)
@@ -623,10 +629,10 @@ __device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q
     sm.ttot[lane] = tot;
     sm.cpre[lane] = inc - ch;
     if (lane == 63) {
-      sm.n_chunks = inc;
-      sm.chunk_base = inc > 0 ? atomicAdd(&c->map_chunks, inc) : 0;
+      sm.n_chunks = with_map ? inc : 0;
+      sm.chunk_base = (with_map && inc > 0) ? atomicAdd(&c->map_chunks, inc) : 0;
     }
-    if (lane == 0) {
+    if (lane == 0 && with_map) {
       atomicAdd(reinterpret_cast<unsigned long long*>(&c->q_edges[q]), (unsigned long long)es);
       atomicAdd(&c->n_items[q], n);
     }
@@ -662,7 +668,7 @@ __device__ __forceinline__ void sweep2_emit(const pipe_args& a, ctrl_t* c, int q
   __syncthreads();
 }
 
-template <int NT, int LE, bool DBG, bool E16>
+template <int NT, int LE, bool DBG, bool E16, bool SLICED = false>
 __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_args& bn, ctrl_t* c, int depth,
                                                  bin_sweep2_smem<NT, LE>& sm, int p) {
   constexpr int EPL = E16 ? 8 : 4;  // entries per 16-byte load
@@ -875,7 +881,16 @@ __device__ __forceinline__ void bin_sweep2_block(const pipe_args& a, const bin_a
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int w = w0 + j * NT + tid;
-        if (w < words) sm.bm[w] = cand[j] & ~old[j];
+        unsigned nw = cand[j] & ~old[j];
+        if constexpr (SLICED) {
+          // vertices of another rank: reported to their owner through the outgoing bitmap (the bit just set in `visited`
+          // means "reported" for them), never emitted here
+          if (nw != 0u && (gw0 + w < bn.part_wlo || gw0 + w >= bn.part_whi)) {
+            (void)__hip_atomic_fetch_or(&bn.part_send[gw0 + w], nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nw = 0u;
+          }
+        }
+        if (w < words) sm.bm[w] = nw;
       }
     }
     __syncthreads();

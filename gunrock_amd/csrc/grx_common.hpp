@@ -206,6 +206,7 @@ struct grx_graph {
   bool has_transpose = false;
   unsigned* closed0 = nullptr;  // bitmap: vertices without in-edges (direction-optimising BFS), built lazily; owned
   int32_t closed0_words = 0;
+  const void* closed0_of = nullptr;  // the in-edge offsets it was built from (the transpose, or the rows a partition brought)
   int32_t* bu_heads = nullptr;     // {first, second in-neighbour} per vertex (bottom-up probes), built lazily; owned
   const void* bu_heads_of = nullptr;  // the in-edge array it was built from (CSR of a symmetric graph, or the transpose)
   // binned top-down levels (grx_bin.hpp), built lazily; owned

@@ -174,6 +174,11 @@ struct plan_in {
   int32_t* bin_fill = nullptr;
   int32_t* bin_queue = nullptr;  // per-XCD claim queue heads (16 slots, bin_pad apart), zeroed with the fill counters
   int bin_nb = 0, bin_pad = 0;
+  // partitioned searches (round 6, grx_bfs_kernels.hpp part_args): the search is over when the frontier of ALL ranks is empty
+  // (g_n = its all-reduced size; -1: single GPU, this rank's tile count decides) -- a rank whose own share is empty still
+  // counts the level -- and "a quarter of the graph" means a quarter of this rank's share
+  long long g_n = -1;
+  int part_P = 1;
 };
 
 template <int BLOCK>
@@ -187,7 +192,7 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
   const int mode = in.mode;
   if (done) return;
   if (external_control == 1 && mode != 0) return;
-  if (!external_control && nt == 0) {
+  if (!external_control && (in.g_n >= 0 ? in.g_n == 0 : nt == 0)) {
     if (tid == 0) {
       c->done = 1;
       c->level = level;  // == number of advance iterations executed
@@ -314,7 +319,7 @@ __device__ __forceinline__ void plan_body(const pipe_args& a, ctrl_t* c, int ext
       c->q_edges[p] = edges;
       if (in.bin_min > 0 || in.mid_v > 0) {
         int mode = 0;
-        const bool early = in.bin_early_div > 1 && c->vertices_visited * 4 < (long long)a.V;  // (this frontier included)
+        const bool early = in.bin_early_div > 1 && c->vertices_visited * 4 * in.part_P < (long long)a.V;  // (this frontier included)
         const long long bin_from = early ? in.bin_min / in.bin_early_div : in.bin_min;
         const bool fat = in.bin_min > 0 && edges >= bin_from &&
                          (in.bin_max_degree <= 0 || edges <= (long long)in.bin_max_degree * nitems);

@@ -3,7 +3,7 @@
 
 The reference has no multi-GPU path (every operator throws when
 `context.size() != 1`, framework/operators/advance/advance.hxx:129-132); this is
-the MI355X design of DESIGN.md section 7 (device side: csrc/grx_dist.hip):
+the MI355X design of DESIGN.md section 7 (device side: the second half of csrc/grx_bfs.hip):
 
   rank r owns the vertex slice [r * S, min((r + 1) * S, V)) -- S = slice_bits(V, P), a
   multiple of 2048 -- with its out-rows and, for the bottom-up step, its in-rows.
@@ -171,6 +171,23 @@ class GrxEngine:
             raise ValueError("distances must hold V labels or at least the owned slice")
         _capi.check(fn(self._h, int(source), int(OPT if optimized else forward), C.c_void_p(distances.data_ptr())))
 
+    def run(self, source, distances, optimized=True):
+        """A whole search in ONE C call (grx_bfs_dist_run): with one rank exactly the single-GPU engine; with more, the
+        in-library RCCL transport (enable_library_transport) carries the per-level exchange."""
+        from . import forward, optimized as OPT
+        n = int(distances.numel())
+        if n >= self.V:
+            local = 0
+        elif n >= self.hi - self.lo:
+            local = 1
+        else:
+            raise ValueError("distances must hold V labels or at least the owned slice")
+        s = _capi.grx_run_stats_t()
+        _capi.check(_capi.lib().grx_bfs_dist_run(self._h, int(source), int(OPT if optimized else forward),
+                                                 C.c_void_p(distances.data_ptr()), local, C.byref(s)))
+        return {"edges_visited": s.edges_visited, "vertices_visited": s.vertices_visited,
+                "search_depth": s.search_depth, "elapsed_ms": s.elapsed_ms}
+
     def pre(self, part=0):
         _capi.check(_capi.lib().grx_bfs_dist_pre(self._h, int(part)))
 
@@ -337,8 +354,16 @@ def bfs(engine, dist, source, distances, optimized=True, first_batch=4):
     import contextlib
     on_stream = torch.cuda.stream(engine.stream) if getattr(engine, "stream", None) is not None \
         else contextlib.nullcontext()
+    import os
+    whole = hasattr(engine, "run") and os.environ.get("GRX_DIST_LEVEL_GROUPS", "0") != "1"
+    if whole and (engine.P == 1 or getattr(engine, "library_transport", False)):
+        # ONE C call per search (grx_bfs_dist_run).  One rank: the partition of one slice is the graph, and the search is the
+        # single-GPU engine's, launch schedule included.  More ranks: the library runs the collectives itself -- begin, the
+        # seed's all-reduce, batches of level groups with one look at `done` each, end.
+        with on_stream:
+            return _remember_groups(engine, engine.run(source, distances, optimized))
     if getattr(engine, "library_transport", False):
-        # the library runs the collectives itself: begin, then batches of level groups (one C call each)
+        # (GRX_DIST_LEVEL_GROUPS=1: the same from Python, one C call per batch of level groups)
         L = _capi.lib()
         with on_stream:
             engine.begin(source, distances, optimized)

@@ -298,21 +298,29 @@ grx_status_t grx_debug_ctrl(grx_context_t ctx, int32_t* out, int32_t n);
  * The reference has no multi-GPU execution (every operator throws when
  * context.size() != 1: framework/operators/advance/advance.hxx:129-132).  One process
  * per GPU drives these calls and runs the two collectives of a level group with RCCL
- * (torch.distributed: all_to_all_single of fixed-size bitmaps, all_reduce of 4 words);
- * see gunrock_amd/distributed.py, gunrock_amd/csrc/grx_dist.hip and DESIGN.md section 7.
+ * (inside the library after grx_bfs_dist_comm_init, or torch.distributed: all_to_all_single
+ * of fixed-size bitmaps, all_reduce of 4 words); see gunrock_amd/distributed.py, the second
+ * half of gunrock_amd/csrc/grx_bfs.hip and DESIGN.md section 7.
+ *
+ * A rank runs the single-GPU ENGINE on the rows it owns (round 6): the same search object, the same kernels --
+ * binned scatter + sweep on fat levels, the second bottom-up body, the claim-per-edge advance on thin levels -- with
+ * the partition's rule for targets of other ranks (reported once through the outgoing bitmap) and one kernel behind the
+ * exchange that claims what the peers reported.  With ONE rank a partitioned search IS grx_bfs.
  *
  * Partition: S = grx_bfs_dist_slice_bits(V, n_ranks) (a multiple of 2048); rank r owns
  * vertices [r * S, min((r + 1) * S, V)).  `out_rows` holds the CSR rows of the owned
  * vertices with GLOBAL column ids (n_vertices = global V, other rows empty); `in_rows`
  * the same for the in-edges (NULL: the graph is symmetric, or no bottom-up step).
  * Caller-owned device buffers (torch tensors in the Python driver):
- *   d_send, d_recv : parts * n_ranks * (S / 32) 32-bit words each
+ *   d_send, d_recv : parts * n_ranks * (S / 32) 32-bit words each (zero-initialised)
  *   d_stats_local, d_stats_global : int64[4]
  * Per level group the caller enqueues, all asynchronously on the context's stream:
  *   grx_bfs_dist_pre(h, 0); all_to_all_single(recv[0] <- send[0]);
- *   [parts == 2: grx_bfs_dist_pre(h, 1); all_to_all_single(recv[1] <- send[1]);]
+ *   [parts == 2, kept for callers of the two-halves protocol: grx_bfs_dist_pre(h, 1) is a no-op and half 1 of the
+ *    buffers stays empty -- every report of a level travels in half 0]
  *   grx_bfs_dist_post(h); all_reduce(stats_global <- stats_local)
- * -- blindly, several groups per grx_bfs_dist_poll; groups after `done` are no-ops. */
+ * -- blindly, several groups per grx_bfs_dist_poll; groups after `done` are no-ops.
+ * Or, one call per search: grx_bfs_dist_run (below). */
 typedef struct grx_bfs_dist* grx_bfs_dist_t;
 int32_t grx_bfs_dist_slice_bits(int32_t n_vertices, int32_t n_ranks);
 grx_status_t grx_bfs_dist_create(grx_context_t ctx, grx_graph_t out_rows, grx_graph_t in_rows_or_null,
@@ -397,6 +405,13 @@ grx_status_t grx_bfs_dist_seed_stats(grx_bfs_dist_t h);
 grx_status_t grx_bfs_dist_groups(grx_bfs_dist_t h, int32_t n);
 grx_status_t grx_bfs_dist_capture_group(grx_bfs_dist_t h);
 int32_t grx_bfs_dist_group_is_captured(grx_bfs_dist_t h);
+/* A whole partitioned search in ONE call.  n_ranks == 1: exactly grx_bfs (same search object, kernels and launch
+ * schedule).  n_ranks > 1: after grx_bfs_dist_comm_init -- begin, the seed's all-reduce, batches of level groups (the first
+ * as long as the previous search on the handle) with one look at `done` per batch, end; every rank must call it alike.
+ * labels_are_local != 0: d_labels holds the owned slice only (as grx_bfs_dist_begin_local), else V entries of which the
+ * owned range is written.  stats: edges / vertices are this rank's share, search_depth is global. */
+grx_status_t grx_bfs_dist_run(grx_bfs_dist_t h, int32_t source, int32_t advance_direction, int32_t* d_labels,
+                              int32_t labels_are_local, grx_run_stats_t* stats);
 
 /* ---- host-side ingest (same semantics as the reference) ---- */
 

@@ -55,7 +55,7 @@ class _Shifted:
 
 class FakeEngine:
     """Host stand-in for GrxEngine with the same contract (tests only): numpy versions of
-    the head / prep / advance / apply / bottom-up / stats kernels of csrc/grx_dist.hip."""
+    the head / prep / advance / apply / bottom-up / stats steps of a partitioned level group (csrc/grx_bfs.hip)."""
     stream = None
 
     def __init__(self, out_rows, in_rows, rank, n_ranks, n_edges_global, overlap=False):
@@ -303,7 +303,10 @@ def test_two_ranks_real_kernels_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_single_rank_dist_path_equals_plain_bfs(gr, gpu_ctx):
+def test_single_rank_dist_path_equals_plain_bfs(gr, gpu_ctx, monkeypatch):
+    """One rank: the partitioned search IS the single-GPU engine (grx_bfs_dist_run -> the same search object, kernels and
+    launch schedule as grx_bfs), and the level-group protocol (GRX_DIST_LEVEL_GROUPS=1: pre / exchange / post / all-reduce
+    driven from Python, recorded as a HIP graph after the first search) gives the same depths."""
     import torch
     from gunrock_amd import distributed as D
     V, E = 1 << 16, 1 << 20
@@ -312,22 +315,93 @@ def test_single_rank_dist_path_equals_plain_bfs(gr, gpu_ctx):
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
     src = int(np.argmax(np.diff(g.row_offsets)))
     want, _, ev = O.bfs_queue(g, src)
-    for overlap in (False, True):
-        eng = D.GrxEngine(props, c, 0, 1, "cuda:0", E, in_rows=cin, overlap=overlap)
-        d = torch.empty(V, dtype=torch.int32, device="cuda:0")
-        for optimized in (True, False):
-            st = D.bfs(eng, None, src, d, optimized=optimized)
-            assert np.array_equal(d.cpu().numpy(), want) and st["edges_visited"] == ev
-            # the first search recorded the level group as a HIP graph (overlap off): these replay it,
-            # from the same and from another source
-            st = D.bfs(eng, None, src, d, optimized=optimized)
-            assert np.array_equal(d.cpu().numpy(), want) and st["edges_visited"] == ev
-            src2 = int(np.argsort(np.diff(g.row_offsets))[-7])
-            want2, _, ev2 = O.bfs_queue(g, src2)
-            st = D.bfs(eng, None, src2, d, optimized=optimized)
-            assert np.array_equal(d.cpu().numpy(), want2) and st["edges_visited"] == ev2
-        if not overlap:
-            assert getattr(eng, "_graph", None) is not None or getattr(eng, "_graph_failed", False)
+    for groups in ("0", "1"):
+        monkeypatch.setenv("GRX_DIST_LEVEL_GROUPS", groups)
+        for overlap in (False, True):
+            eng = D.GrxEngine(props, c, 0, 1, "cuda:0", E, in_rows=cin, overlap=overlap)
+            d = torch.empty(V, dtype=torch.int32, device="cuda:0")
+            for optimized in (True, False):
+                st = D.bfs(eng, None, src, d, optimized=optimized)
+                assert np.array_equal(d.cpu().numpy(), want) and st["edges_visited"] == ev
+                # (level groups, overlap off: the first search recorded the group as a HIP graph, these replay it)
+                st = D.bfs(eng, None, src, d, optimized=optimized)
+                assert np.array_equal(d.cpu().numpy(), want) and st["edges_visited"] == ev
+                src2 = int(np.argsort(np.diff(g.row_offsets))[-7])
+                want2, _, ev2 = O.bfs_queue(g, src2)
+                st = D.bfs(eng, None, src2, d, optimized=optimized)
+                assert np.array_equal(d.cpu().numpy(), want2) and st["edges_visited"] == ev2
+            if groups == "1" and not overlap:
+                assert getattr(eng, "_graph", None) is not None or getattr(eng, "_graph_failed", False)
+    monkeypatch.delenv("GRX_DIST_LEVEL_GROUPS", raising=False)
+
+
+def _part_worker(rank, world, port, out_dir, V, E, kinds):
+    """`world` ranks sharing cuda:0, gloo carrying the exchange: the partitioned ENGINE (binned levels, second bottom-up
+    body) on graphs large enough for its fat-level bodies."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import gunrock_amd as gr
+    from gunrock_amd import distributed as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    results = {}
+    for kind, seed in kinds:
+        props, full = gr.generate(kind, V, E, seed=seed)
+        bounds = D.vertex_bounds(V, world)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        _, mine = gr.generate_rows(kind, V, E, lo, hi, seed=seed)
+        mine_in = None
+        if kind == "rmat":
+            _, mine_in = gr.generate_rows(kind, V, E, lo, hi, seed=seed, in_rows=True)
+        e_global = int(full.number_of_nonzeros)
+        order = np.argsort(np.diff(full.row_offsets))
+        eng = D.GrxEngine(props, mine, rank, world, "cuda:0", e_global, in_rows=mine_in)
+        d = eng.new_labels()
+        for s in (int(order[-1]), int(order[-9]), int(order[len(order) // 2]), 0):
+            for optimized in (True, False):
+                for rep in range(2):  # (the second search replays the recorded level group where that is possible)
+                    st = D.bfs(eng, dist, s, d, optimized=optimized)
+                results["%s_%d_%d" % (kind, s, int(optimized))] = (d.cpu().numpy()[:hi - lo].copy(), lo, hi,
+                                                                   st["edges_visited"], st["search_depth"])
+        del eng
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), np.array([results], dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_engine_bodies_on_one_gpu(world, tmp_path):
+    """The partition on the engine's bodies (round 6): 2^20 vertices / 2^24 edges, so that the levels behind a hub source
+    are BINNED (scatter + sweep, words of other ranks' vertices handed to the outgoing bitmap) and a direction-optimising
+    search runs the second bottom-up body against the gathered frontier; a 3-rank split leaves ragged slices.  Depths of
+    every owned slice == the oracle's, traversed edges sum to the oracle's count."""
+    import torch.multiprocessing as mp
+    import gunrock_amd as gr
+    V, E = 1 << 20, 1 << 24
+    kinds = (("rmat", 11), ("rmat_sym", 12))
+    port = free_port()
+    mp.spawn(_part_worker, args=(world, port, str(tmp_path), V, E, kinds), nprocs=world, join=True)
+    per_rank = [np.load(os.path.join(str(tmp_path), "p%d.npy" % r), allow_pickle=True)[0] for r in range(world)]
+    for kind, seed in kinds:
+        _, full = gr.generate(kind, V, E, seed=seed)
+        g = O.Csr(full.row_offsets, full.column_indices, full.nonzero_values)
+        order = np.argsort(np.diff(full.row_offsets))
+        for s in (int(order[-1]), int(order[-9]), int(order[len(order) // 2]), 0):
+            want, _, ev = O.bfs_queue(g, s)
+            for optimized in (1, 0):
+                key = "%s_%d_%d" % (kind, s, optimized)
+                got = np.full(V, -1, np.int32)
+                edges = 0
+                for r in range(world):
+                    part, lo, hi, e_r, depth = per_rank[r][key]
+                    got[lo:hi] = part
+                    edges += e_r
+                assert np.array_equal(got, want), key
+                assert edges == ev, key
+                assert depth == want[want != INF].max() + 1, key
 
 
 @pytest.mark.gpu

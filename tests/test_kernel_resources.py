@@ -14,7 +14,8 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 PER_LEVEL = ("bfs_head_kernel", "bfs_level_kernel", "bfs_level_bin_kernel", "bfs_source_kernel",
              "sssp_head_kernel", "sssp_level_kernel", "sssp_nf_head_kernel", "sssp_nf_level_kernel",
              "pr_pull_kernel", "pr_pull_xcd_kernel", "pr_combine_kernel", "pr_scalar_kernel",
-             "dist_head_kernel", "dist_prep_kernel", "dist_advance_kernel", "dist_post_kernel", "dist_stats_kernel",
+             "bfs_head_part_kernel", "bfs_level_bin_part_kernel", "bfs_level_part_kernel", "bfs_part_prep_kernel",
+             "bfs_part_post_kernel", "bfs_part_stats_kernel",
              "sdist_head_kernel", "sdist_advance_kernel", "sdist_post_kernel")
 
 
