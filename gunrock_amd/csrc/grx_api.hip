@@ -333,6 +333,7 @@ grx_status_t grx_graph_destroy(grx_graph_t g) {
   if (g->t_w) (void)hipFree(g->t_w);
   if (g->closed0) (void)hipFree(g->closed0);
   if (g->bu_heads) (void)hipFree(g->bu_heads);
+  if (g->hf_ci) (void)hipFree(g->hf_ci);
   if (g->bin_off) (void)hipFree(g->bin_off);
   if (g->rb_off) (void)hipFree(g->rb_off);
   if (g->rb_g2b16) (void)hipFree(g->rb_g2b16);

@@ -1174,11 +1174,11 @@ struct bfs_search {
 };
 
 using part_level_fn = void (*)(pipe_args, dobfs_args, bfs_policy_part, int);
-static int part_level_grid(grx_context_t ctx, grx_graph_t g, part_level_fn fn, int limit) {
+// (`full`: the widest grid the graph is given -- decided by the density of the WHOLE graph, not of the rows a rank holds)
+static int part_level_grid(grx_context_t ctx, int full, part_level_fn fn, int limit) {
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, ADV_BLOCK, 0) != hipSuccess || n < 1) n = 4;
   if (n > limit) n = limit;
-  const int full = advance_grid_for(ctx, g);
   const int resident = ctx->num_cus * n;
   return full < resident ? full : resident;
 }
@@ -1238,6 +1238,8 @@ grx_status_t bfs_search::setup(grx_context_t ctx_, grx_graph_t g_, int32_t src_,
   }
   const size_t bm_words = 4 * (((size_t)g->V + 127) / 128);  // whole 16-byte groups: 64-vertex chunks, uint4 clears
   hipStream_t s = ctx->stream;
+  // widest per-level grid (advance_grid_for: one workgroup per CU on road-like graphs) -- by the density of the whole graph
+  const int grid_full = part ? ((g->V > 0 && e_all < 4ll * g->V) ? ctx->num_cus : ctx->num_cus * 8) : advance_grid_for(ctx, g);
   // Forward-only runs on dense graphs keep a visited bitmap too: it pre-filters the label probes of
   // the claim-per-edge advance and carries the binned fat levels (grx_bin.hpp).
   // Tuning knobs: GRX_TD_BITMAP=0 (no bitmap at all), GRX_TD_PRE=0 (no pre-filter), GRX_TD_BIN=0 (no
@@ -1292,8 +1294,11 @@ grx_status_t bfs_search::setup(grx_context_t ctx_, grx_graph_t g_, int32_t src_,
       if (st != GRX_SUCCESS) return st;
     }
     if (part) {
+      // the in-rows the partition brought, their hub sources first (built once per handle; without it: as they came)
+      st = graph_build_hub_first(ctx, gt);
+      if (st != GRX_SUCCESS) return st;
       d.t_ro = gt->ro;
-      d.t_ci = gt->ci;
+      d.t_ci = gt->hf_state == 1 ? gt->hf_ci : gt->ci;
     } else {
       d.t_ro = use_csr ? g->ro : g->t_ro;
       d.t_ci = use_csr ? g->ci : g->t_ci;
@@ -1346,12 +1351,12 @@ grx_status_t bfs_search::setup(grx_context_t ctx_, grx_graph_t g_, int32_t src_,
       // the partition's builds of the level kernel; the second bottom-up body under the same condition as below
       part_bu2 = false;
       if (d.heads && env_int("GRX_BU2", 1) != 0) {
-        const int grid2 = part_level_grid(ctx, g, bfs_level_part_kernel<2, true>, 4);
+        const int grid2 = part_level_grid(ctx, grid_full, bfs_level_part_kernel<2, true>, 4);
         const long long chunks = (long long)bm_words / 2, per_round = (long long)grid2 * (ADV_BLOCK / 64) * 2;
         if ((chunks + per_round - 1) / per_round * 2 <= 128) part_bu2 = true;
       }
-      d.bu_grid = part_bu2 ? part_level_grid(ctx, g, bfs_level_part_kernel<2, true>, 4)
-                           : part_level_grid(ctx, g, bfs_level_part_kernel<2, false>, 8);
+      d.bu_grid = part_bu2 ? part_level_grid(ctx, grid_full, bfs_level_part_kernel<2, true>, 4)
+                           : part_level_grid(ctx, grid_full, bfs_level_part_kernel<2, false>, 8);
     } else {
       if (d.heads && env_int("GRX_BU2", 1) != 0) {
         // second bottom-up body: needs the dense array and all chunks of a wave in 128 slots
@@ -1537,7 +1542,7 @@ grx_status_t bfs_search::setup(grx_context_t ctx_, grx_graph_t g_, int32_t src_,
   if (!dopt && variant == 0) {
     static const int per_cu_scatter = resident_per_cu(bfs_level_bin_kernel);
     const int resident = ctx->num_cus * per_cu_scatter;
-    const int full = advance_grid_for(ctx, g);  // one workgroup per CU on road-like graphs
+    const int full = grid_full;  // one workgroup per CU on road-like graphs
     grid_scatter = full < resident ? full : resident;
     if (const int k = env_int("GRX_LEVEL_WG_PER_CU", 0); k > 0) grid_scatter = std::min(grid_scatter, ctx->num_cus * k);  // (tuning aid)
   }

@@ -209,6 +209,8 @@ struct grx_graph {
   const void* closed0_of = nullptr;  // the in-edge offsets it was built from (the transpose, or the rows a partition brought)
   int32_t* bu_heads = nullptr;     // {first, second in-neighbour} per vertex (bottom-up probes), built lazily; owned
   const void* bu_heads_of = nullptr;  // the in-edge array it was built from (CSR of a symmetric graph, or the transpose)
+  int32_t* hf_ci = nullptr;        // partitioned searches: the column array with every row's hub entries first (grx_transpose.hip); owned
+  int32_t hf_state = 0;            // 0: not built, 1: usable, 2: not available
   // binned top-down levels (grx_bin.hpp), built lazily; owned
   int32_t* bin_off = nullptr;   // static bin offsets (in-edges per vertex range)
   unsigned char* bin_tab8 = nullptr;  // granule -> bin, bin -> owning XCD

@@ -22,6 +22,10 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a);
 // Build (once) and cache the transpose of g in the graph handle.
 grx_status_t graph_build_transpose(grx_context_t ctx, grx_graph_t g);
 
+// Partitioned searches: a copy of g's column array with every row's hub entries first (same offsets), built once per handle
+// into g->hf_ci (hf_state 1) -- or not at all (hf_state 2: no room, switched off) -- see grx_transpose.hip.
+grx_status_t graph_build_hub_first(grx_context_t ctx, grx_graph_t g);
+
 // Verify (once per graph handle, cached) that the CSR equals its transpose: the caller-supplied
 // `symmetric` property is only trusted after this check (direction-optimising BFS uses the CSR
 // itself as the in-edge list of a symmetric graph).
