@@ -114,5 +114,7 @@ def build(force=False, verbose=False):
 if __name__ == "__main__":
     if "--timers" in sys.argv:
         build_variant("timers", ["GRX_MID_TIMERS"], verbose=True)
+    elif "--fine-timers" in sys.argv:  # every sub-phase of the many-levels body behind a full wait (tools/mid_phases.py)
+        build_variant("fine", ["GRX_MID_TIMERS=2"], verbose=True)
     else:
         build(force="--force" in sys.argv, verbose=True)

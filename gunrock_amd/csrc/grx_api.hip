@@ -163,6 +163,7 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   a->mid_exit_v = MID_EXIT_V;
   a->mid_exit_e = MID_EXIT_E;
   a->mid_hub_deg = 16;
+  a->mid_refill_max = 0;
   if (const char* e = getenv("GRX_MID_HUB_DEG")) a->mid_hub_deg = atoi(e);
   if (const char* e = getenv("GRX_MID_EXIT_E")) { const int x = atoi(e); if (x >= 1) a->mid_exit_e = x; }
   if (const char* e = getenv("GRX_MID_SEG_CAP")) { const int x = atoi(e); if (x >= 0 && x <= MID_SEG) a->mid_seg_cap = x; }    // test knobs

@@ -1102,11 +1102,11 @@ static int level_grid(grx_context_t ctx, grx_graph_t g, level_build* lb) {
 // tuning aid: the control block's spare counters as they are on the device now (GRX_MID_DEBUG=1: per-phase clock sums
 // of the multi-level body, grx_mid.hpp)
 extern "C" grx_status_t grx_debug_ctrl(grx_context_t ctx, int32_t* out, int32_t n) {
-  if (!ctx || !out || n < 1 || n > 5) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_debug_ctrl: 1..5 counters");
+  if (!ctx || !out || n < 1 || n > 13) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_debug_ctrl: 1..13 counters");
   GRX_HIP(hipStreamSynchronize(ctx->stream));
   ctrl_t h;
   GRX_HIP(hipMemcpy(&h, ctx->d_ctrl, sizeof(ctrl_t), hipMemcpyDeviceToHost));
-  for (int i = 0; i < n; ++i) out[i] = h.spare[i];
+  for (int i = 0; i < n; ++i) out[i] = i < 5 ? h.spare[i] : h.dbg_fine[i - 5];
   return GRX_SUCCESS;
 }
 

@@ -105,6 +105,7 @@ struct ctrl_t {
   uint32_t mid_reg;         // registrations of workgroups on the home XCD (bit 31: window closed)
   int32_t mid_G;            // number of workgroups taking part (published by the leader)
   int32_t bin_want;         // bit g: the head of launch group g found a level fat enough to be binned (grx_bin.hpp)
+  int32_t dbg_fine[8];      // -DGRX_MID_TIMERS=2 builds: clock sums of the many-levels body's sub-phases (tools/mid_phases.py)
 };
 
 struct level_rec {

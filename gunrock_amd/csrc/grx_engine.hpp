@@ -77,7 +77,7 @@ inline int advance_grid(grx_context_t ctx) { return ctx->num_cus * 8; }
 // per CU is plenty there; scale-free graphs get the full 8 per CU.
 inline int advance_grid_for(grx_context_t ctx, grx_graph_t g) {
   const bool road_like = g->V > 0 && (long long)g->E < 4ll * g->V;
-  return road_like ? ctx->num_cus : ctx->num_cus * 8;
+  return road_like ? ctx->num_cus * (GRX_MID_WGS / 32) : ctx->num_cus * 8;
 }
 
 // Generic host loop: `launch_level(stream, i)` enqueues level group i (head + level kernels);

@@ -38,7 +38,10 @@ constexpr int ADV_ITEMS = 8;         // atoms per thread per chunk
 constexpr int CHUNK = ADV_BLOCK * ADV_ITEMS;  // 2048 atoms
 constexpr int PLAN_BLOCK = 1024;
 constexpr int TILE_RESERVE = 4;      // tile indices a workgroup reserves per global atomic
-constexpr int MID_FLAG_WORDS = 64;   // grx_mid.hpp: 2 x MID_WGS barrier words
+#ifndef GRX_MID_WGS
+#define GRX_MID_WGS 32
+#endif
+constexpr int MID_FLAG_WORDS = 2 * GRX_MID_WGS;   // grx_mid.hpp: 2 x MID_WGS barrier words
 
 struct pipe_args {
   const int32_t* ro;
@@ -61,6 +64,8 @@ struct pipe_args {
   int32_t mid_exit_v;        // second version: a frontier beyond this many vertices goes back to the regular kernels (<= MID_EXIT_V)
   int32_t mid_exit_e;        // ... or beyond this many out-edges (MID_EXIT_E)
   int32_t mid_hub_deg;       // ... or averaging more than this many out-edges per vertex (0: no such rule)
+  int32_t mid_refill_max;    // policies that refill (near-far SSSP): a drained bucket is followed by the next one INSIDE the launch
+                             // while the far pile holds at most this many entries (0: every bucket change goes through the head kernel)
 };
 
 // The search is over: final counters and the elapsed device time go to the host-pinned mailbox

@@ -55,18 +55,23 @@ namespace grx {
 #define GRX_MID_FN __device__ __forceinline__
 #endif
 
-constexpr int MID_WGS = 32;          // workgroups that stay (the rest of the grid leaves at once)
+constexpr int MID_WGS = GRX_MID_WGS; // workgroups that stay (32: one per CU of an XCD; the rest of the grid leaves at once)
+static_assert(MID_WGS == 32 || MID_WGS == 64, "the exchange reads every workgroup's word with one wave");
 constexpr int MID_ENTER_V = 8192;    // a level enters with at most this many frontier vertices ...
 constexpr int MID_ENTER_E = 65536;   // ... and out-edges
 constexpr int MID_TILE_E = 4096;     // ... none of its tiles (the 256 slots one workgroup stages) holding more than two chunks of them
 constexpr int MID_EXIT_V = 131072;   // a frontier beyond this goes back to the regular kernels
 constexpr int MID_EXIT_E = 4 * MID_ENTER_E;  // ... and so does one with more out-edges than this (8 chunks per workgroup)
 constexpr int MID_SPIN_LIMIT = 1 << 22;
+#ifndef GRX_MID_TM_ITEMS
+#define GRX_MID_TM_ITEMS 8
+#endif
+constexpr int MID_TM_ITEMS = GRX_MID_TM_ITEMS;  // a block whose rows are all at most this long is expanded thread-mapped (second build of the chunk)
 constexpr int MID_AUX_CAP = MID_EXIT_V + TILE;  // queue entries that carry their row start / degree along
 // second version (mid_levels_body2): every workgroup appends to a PRIVATE region of the next queue -- no reservation
 // atomic -- and the barrier carries the counts; what does not fit goes to a shared overflow area behind the regions
 static_assert(MID_FLAG_WORDS == 2 * MID_WGS, "two sets of flag words");
-constexpr int MID_SEG = 16384;
+constexpr int MID_SEG = 16384 * 32 / MID_WGS;
 constexpr int MID_SEG_TILES = MID_SEG / TILE;
 constexpr int MID_OVF_BASE = MID_WGS * MID_SEG;
 constexpr int MID_AUX2_CAP = MID_OVF_BASE;      // int4 {row start, degree, state, -} per entry of the private regions
@@ -82,11 +87,12 @@ struct policy_carries_state<Policy, std::void_t<decltype(&Policy::carry_state)>>
 template <class Policy>
 struct mid_smem {
   advance_smem<Policy> adv;
-  int out_rs[TILE + CHUNK];   // row start / degree of the staged output vertices (parallel to adv.out)
+#if defined(GRX_MID_BOTH) || defined(GRX_MID_FIRST_VERSION)
+  int out_rs[TILE + CHUNK];   // first version: row start / degree of the staged output vertices (parallel to adv.out)
   int out_deg[TILE + CHUNK];
+#endif
   int tcount[ADV_BLOCK];      // entering level: counts of this workgroup's next 256 tiles
   int side[policy_has_side<Policy>::value ? (TILE + CHUNK) : 1];  // staged side-pile entries (near-far SSSP)
-  int out_st[policy_carries_state<Policy>::value ? (TILE + CHUNK) : 1];  // state of the staged output vertices (policies that carry it along)
   int seg_pre[MID_WGS + 1];   // second version: entries of the private regions before region i
   int side_cnt;
   int side_base;
@@ -96,6 +102,7 @@ struct mid_smem {
   int ok;
   int rank;
   int out_edges;      // second version: out-degree sum of the entries this workgroup appended this level
+  int ovf;            // ... and whether any of them went to the shared overflow area
   int next_edges;     // ... and (in units of 128, from the exchange words) of the whole next level
 };
 
@@ -115,6 +122,14 @@ template <class Policy, class = void>
 struct policy_drained_is_done : std::true_type {};
 template <class Policy>
 struct policy_drained_is_done<Policy, std::void_t<decltype(Policy::drained_is_done)>> : std::bool_constant<Policy::drained_is_done> {};
+
+// optional policy hooks `refill_decide / refill_rebind / refill_entry / refill_class / refill_keep_store` (near-far SSSP, round 6):
+// a drained frontier is not the end of the launch -- the next bucket is pulled out of the policy's side pile by the resident
+// workgroups (second version of the body only; see sssp_nf_policy)
+template <class Policy, class = void>
+struct policy_refills : std::false_type {};
+template <class Policy>
+struct policy_refills<Policy, std::void_t<decltype(&Policy::refill_decide)>> : std::true_type {};
 
 // policies whose claims can be told to execute in the local L2 (see above)
 template <class Policy, class = void>
@@ -538,7 +553,8 @@ __device__ __forceinline__ bool mid_exchange(const pipe_args& a, int G, int w, i
     const int e128 = lane < G ? (int)((v >> 15) & 0xffffull) : 0;
     const bool ovf = lane < G && ((v >> 31) & 1ull) != 0ull;
     const int inc = dev::wave_inclusive_sum(cnt);
-    if (lane <= MID_WGS) sm.seg_pre[lane] = inc - cnt;  // lanes >= G: the total
+    if (lane < MID_WGS) sm.seg_pre[lane] = inc - cnt;  // (lanes >= G: the total)
+    if (lane == MID_WGS - 1) sm.seg_pre[MID_WGS] = inc;
     const bool any_ovf = dev::ballot(ovf) != 0ull;
     const int e_next = dev::wave_sum(e128);
     if (lane == 0) {
@@ -604,7 +620,8 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
   int n_in = ((level & 1) ? h.nt1 : h.nt0) * TILE;     // slots to look at
   int n_priv = 0;                                      // of which in the private regions (levels after the first)
   int my_pub = 0;                                      // entries of MY region in the current input queue
-  long long my_edges = 0, my_vertices = 0;
+  unsigned t_edges = 0u;  // out-edges / vertices THIS THREAD expanded on the levels after the entering one (summed when the launch ends)
+  int t_vertices = 0;
   // tuning aid (GRX_MID_DEBUG=1): wall-clock ticks the leader spends per phase, summed over the levels of the launch ->
   // ctrl.spare[0..3] {input staged | column indices + claims + compaction | flush | exchange}, spare[4] += levels
 #ifdef GRX_MID_TIMERS
@@ -613,6 +630,22 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
   constexpr bool dbg = false;
 #endif
   long long dbg_ph[4] = {0, 0, 0, 0}, dbg_t = dbg ? (long long)wall_clock64() : 0ll;
+  // -DGRX_MID_TIMERS=2: the sub-phases of a level, every one behind a FULL wait of every thread (so the loads a phase issues are
+  // no longer in the shadow of the next phase's: the sum is longer than a level of the product build -- what it shows is the
+  // latency of each dependent step) -> ctrl.dbg_fine[0..7]
+#if defined(GRX_MID_TIMERS) && GRX_MID_TIMERS == 2
+  long long dbg_f[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_ft = 0ll;
+  auto fine_mark = [&](int i) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (dbg) {
+      const long long now = (long long)wall_clock64();
+      if (i >= 0) dbg_f[i] += now - dbg_ft;
+      dbg_ft = now;
+    }
+  };
+#else
+  auto fine_mark = [&](int) {};
+#endif
   int dbg_levels = 0;
   auto dbg_mark = [&](int i) {
     if (dbg) {
@@ -621,6 +654,8 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
       dbg_t = now;
     }
   };
+  if (tid == 0) { ad.cnt = 0; sm.side_cnt = 0; sm.out_edges = 0; sm.ovf = 0; }
+  __syncthreads();
   for (;;) {
     const int p = level & 1;
     const int32_t* qin = a.frontier[p];
@@ -630,32 +665,25 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
     int* ovf_cnt = &c->mid_cnt[(level + 1) % 3];
     if (w == 0 && tid == 0) __hip_atomic_store(&c->mid_cnt[(level + 2) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     pol.set_level(level);
-    if (tid == 0) { ad.cnt = 0; sm.side_cnt = 0; sm.out_edges = 0; }
-    __syncthreads();
-    int my_out = 0;     // entries appended to my region this level (uniform)
-    unsigned my_ovf = 0u;
-    // append sm.adv.out[lo .. lo + k) (+ their row start / degree / state) to the next queue.  Block-wide.
-    auto flush = [&](int lo, int k) {
-      int base;
-      if (my_out + k <= a.mid_seg_cap) {
-        base = w * MID_SEG + my_out;
-        my_out += k;
-      } else {
-        if (tid == 0) sm.base = __hip_atomic_fetch_add(ovf_cnt, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __syncthreads();
-        base = MID_OVF_BASE + sm.base;
-        my_ovf = 0x80000000u;
+    if (epoch == 0) fine_mark(-1);
+    // (the level's LDS counters were zeroed behind the previous level's exchange, by thread 0 -- every use of them below sits
+    // behind at least one barrier of this level)
+    // Accepted neighbours leave for the next queue AT ONCE, from registers (round 6; they used to be staged in LDS and copied out
+    // by a flush behind one more barrier): a wave reserves positions for the accepted atoms of all its 8 item groups with ONE LDS
+    // atomic on the level's running count, position i of the level lives at w * MID_SEG + i, whatever does not fit the region goes
+    // to the shared overflow area entry by entry (never on the graphs this body is for).
+    const int out_base = w * MID_SEG;
+    const int out_cap = a.mid_seg_cap;
+    int dsum = 0;  // out-degrees of the entries this thread appended
+    auto append = [&](int pos, int v, int rs, int dg, int stbits) {
+      int addr = out_base + pos;
+      if (pos >= out_cap) {
+        addr = MID_OVF_BASE + __hip_atomic_fetch_add(ovf_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        sm.ovf = 1;
       }
-      int dsum = 0;
-      for (int i = tid; i < k; i += ADV_BLOCK) {
-        qout[base + i] = ad.out[lo + i];
-        dsum += sm.out_deg[lo + i];
-        if (base + i < MID_AUX2_CAP)
-          aux_out[base + i] = make_int4(sm.out_rs[lo + i], sm.out_deg[lo + i], CARRY ? sm.out_st[CARRY ? lo + i : 0] : 0, 0);
-      }
-      dsum = dev::wave_sum(dsum);
-      if (lane == 0 && dsum) atomicAdd(&sm.out_edges, dsum);
-      __syncthreads();
+      qout[addr] = v;
+      if (addr < MID_AUX2_CAP) aux_out[addr] = make_int4(rs, dg, stbits, 0);
+      dsum += dg;
     };
     const int n_blocks = (n_in + TILE - 1) / TILE;
     for (int i0 = 0; w + i0 * G < n_blocks; i0 += first ? ADV_BLOCK : 1) {
@@ -716,112 +744,156 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
             }
           }
         }
-        int tot;
-        const int ex = dev::block_exclusive_sum<ADV_BLOCK>(deg, ad.wave, &tot);
-        ad.seg[tid] = ex;
-        ad.start[tid] = rs;
-        ad.src[tid] = v;
-        ad.state[tid] = st;
-        if (tid == 0) ad.seg[TILE] = tot;
-        const int n_valid = __syncthreads_count(v >= 0);
-        dbg_mark(0);
-        if (!first) {
-          my_edges += tot;
-          my_vertices += n_valid;
+        fine_mark(0);  // queue entry, {row start, degree}, label: loaded
+        if (!first) {  // (the head accounted for the entering level)
+          t_edges += deg;
+          t_vertices += v >= 0 ? 1 : 0;
         }
-        for (int a0 = 0; a0 < tot; a0 += CHUNK) {
-          const int a_end = min(tot, a0 + CHUNK);
-          int e_k[ADV_ITEMS], slot_k[ADV_ITEMS], n_k[ADV_ITEMS], cand_k[ADV_ITEMS];
+        // A block whose vertices all have at most MID_TM_ITEMS out-edges -- every block of a road network -- is expanded THREAD-MAPPED
+        // (round 6): a lane walks the row of its own vertex, so there is no degree scan, nothing staged in LDS and no owner search
+        // (8 dependent LDS reads per atom: 1.14 us of a 7.25 us level on the road stand-in, the scan 0.58 -- profiles/r6_c15_*).
+        // The balanced walk below is for blocks that hold a longer row.
+        const bool tm = __syncthreads_or(deg > MID_TM_ITEMS) == 0;
+        int tot = 0;
+        if (!tm) {
+          const int ex = dev::block_exclusive_sum<ADV_BLOCK>(deg, ad.wave, &tot);
+          ad.seg[tid] = ex;
+          ad.start[tid] = rs;
+          ad.src[tid] = v;
+          ad.state[tid] = st;
+          if (tid == 0) ad.seg[TILE] = tot;
+          __syncthreads();
+        }
+        dbg_mark(0);
+        fine_mark(1);  // block scan, LDS staged
+        // One chunk: every phase issues the operations of all IT items of a lane before any result is used.  Two builds of it
+        // (round 6): 8 items over the staged block (2048 atoms, balanced as in the level kernels) and the thread-mapped one.
+        // (Measured on the way: guarding item groups that hold no atom with a uniform `k < kmax` inside ONE build turned every
+        // guarded load into a wait at the join -- 83.5 -> 99.6 ms on the weighted road stand-in, profiles/r6_c11_*; a second
+        // balanced build of 3 items for blocks of <= 768 out-edges: 83.8 -> 81.4 ms weighted, nothing on unit weights, r6_c12_*.)
+        auto do_chunk = [&](auto items_c, auto tm_c, const int a0, const int a_end) {
+          constexpr int IT = decltype(items_c)::value;
+          constexpr bool TM = decltype(tm_c)::value;  // thread-mapped: item k of a lane is out-edge k of its own vertex
+          int e_k[IT], slot_k[IT], n_k[IT], cand_k[IT];
 #pragma unroll
-          for (int k = 0; k < ADV_ITEMS; ++k) {
-            const int atom = a0 + k * ADV_BLOCK + tid;
-            int lo = 0;
-            if (atom < a_end) {
-#pragma unroll
-              for (int step = TILE / 2; step >= 1; step >>= 1)
-                if (ad.seg[lo + step] <= atom) lo += step;
-              e_k[k] = ad.start[lo] + (atom - ad.seg[lo]);
-            } else {
-              e_k[k] = -1;
-            }
-            slot_k[k] = lo;
-          }
-#pragma unroll
-          for (int k = 0; k < ADV_ITEMS; ++k) n_k[k] = a.ci[e_k[k] >= 0 ? e_k[k] : 0];
-          bool pre_k[ADV_ITEMS];
-#pragma unroll
-          for (int k = 0; k < ADV_ITEMS; ++k) {
-            const bool ok = e_k[k] >= 0;
+          for (int k = 0; k < IT; ++k) {
+            e_k[k] = -1;
+            slot_k[k] = 0;
+            n_k[k] = 0;
             cand_k[k] = 0;
-            bool pass;
-            if constexpr (policy_has_prepare<Policy>::value)
-              pass = pol.prepare(ad.state[slot_k[k]], n_k[k], ok ? e_k[k] : 0, cand_k[k]);
-            else
-              pass = pol.precheck(ad.state[slot_k[k]], n_k[k], ok ? e_k[k] : 0, cand_k[k]);
-            pre_k[k] = pass & ok;
-          }
-          int r1_k[ADV_ITEMS], r2_k[ADV_ITEMS];
+            if constexpr (TM) {
+              if (k < deg) e_k[k] = rs + k;
+            } else {
+              const int atom = a0 + k * ADV_BLOCK + tid;
+              int lo = 0;
+              if (atom < a_end) {
 #pragma unroll
-          for (int k = 0; k < ADV_ITEMS; ++k) {
+                for (int step = TILE / 2; step >= 1; step >>= 1)
+                  if (ad.seg[lo + step] <= atom) lo += step;
+                e_k[k] = ad.start[lo] + (atom - ad.seg[lo]);
+              }
+              slot_k[k] = lo;
+            }
+          }
+          fine_mark(2);  // owner of every atom found (LDS search)
+#pragma unroll
+          for (int k = 0; k < IT; ++k)
+            n_k[k] = a.ci[e_k[k] >= 0 ? e_k[k] : 0];
+          bool pre_k[IT];
+#pragma unroll
+          for (int k = 0; k < IT; ++k) {
+            pre_k[k] = false;
+            {
+              const bool ok = e_k[k] >= 0;
+              bool pass;
+              typename Policy::src_state st_k = st;
+              if constexpr (!TM) st_k = ad.state[slot_k[k]];
+              if constexpr (policy_has_prepare<Policy>::value)
+                pass = pol.prepare(st_k, n_k[k], ok ? e_k[k] : 0, cand_k[k]);
+              else
+                pass = pol.precheck(st_k, n_k[k], ok ? e_k[k] : 0, cand_k[k]);
+              pre_k[k] = pass & ok;
+            }
+          }
+          fine_mark(3);  // column indices (+ weights / the read-only probe of a policy without `prepare`)
+          int r1_k[IT], r2_k[IT];
+#pragma unroll
+          for (int k = 0; k < IT; ++k) {
             r1_k[k] = 0;
             r2_k[k] = 0;
             if (pre_k[k]) r1_k[k] = pol.claim(n_k[k], cand_k[k]);
           }
           // row offsets of every neighbour (n_k is a valid vertex even where there is no edge), issued behind the
           // claims: they are on their way while the claims are, and only the accepted ones are used
-          int nrs_k[ADV_ITEMS], nre_k[ADV_ITEMS];
+          int nrs_k[IT], nre_k[IT];
 #pragma unroll
-          for (int k = 0; k < ADV_ITEMS; ++k) {
-            nrs_k[k] = a.ro[n_k[k]];
-            nre_k[k] = a.ro[n_k[k] + 1];
+          for (int k = 0; k < IT; ++k) {
+            nrs_k[k] = 0;
+            nre_k[k] = 0;
+            {
+              nrs_k[k] = a.ro[n_k[k]];
+              nre_k[k] = a.ro[n_k[k] + 1];
+            }
           }
+          fine_mark(4);  // first claim + row offsets of the neighbours
           if constexpr (policy_two_claims<Policy>::value) {
 #pragma unroll
-            for (int k = 0; k < ADV_ITEMS; ++k) {
+            for (int k = 0; k < IT; ++k) {
               const bool need = pre_k[k] & pol.need2(r1_k[k], cand_k[k]);
               if (need) r2_k[k] = pol.claim2(n_k[k]);
             }
           }
-          int code_k[ADV_ITEMS];
+          fine_mark(5);  // second claim
+          int code_k[IT];
 #pragma unroll
-          for (int k = 0; k < ADV_ITEMS; ++k) {
+          for (int k = 0; k < IT; ++k) {
             code_k[k] = 0;
             if (pre_k[k]) code_k[k] = pol.code(r1_k[k], r2_k[k], n_k[k], cand_k[k]);
           }
+          {
+            unsigned long long m_k[IT];
+            int before_k[IT];
+            int n_keep = 0;
 #pragma unroll
-          for (int k = 0; k < ADV_ITEMS; ++k) {
-            const bool keep = code_k[k] == 1;
-            const unsigned long long m = dev::ballot(keep);
-            if (m) {
+            for (int k = 0; k < IT; ++k) {
+              m_k[k] = dev::ballot(code_k[k] == 1);
+              before_k[k] = n_keep;
+              n_keep += __popcll(m_k[k]);
+            }
+            if (n_keep) {  // (uniform in the wave)
               int at = 0;
-              if (lane == 0) at = atomicAdd(&ad.cnt, __popcll(m));
+              if (lane == 0) at = atomicAdd(&ad.cnt, n_keep);
               at = dev::wave_bcast0(at);
-              if (keep) {
-                const int pos = at + dev::mask_rank(m);
-                ad.out[pos] = n_k[k];
-                sm.out_rs[pos] = nrs_k[k];
-                sm.out_deg[pos] = nre_k[k] - nrs_k[k];
-                if constexpr (CARRY) sm.out_st[pos] = cand_k[k];
-                if constexpr (policy_has_accept<Policy>::value) pol.on_accept(n_k[k]);
-              }
-            }
-          }
-          if constexpr (SIDE) {
 #pragma unroll
-            for (int k = 0; k < ADV_ITEMS; ++k) {
-              const bool aside = code_k[k] == 2;
-              const unsigned long long ms = dev::ballot(aside);
-              if (ms) {
-                int at = 0;
-                if (lane == 0) at = atomicAdd(&sm.side_cnt, __popcll(ms));
-                at = dev::wave_bcast0(at);
-                if (aside) sm.side[at + dev::mask_rank(ms)] = n_k[k];
+              for (int k = 0; k < IT; ++k) {
+                if (code_k[k] == 1) {
+                  append(at + before_k[k] + dev::mask_rank(m_k[k]), n_k[k], nrs_k[k], nre_k[k] - nrs_k[k], CARRY ? cand_k[k] : 0);
+                  if constexpr (policy_has_accept<Policy>::value) pol.on_accept(n_k[k]);
+                }
               }
             }
           }
-          __syncthreads();
           if constexpr (SIDE) {
+            unsigned long long m_k[IT];
+            int before_k[IT];
+            int n_side = 0;
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+              m_k[k] = dev::ballot(code_k[k] == 2);
+              before_k[k] = n_side;
+              n_side += __popcll(m_k[k]);
+            }
+            if (n_side) {
+              int at = 0;
+              if (lane == 0) at = atomicAdd(&sm.side_cnt, n_side);
+              at = dev::wave_bcast0(at);
+#pragma unroll
+              for (int k = 0; k < IT; ++k)
+                if (code_k[k] == 2) sm.side[at + before_k[k] + dev::mask_rank(m_k[k])] = n_k[k];
+            }
+            __syncthreads();
             const int sc = sm.side_cnt;
+            __syncthreads();  // (every wave has read the count before any wave adds to it again)
             if (sc >= ADV_BLOCK) {
               if (tid == 0) sm.side_base = pol.side_reserve(c, sc);
               __syncthreads();
@@ -832,46 +904,136 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
               __syncthreads();
             }
           }
+        };
+        if (tm) {
+          do_chunk(std::integral_constant<int, MID_TM_ITEMS>{}, std::true_type{}, 0, 0);
           dbg_mark(1);
-          int cnt = ad.cnt;
-          if (cnt >= TILE) {  // the last k * TILE entries leave, the first cnt % TILE stay
-            const int k = cnt / TILE;
-            flush(cnt - k * TILE, k * TILE);
-            cnt -= k * TILE;
+          fine_mark(6);
+        } else {
+          for (int a0 = 0; a0 < tot; a0 += CHUNK) {
+            do_chunk(std::integral_constant<int, ADV_ITEMS>{}, std::false_type{}, a0, min(tot, a0 + CHUNK));
+            dbg_mark(1);
+            fine_mark(6);  // compaction, appends (stores acknowledged), side pile
           }
-          if (tid == 0) ad.cnt = cnt;
-          __syncthreads();
         }
         __syncthreads();  // seg / start / src are rewritten by the next block of slots
       }
       __syncthreads();  // tcount is rewritten by the next batch of tile counts
     }
-    {
-      const int rem = ad.cnt;
-      if (rem > 0) flush(0, rem);
-    }
     if constexpr (SIDE) {
-      const int sc = sm.side_cnt;
+      const int sc = sm.side_cnt;  // (uniform: every change of it is followed by a barrier)
       if (sc > 0) {
         if (tid == 0) sm.side_base = pol.side_reserve(c, sc);
         __syncthreads();
         const int sb = sm.side_base;
         if (sb >= 0) side_flush(pol, sm.side, sb, sc);
+        if (tid == 0) sm.side_cnt = 0;
         __syncthreads();
       }
     }
+    // what this workgroup appended: entries (the first out_cap of them in its region) and their out-degree sum
+    auto level_totals = [&]() {
+      dsum = dev::wave_sum(dsum);
+      if (lane == 0 && dsum) atomicAdd(&sm.out_edges, dsum);
+      dsum = 0;
+      __syncthreads();
+    };
+    level_totals();
+    int my_out = min(ad.cnt, out_cap);            // entries appended to my region this level (uniform)
+    unsigned my_ovf = sm.ovf ? 0x80000000u : 0u;
     dbg_mark(2);
     static_assert(MID_SEG <= 0x7fff, "the entry count of a region fits 15 bits of the exchange word");
     const unsigned e128 = (unsigned)min(sm.out_edges >> 7, 0xffff);  // (every flush ended with a barrier)
     if (!mid_exchange(a, G, w, epoch, (unsigned)my_out | (e128 << 15) | my_ovf, ovf_cnt, sm)) { fail_out(); return; }
     dbg_mark(3);
+    fine_mark(7);  // totals + exchange
+    if constexpr (policy_refills<Policy>::value) {
+      static_assert(SIDE, "a refilling policy keeps a side pile");
+      if (a.mid_refill_max > 0 && sm.seg_pre[MID_WGS] == 0 && sm.n_ovf == 0) {
+        // The frontier has drained (every workgroup read the same 32 counts).  The leader does the bucket bookkeeping -- every
+        // workgroup's pile entries and their minimum landed in the home L2 before its flag did -- and its word of one more
+        // exchange says whether the next bucket is pulled out of the pile here, or the launch ends as it used to.
+        unsigned dec = 0u;
+        if (w == 0 && tid == 0) dec = pol.refill_decide(c, a.mid_refill_max) ? 1u : 0u;
+        if (!mid_exchange(a, G, w, epoch, dec, ovf_cnt, sm)) { fail_out(); return; }
+        const bool go = sm.seg_pre[1] != 0;  // the leader's word
+        __syncthreads();
+        if (go) {
+          const int n_pile = pol.refill_rebind(c);
+          if (tid == 0) { ad.cnt = 0; sm.side_cnt = 0; sm.out_edges = 0; sm.ovf = 0; }
+          __syncthreads();
+          unsigned kmin = 0xffffffffu;
+          for (int b = w; b * TILE < n_pile; b += G) {
+            const int i = b * TILE + tid;
+            int v = 0, cls = 0, rs = 0, dg = 0;
+            unsigned key = 0u;
+            if (i < n_pile) {
+              v = pol.refill_entry(i);
+              cls = pol.refill_class(pol.load_source(v), key);
+              if (cls == 2) kmin = min(kmin, key);
+            }
+            if (cls == 1) {
+              rs = a.ro[v];
+              dg = a.ro[v + 1] - rs;
+            }
+            const unsigned long long mn = dev::ballot(cls == 1);
+            if (mn) {
+              int at = 0;
+              if (lane == 0) at = atomicAdd(&ad.cnt, __popcll(mn));
+              at = dev::wave_bcast0(at);
+              if (cls == 1) append(at + dev::mask_rank(mn), v, rs, dg, (int)key);  // (key: the label's bits, for policies that carry it)
+            }
+            const unsigned long long mk = dev::ballot(cls == 2);
+            if (mk) {
+              int at = 0;
+              if (lane == 0) at = atomicAdd(&sm.side_cnt, __popcll(mk));
+              at = dev::wave_bcast0(at);
+              if (cls == 2) sm.side[at + dev::mask_rank(mk)] = v;
+            }
+            __syncthreads();
+            const int sc = sm.side_cnt;
+            __syncthreads();
+            if (sc >= ADV_BLOCK) {  // entries that stay: to the pile that receives appends from now on
+              if (tid == 0) sm.side_base = pol.side_reserve(c, sc);
+              __syncthreads();
+              const int sb = sm.side_base;
+              if (sb >= 0)
+                for (int k = tid; k < sc; k += ADV_BLOCK) pol.refill_keep_store(sb + k, sm.side[k]);
+              __syncthreads();
+              if (tid == 0) sm.side_cnt = 0;
+              __syncthreads();
+            }
+          }
+          {
+            const int sc = sm.side_cnt;
+            if (sc > 0) {
+              if (tid == 0) sm.side_base = pol.side_reserve(c, sc);
+              __syncthreads();
+              const int sb = sm.side_base;
+              if (sb >= 0)
+                for (int k = tid; k < sc; k += ADV_BLOCK) pol.refill_keep_store(sb + k, sm.side[k]);
+              if (tid == 0) sm.side_cnt = 0;
+              __syncthreads();
+            }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o, 64));
+          if (lane == 0 && kmin != 0xffffffffu) pol.side_commit(kmin);
+          level_totals();
+          my_out = min(ad.cnt, out_cap);
+          my_ovf = sm.ovf ? 0x80000000u : 0u;
+          const unsigned e128r = (unsigned)min(sm.out_edges >> 7, 0xffff);
+          if (!mid_exchange(a, G, w, epoch, (unsigned)my_out | (e128r << 15) | my_ovf, ovf_cnt, sm)) { fail_out(); return; }
+        }
+      }
+    }
     ++dbg_levels;
     n_priv = sm.seg_pre[MID_WGS];
     n_in = n_priv + sm.n_ovf;
     my_pub = my_out;
     first = false;
     ++level;
-    __syncthreads();
+    if (tid == 0) { ad.cnt = 0; sm.out_edges = 0; sm.ovf = 0; }  // (every thread read them in front of the exchange's barriers)
     // A level that has outgrown this body goes back to the regular kernels: too many vertices, or -- scale-free graphs: a
     // few thousand vertices a level before the hubs -- too many out-edges for the 32 workgroups of one XCD (round 4: three of
     // 16 random sources of the LJ stand-in spent 5 ms in here on levels of 10^5 vertices / 10^6 edges).
@@ -887,12 +1049,19 @@ GRX_MID_FN void mid_levels_body2(const pipe_args& a, ctrl_t* c, Policy& pol, mid
   if (dbg) {
     for (int i = 0; i < 4; ++i) atomicAdd(&c->spare[i], (int)dbg_ph[i]);
     atomicAdd(&c->spare[4], dbg_levels);
+#if defined(GRX_MID_TIMERS) && GRX_MID_TIMERS == 2
+    for (int i = 0; i < 8; ++i) atomicAdd(&c->dbg_fine[i], (int)dbg_f[i]);
+#endif
   }
-  if (tid == 0 && (my_edges | my_vertices)) {
-    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&c->edges_visited), (unsigned long long)my_edges,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&c->vertices_visited), (unsigned long long)my_vertices,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  {
+    const long long w_edges = dev::wave_sum_u32_wide(t_edges);
+    const int w_vertices = dev::wave_sum(t_vertices);
+    if (lane == 0 && (w_edges | w_vertices)) {
+      __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&c->edges_visited), (unsigned long long)w_edges,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&c->vertices_visited), (unsigned long long)w_vertices,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   }
   if (n_in == 0 && !policy_drained_is_done<Policy>::value) {
     // the bucket is drained, not the search (ctrl.mode stays 3: see the first version)

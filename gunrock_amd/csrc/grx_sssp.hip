@@ -111,18 +111,73 @@ struct sssp_nf_policy {
   float hi;
   int32_t* far_out;
   unsigned* min_far;
+  const int32_t* refill_in;  // the pile a bucket is being pulled from (refill_rebind)
   int l2_local;  // set by mid_levels_body: the launch sits on one XCD, label / stamp atomics may execute in its L2
+  int sel;       // the far pile that receives appends (ctrl.nf_sel as of begin / refill_rebind)
+  float lo;      // lower bound of the current bucket
 
   __device__ __forceinline__ void set_level(int l) { level = l; }
 
   __device__ __forceinline__ void begin(ctrl_t* c) {
     level = c->level;
     hi = c->nf_hi;
+    lo = c->nf_lo;
+    sel = c->nf_sel;
     // (a select, not far[sel]: a dynamically indexed member forces the whole by-value policy into memory -- the compiler
     // then keeps one copy per thread in LDS, 20 KB, which pushed this kernel past 64 KB of LDS: see sssp_nf_level_kernel)
-    far_out = c->nf_sel ? nf.far[1] : nf.far[0];
+    far_out = sel ? nf.far[1] : nf.far[0];
     min_far = &c->nf_min_far;
   }
+
+  // ---- the NEXT BUCKET inside a many-levels launch (grx_mid.hpp, `policy_refills`; round 6) ------------------------------
+  // A road-network search changes bucket ~1000 times, and every change used to end the launch: head kernel (bucket
+  // bookkeeping) -> level kernel that only pulls the bucket out of the pile -> head kernel (plan) -> level kernel, ~30 us of
+  // launches and heads around ~6 levels of ~9 us.  Inside the launch it is the leader's bookkeeping, one exchange to publish
+  // it, the pile dealt out in blocks of 256 entries to the resident workgroups, and the exchange every level ends with.
+  // Everything the launch shares lives in the home XCD's L2 (workgroup-scope atomics, loads past the L1), as the labels do.
+  // One thread of the leader.  Returns false: leave it to the head kernel (pile empty = end of the search, pile too large for
+  // 32 workgroups, overflow).  What it writes is what sssp_nf_head_kernel writes.
+  __device__ __forceinline__ bool refill_decide(ctrl_t* c, int max_n) {
+    const int far_n = __hip_atomic_load(&c->nf_far_n[sel], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (far_n <= 0 || far_n > max_n || far_n > nf.capacity) return false;
+    const float delta = c->nf_delta;  // (constant during a search)
+    const float closest = __uint_as_float(__hip_atomic_load(&c->nf_min_far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const float lo2 = hi;
+    float hi2 = lo2 + delta;
+    if (closest >= hi2 && closest < FLT_MAX) {
+      hi2 = (floorf(closest / delta) + 1.0f) * delta;
+      if (!(hi2 > closest)) hi2 = nextafterf(closest, FLT_MAX);
+    }
+    if (!(hi2 > lo2)) hi2 = nextafterf(lo2, FLT_MAX);
+    __hip_atomic_store(&c->nf_lo, lo2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&c->nf_hi, hi2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&c->nf_min_far, 0x7f7fffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&c->nf_far_n[sel ^ 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&c->nf_sel, sel ^ 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    (void)__hip_atomic_fetch_add(&c->nf_phases, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return true;
+  }
+  // every thread, behind the exchange that published the decision: the new bucket, past the L1.  Returns the entries of the
+  // pile the bucket is pulled from (the one that received appends so far).
+  __device__ __forceinline__ int refill_rebind(ctrl_t* c) {
+    const int n = __hip_atomic_load(&c->nf_far_n[sel], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    refill_in = far_out;
+    lo = __hip_atomic_load(&c->nf_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hi = __hip_atomic_load(&c->nf_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sel ^= 1;
+    far_out = sel ? nf.far[1] : nf.far[0];
+    return min(n, nf.capacity);
+  }
+  __device__ __forceinline__ int refill_entry(int i) const {
+    return __hip_atomic_load(&refill_in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // 1: the label lies in the bucket -> frontier; 2: beyond it -> stays in the (new) pile, key = its ordered bits; 0: stale
+  // (sssp_split_body)
+  __device__ __forceinline__ int refill_class(src_state dv, unsigned& key) const {
+    key = __float_as_uint(dv);
+    return dv >= hi ? 2 : (dv >= lo ? 1 : 0);
+  }
+  __device__ __forceinline__ void refill_keep_store(int i, int v) const { far_out[i] = v; }
   // past the L1: inside a multi-level launch the label may have been lowered by an atomic (performed in L2) since
   // this CU last read the line
   __device__ __forceinline__ src_state load_source(int v) const {
@@ -172,8 +227,8 @@ struct sssp_nf_policy {
   // one reservation atomic per flush of the workgroup's side buffer
   __device__ __forceinline__ int side_reserve(ctrl_t* c, int n) const {
     // (inside mid_levels_body only workgroups of ONE XCD touch the pile counters: the atomic may execute in its L2)
-    const int base = l2_local ? __hip_atomic_fetch_add(&c->nf_far_n[c->nf_sel], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                              : atomicAdd(&c->nf_far_n[c->nf_sel], n);
+    const int base = l2_local ? __hip_atomic_fetch_add(&c->nf_far_n[sel], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                              : atomicAdd(&c->nf_far_n[sel], n);
     if (base + n > nf.capacity) {
       c->nf_overflow = 1;
       return -1;
@@ -191,6 +246,29 @@ struct sssp_nf_policy {
   __device__ __forceinline__ void side_commit(unsigned key_min) const {
     if (l2_local) (void)__hip_atomic_fetch_min(min_far, key_min, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else atomicMin(min_far, key_min);
+  }
+};
+
+// The near-far policy INSIDE a many-levels launch (grx_mid.hpp), round 6: ONE atomic per relaxed edge and no label load per
+// expanded vertex.  The level-synchronous kernels let a vertex join the next frontier once per level (second atomic: the stamp)
+// and read its label when they expand it (it may have dropped again after it joined).  Here EVERY improving relaxation appends
+// {vertex, the label it wrote}: a vertex improved twice in one level is expanded twice, the second time from the lower label --
+// the relaxations of the stale entry are no-ops or short-lived, the fixed point is the same -- and in exchange a level's chain
+// loses two dependent round trips (the stamp exchange behind the atomicMin, the label load behind the queue entry): on the
+// weighted road stand-in 13.4 us per level with both.  The stamps stay as the level-synchronous kernels left them (older
+// levels), so a search may move between the two kinds of kernels in both directions.
+// MEASURED AND NOT ADOPTED (-DGRX_NF_CARRY builds it): +31 % relaxations (158.5 M against 121.2 M on the weighted road stand-in)
+// for 1.6 % of the time (97.3 against 98.9 ms) -- profiles/r6_c10_*.
+struct sssp_nf_mid_policy : sssp_nf_policy {
+  static constexpr bool two_claims = false;
+  __device__ __forceinline__ bool carry_state() const { return true; }
+  __device__ __forceinline__ src_state state_from_bits(int b) const { return __int_as_float(b); }
+  __device__ __forceinline__ int code(int raw1, int, int, int cand) const {
+    const float nd = __int_as_float(cand), old = __int_as_float(raw1);
+    if (!(nd < old)) return 0;
+    if (nd < hi) return 1;
+    if (old != FLT_MAX && old >= hi) return 0;  // (already waits in the far pile: sssp_nf_policy::code)
+    return 2;
   }
 };
 
@@ -426,11 +504,17 @@ __device__ __forceinline__ void sssp_split_body(const pipe_args& a, const sssp_n
 __global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, sssp_nf_args nf, sssp_nf_policy pol,
                                                                   uint32_t xcc_mask) {
   // one of three bodies runs per launch: their LDS is overlaid
-  constexpr size_t LDS_BYTES = sizeof(mid_smem<sssp_nf_policy>) > sizeof(split_smem) ? sizeof(mid_smem<sssp_nf_policy>)
-                                                                                      : sizeof(split_smem);
+#ifdef GRX_NF_CARRY
+  using mid_policy = sssp_nf_mid_policy;
+#else
+  using mid_policy = sssp_nf_policy;
+#endif
+  constexpr size_t LDS_MID = sizeof(mid_smem<mid_policy>) > sizeof(advance_smem<sssp_nf_policy>) ? sizeof(mid_smem<mid_policy>)
+                                                                                               : sizeof(advance_smem<sssp_nf_policy>);
+  constexpr size_t LDS_BYTES = LDS_MID > sizeof(split_smem) ? LDS_MID : sizeof(split_smem);
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
-  mid_smem<sssp_nf_policy>& msm = *reinterpret_cast<mid_smem<sssp_nf_policy>*>(lds_raw);
-  advance_smem<sssp_nf_policy>& sm = msm.adv;
+  mid_smem<mid_policy>& msm = *reinterpret_cast<mid_smem<mid_policy>*>(lds_raw);
+  advance_smem<sssp_nf_policy>& sm = *reinterpret_cast<advance_smem<sssp_nf_policy>*>(lds_raw);
   split_smem& ssm = *reinterpret_cast<split_smem*>(lds_raw);
   ctrl_t* c = a.ctrl;
   const level_head h = load_level_head(c);  // one batch of loads, with nf_split
@@ -447,10 +531,16 @@ __global__ __launch_bounds__(ADV_BLOCK) void sssp_nf_level_kernel(pipe_args a, s
                                          a.chunk_tile);
     return;
   }
-  mid_levels_run(a, c, pol, msm, h, xcc_mask);  // many iterations inside the current bucket, in this one launch
+  {
+    mid_policy mp;
+    static_cast<sssp_nf_policy&>(mp) = pol;
+    mid_levels_run(a, c, mp, msm, h, xcc_mask);  // many iterations inside the current bucket, in this one launch
+  }
 #else
-  if (h.mode == 3) {  // many iterations inside the current bucket, in this one launch
-    mid_levels_run(a, c, pol, msm, h, xcc_mask);
+  if (h.mode == 3) {  // many iterations -- and, the far pile permitting, many buckets -- in this one launch
+    mid_policy mp;
+    static_cast<sssp_nf_policy&>(mp) = pol;
+    mid_levels_run(a, c, mp, msm, h, xcc_mask);
     return;
   }
   advance_block<sssp_nf_policy, false>(a, c, pol, sm, h.level & 1, blockIdx.x, gridDim.x, h.total_chunks,
@@ -829,6 +919,8 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     // near-far: 2 = this iteration only pulled a bucket out of the far pile; plain: the level's mode (2 = binned relaxation,
     // 3 = many levels in this launch)
     r.bottom_up = near_far ? 2 * h.nf_split : h.mode;
+    r.bu_open = h.level;    // (SSSP records: the level the search stands at behind this group -- many levels per launch show as jumps --
+    r.bu_probes = h.mode;   // and the body its level kernel ran: 0 relax-per-edge advance, 2 binned relaxation, 3 many levels)
     prof_v = h.vertices_visited;
     prof_e = h.edges_visited;
     // the group that only detected the end carries no work; one that ran the last iterations itself (many per
@@ -836,7 +928,8 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
     if (h.done && r.frontier_size == 0 && r.edges == 0) ctx->levels.pop_back();
   };
   if (near_far) {
-    sssp_nf_policy pol{d_dist, stamp, w_eff ? w_eff : g->w, nf, 0, 0.0f, nullptr, nullptr, 0};
+    sssp_nf_policy pol{d_dist, stamp, w_eff ? w_eff : g->w, nf, 0, 0.0f, nullptr, nullptr, nullptr, 0, 0, 0.0f};
+    a.mid_refill_max = sssp_env_int("GRX_NF_FOLD", 65536);  // (0: every bucket change through the head kernel, as before round 6)
     st = run_levels(ctx, opt, [&](hipStream_t stream, int) {
       group(stream,
             [&] { hipLaunchKernelGGL(sssp_nf_head_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a, nf, mid_v, mid_e); },
@@ -974,7 +1067,7 @@ extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
     return fail(GRX_ERROR_UNSUPPORTED, "Load balance type not supported.");
   GRX_HIP(hipSetDevice(ctx->device));
 
-  // bucket width: 128 x (mean weight) / (mean degree)  (4 x Davidson et al.'s constant, see below); unit-weight
+  // bucket width: 64 x (mean weight) / (mean degree)  (2 x Davidson et al.'s constant, see below); unit-weight
   // graphs (values == NULL) are already level-synchronous => plain schedule
   bool near_far = g->w != nullptr && g->E > 0 && !(opt.engine_flags & GRX_FLAG_SSSP_PLAIN);
   float delta = FLT_MAX;
@@ -1017,13 +1110,17 @@ extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
     const double mean_deg = std::max(1.0, (double)g->E / (double)std::max(1, g->V));
     // GRX_NF_DELTA_SCALE: tuning knob (bucket width multiplier)
     const char* dsc = getenv("GRX_NF_DELTA_SCALE");
-    // Width 128 x mean weight / mean degree: four times Davidson et al.'s constant.  Measured on the
+    // Rounds 1-5: width 128 x mean weight / mean degree, four times Davidson et al.'s constant.  Measured on the
     // weighted road stand-in (tools/history/ab_sssp_delta.py), width / iterations / relaxations / time:
     //   16: 10417 / 65 M / 192 ms   32: 8603 / 74 M / 164 ms   64: 7463 / 92 M / 150 ms
     //   128: 6749 / 130 M / 143 ms   256: 6313 / 213 M / 144 ms
     // -- an iteration is ~19 us of launch and latency, so fewer, fatter iterations win until the
     // extra relaxations catch up.
-    const double dlt = 128.0 * mean_w / mean_deg * ((dsc && atof(dsc) > 0.0) ? atof(dsc) : 1.0);
+    // Round 6: the whole search of a road network is ONE launch now (buckets change inside it, grx_mid.hpp `policy_refills`), a
+    // level costs ~8 us + its relaxations, and a bucket change costs no launch: width / iterations / relaxations / time
+    //   32: 8587 / 72 M / 81.1 ms   64: 7457 / 87 M / 75.5 ms   96: 7001 / 104 M / 76.7 ms   128: 6742 / 121 M / 79.8 ms
+    //   192: 6475 / 158 M / 89.0 ms   256: 6307 / 197 M / 99.7 ms          (profiles/r6_c13_delta.txt)
+    const double dlt = 64.0 * mean_w / mean_deg * ((dsc && atof(dsc) > 0.0) ? atof(dsc) : 1.0);
     if (!(mean_w > 0.0) || !std::isfinite(dlt) || dlt <= 0.0) near_far = false;  // zero / negative weights
     // dense, low-diameter graphs finish in a dozen levels: label-correcting wastes little
     // there and the pile handling only costs (measured: LJ stand-in 4.8 ms plain vs 7.2 ms)
