@@ -154,6 +154,10 @@ def attach_traffic(r, pmc, cls, per_step=False):
         r["traffic_per_step"] = int(tr)
         tr /= max(1, r["launches_per_step"])
     r["traffic"] = int(tr)
+    r["traffic_committed"] = True  # from the committed counter passes of THESE sources, not from this run (see traffic_source)
+    if k.get("SQ_LDS_IDX_ACTIVE_per_launch"):
+        # LDS bank conflicts of the class's kernels (north_star: "LDS bank conflicts on filter" -- the filter is fused into these)
+        r["lds_bank_conflict_ratio"] = round(k.get("SQ_LDS_BANK_CONFLICT_per_launch", 0.0) / k["SQ_LDS_IDX_ACTIVE_per_launch"], 3)
     r["traffic_source"] = ("%s class '%s': FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes of this command on "
                            "these sources, NOT re-measured in this run (raw counters; gfx950 tallies wide coalesced "
                            "reads at 1/2)" % (pmc.get("_file", "profiles/"), cls))
@@ -205,7 +209,8 @@ def pair_hash_weights(csr, seed=42):
     return (1 + (h % np.uint64(1000))).astype(np.float32)
 
 
-def slim(r, keys=("frac", "achieved", "peak", "unit", "bound", "traffic", "avg_launch_us", "launches_per_step",
+def slim(r, keys=("frac", "achieved", "peak", "unit", "bound", "traffic", "traffic_committed", "lds_bank_conflict_ratio",
+                  "avg_launch_us", "launches_per_step",
                   "alg_bytes_per_step", "kernel_ms_per_step", "fat_levels_frac", "rocprof_avg_launch_us")):
     return None if r is None else {k: r[k] for k in keys if k in r}
 
@@ -328,6 +333,13 @@ def main():
                            round(l["other_ms"], 4)] for l in prof]
     roofline["levels_columns"] = "frontier vertices, out-edges, mode (2 = binned), level kernel(s) ms, head kernel ms"
 
+    # --- configs[1] on the LITERAL kernel its text names: every level on the load-balanced claim-per-edge advance (advance_block,
+    # the engine's merge-path body) + fused compact filter, no binned levels, no many-levels body (GRX_FLAG_LB_STRICT)
+    strict_o = bfs_opts(gr.forward, gr.FLAG_ASYNC_RETURN | gr.FLAG_LB_STRICT)
+    strict_ms = timed(lambda: gr.bfs(G, src, dist_t, None, ctx, strict_o), sync, args.steps, 2)
+    strict_same = bool(np.array_equal(dist_t.cpu().numpy(), bfs_gpu_depths))
+    gr.bfs(G, src, dist_t, None, ctx, bfs_opts(gr.forward))  # (the handle's hints back on the default schedule)
+
     # --- direction-optimising search on the same graph (engine extension)
     do = None
     if "bfs_do" in only:
@@ -403,6 +415,9 @@ def main():
                                      "advance + compact filter, advance_direction = forward",
                          "data_file": info["file"], "n_vertices": V, "n_edges": E, "source": src,
                          "advance_load_balance": args.lb, "filter": "compact (fused into the advance)",
+                         "strict_merge_path_ms": round(strict_ms, 4), "strict_merge_path_mteps": round(edges_rank / (strict_ms * 1e3), 1),
+                         "strict_merge_path_note": "same search, GRX_FLAG_LB_STRICT: every level on advance_block (merge-path balance, "
+                                                   "claim per edge); equal depths: %s" % strict_same,
                          "advance_direction": "forward", "completion": "GRX_FLAG_ASYNC_RETURN, K steps bracketed by syncs",
                          "parallelism": "single GPU (the single-GPU engine; the partitioned path is used for N > 1 only)",
                          "edges_visited_per_step": edges_rank, "search_depth": st["search_depth"],
@@ -487,6 +502,8 @@ def main():
                             "cpu1 = 1-core oracle on the same workload, eq_cpu = GPU result == oracle's, viol = oracle "
                             "fixed-point violations; full objects: " + (os.path.relpath(path, ROOT) if path else "--detail FILE"))
     line["config"] = cfg
+    if multi:
+        line["cold_unknown_source_mteps"] = multi.get("forward_cold_mteps")  # 16 other sources, no launch history used at all
     r = slim(roofline)
     r["kernel"] = "forward BFS level kernels (advance_block; bfs_scatter2 + bfs_sweep2 on fat levels)"
     r["traffic_class"] = "topdown_fat (per fat level)" if roofline.get("traffic") else None

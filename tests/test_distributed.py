@@ -489,3 +489,102 @@ def test_c5_twitter_standin_eight_ranks_one_gpu(tmp_path):
     if torch.cuda.is_available() and torch.cuda.mem_get_info(0)[0] < (96 << 30):
         pytest.skip("needs ~96 GB of free device memory for eight resident ranks")
     _c5_ranks_one_gpu(8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["lj", "twitter"])
+def test_one_rank_partition_is_the_engine_at_full_size(gr, gpu_ctx, name):
+    """a partition of ONE slice must not be slower than the single-GPU engine -- it IS the engine
+    (grx_bfs_dist_run builds the same search object and launch schedule as grx_bfs).  BASELINE configs[1] / configs[4]
+    stand-ins at full size, forward and direction-optimising: median wall time of the partitioned call <= 1.15 x the plain
+    call's (+ 20 us of Python around the C call), equal depths."""
+    import time
+    import torch
+    from gunrock_amd import distributed as D
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS
+    wl = WORKLOADS[name]
+    if torch.cuda.mem_get_info(0)[0] < (40 << 30):
+        pytest.skip("needs ~40 GB of free device memory")
+    V = wl["V"]
+    props, c = gr.generate(wl["kind"], V, wl["entries"], wl["a"], wl["b"], wl["c"], seed=42)
+    cin = None
+    if wl["kind"] == "rmat":
+        _, cin = gr.generate_rows(wl["kind"], V, wl["entries"], 0, V, wl["a"], wl["b"], wl["c"], seed=42, in_rows=True)
+    src = int(np.argmax(np.diff(c.row_offsets)))
+    E = int(c.number_of_nonzeros)
+    G = gr.build_graph(props, c, gpu_ctx, device="cuda:0")
+    eng = D.GrxEngine(props, c, 0, 1, "cuda:0", E, in_rows=cin)
+    d0 = torch.empty(V, dtype=torch.int32, device="cuda:0")
+    d1 = eng.new_labels()
+
+    def median_ms(f, n=9):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            f()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t) * 1e3)
+        return sorted(ts)[n // 2]
+
+    for optimized in (False, True):
+        o = gr.options_t(advance_load_balance=gr.merge_path, enable_filter=True, filter_algorithm=gr.compact,
+                         advance_direction=gr.optimized if optimized else gr.forward)
+        plain = lambda: gr.bfs(G, src, d0, None, gpu_ctx, o)  # noqa: E731
+        part = lambda: D.bfs(eng, None, src, d1, optimized=optimized)  # noqa: E731
+        for _ in range(3):
+            plain()
+            part()
+        t_plain, t_part = median_ms(plain), median_ms(part)
+        assert torch.equal(d0, d1[:V]), (name, optimized)
+        assert t_part <= 1.15 * t_plain + 0.02, (name, optimized, t_part, t_plain)
+
+
+@pytest.mark.gpu
+def test_eight_slices_shrink_the_work_of_a_rank():
+    """with the partition on the engine's bodies a rank of eight really does an eighth of the fat levels'
+    work.  tools/part_sim.py steps P ranks of the C5' stand-in (BASELINE configs[4], full size) in lockstep inside ONE process on
+    ONE GPU -- nothing else runs while a rank's kernels are timed -- with device copies for the exchange.  What is asserted is
+    what the hardware gives: the two fat forward levels of one rank of eight take <= 1/4 of the single-GPU engine's (they
+    measure ~1/5: 33 M edges per rank and level leave the scatter at its start-up cost and the sweep at its per-item floor),
+    the whole forward search's kernels <= 0.4 x, and a direction-optimising search -- every level at its latency floor already
+    on one GPU -- does not get slower per rank.  Depth and traversed edges equal the single-GPU search's."""
+    import torch
+    if torch.cuda.mem_get_info(0)[0] < (96 << 30):
+        pytest.skip("needs ~96 GB of free device memory for eight resident slices")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, ROOT)
+    import part_sim
+    from bench import WORKLOADS
+    wl = WORKLOADS["twitter"]
+    res = {}
+    for P in (1, 8):
+        engs, src, e_tot, V = part_sim.build_engines(wl, P)
+        labels = [e.new_labels() for e in engs]
+        for optimized in (False, True):
+            part_sim.lockstep_search(engs, src, labels, optimized)
+            best = None
+            for _ in range(3):
+                levels, stats = part_sim.lockstep_search(engs, src, labels, optimized)
+                tot = sum(max(p) + max(q) for p, q in levels)
+                if best is None or tot < best[0]:
+                    best = (tot, levels, stats)
+            res[(P, optimized)] = (best[0], [max(p) + max(q) for p, q in best[1]], sum(s["edges_visited"] for s in best[2]),
+                                   best[2][0]["search_depth"])
+        del engs, labels
+        torch.cuda.empty_cache()
+    for optimized in (False, True):
+        assert res[(1, optimized)][2:] == res[(8, optimized)][2:], (optimized, res)
+    one, eight = res[(1, False)], res[(8, False)]
+    fat1 = sorted(one[1])[-2:]
+    fat8 = sorted(eight[1])[-2:]
+    assert sum(fat8) <= 0.25 * sum(fat1), (fat1, fat8)
+    assert eight[0] <= 0.4 * one[0], (one[0], eight[0])
+    assert res[(8, True)][0] <= 1.1 * res[(1, True)][0], (res[(1, True)][0], res[(8, True)][0])
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "part_sim_c5_1_vs_8.json"), "w") as f:
+        import json
+        json.dump({"%d_%s" % (p, "optimized" if o else "forward"): {"kernel_ms": round(v[0], 4), "levels_ms": [round(x, 4) for x in v[1]],
+                                                                    "edges": v[2], "depth": v[3]} for (p, o), v in res.items()}, f)
