@@ -1,8 +1,12 @@
-// warp_mapped.hxx -- one 64-lane wavefront per input vertex; lanes stride the
-// neighbour list, so column-index / weight reads of a row are fully coalesced.
-// The reference only declares the enum (operators/configs.hxx:54) and throws
-// "Load balance type not supported." (advance/advance.hxx:272-274); this is the
-// real thing.  Best for medium-to-high uniform degrees.
+// warp_mapped.hxx -- a 64-lane wavefront per window of 64 input slots.  Rows of 64 neighbours or more are walked by the whole
+// wave, lanes on consecutive neighbours (coalesced column-index / weight reads); SHORT rows are PACKED: the wave scans the
+// degrees of its window and its lanes take consecutive neighbours of the concatenated rows, four at a time.
+// The reference only declares the enum (operators/configs.hxx:54) and throws "Load balance type not supported."
+// (advance/advance.hxx:272-274); this is the real thing.
+// Round 6: rounds 1-5 let the wave walk EVERY row with neighbours on its own, one after the other -- a row of 14 neighbours (the
+// LJ stand-in's mean) kept 14 of 64 lanes busy for a whole dependent round trip, a row of a road network 2 or 3: the slowest
+// load balance of the family (7.55 ms for a BFS of the LJ stand-in against 4.47 block-mapped), and the one BASELINE configs[2]
+// names.  Output positions are unchanged: neighbour k of slot i at output[segments[i] + k].
 #pragma once
 
 #include <gunrock/framework/operators/advance/helpers.hxx>
@@ -12,16 +16,34 @@ namespace operators {
 namespace advance {
 namespace warp_mapped {
 
+constexpr int ROUND = 4;  // atoms of the packed rows a lane carries through the phases together
+
 template <advance_io_type_t output_type, typename graph_t, typename operator_t, typename type_t, typename edge_t>
 __global__ __launch_bounds__(256) void kernel(graph_t G, operator_t op, const type_t* input, std::size_t n,
                                               type_t* output, const edge_t* segments) {
   using vertex_t = typename graph_t::vertex_type;
+  using weight_t = typename graph_t::weight_type;
+  // one window per wave of the workgroup; only its own wave touches it (no barrier: a wave's LDS operations complete in order)
+  __shared__ int s_seg[4][65];
+  __shared__ int s_start[4][64];
+  __shared__ int s_base[4][64];
+  __shared__ type_t s_src[4][64];
   const int lane = grx::dev::lane_id();
+  const int wv = (int)threadIdx.x >> 6;
+  int* seg = s_seg[wv];
+  int* st = s_start[wv];
+  int* ob = s_base[wv];
+  type_t* sv = s_src[wv];
   const std::size_t waves = ((std::size_t)gridDim.x * blockDim.x) >> 6;
-  // A wave takes 64 consecutive slots at a time: the lanes load them (one coalesced read of the slots, their row offsets and
-  // their output positions), a ballot keeps the slots that have neighbours, and the wave walks those one after the other with
-  // the lanes on consecutive neighbours.  (Round 4: with one slot per wave iteration, the input of a BFS level WITHOUT a filter --
-  // 36 M slots, 0.5 M of them valid, on the LJ stand-in -- cost one dependent load per slot and wave.)
+  auto visit = [&](vertex_t src, edge_t e, vertex_t nbr, weight_t w, edge_t at) {
+    // mutable lvalues: user operators may take (vertex_t&, vertex_t&, edge_t const&, weight_t const&) like the reference's
+    // hits.hxx:137
+    const bool keep = op(src, nbr, e, w);
+    if constexpr (output_type != advance_io_type_t::none) {
+      const type_t emitted = (output_type == advance_io_type_t::edges) ? (type_t)e : (type_t)nbr;
+      output[at] = keep ? emitted : gunrock::numeric_limits<type_t>::invalid();
+    }
+  };
   for (std::size_t i0 = (((std::size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64; i0 < n; i0 += waves * 64) {
     const std::size_t i = i0 + (std::size_t)lane;
     type_t v = gunrock::numeric_limits<type_t>::invalid();
@@ -34,26 +56,79 @@ __global__ __launch_bounds__(256) void kernel(graph_t G, operator_t op, const ty
         base = segments[i];
       }
     }
-    unsigned long long m = grx::dev::ballot(deg > 0);
+    // ---- long rows: the whole wave, one row after the other
+    unsigned long long m = grx::dev::ballot(deg >= (edge_t)64);
     while (m) {
       const int l = __builtin_ctzll(m);
       m &= m - 1ull;
       const type_t rv = (type_t)__builtin_amdgcn_readlane((int)v, l);
       const edge_t rf = (edge_t)__builtin_amdgcn_readlane((int)first, l), rd = (edge_t)__builtin_amdgcn_readlane((int)deg, l),
                    rb = (edge_t)__builtin_amdgcn_readlane((int)base, l);
-      for (edge_t k = lane; k < rd; k += 64) {
-        // mutable lvalues: user operators may take (vertex_t&, vertex_t&, edge_t const&, weight_t const&)
-        // like the reference's hits.hxx:137
-        edge_t e = rf + k;
-        vertex_t src = (vertex_t)rv, nbr = G.get_destination_vertex(e);
-        auto w = G.get_edge_weight(e);
-        const bool keep = op(src, nbr, e, w);
-        if constexpr (output_type != advance_io_type_t::none) {
-          const type_t emitted = (output_type == advance_io_type_t::edges) ? (type_t)e : (type_t)nbr;
-          output[rb + k] = keep ? emitted : gunrock::numeric_limits<type_t>::invalid();
-        }
+      // ROUND neighbours per lane and trip, their loads issued together (one at a time, a trip was a dependent chain of load ->
+      // operator -> store: ~2 us per 64 neighbours of a hub)
+      for (edge_t k0 = 0; k0 < rd; k0 += 64 * ROUND) {
+        edge_t e[ROUND];
+        vertex_t nbr[ROUND];
+        weight_t w[ROUND];
+#pragma unroll
+        for (int k = 0; k < ROUND; ++k) e[k] = rf + min(k0 + (edge_t)(k * 64 + lane), rd - 1);
+#pragma unroll
+        for (int k = 0; k < ROUND; ++k) nbr[k] = G.get_destination_vertex(e[k]);
+#pragma unroll
+        for (int k = 0; k < ROUND; ++k) w[k] = G.get_edge_weight(e[k]);
+#pragma unroll
+        for (int k = 0; k < ROUND; ++k)
+          if (k0 + (edge_t)(k * 64 + lane) < rd) visit((vertex_t)rv, e[k], nbr[k], w[k], rb + k0 + (edge_t)(k * 64 + lane));
       }
     }
+    // ---- short rows, packed
+    const int sdeg = deg < (edge_t)64 ? (int)deg : 0;
+    const int inc = grx::dev::wave_inclusive_sum(sdeg);
+    const int total = __builtin_amdgcn_readlane(inc, 63);
+    if (total == 0) continue;  // (uniform)
+    seg[lane] = inc - sdeg;
+    st[lane] = (int)first;
+    ob[lane] = (int)base;
+    sv[lane] = v;
+    if (lane == 63) seg[64] = total;
+    __builtin_amdgcn_wave_barrier();  // (compiler-level: the window is read by other lanes of this wave below)
+    for (int a0 = 0; a0 < total; a0 += 64 * ROUND) {
+      int atom[ROUND], lo[ROUND];
+#pragma unroll
+      for (int k = 0; k < ROUND; ++k) {
+        atom[k] = min(a0 + k * 64 + lane, total - 1);  // (atoms past the end repeat the last one: their loads stay in range)
+        lo[k] = 0;
+      }
+      // owner of every atom: largest slot with seg[slot] <= atom (rows without neighbours repeat their neighbour's offset and
+      // are stepped over), ROUND searches step together
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1) {
+        int probe[ROUND];
+#pragma unroll
+        for (int k = 0; k < ROUND; ++k) probe[k] = seg[lo[k] + step];
+#pragma unroll
+        for (int k = 0; k < ROUND; ++k)
+          if (probe[k] <= atom[k]) lo[k] += step;
+      }
+      edge_t e[ROUND], at[ROUND];
+      vertex_t src[ROUND], nbr[ROUND];
+      weight_t w[ROUND];
+#pragma unroll
+      for (int k = 0; k < ROUND; ++k) {
+        const int off = atom[k] - seg[lo[k]];
+        e[k] = (edge_t)(st[lo[k]] + off);
+        at[k] = (edge_t)(ob[lo[k]] + off);
+        src[k] = (vertex_t)sv[lo[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < ROUND; ++k) nbr[k] = G.get_destination_vertex(e[k]);
+#pragma unroll
+      for (int k = 0; k < ROUND; ++k) w[k] = G.get_edge_weight(e[k]);
+#pragma unroll
+      for (int k = 0; k < ROUND; ++k)
+        if (a0 + k * 64 + lane < total) visit(src[k], e[k], nbr[k], w[k], at[k]);
+    }
+    __builtin_amdgcn_wave_barrier();  // (the next window overwrites this one)
   }
 }
 
