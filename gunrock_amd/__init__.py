@@ -444,6 +444,11 @@ def run_stats(context):
             "search_depth": s.search_depth, "elapsed_ms": s.elapsed_ms, "aux": s.reserved}
 
 
+def has_block_async():
+    """True when the loaded library carries the block-asynchronous relaxation (gunrock_amd/libgrx_block.so; not the default)."""
+    return bool(_capi.lib().grx_has_block_async())
+
+
 def block_stats(context):
     """Statistics of the last block-asynchronous search on the context (road-like graphs, grx_block.hip);
     supersteps == 0: the last search took another path."""

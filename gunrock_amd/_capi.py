@@ -120,6 +120,7 @@ def lib():
         "grx_get_run_stats": (i32, [vp, P(grx_run_stats_t)]),
         "grx_get_level_profile": (i32, [vp, P(grx_level_profile_t), i32, P(i32)]),
         "grx_get_block_stats": (i32, [vp, P(grx_block_stats_t)]),
+        "grx_has_block_async": (i32, []),
         "grx_csr_hash": (i32, [vp, i32, i32, vp, vp, vp, P(C.c_uint64)]),
         "grx_debug_block_search_host": (i32, [vp, i32, i32, i32, C.c_uint32, vp, P(grx_block_stats_t)]),
         "grx_host_csr_load_mtx": (i32, [C.c_char_p, P(vp)]),

@@ -17,8 +17,12 @@ LIB = os.path.join(HERE, "libgrx.so")
 OBJ = os.path.join(HERE, "_obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["grx_api.hip", "grx_bfs.hip", "grx_sssp.hip", "grx_pr.hip", "grx_transpose.hip", "grx_dist_sssp.hip", "grx_block.hip",
-           "grx_host.cpp"]
+SOURCES = ["grx_api.hip", "grx_bfs.hip", "grx_sssp.hip", "grx_pr.hip", "grx_transpose.hip", "grx_dist_sssp.hip", "grx_host.cpp"]
+# The block-asynchronous relaxation for road-like graphs (grx_block.hip, 1000 lines; opt-in GRX_BLOCK=1, measured no better than the
+# level-synchronous kernels: DESIGN.md 3.7) is NOT part of the default library since round 6.  `python -m gunrock_amd.build
+# --with-block` builds gunrock_amd/libgrx_block.so (all of the above + that file, -DGRX_WITH_BLOCK); its tests run against it with
+# GRX_TEST_BLOCK=1 (tests/test_block_variant.py).
+BLOCK_SOURCES = SOURCES + ["grx_block.hip"]
 FLAGS = ["-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics",
          "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include")]
@@ -66,7 +70,7 @@ def _compile(src):
     return obj
 
 
-def build_variant(name, defines, verbose=False):
+def build_variant(name, defines, verbose=False, sources=None):
     """A second build of the same sources with extra -D flags, as gunrock_amd/libgrx_<name>.so (tuning aids only:
     e.g. `timers` = -DGRX_MID_TIMERS, the per-phase clocks of the multi-level body).  Loaded through GRX_LIB_PATH."""
     lib = os.path.join(HERE, "libgrx_%s.so" % name)
@@ -85,7 +89,7 @@ def build_variant(name, defines, verbose=False):
         return obj
 
     with ThreadPoolExecutor(max_workers=8) as ex:
-        objs = list(ex.map(one, SOURCES))
+        objs = list(ex.map(one, sources or SOURCES))
     r = subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + objs + ["-lpthread", "-ldl"],
                        capture_output=True, text=True)
     if r.returncode != 0:
@@ -114,6 +118,8 @@ def build(force=False, verbose=False):
 if __name__ == "__main__":
     if "--timers" in sys.argv:
         build_variant("timers", ["GRX_MID_TIMERS"], verbose=True)
+    elif "--with-block" in sys.argv:
+        build_variant("block", ["GRX_WITH_BLOCK"], verbose=True, sources=BLOCK_SOURCES)
     elif "--fine-timers" in sys.argv:  # every sub-phase of the many-levels body behind a full wait (tools/mid_phases.py)
         build_variant("fine", ["GRX_MID_TIMERS=2"], verbose=True)
     else:

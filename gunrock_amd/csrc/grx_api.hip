@@ -174,9 +174,27 @@ grx_status_t pipeline_prepare(grx_context_t ctx, grx_graph_t g, pipe_args* a) {
   return GRX_SUCCESS;
 }
 
+#ifndef GRX_WITH_BLOCK
+// The default library does not carry grx_block.hip (gunrock_amd/build.py): the searches take their level-synchronous paths.
+grx_status_t blk_prepare(grx_context_t, grx_graph_t, bool, bool* usable) {
+  if (usable) *usable = false;
+  return GRX_SUCCESS;
+}
+grx_status_t blk_search(grx_context_t, grx_graph_t, int32_t, const grx_options_t&, bool, void*, float*) {
+  return fail(GRX_ERROR_UNSUPPORTED, "block-asynchronous relaxation is not part of this build (python -m gunrock_amd.build --with-block)");
+}
+void blk_graph_free(void*) {}
+#endif
+
 }  // namespace grx
 
 using namespace grx;
+
+#ifndef GRX_WITH_BLOCK
+extern "C" grx_status_t grx_debug_block_search_host(grx_host_csr_t, int32_t, int32_t, int32_t, uint32_t, uint32_t*, grx_block_stats_t*) {
+  return fail(GRX_ERROR_UNSUPPORTED, "grx_debug_block_search_host: not part of this build (python -m gunrock_amd.build --with-block)");
+}
+#endif
 
 extern "C" {
 
@@ -404,6 +422,16 @@ grx_status_t grx_get_run_stats(grx_context_t ctx, grx_run_stats_t* out) {
   if (!ctx || !out) return fail(GRX_ERROR_INVALID_ARGUMENT, "grx_get_run_stats: null argument");
   *out = ctx->stats;
   return GRX_SUCCESS;
+}
+
+/* 1: this build of the library carries the block-asynchronous relaxation for road-like graphs (grx_block.hip, -DGRX_WITH_BLOCK:
+ * `python -m gunrock_amd.build --with-block`), 0: it does not (the default since round 6) and GRX_BLOCK=1 has no effect */
+int32_t grx_has_block_async(void) {
+#ifdef GRX_WITH_BLOCK
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 grx_status_t grx_get_block_stats(grx_context_t ctx, grx_block_stats_t* out) {

@@ -1206,8 +1206,8 @@ grx_status_t bfs_search::setup(grx_context_t ctx_, grx_graph_t g_, int32_t src_,
       env_int("GRX_LB_STRICT", 0) == 0) {
     bool use = false;
     st = blk_prepare(ctx, g, false, &use);
-    if (st != GRX_SUCCESS) return st;
-    if (use) {
+    if (st != GRX_SUCCESS && !build_failed_softly(st)) return st;
+    if (st == GRX_SUCCESS && use) {
       answered = true;
       return blk_search(ctx, g, src, opt, false, d_dist, elapsed_ms);
     }
@@ -1252,8 +1252,8 @@ grx_status_t bfs_search::setup(grx_context_t ctx_, grx_graph_t g_, int32_t src_,
   use_bins = fwd_bm && e_all >= 4ll * g->V && env_int("GRX_TD_BIN", 1) != 0;
   if (use_bins) {
     st = graph_build_bins(ctx, g);
-    if (st != GRX_SUCCESS) return st;
-    use_bins = g->bin_state == 1;
+    if (st != GRX_SUCCESS && !build_failed_softly(st)) return st;
+    use_bins = st == GRX_SUCCESS && g->bin_state == 1;  // (no room for the tables: fat levels on the claim-per-edge advance)
   }
   if (use_bins) {
     // per-SEARCH scratch of the binned levels, owned by the context: the E-entry candidate array (+ the tail of a 16-byte
@@ -1635,7 +1635,9 @@ void bfs_search::launch_group(hipStream_t stream, int seq) {
   // level kernel may end a search too): the level kernel behind that head was a 4 us no-op in front of the next search.  A search that does not end there after all is left untouched by that head
   // (plan_in::only_finish) and continues in the next group.  GRX_LAST_HEAD_ONLY=0: off
   // (direction-optimising searches: the same source as the last such search on the handle, grx_graph::do_last_src)
-  const bool only_head = (exact || do_repeat) && ended_in_head && !profile && hold_after > 0 && seq == hold_after - 1 && !bins_here && env_int("GRX_LAST_HEAD_ONLY", 1) != 0;
+  // (not with a cap on the iterations: a head-only group would use up one of the caller's groups without advancing a level)
+  const bool only_head = (exact || do_repeat) && ended_in_head && !profile && hold_after > 0 && seq == hold_after - 1 && !bins_here &&
+                         opt.max_iterations == 0 && env_int("GRX_LAST_HEAD_ONLY", 1) != 0;
   const bool level_here = !(exact && bins_here && seq < 32) && !only_head;
   bn.allowed = bins_here ? 1 : 0;
   bn.no_level = (level_here || only_head) ? 0 : 1;

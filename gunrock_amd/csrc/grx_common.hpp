@@ -187,6 +187,15 @@ struct lazy_state {
   grx_status_t done(int32_t v, grx_status_t rc = GRX_SUCCESS) { *st = v; decided = true; return rc; }
 };
 
+// A lazy per-graph build that failed for want of memory (or on a HIP error of its own launches) is not a reason to fail the
+// SEARCH: the caller runs without what the build would have provided -- slower, same result -- and the build is tried again by the
+// next call (its state word went back to 0).  Hard errors (invalid input) are returned.  ADVICE r5.
+inline bool build_failed_softly(grx_status_t st) {
+  if (st != GRX_ERROR_OUT_OF_MEMORY && st != GRX_ERROR_HIP) return false;
+  (void)hipGetLastError();
+  return true;
+}
+
 struct grx_graph {
   grx_context_t ctx = nullptr;
   // Serialises the LAZY per-graph builds (transpose, bin tables, two-neighbour array, pull layouts, block structure, weight

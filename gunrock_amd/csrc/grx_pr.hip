@@ -807,7 +807,10 @@ static grx_status_t build_pr_xcd_layout(grx_context_t ctx, grx_graph_t g) {
     GRX_HIP(hipStreamSynchronize(s));
     rb.release();
   }
-  if (!g->xb_ro) GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ro), (n_off + 2) * sizeof(int32_t)));
+  // (an earlier attempt that failed behind this point may have left a buffer sized for ANOTHER block count -- GRX_PR_XB and E / V are
+  // read afresh on every attempt: never reuse it)
+  if (g->xb_ro) { (void)hipFree(g->xb_ro); g->xb_ro = nullptr; }
+  GRX_HIP(hipMalloc(reinterpret_cast<void**>(&g->xb_ro), (n_off + 2) * sizeof(int32_t)));
   const bool unit = graph_unit_weights(g);  // no weight stream needed (graph_weight_stats ran)
   // stable radix sort of the edges by (source block, destination) (grx_sort.hpp): the round 1-3 version counted and filled
   // with one global atomic per edge -- 124 ms for the 182 M edges of the kron stand-in

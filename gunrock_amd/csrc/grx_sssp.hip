@@ -838,9 +838,9 @@ static grx_status_t run_sssp(grx_context_t ctx, grx_graph_t g, int32_t src, cons
                          (long long)g->E >= (long long)sssp_env_int("GRX_RBIN_MIN_GRAPH_EDGES", 1 << 22);
   if (want_bins) {
     st = graph_build_relax_bins(ctx, g);
-    if (st != GRX_SUCCESS) return st;
+    if (st != GRX_SUCCESS && !build_failed_softly(st)) return st;
   }
-  bool use_rbins = want_bins && g->rb_state == 1;
+  bool use_rbins = want_bins && st == GRX_SUCCESS && g->rb_state == 1;
   if (use_rbins) {
     // per-SEARCH scratch, owned by the context: 6 bytes per edge.  When it cannot be had the search runs on the relax-per-edge
     // levels -- slower, same result -- instead of failing.
@@ -1098,7 +1098,8 @@ extern "C" grx_status_t grx_sssp(grx_context_t ctx, grx_graph_t g, int32_t src,
     bool use = false;
     if (!(strict && *strict == '1')) {
       grx_status_t bst = blk_prepare(ctx, g, true, &use);
-      if (bst != GRX_SUCCESS) return bst;
+      if (bst != GRX_SUCCESS && !build_failed_softly(bst)) return bst;
+      if (bst != GRX_SUCCESS) use = false;
     }
     if (use) return blk_search(ctx, g, src, opt, true, d_dist, elapsed_ms);
   }

@@ -256,6 +256,9 @@ typedef struct grx_block_stats {
   double build_ms;         /* one-time cost of the block structure of this graph (host partitioner + upload) */
 } grx_block_stats_t;
 grx_status_t grx_get_block_stats(grx_context_t ctx, grx_block_stats_t* out);
+/* 1: this build carries that path (gunrock_amd/libgrx_block.so, `python -m gunrock_amd.build --with-block`), 0: it does not -- the
+ * default library since round 6: the path is opt-in and measured no better than the level-synchronous kernels */
+int32_t grx_has_block_async(void);
 
 /* HOST emulation of that schedule on a host CSR (the partitioner, the block structure and the superstep / bucket / local
  * round logic of grx_block.hip, executed serially): test infrastructure of the CPU suite, never called by a product path.

@@ -93,6 +93,24 @@ def test_xcd_blocked_layout_equals_plain_layout(gr, gpu_ctx, golden):
         check(g, p_xcd, it_xcd)
 
 
+def test_row_blocks_sorted_by_source_give_the_same_bits(gr, gpu_ctx, monkeypatch):
+    """GRX_PR_SORT_BLOCKS=1 (opt-in: the entries of a row block sorted by source, xb_pos) reorders the GATHERS only -- every
+    product lands at the same position of the same float64 prefix sums -- so ranks and iteration count must be bit-identical
+    to the default layout's.  Also with another source-block count on a fresh handle (GRX_PR_XB: the offsets buffer is sized
+    per count)."""
+    _, c = gr.generate("rmat_sym", 1 << 16, 1_200_000, seed=21)  # hubs => long-row pieces, 18 edges per vertex
+    g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
+    for xb in ("4", "8"):
+        monkeypatch.setenv("GRX_PR_XB", xb)
+        monkeypatch.delenv("GRX_PR_SORT_BLOCKS", raising=False)
+        p0, it0 = run_pr(gr, gpu_ctx, g, engine_flags=0x80)
+        monkeypatch.setenv("GRX_PR_SORT_BLOCKS", "1")
+        p1, it1 = run_pr(gr, gpu_ctx, g, engine_flags=0x80)
+        assert it0 == it1
+        assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32)), xb
+        check(g, p1, it1)
+
+
 def test_hub_rows_are_split(gr, gpu_ctx):
     # symmetric R-MAT: in-degree hubs far beyond one workgroup's 2048-nnz block
     _, c = gr.generate("rmat_sym", 1 << 16, 1_500_000, seed=3)

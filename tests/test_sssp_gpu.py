@@ -127,14 +127,17 @@ def test_full_size_road_standin_properties(gr, gpu_ctx, monkeypatch):
     g = O.Csr(c.row_offsets, c.column_indices, c.nonzero_values)
     assert 55_000_000 < g.n_edges < 60_000_000
     src = (4894 // 2) * 4894 + 4894 // 2
-    # block-asynchronous relaxation (grx_block.hip, GRX_BLOCK=1); GRX_FLAG_NO_BLOCK_ASYNC: the near-far schedule
-    monkeypatch.setenv("GRX_BLOCK", "1")
+    # the near-far schedule; on a library built with the block-asynchronous relaxation (grx_block.hip: libgrx_block.so,
+    # GRX_BLOCK=1) that path too -- GRX_FLAG_NO_BLOCK_ASYNC then selects near-far
+    blocky = gr.has_block_async()
+    if blocky:
+        monkeypatch.setenv("GRX_BLOCK", "1")
     got = []
     for o in (None, gr.options_t(engine_flags=gr.FLAG_NO_BLOCK_ASYNC)):
         d, st = run_sssp(gr, gpu_ctx, g.row_offsets, g.column_indices, g.values, src, o)
         assert (d < FMAX).sum() > g.n_vertices // 2
         assert O.check_sssp(g, src, d) == 0
-        assert (gr.block_stats(gpu_ctx)["supersteps"] > 0) == (o is None)
+        assert (gr.block_stats(gpu_ctx)["supersteps"] > 0) == (o is None and blocky)
         got.append(d)
     assert np.array_equal(got[0], got[1])
 
@@ -150,8 +153,9 @@ def test_full_size_road_standin_unit_weights(gr, gpu_ctx, monkeypatch):
     src = (4894 // 2) * 4894 + 4894 // 2
     depths, _, ev = O.bfs_queue(g, src)
     reached = depths != np.iinfo(np.int32).max
-    monkeypatch.setenv("GRX_BLOCK", "1")
-    # default: the BFS engine (block-asynchronous on this road-like graph with GRX_BLOCK=1) + one pass depths -> distances;
+    if gr.has_block_async():
+        monkeypatch.setenv("GRX_BLOCK", "1")
+    # default: the BFS engine (block-asynchronous on this road-like graph with GRX_BLOCK=1 on libgrx_block.so) + one pass depths -> distances;
     # GRX_FLAG_SSSP_NO_BFS: the SSSP paths (block-asynchronous with the weight array; with GRX_FLAG_NO_BLOCK_ASYNC the
     # level-synchronous relaxation kernels of grx_sssp.hip); GRX_FLAG_NO_BLOCK_ASYNC alone: the level-synchronous BFS engine
     for flags in (0, gr.FLAG_SSSP_NO_BFS, gr.FLAG_SSSP_NO_BFS | gr.FLAG_NO_BLOCK_ASYNC, gr.FLAG_NO_BLOCK_ASYNC):
