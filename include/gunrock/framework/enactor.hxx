@@ -77,6 +77,11 @@ struct enactor_t {
         f.set_resizing_factor(properties.frontier_sizing_factor);
         f.reserve(initial_size);
       }
+      // ... and the scanned degrees of an input frontier (one per slot + 1): an input holds at most the previous advance's output,
+      // i.e. at most E slots.  Grown on demand (upstream: `scanned_work_domain(V)` and a resize inside compute_output_offsets) the
+      // vector was re-allocated in the middle of every search whose level outgrew V slots -- hipMalloc + copy + hipFree of 145 MB,
+      // 1.7-2.0 ms of the 3.1 ms of a `merge_path` BFS without a filter on the LJ stand-in (round 6, profiles/r6_c22_*).
+      scanned_work_domain.resize(initial_size + 1);
     }
   }
   virtual ~enactor_t() {}
