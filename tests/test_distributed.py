@@ -538,6 +538,7 @@ def test_one_rank_partition_is_the_engine_at_full_size(gr, gpu_ctx, name):
             part()
         t_plain, t_part = median_ms(plain), median_ms(part)
         assert torch.equal(d0, d1[:V]), (name, optimized)
+        print("one rank == engine: %s %s plain %.4f ms partitioned call %.4f ms" % (name, "optimized" if optimized else "forward", t_plain, t_part))
         assert t_part <= 1.15 * t_plain + 0.02, (name, optimized, t_part, t_plain)
 
 
