@@ -1,7 +1,8 @@
 """The many-levels-per-launch body (gunrock_amd/csrc/grx_mid.hpp) on the paths a benchmark graph never takes:
 the shared overflow area behind the private output regions, the hand-back of a growing frontier to the regular
 kernels, the launch-pair-per-level schedule.  Test knobs (read per run by the library): GRX_MID_SEG_CAP = entries of a
-private region in use, GRX_MID_EXIT_V = frontier size at which the body hands back, GRX_MID=0.
+private region in use, GRX_MID_EXIT_V = frontier size at which the body hands back, GRX_MID=0, GRX_NF_FOLD = far-pile size up to which a near-far search
+changes bucket inside the launch.
 BFS depths / SSSP distances must equal the oracle's bit for bit in every configuration
 (what the reference's --validate checks: examples/algorithms/bfs/bfs.cu:96-113, sssp/sssp.cu)."""
 import os
@@ -12,7 +13,7 @@ import pytest
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
-KNOBS = ("GRX_MID_SEG_CAP", "GRX_MID_EXIT_V", "GRX_MID_VERSION", "GRX_MID")
+KNOBS = ("GRX_MID_SEG_CAP", "GRX_MID_EXIT_V", "GRX_MID_VERSION", "GRX_MID", "GRX_NF_FOLD")
 CONFIGS = (
     {},                                                   # defaults
     {"GRX_MID_SEG_CAP": "256"},                           # a workgroup's second flush of a level overflows
@@ -20,6 +21,11 @@ CONFIGS = (
     {"GRX_MID_EXIT_V": "3000"},                           # early hand-back (regions become tiles)
     {"GRX_MID_SEG_CAP": "256", "GRX_MID_EXIT_V": "9000"}, # hand-back with a non-empty overflow area
     {"GRX_MID": "0"},                                     # one launch pair per level
+    # near-far SSSP (round 6: the next bucket is pulled out of the far pile inside the launch while the pile is small enough)
+    {"GRX_NF_FOLD": "0"},                                 # every bucket change through the head kernel, as before round 6
+    {"GRX_NF_FOLD": "300"},                               # small piles inside the launch, larger ones through the head
+    {"GRX_NF_FOLD": "65536", "GRX_MID_SEG_CAP": "0"},     # the pulled bucket goes through the overflow area
+    {"GRX_NF_FOLD": "65536", "GRX_MID_SEG_CAP": "256", "GRX_MID_EXIT_V": "3000"},  # ... and is handed back as tiles
 )
 
 
