@@ -35,8 +35,8 @@ class standard_context_t {
   util::timer_t _timer;
   int* _mailbox = nullptr;  // pinned host, 64 ints
   int* _mailbox_dev = nullptr;  // the same words as kernels address them (null: not mapped -- sizes come back by copy)
-  void* _scratch[4] = {nullptr, nullptr, nullptr, nullptr};  // growable device scratch slots
-  std::size_t _scratch_bytes[4] = {0, 0, 0, 0};
+  void* _scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // growable device scratch slots
+  std::size_t _scratch_bytes[5] = {0, 0, 0, 0, 0};
   // state another layer ties to THIS context's lifetime (the pre-compiled engine keeps its
   // grx_context here: it references _stream and must die before it)
   void* _attached = nullptr;

@@ -81,13 +81,22 @@ void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, w
 
   std::size_t total;
   const edge_t* seg;
+  int max_degree = 0;
   if constexpr (whole_graph) {
     total = (std::size_t)G.get_number_of_edges();  // the CSR offsets ARE the scan
     seg = G.get_row_offsets();
   } else {
-    total = compute_output_offsets(G, input, segments, ctx, false);
+    constexpr bool own_kernel = lb == load_balance_t::thread_mapped || lb == load_balance_t::warp_mapped || lb == load_balance_t::block_mapped;
+    total = compute_output_offsets(G, input, segments, ctx, false, own_kernel ? &max_degree : nullptr);
     seg = memory::raw_pointer_cast(segments.data());
   }
+  // A frontier of HUBS on a mapping that gives a row to one thread / wave / workgroup (round 6): the level behind the 125 k-edge
+  // source of the LJ stand-in was ONE wave's 1.8 ms (warp_mapped; thread_mapped 0.58, block_mapped 0.51) against 16 us on the
+  // merge-path kernel, the level of its neighbours 2.7 / 2.2 / 1.9 ms against 0.46 (profiles/r6_c34_*).  The output is the
+  // same for every load balance (neighbour k of slot i at segments[i] + k), so such a frontier -- its longest row holds
+  // >= 2048 neighbours and is either 16 x the mean row or more than a 1024th of the level -- runs on the merge-path kernel
+  // whatever was asked for; the longest row comes back with the total from the scan of the degrees.
+  const bool hubs = max_degree >= 2048 && ((std::size_t)max_degree * n >= 16 * total || total / (std::size_t)max_degree < 1024);
   benchmark::LOG_EDGES_HOST(total);
   benchmark::LOG_VERTICES_HOST(n);
 
@@ -99,7 +108,9 @@ void execute(graph_t& G, operator_t op, frontier_t* input, frontier_t* output, w
   }
   if (total == 0) return;
 
-  if constexpr (lb == load_balance_t::thread_mapped)
+  if (hubs && lb != load_balance_t::merge_path && lb != load_balance_t::merge_path_v2)
+    merge_path::launch<output_type>(G, op, in, n, out, seg, total, ctx);
+  else if constexpr (lb == load_balance_t::thread_mapped)
     thread_mapped::launch<output_type>(G, op, in, n, out, seg, ctx);
   else if constexpr (lb == load_balance_t::warp_mapped)
     warp_mapped::launch<output_type>(G, op, in, n, out, seg, ctx);
