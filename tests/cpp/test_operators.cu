@@ -184,6 +184,54 @@ int main() {
   run_advance(operators::load_balance_t::merge_path, "advance.merge_path");
   run_advance(operators::load_balance_t::merge_path_v2, "advance.merge_path_v2");
   run_advance(operators::load_balance_t::bucketing, "advance.bucketing");
+  // (round 6: that input is a frontier of HUBS -- its longest row is half of the level -- which advance::execute runs on the
+  // merge-path kernel for every load balance.  The kernels' OWN long-row paths -- rows for the wave, rows of 2048+ for the
+  // workgroup -- need a frontier whose long rows are the rule, not the exception: 1200 rows of 2100 neighbours each.)
+  {
+    const int V2 = 4000;
+    std::vector<std::vector<int>> adj2(V2);
+    for (int v = 0; v < V2; ++v) {
+      const int deg = v < 1200 ? 2100 : (v % 5 == 0 ? 0 : (int)(rng() % 90));
+      for (int k = 0; k < deg; ++k) adj2[v].push_back((int)(rng() % V2));
+    }
+    std::vector<int> I2, J2;
+    for (int v = 0; v < V2; ++v)
+      for (int n : adj2[v]) { I2.push_back(v); J2.push_back(n); }
+    format::coo_t<memory_space_t::host, vertex_t, edge_t, weight_t> coo2(V2, V2, (edge_t)I2.size());
+    for (size_t k = 0; k < I2.size(); ++k) { coo2.row_indices[k] = I2[k]; coo2.column_indices[k] = J2[k]; coo2.nonzero_values[k] = 1.0f; }
+    csr_t csr2;
+    csr2.from_coo(coo2);
+    auto G2 = graph::build<memory_space_t::device>(props, csr2);
+    dummy_problem_t problem2(G2, context);
+    dummy_enactor_t E2(&problem2, context);
+    std::vector<int> input2;
+    for (int v = 0; v < 1200; ++v) input2.push_back(v);
+    for (int v : {1203, -1, 1300, 3999, 1205, 7}) input2.push_back(v);
+    std::vector<int> expect2, expect_calls2(V2, 0);
+    for (int v : input2) {
+      if (v < 0) continue;
+      for (int n : adj2[v]) { expect2.push_back((n & 1) == 0 ? n : -1); expect_calls2[v]++; }
+    }
+    thrust::device_vector<int> calls2(V2);
+    thrust::device_vector<int> d_in2(input2.begin(), input2.end());
+    auto run2 = [&](operators::load_balance_t lb, const char* name) {
+      thrust::fill(calls2.begin(), calls2.end(), 0);
+      auto* in = E2.get_input_frontier();
+      in->resize(input2.size());
+      hipMemcpy(in->data(), d_in2.data().get(), input2.size() * sizeof(int), hipMemcpyDeviceToDevice);
+      operators::advance::execute_runtime(G2, &E2, even_neighbors_t{calls2.data().get()}, lb, *context);
+      auto out = download(*E2.get_input_frontier());
+      thrust::host_vector<int> hc = calls2;
+      bool ok = out == expect2;
+      for (int v = 0; v < V2 && ok; ++v) ok = hc[v] == expect_calls2[v];
+      check(name, ok);
+    };
+    run2(operators::load_balance_t::thread_mapped, "advance.long_rows.thread_mapped");
+    run2(operators::load_balance_t::warp_mapped, "advance.long_rows.warp_mapped");
+    run2(operators::load_balance_t::block_mapped, "advance.long_rows.block_mapped");
+    run2(operators::load_balance_t::merge_path, "advance.long_rows.merge_path");
+    run2(operators::load_balance_t::bucketing, "advance.long_rows.bucketing");
+  }
   // fused advance + compact (extension): the kept neighbours of the same call, as a multiset, and one op call per edge
   {
     thrust::fill(calls.begin(), calls.end(), 0);
